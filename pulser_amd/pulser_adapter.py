@@ -1,0 +1,91 @@
+"""Optional adapter: live ``pulser`` objects -> plain problem bundles.
+
+Only duck-typed attribute access; ``pulser`` itself is never imported here, so
+the module loads on machines without it.  Used (a) by users who have pulser
+installed and want ``QutipEmulator.from_sequence(seq)`` to work unchanged, and
+(b) by ``tests/golden/make_fixtures.py`` in the build container to capture the
+inputs the reference would hand to QuTiP.
+
+Follows how ``pulser_simulation.hamiltonian.Hamiltonian`` consumes its
+arguments (pulser-simulation/pulser_simulation/hamiltonian.py:45-81, 246-439)
+and how ``QutipEmulator`` iterates noise trajectories (simulation.py:299-311).
+"""
+
+from __future__ import annotations
+
+from typing import Any, Iterator
+
+import numpy as np
+
+
+def _np(x: Any) -> np.ndarray:
+    if hasattr(x, "as_array"):
+        return np.array(x.as_array(detach=True))
+    return np.array(x)
+
+
+def problem_from_trajectory(
+    hdata: Any, traj: Any, noisy_samples: Any, reps: int, sampling_rate: float
+) -> dict[str, Any]:
+    """One (trajectory, samples, reps) of ``HamiltonianData.noisy_samples``
+    (pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py:536-546) as a
+    problem bundle."""
+    basis = hdata.basis_data
+    lind = hdata.lindblad_data
+    qids = list(traj.register.qubits)
+    index = {q: i for i, q in enumerate(qids)}
+    nested = noisy_samples.to_nested_dict()
+    samples: dict[str, Any] = {"Global": {}, "Local": {}}
+    for b, s in nested["Global"].items():
+        if s:
+            samples["Global"][b] = {k: _np(v) for k, v in s.items()}
+    for b, per_q in nested["Local"].items():
+        if per_q:
+            samples["Local"][b] = {
+                index[q]: {k: _np(v) for k, v in s.items()}
+                for q, s in per_q.items()
+            }
+    collapse = []
+    for coeff, op in lind.local_collapse_ops:
+        if isinstance(op, str):
+            collapse.append((complex(coeff) if np.iscomplexobj(coeff) else float(coeff), op))
+        else:
+            collapse.append((complex(coeff) if np.iscomplexobj(coeff) else float(coeff), np.array(op, dtype=complex)))
+    paulis = {
+        k: [(complex(c), name) for c, name in v]
+        for k, v in lind.depolarizing_pauli_2ds.items()
+    }
+    mask = noisy_samples._slm_mask
+    coords = np.array([_np(traj.register.qubits[q]) for q in qids], dtype=float)
+    return {
+        "n_qudits": len(qids),
+        "qubit_ids": tuple(str(q) for q in qids),
+        "coords": coords,
+        "eigenbasis": list(basis.eigenbasis),
+        "basis_name": basis.basis_name,
+        "interaction_type": basis.interaction_type,
+        "duration": int(noisy_samples.max_duration),
+        "sampling_rate": float(sampling_rate),
+        "samples": samples,
+        "interaction_matrix": _np(traj.interaction_matrix),
+        "bad_atoms": np.array([bool(traj.bad_atoms[q]) for q in qids]),
+        "collapse_ops": collapse,
+        "depolarizing_pauli_2ds": paulis,
+        "slm_end": int(mask.end),
+        "slm_targets": tuple(index[q] for q in mask.targets),
+        "reps": int(reps),
+    }
+
+
+def problems_from_hamiltonian_data(
+    hdata: Any, sampling_rate: float
+) -> Iterator[dict[str, Any]]:
+    """All trajectories of a ``pulser._hamiltonian_data.HamiltonianData``."""
+    for traj, noisy, reps in hdata.noisy_samples:
+        yield problem_from_trajectory(hdata, traj, noisy, reps, sampling_rate)
+
+
+def channel_amp_det(samples_obj: Any) -> list[tuple[np.ndarray, np.ndarray]]:
+    """(amp, det) per channel of a ``SequenceSamples`` - the input of the
+    default ``max_step`` rule (simulation.py:663-687, 768-776)."""
+    return [(_np(cs.amp), _np(cs.det)) for cs in samples_obj.samples_list]

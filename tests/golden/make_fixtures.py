@@ -1,0 +1,498 @@
+"""Generate the golden fixtures under tests/golden/ (run in the BUILD container).
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 \
+        PYTHONPATH=/tmp/shim:/root/reference/pulser-core:/root/repo \
+        python /root/repo/tests/golden/make_fixtures.py
+
+* Inputs are captured by importing the reference's ``pulser-core`` (read-only,
+  never shipped; needs the no-op ``jsonschema``/``referencing`` stand-in of
+  SURVEY.md Appendix B1 in /tmp/shim) and replaying the constructor order of
+  ``QutipEmulator`` (pulser-simulation/pulser_simulation/simulation.py:130-230)
+  so that the global ``np.random`` stream is consumed exactly as the reference
+  does.
+* Expected outputs are (a) the literal golden values of the reference's own
+  tests (known answers, cited per fixture) and (b) outputs of the CPU oracle
+  (``oracle/``) at QuTiP-default and at tight tolerances.
+
+Fixtures are data only: arrays + JSON metadata (``pulser_amd.problem.save_problem``).
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import pulser  # noqa: E402
+from pulser import NoiseModel, Pulse, Register, Sequence  # noqa: E402
+from pulser._hamiltonian_data import HamiltonianData  # noqa: E402
+from pulser.devices import AnalogDevice, DigitalAnalogDevice, MockDevice  # noqa: E402
+from pulser.noise_model import _LEGACY_DEFAULTS  # noqa: E402
+from pulser.sampler import sampler  # noqa: E402
+from pulser.waveforms import BlackmanWaveform, RampWaveform  # noqa: E402
+
+from oracle import qutip_path as qp  # noqa: E402
+from oracle import sampling as osamp  # noqa: E402
+from pulser_amd import problem as P  # noqa: E402
+from pulser_amd.pulser_adapter import (  # noqa: E402
+    channel_amp_det,
+    problems_from_hamiltonian_data,
+)
+
+warnings.simplefilter("ignore")
+
+
+def capture(seq, noise_model, sampling_rate=1.0, n_trajectories=None):
+    """Replay ``QutipEmulator.from_sequence`` up to the solver call."""
+    samples = sampler.sample(seq, extended_duration=seq.get_duration())
+    T = samples.max_duration
+    ext = samples.extend_duration(T + 1)  # simulation.py:173
+    nm = noise_model or NoiseModel()
+    ntraj = n_trajectories if n_trajectories is not None else nm.runs
+    hd = HamiltonianData(ext, seq.register, seq.device, nm, ntraj)  # :208
+    problems = list(problems_from_hamiltonian_data(hd, sampling_rate))
+    # set_evaluation_times("Full") -> hidden noiseless HamiltonianData (:266-297)
+    HamiltonianData(ext, seq.register, seq.device, NoiseModel(), 1)
+    opts = qp.default_options(channel_amp_det(ext), T)
+    tlist = qp.sampling_times(T + 1, sampling_rate)
+    eval_times = np.union1d(tlist, [0.0, T * 1e-3])  # :596-598
+    meas = ext._measurement
+    bname = problems[0]["basis_name"]
+    if not meas:
+        meas = "digital" if "all" in bname else bname.replace("_with_error", "")
+    aux = {
+        "T": int(T),
+        "eval_times": eval_times,
+        "options": {k: float(v) for k, v in opts.items()},
+        "meas_basis": meas,
+        "matching_meas_basis": bool(meas in bname),
+        "channel_amp_det": [np.stack(ad) for ad in channel_amp_det(ext)],
+    }
+    return problems, aux, hd
+
+
+def solve(problem, aux, psi0=None, tight=False):
+    ham = qp.build_hamiltonian(problem)
+    if psi0 is None:
+        psi0 = qp.all_ground_state(problem["n_qudits"], problem["eigenbasis"])
+    opts = dict(aux["options"])
+    if tight:
+        opts.update(qp.TIGHT)
+    fn = qp.mesolve if problem["collapse_ops"] else qp.sesolve
+    return fn(ham, psi0, aux["eval_times"], **opts)
+
+
+# ---------------------------------------------------------------------------
+# 1. test_simulation.py:978-1040  (1 atom, 7 noise combos, seed 123)
+# ---------------------------------------------------------------------------
+
+Z2 = np.array([[1, 0], [0, -1]], dtype=complex)
+
+RYDBERG_CASES = [
+    (("dephasing",), {"0": 572, "1": 428}, 1),
+    (("relaxation",), {"0": 572, "1": 428}, 1),
+    (("eff_noise",), {"0": 572, "1": 428}, 1),
+    (("depolarizing",), {"0": 561, "1": 439}, 3),
+    (("dephasing", "depolarizing", "relaxation"), {"0": 562, "1": 438}, 5),
+    (("eff_noise", "dephasing"), {"0": 573, "1": 427}, 2),
+    (("eff_noise", "leakage"), {"0": 572, "1": 428}, 1),
+]
+
+
+def legacy_params(noise):
+    params = {
+        p: _LEGACY_DEFAULTS[p]
+        for p in NoiseModel._find_relevant_params(
+            [n for n in noise if n not in ["leakage", "eff_noise"]],
+            state_prep_error=_LEGACY_DEFAULTS["state_prep_error"],
+            amp_sigma=_LEGACY_DEFAULTS["amp_sigma"],
+            laser_waist=_LEGACY_DEFAULTS["laser_waist"],
+        )
+    }
+    return params
+
+
+def gen_noises_rydberg():
+    for k, (noise, golden, n_ops) in enumerate(RYDBERG_CASES):
+        np.random.seed(123)
+        reg = Register.from_coordinates([(0, 0)], prefix="q")
+        seq = Sequence(reg, DigitalAnalogDevice)
+        seq.declare_channel("ch0", "rydberg_global")
+        seq.add(Pulse.ConstantPulse(2500, np.pi, 0, 0), "ch0")
+        params = legacy_params(noise)
+        with_leakage = "leakage" in noise
+        if with_leakage or "eff_noise" in noise:
+            params["eff_noise_opers"] = [
+                np.array([[1, 0, 0], [0, 0, 0], [0, 0, 0]], dtype=complex)
+                if with_leakage
+                else Z2
+            ]
+            params["eff_noise_rates"] = [0.1 if with_leakage else 0.025]
+        ntraj = params.pop("runs", None)
+        problems, aux, _ = capture(
+            seq, NoiseModel(with_leakage=with_leakage, **params), 0.01, ntraj
+        )
+        assert len(problems) == 1
+        rng_state_after_ctor = np.random.get_state()[1][:4].copy()
+        states = solve(problems[0], aux)
+        counter = osamp.sample_state(
+            states, aux["eval_times"], aux["eval_times"][-1], 1000,
+            problems[0]["n_qudits"], problems[0]["eigenbasis"],
+            aux["meas_basis"], aux["matching_meas_basis"],
+        )
+        ok = dict(counter) == golden
+        print(f"noises_rydberg[{k}] {noise}: oracle {dict(counter)} golden {golden} {'OK' if ok else 'MISMATCH'}")
+        tight = solve(problems[0], aux, tight=True)
+        P.save_problem(
+            os.path.join(HERE, f"noises_rydberg_{k}.npz"),
+            problems[0],
+            aux=aux,
+            seed=123,
+            noise=list(noise),
+            n_collapse_ops=n_ops,
+            reference_golden_counter=golden,
+            reference_cite="tests/pulser_simulation/test_simulation.py:978-1040",
+            oracle_final_state_default=states[-1],
+            oracle_final_state_tight=tight[-1],
+            oracle_lookup_index=osamp.index_from_time(aux["eval_times"], aux["eval_times"][-1]),
+            oracle_lookup_state_default=states[osamp.index_from_time(aux["eval_times"], aux["eval_times"][-1])],
+            rng_probe_after_ctor=rng_state_after_ctor,
+        )
+
+
+# ---------------------------------------------------------------------------
+# 2. test_simulation.py:1079-1160 (3 atoms, digital basis, local pulses)
+# ---------------------------------------------------------------------------
+
+deph_res = {"111": 978, "110": 12, "011": 7, "101": 3}
+depo_res = {"111": 827, "101": 63, "011": 59, "110": 40, "010": 5, "001": 4, "000": 1, "100": 1}
+deph_depo_res = {"111": 807, "101": 64, "011": 60, "110": 56, "001": 5, "010": 4, "100": 3, "000": 1}
+eff_deph_res = {"111": 961, "101": 15, "110": 14, "011": 9, "001": 1}
+DIGITAL_CASES = [
+    (("dephasing",), deph_res, 1),
+    (("eff_noise",), deph_res, 1),
+    (("depolarizing",), depo_res, 3),
+    (("dephasing", "depolarizing"), deph_depo_res, 4),
+    (("eff_noise", "dephasing"), eff_deph_res, 2),
+    (("eff_noise", "leakage"), deph_res, 1),
+    (("eff_noise", "leakage", "dephasing"), eff_deph_res, 2),
+]
+
+
+def seq_digital():
+    reg = Register(
+        {
+            "control1": np.array([-4.0, 0.0]),
+            "target": np.array([0.0, 4.0]),
+            "control2": np.array([4.0, 0.0]),
+        }
+    )
+    pi_y = Pulse.ConstantDetuning(BlackmanWaveform(1000, np.pi), 0.0, -np.pi / 2)
+    seq = Sequence(reg, DigitalAnalogDevice)
+    seq.declare_channel("raman", "raman_local", "control1")
+    seq.add(pi_y, "raman")
+    seq.target("target", "raman")
+    seq.add(pi_y, "raman")
+    seq.target("control2", "raman")
+    seq.add(pi_y, "raman")
+    return seq
+
+
+def gen_noises_digital():
+    for k, (noise, golden, n_ops) in enumerate(DIGITAL_CASES):
+        np.random.seed(123)
+        params = legacy_params(noise)
+        if "dephasing" in noise:
+            params["hyperfine_dephasing_rate"] = 0.05
+        with_leakage = "leakage" in noise
+        if with_leakage or "eff_noise" in noise:
+            params["eff_noise_opers"] = [
+                np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=complex)
+                if with_leakage
+                else Z2
+            ]
+            params["eff_noise_rates"] = [0.1 if with_leakage else 0.025]
+        params.pop("runs", None)
+        problems, aux, _ = capture(
+            seq_digital(), NoiseModel(with_leakage=with_leakage, **params), 0.01
+        )
+        states = solve(problems[0], aux)
+        counter = osamp.sample_state(
+            states, aux["eval_times"], aux["eval_times"][-1], 1000,
+            problems[0]["n_qudits"], problems[0]["eigenbasis"],
+            aux["meas_basis"], aux["matching_meas_basis"],
+        )
+        ok = dict(counter) == golden
+        print(f"noises_digital[{k}] {noise}: {'OK' if ok else 'MISMATCH'} {dict(counter)}")
+        tight = solve(problems[0], aux, tight=True)
+        idx = osamp.index_from_time(aux["eval_times"], aux["eval_times"][-1])
+        P.save_problem(
+            os.path.join(HERE, f"noises_digital_{k}.npz"),
+            problems[0],
+            aux=aux,
+            seed=123,
+            noise=list(noise),
+            n_collapse_ops=n_ops,
+            reference_golden_counter=golden,
+            reference_cite="tests/pulser_simulation/test_simulation.py:1079-1160",
+            oracle_final_state_default=states[-1],
+            oracle_final_state_tight=tight[-1],
+            oracle_lookup_index=idx,
+            oracle_lookup_state_default=states[idx],
+        )
+
+
+# ---------------------------------------------------------------------------
+# 3. test_simulation.py:2156-2190 (3 atoms, custom initial state, golden state)
+# ---------------------------------------------------------------------------
+
+GOLDEN_3ATOM = np.array(
+    [
+        0.28985369 + 0.13530479j,
+        0.40220557 + 0.0j,
+        0.27445983 + 0.15541026j,
+        0.29608403 + 0.06155379j,
+        0.40220557 + 0.0j,
+        0.36173532 - 0.01617572j,
+        0.29608403 + 0.06155379j,
+        0.36931122 - 0.15570528j,
+    ]
+)
+
+
+def gen_three_atom_state():
+    seq = Sequence(
+        Register({"q0": (-6, 0), "q1": (0, 0), "q2": (6, 0)}), AnalogDevice
+    )
+    seq.declare_channel("ising", "rydberg_global")
+    seq.add(Pulse.ConstantPulse(4000, 9.28, 18.7, 0), "ising")
+    problems, aux, _ = capture(seq, None)
+    psi0 = np.ones(8, dtype=complex) / np.sqrt(8)  # .unit() simulation.py:523-525
+    states = solve(problems[0], aux, psi0=psi0)
+    tight = solve(problems[0], aux, psi0=psi0, tight=True)
+    idx = osamp.index_from_time(aux["eval_times"], aux["eval_times"][-1])
+    st = states[idx]
+    ph = np.angle(st[np.argmax(np.abs(st))])
+    err = np.max(np.abs(st * np.exp(-1j * ph) - GOLDEN_3ATOM))
+    print(f"three_atom_state: lookup idx {idx} of {len(states)}; |oracle - golden| = {err:.2e}")
+    P.save_problem(
+        os.path.join(HERE, "three_atom_state.npz"),
+        problems[0],
+        aux=aux,
+        initial_state=psi0,
+        reference_golden_state=GOLDEN_3ATOM,
+        reference_cite="tests/pulser_simulation/test_simulation.py:2156-2190 (rtol 1e-2, global phase removed)",
+        oracle_lookup_index=idx,
+        oracle_states_default=np.stack([states[0], states[len(states) // 2], states[idx], states[-1]]),
+        oracle_states_tight=np.stack([tight[0], tight[len(tight) // 2], tight[idx], tight[-1]]),
+        oracle_state_indices=np.array([0, len(states) // 2, idx, len(states) - 1]),
+    )
+
+
+# ---------------------------------------------------------------------------
+# 4. BASELINE.json configs
+# ---------------------------------------------------------------------------
+
+
+def anneal_sequence(reg, device=MockDevice):
+    """tests/pulser_simulation/test_qutip_backend_v2.py:56-88 on ``reg``."""
+    omega_max = 4 * 2 * np.pi
+    U = omega_max / 2
+    d0, df = -6 * U, 2 * U
+    t_rise, t_fall = 500, 1000
+    t_sweep = int((df - d0) / (2 * np.pi * 10) * 1000)
+    seq = Sequence(reg, device)
+    seq.declare_channel("ising_global", "rydberg_global")
+    seq.add(Pulse.ConstantDetuning(RampWaveform(t_rise, 0.0, omega_max), d0, 0.0), "ising_global")
+    seq.add(Pulse.ConstantAmplitude(omega_max, RampWaveform(t_sweep, d0, df), 0.0), "ising_global")
+    seq.add(Pulse.ConstantDetuning(RampWaveform(t_fall, omega_max, 0.0), df, 0.0), "ising_global")
+    return seq
+
+
+def blockade_radius():
+    return MockDevice.rydberg_blockade_radius(4 * 2 * np.pi / 2)
+
+
+def pick(states, idxs):
+    return np.stack([states[i] for i in idxs])
+
+
+def gen_cfg1():
+    """4-atom square, global Blackman pi pulse, sesolve (plumbing)."""
+    reg = Register.square(2, spacing=5.0, prefix="q")
+    seq = Sequence(reg, MockDevice)
+    seq.declare_channel("ryd", "rydberg_global")
+    seq.add(Pulse.ConstantDetuning(BlackmanWaveform(1000, np.pi), 0.0, 0.0), "ryd")
+    problems, aux, _ = capture(seq, None)
+    p = problems[0]
+    # the synthetic generators must reproduce pulser's inputs exactly
+    coords = P.register_coords(P.square_rect(2, 2), 5.0)
+    assert np.array_equal(coords, p["coords"]), (coords, p["coords"])
+    syn_amp = np.concatenate([P.blackman_samples(1000, np.pi), [0.0]])
+    assert np.array_equal(syn_amp, p["samples"]["Global"]["ground-rydberg"]["amp"])
+    assert np.array_equal(P.interaction_matrix(coords, P.C6_LEVEL70), p["interaction_matrix"])
+    states = solve(p, aux)
+    tight = solve(p, aux, tight=True)
+    idx = osamp.index_from_time(aux["eval_times"], aux["eval_times"][-1])
+    np.random.seed(123)
+    counter = osamp.sample_state(states, aux["eval_times"], aux["eval_times"][-1], 1000, 4, p["eigenbasis"], "ground-rydberg")
+    sel = [0, 250, 500, 750, idx, len(states) - 1]
+    print(f"cfg1: lookup idx {idx}; counter {dict(counter)}")
+    P.save_problem(
+        os.path.join(HERE, "cfg1_square4_pi.npz"), p, aux=aux, seed=123,
+        oracle_counter_default=dict(counter),
+        oracle_lookup_index=idx,
+        oracle_state_indices=np.array(sel),
+        oracle_states_default=pick(states, sel),
+        oracle_states_tight=pick(tight, sel),
+    )
+
+
+def gen_cfg2(n=12, name="cfg2_chain12_anneal"):
+    """n-atom chain at the blockade radius, analog Ising anneal, sesolve."""
+    rb = blockade_radius()
+    reg = Register.rectangle(1, n, rb, prefix="q")
+    problems, aux, _ = capture(anneal_sequence(reg), None)
+    p = problems[0]
+    coords = P.register_coords(P.square_rect(1, n), rb)
+    assert np.allclose(coords, p["coords"], rtol=0, atol=1e-12)
+    syn = P.anneal_samples()
+    for k in ("amp", "det", "phase"):
+        assert np.array_equal(syn[k], p["samples"]["Global"]["ground-rydberg"][k]), k
+    assert np.allclose(P.interaction_matrix(p["coords"], P.C6_LEVEL70), p["interaction_matrix"], rtol=1e-15)
+    aux_min = dict(aux)
+    sel_t = np.array([0.0, 0.5, 1.3, 2.1, 3.099, 3.1])
+    aux_min["eval_times"] = sel_t
+    counter = [0]
+    import time
+    t0 = time.time()
+    states = qp.sesolve(qp.build_hamiltonian(p), qp.all_ground_state(n, p["eigenbasis"]), sel_t, counter=counter, **aux["options"])
+    wall = time.time() - t0
+    tight = solve(p, aux_min, tight=True)
+    print(f"{name}: default zvode {counter[0]} RHS evals in {wall:.2f}s; |default-tight|max = {np.max(np.abs(states[-1]-tight[-1])):.2e}; norm drift {np.linalg.norm(states[-1])-1:.2e}")
+    # keep the fixture small: only the scalar inputs + the states
+    small = {k: v for k, v in p.items() if k != "samples"}
+    small["samples"] = {"Global": {}, "Local": {}}  # regenerated by pulser_amd.problem.anneal_samples
+    P.save_problem(
+        os.path.join(HERE, name + ".npz"), small, aux={k: v for k, v in aux.items() if k not in ("eval_times", "channel_amp_det")},
+        synthetic="anneal_samples() on a 1 x n chain at the blockade radius",
+        blockade_radius=float(rb),
+        eval_times=sel_t,
+        oracle_states_default=np.stack(states),
+        oracle_states_tight=np.stack(tight),
+        oracle_rhs_evals_default=counter[0],
+    )
+
+
+def gen_cfg3_small(rows=2, cols=3):
+    """cfg3 physics (triangular register, dephasing + SPAM measurement errors,
+    mesolve) at an oracle-sized N."""
+    rb = blockade_radius()
+    reg = Register.triangular_lattice(rows, cols, rb, prefix="q")
+    nm = NoiseModel(dephasing_rate=0.05, p_false_pos=0.01, p_false_neg=0.05)
+    np.random.seed(7)
+    problems, aux, _ = capture(anneal_sequence(reg), nm)
+    p = problems[0]
+    n = p["n_qudits"]
+    coords = P.register_coords(P.triangular_rect(rows, cols), rb)
+    assert np.allclose(coords, p["coords"], rtol=0, atol=1e-12), (coords, p["coords"])
+    sel_t = np.array([0.0, 0.5, 1.3, 2.1, 3.099, 3.1])
+    aux2 = dict(aux)
+    aux2["eval_times"] = sel_t
+    states = solve(p, aux2)
+    tight = solve(p, aux2, tight=True)
+    np.random.seed(123)
+    w = osamp.weights(states[-2], n, p["eigenbasis"], "ground-rydberg")
+    c0 = osamp.get_samples(w, 1000, n)
+    c1 = osamp.spam_flips(c0, 0.01, 0.05)
+    print(f"cfg3_small N={n}: collapse {p['collapse_ops']}; trace {np.trace(states[-1]).real:.8f}; |default-tight| {np.max(np.abs(states[-1]-tight[-1])):.2e}")
+    small = {k: v for k, v in p.items() if k != "samples"}
+    small["samples"] = {"Global": {}, "Local": {}}
+    P.save_problem(
+        os.path.join(HERE, f"cfg3_tri{n}_dephasing.npz"), small,
+        aux={k: v for k, v in aux.items() if k not in ("eval_times", "channel_amp_det")},
+        rows=rows, cols=cols, blockade_radius=float(rb),
+        eval_times=sel_t, seed=123,
+        meas_errors={"epsilon": 0.01, "epsilon_prime": 0.05},
+        oracle_states_default=np.stack(states),
+        oracle_states_tight=np.stack(tight),
+        oracle_counter_t3099_noflip=dict(c0),
+        oracle_counter_t3099_spam=dict(c1),
+    )
+
+
+def gen_cfg4(n=12, ntraj=1024, keep=3):
+    """12-atom chain, doppler + amplitude + SPAM noise, seed 0, 1024 trajectories."""
+    rb = blockade_radius()
+    reg = Register.rectangle(1, n, rb, prefix="q")
+    nm = NoiseModel(temperature=50.0, amp_sigma=0.05, state_prep_error=0.005,
+                    p_false_pos=0.01, p_false_neg=0.05)
+    np.random.seed(0)
+    samples = sampler.sample(anneal_sequence(reg), extended_duration=3100)
+    ext = samples.extend_duration(3101)
+    hd = HamiltonianData(ext, reg, MockDevice, nm, ntraj)
+    rng_after = np.random.get_state()[1][:4].copy()
+    qids = list(reg.qubits)
+    bad = np.array([[t.trajectory.bad_atoms[q] for q in qids] for t in hd.noise_trajectories])
+    dop = np.array([[t.trajectory.doppler_detune[q] for q in qids] for t in hd.noise_trajectories])
+    ampf = np.array([t.trajectory.amp_fluctuations["ising_global"] for t in hd.noise_trajectories])
+    reps = np.array([t.reps for t in hd.noise_trajectories])
+    it = hd.noisy_samples
+    from pulser_amd.pulser_adapter import problem_from_trajectory
+    kept = []
+    for _ in range(keep):
+        traj, noisy, r = next(it)
+        kept.append(problem_from_trajectory(hd, traj, noisy, r, 1.0))
+    sel_t = np.array([0.0, 1.3, 3.099, 3.1])
+    opts = qp.default_options(channel_amp_det(ext), 3100)
+    outs, outs_t = [], []
+    for p in kept:
+        ham = qp.build_hamiltonian(p)
+        psi0 = qp.all_ground_state(n, p["eigenbasis"])
+        outs.append(np.stack(qp.sesolve(ham, psi0, sel_t, **opts)))
+        o2 = dict(opts); o2.update(qp.TIGHT)
+        outs_t.append(np.stack(qp.sesolve(ham, psi0, sel_t, **o2)))
+    print(f"cfg4: {len(hd.noise_trajectories)} trajectories, bad atoms total {bad.sum()}, amp mean {ampf.mean():.4f}; kept {keep}")
+    # per-trajectory samples are affine in the base samples -> store only traj 0 in full
+    first = kept[0]
+    P.save_problem(
+        os.path.join(HERE, "cfg4_chain12_noise.npz"), first,
+        seed=0, n_trajectories=ntraj,
+        noise_model=dict(temperature=50.0, amp_sigma=0.05, state_prep_error=0.005, p_false_pos=0.01, p_false_neg=0.05),
+        blockade_radius=float(rb),
+        traj_bad_atoms=bad, traj_doppler=dop, traj_amp_fluctuation=ampf, traj_reps=reps,
+        rng_probe_after_ctor=rng_after,
+        options={k: float(v) for k, v in opts.items()},
+        eval_times=sel_t,
+        kept_det=np.stack([[p["samples"]["Local"]["ground-rydberg"][q]["det"] for q in range(n)] for p in kept])[:, :, ::100],
+        kept_amp=np.stack([[p["samples"]["Local"]["ground-rydberg"][q]["amp"] for q in range(n)] for p in kept])[:, :, ::100],
+        kept_interaction=np.stack([p["interaction_matrix"] for p in kept]),
+        oracle_states_default=np.stack(outs),
+        oracle_states_tight=np.stack(outs_t),
+    )
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rydberg", "digital", "three", "cfg1", "cfg2", "cfg3", "cfg4"]
+    print("pulser", pulser.__version__)
+    if "rydberg" in which:
+        gen_noises_rydberg()
+    if "digital" in which:
+        gen_noises_digital()
+    if "three" in which:
+        gen_three_atom_state()
+    if "cfg1" in which:
+        gen_cfg1()
+    if "cfg2" in which:
+        gen_cfg2(12, "cfg2_chain12_anneal")
+        gen_cfg2(8, "cfg2_chain8_anneal")
+    if "cfg3" in which:
+        gen_cfg3_small(2, 2)
+        gen_cfg3_small(2, 3)
+    if "cfg4" in which:
+        gen_cfg4()
