@@ -1,0 +1,189 @@
+/*
+ * rydemu.h - C ABI of librydemu.so, the MI355X (gfx950) emulation core.
+ *
+ * This is the native seam of the pulser_simulation classical-emulation path.
+ * In the reference (pasqal-io/Pulser 1.10dev0, paths relative to the repo root)
+ * the seam is the single call
+ *
+ *     solver_fn(hamiltonian._hamiltonian, self.initial_state,
+ *               self._eval_times_array, c_ops=..., options=options)
+ *     -- pulser-simulation/pulser_simulation/simulation.py:729-735
+ *
+ * whose inputs are built by Hamiltonian._construct_hamiltonian
+ * (pulser-simulation/pulser_simulation/hamiltonian.py:246-439) and whose
+ * outputs are `result.states` (simulation.py:739-748).  Every entry point
+ * below names the reference interface it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types, no exceptions.
+ *  - return 0 on success, negative ryd_status on error; ryd_last_error() gives
+ *    a thread-local message.
+ *  - `*_dev` pointers are DEVICE pointers owned by the caller (e.g.
+ *    torch.Tensor.data_ptr()); host pointers are plain.  The library borrows
+ *    them for the duration of the call.  `stream` is a hipStream_t (may be 0).
+ *  - The handle owns its device tables (spline coefficients, interaction
+ *    diagonal, per-stage coefficient buffers, Taylor work vectors).
+ *  - One handle per device and stream; not thread-safe; re-entrant across
+ *    handles.  Calls are asynchronous on `stream` unless documented.
+ *  - State layout: complex128 (re, im interleaved).  ket: [batch][2^N], basis
+ *    index = sum_k s_k 2^(N-1-k), s_k = 0 <=> atom k in |r>, 1 <=> |g>
+ *    (docs/source/conventions.md:58-73).  Density matrix: row-major
+ *    [batch][2^N][2^N], element (a, b) at a * 2^N + b.
+ */
+#ifndef RYDEMU_H
+#define RYDEMU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RYD_ABI_VERSION 1
+#define RYD_MAX_QUBITS 30
+
+typedef enum ryd_status {
+  RYD_OK = 0,
+  RYD_ERR_INVALID = -1,     /* bad argument */
+  RYD_ERR_HIP = -2,         /* HIP runtime error */
+  RYD_ERR_UNSUPPORTED = -3, /* valid in the reference, not built yet */
+  RYD_ERR_STATE = -4        /* call order (tables not set) */
+} ryd_status;
+
+typedef enum ryd_mode {
+  RYD_SESOLVE = 0, /* i d/dt psi = H(t) psi          (qutip.sesolve) */
+  RYD_MESOLVE = 1  /* d/dt rho = -i[H,rho] + D[rho]  (qutip.mesolve) */
+} ryd_mode;
+
+typedef struct ryd_handle ryd_handle;
+
+typedef struct ryd_config {
+  int32_t abi_version; /* RYD_ABI_VERSION */
+  int32_t n_qubits;    /* N, 1..RYD_MAX_QUBITS (mesolve: 2N <= RYD_MAX_QUBITS) */
+  int32_t batch;       /* B independent states evolved together (trajectories) */
+  int32_t mode;        /* ryd_mode */
+  int32_t device;      /* HIP device ordinal */
+  int32_t tile_bits;   /* 0 = default (12); LDS tile = 2^tile_bits amplitudes */
+  int32_t reserved[2];
+} ryd_config;
+
+/* Per (trajectory b, atom k) description of the time-dependent coefficients,
+ * the factored form of the noisy samples of
+ * HamiltonianData._sample_with_trajectory
+ * (pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py:408-534):
+ *   c_k(t)     = drive_scale * S[drive_series](t)          (complex, = Omega/2 e^{-i phi})
+ *   delta_k(t) = det_scale * Re S[det_series](t) + off_scale * Re S[off_series](t)
+ * series index -1 = absent (coefficient 0).  */
+typedef struct ryd_qdesc {
+  int32_t drive_series;
+  int32_t det_series;
+  int32_t off_series;
+  int32_t pad;
+  double drive_scale;
+  double det_scale;
+  double off_scale;
+} ryd_qdesc;
+
+typedef struct ryd_opts {
+  int32_t taylor_order; /* 0 = choose from norm bound and `tol` */
+  int32_t max_order;    /* cap for the automatic choice (default 24) */
+  double tol;           /* per-exponential truncation bound (default 1e-12) */
+  double max_step;      /* us; 0 = one step per knot interval */
+  double reserved[4];
+} ryd_opts;
+
+typedef struct ryd_stats {
+  int64_t n_applications; /* generator applications G.x since creation/reset */
+  int64_t n_launches;     /* kernel launches of the apply kernel */
+  int64_t n_steps;        /* CF4 steps */
+  int32_t passes;         /* memory passes per application */
+  int32_t last_order;     /* Taylor order used by the last step */
+  double norm_bound;      /* last spectral-norm bound (rad/us) */
+  double reserved[4];
+} ryd_stats;
+
+/* Replaces: construction of Hamiltonian/QobjEvo objects
+ * (hamiltonian.py:45-81).  */
+int ryd_create(const ryd_config* cfg, ryd_handle** out);
+void ryd_destroy(ryd_handle* h);
+
+/* Replaces: qutip.QobjEvo array coefficients with tlist
+ * (hamiltonian.py:436; cubic not-a-knot spline).  `tknots` float64[n_knots]
+ * (us, strictly increasing); `pp` float64[n_series][n_knots-1][4][2]: complex
+ * polynomial coefficients, highest power first, in the local variable
+ * (t - tknots[i]) (scipy PPoly convention).  Host pointers; copied. */
+int ryd_set_series(ryd_handle* h, int32_t n_series, int32_t n_knots,
+                   const double* tknots, const double* pp);
+
+/* Replaces: the per-qubit / global [operator, coefficient] term list of
+ * build_coeffs_ops (hamiltonian.py:333-389).  desc[batch][N], host pointer. */
+int ryd_set_qubit_desc(ryd_handle* h, const ryd_qdesc* desc);
+
+/* Replaces: make_vdw_term / make_interaction_term (hamiltonian.py:260-274,
+ * 296-331).  U float64[n_mats][N][N] symmetric (rows/cols of bad atoms zeroed
+ * by the caller); n_mats is 1 (shared by the batch) or `batch`.  Builds the
+ * static diagonal E0[s] = sum_{i<j} U_ij n_i(s) n_j(s) on the device. */
+int ryd_set_interaction(ryd_handle* h, const double* U, int32_t n_mats);
+
+/* Replaces: Hamiltonian._build_collapse_operators (hamiltonian.py:97-124) and
+ * the c_ops argument of qutip.mesolve (simulation.py:723-727).  The same local
+ * 2x2 collapse operators act on every atom, so the dissipator is given as the
+ * 4x4 local superoperator on the digit pair (a_k, b_k), row-major
+ * S[(2a+b)][(2a'+b')], complex128 interleaved: float64[4][4][2] (host).  Only
+ * the diagonal and the double-flip entries ((a,b)<-(1-a,1-b)) may be non-zero
+ * in this ABI version (dephasing, relaxation, depolarizing, diagonal/flip
+ * eff_noise); anything else returns RYD_ERR_UNSUPPORTED. */
+int ryd_set_dissipator(ryd_handle* h, const double* S);
+
+/* Replaces: one solver call qutip.sesolve/mesolve(H, state, [t0, t1])
+ * (simulation.py:729-735): advances `state_dev` in place from t0 to t1 (us)
+ * with the commutator-free 4th-order Magnus / Taylor stepper. */
+int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
+               const ryd_opts* opts, void* stream);
+
+/* Replaces: QobjEvo.__call__(t) applied to a state (used by
+ * qutip_backend.py:259-264 and QutipOperator.apply_to, qutip_op.py:85-100).
+ * out = G(t) in, G = -iH (sesolve layout) or the Lindbladian (mesolve). */
+int ryd_apply_generator(ryd_handle* h, const void* in_dev, void* out_dev,
+                        double t, void* stream);
+
+/* Replaces: QutipResult._weights before normalisation
+ * (pulser_simulation/qutip_result.py:101-118): w[b][i] = |psi_i|^2 (or
+ * Re rho_ii), index-reversed when `reverse` != 0.  w_dev float64[batch][2^N]. */
+int ryd_probabilities(ryd_handle* h, const void* state_dev, double* w_dev,
+                      int32_t reverse, void* stream);
+
+/* Replaces: expectation of the number operators n_k = |r><r|_k
+ * (default_observables.py Occupation; qutip.expect, simresults.py:132).
+ * out_dev float64[batch][N + 1]: <n_k> for k < N, then the squared norm /
+ * trace in slot N. */
+int ryd_occupations(ryd_handle* h, const void* state_dev, double* out_dev,
+                    void* stream);
+
+/* Replaces: building rho0 = |psi><psi| inside qutip.mesolve for a ket input.
+ * psi_dev complex128[batch][2^N] -> rho_dev complex128[batch][2^N][2^N]. */
+int ryd_ket_to_dm(ryd_handle* h, const void* psi_dev, void* rho_dev,
+                  void* stream);
+
+/* Replaces: density_matrix_aggregator's sum of |psi><psi| over trajectories
+ * (pulser_simulation/aggregators.py:20-37): acc += sum_b w_b |psi_b><psi_b|.
+ * acc_dev complex128[2^N][2^N]; weights host float64[batch] or NULL (=1). */
+int ryd_outer_accumulate(ryd_handle* h, const void* psi_dev,
+                         const double* weights, void* acc_dev, void* stream);
+
+int ryd_get_stats(const ryd_handle* h, ryd_stats* out);
+int ryd_reset_stats(ryd_handle* h);
+
+/* Live timing of the dominant kernel with HIP events on the launch stream
+ * (bench.py roofline leg): enable, run, then read accumulated milliseconds and
+ * launch count of the apply kernel.  Enabling inserts two events per launch. */
+int ryd_set_kernel_timing(ryd_handle* h, int32_t enable);
+int ryd_get_kernel_timing(ryd_handle* h, double* total_ms, int64_t* launches);
+
+const char* ryd_last_error(void);
+int ryd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RYDEMU_H */

@@ -1,0 +1,251 @@
+"""Python face of the C ABI: device tables in, torch tensors as state storage.
+
+PyTorch is plumbing only (device memory, streams).  All arithmetic of the hot
+path happens in the hand-written HIP kernels of ``csrc/rydemu.hip`` through
+``librydemu.so``; this module never computes a fallback on the host.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Mapping, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import RYD_MESOLVE, RYD_SESOLVE, RydConfig, RydOpts, RydQDesc, RydStats
+from .terms import DeviceTables, lower
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "pulser_amd needs an AMD GPU visible to PyTorch-ROCm "
+            "(torch.cuda.is_available() is False); there is no CPU fallback."
+        )
+    return torch
+
+
+class Engine:
+    """One ``ryd_handle``: a batch of B states of N atoms on one device.
+
+    Mirrors the role of the ``QobjEvo`` + solver pair the reference builds at
+    pulser-simulation/pulser_simulation/simulation.py:729-735.
+    """
+
+    def __init__(
+        self,
+        tables: DeviceTables,
+        mode: str = "sesolve",
+        device: int | None = None,
+        tile_bits: int = 0,
+    ) -> None:
+        self.torch = _torch()
+        self.lib = _lib.load()
+        self.tables = tables
+        self.n = tables.n_qubits
+        self.batch = tables.batch
+        self.mode = RYD_MESOLVE if mode == "mesolve" else RYD_SESOLVE
+        self.device_index = (
+            self.torch.cuda.current_device() if device is None else int(device)
+        )
+        self.device = self.torch.device("cuda", self.device_index)
+        cfg = RydConfig(
+            abi_version=_lib.RYD_ABI_VERSION,
+            n_qubits=self.n,
+            batch=self.batch,
+            mode=self.mode,
+            device=self.device_index,
+            tile_bits=tile_bits,
+        )
+        self._h = C.c_void_p()
+        _lib.check(self.lib.ryd_create(C.byref(cfg), C.byref(self._h)))
+        self._upload()
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ryd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self) -> "Engine":
+        return self
+
+    def __exit__(self, *exc: Any) -> None:
+        self.close()
+
+    # -- tables -----------------------------------------------------------
+    def _upload(self) -> None:
+        t = self.tables
+        tk = np.ascontiguousarray(t.tknots, dtype=np.float64)
+        pp = np.ascontiguousarray(t.pp, dtype=np.complex128)
+        _lib.check(
+            self.lib.ryd_set_series(
+                self._h, pp.shape[0], len(tk), tk.ctypes.data, pp.ctypes.data
+            )
+        )
+        desc = np.ascontiguousarray(t.desc)
+        assert desc.dtype.itemsize == C.sizeof(RydQDesc)
+        _lib.check(self.lib.ryd_set_qubit_desc(self._h, desc.ctypes.data))
+        u = np.ascontiguousarray(t.interaction, dtype=np.float64)
+        _lib.check(self.lib.ryd_set_interaction(self._h, u.ctypes.data, u.shape[0]))
+        if self.mode == RYD_MESOLVE and t.dissipator is not None:
+            s = np.ascontiguousarray(t.dissipator, dtype=np.complex128)
+            _lib.check(self.lib.ryd_set_dissipator(self._h, s.ctypes.data))
+
+    @classmethod
+    def from_problems(
+        cls, problems: Sequence[Mapping[str, Any]], mode: str | None = None, **kw: Any
+    ) -> "Engine":
+        tables = lower(problems)
+        if mode is None:
+            mode = "mesolve" if tables.dissipator is not None else "sesolve"
+        return cls(tables, mode=mode, **kw)
+
+    # -- state helpers ----------------------------------------------------
+    @property
+    def dim(self) -> int:
+        return 1 << self.n
+
+    @property
+    def state_shape(self) -> tuple[int, ...]:
+        if self.mode == RYD_MESOLVE:
+            return (self.batch, self.dim, self.dim)
+        return (self.batch, self.dim)
+
+    def _stream(self) -> int:
+        return int(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_state(self, x: Any, shape: tuple[int, ...] | None = None) -> None:
+        torch = self.torch
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.is_contiguous()):
+            raise TypeError("state must be a contiguous CUDA/HIP torch tensor")
+        if x.dtype != torch.complex128:
+            raise TypeError("state must be complex128")
+        if tuple(x.shape) != (shape or self.state_shape):
+            raise ValueError(
+                f"Incompatible shape of state. Expected {shape or self.state_shape}, "
+                f"got {tuple(x.shape)}."
+            )
+
+    def new_state(self, kets: np.ndarray | None = None) -> Any:
+        """Device state from host ket(s) ``complex[B?, 2^N]``; default = all
+        atoms in the last basis state (``g``), simulation.py:498-505."""
+        torch = self.torch
+        if kets is None:
+            host = np.zeros((self.batch, self.dim), dtype=np.complex128)
+            host[:, -1] = 1.0
+        else:
+            host = np.asarray(kets, dtype=np.complex128).reshape(-1, self.dim)
+            if host.shape[0] == 1 and self.batch > 1:
+                host = np.repeat(host, self.batch, axis=0)
+        psi = torch.from_numpy(np.ascontiguousarray(host)).to(self.device)
+        if self.mode != RYD_MESOLVE:
+            return psi
+        rho = torch.empty(self.state_shape, dtype=torch.complex128, device=self.device)
+        _lib.check(
+            self.lib.ryd_ket_to_dm(self._h, psi.data_ptr(), rho.data_ptr(), self._stream())
+        )
+        return rho
+
+    # -- hot path ---------------------------------------------------------
+    def evolve(
+        self,
+        state: Any,
+        t0: float,
+        t1: float,
+        taylor_order: int = 0,
+        tol: float = 0.0,
+        max_step: float = 0.0,
+        max_order: int = 0,
+    ) -> None:
+        """In place: ``state <- U(t1, t0) state`` (times in us)."""
+        self._check_state(state)
+        opts = RydOpts(
+            taylor_order=int(taylor_order),
+            max_order=int(max_order),
+            tol=float(tol),
+            max_step=float(max_step),
+        )
+        _lib.check(
+            self.lib.ryd_evolve(
+                self._h, state.data_ptr(), float(t0), float(t1), C.byref(opts), self._stream()
+            )
+        )
+
+    def apply_generator(self, x: Any, t: float) -> Any:
+        """``G(t) x`` with ``G = -iH`` (sesolve) or the Lindbladian (mesolve)."""
+        self._check_state(x)
+        out = self.torch.empty_like(x)
+        _lib.check(
+            self.lib.ryd_apply_generator(
+                self._h, x.data_ptr(), out.data_ptr(), float(t), self._stream()
+            )
+        )
+        return out
+
+    def probabilities(self, state: Any, reverse: bool = False) -> Any:
+        self._check_state(state)
+        w = self.torch.empty((self.batch, self.dim), dtype=self.torch.float64, device=self.device)
+        _lib.check(
+            self.lib.ryd_probabilities(
+                self._h, state.data_ptr(), w.data_ptr(), int(bool(reverse)), self._stream()
+            )
+        )
+        return w
+
+    def occupations(self, state: Any) -> Any:
+        """float64[B, N+1]: <n_k> and, last, the squared norm / trace."""
+        self._check_state(state)
+        out = self.torch.empty((self.batch, self.n + 1), dtype=self.torch.float64, device=self.device)
+        _lib.check(
+            self.lib.ryd_occupations(self._h, state.data_ptr(), out.data_ptr(), self._stream())
+        )
+        return out
+
+    def outer_accumulate(self, psi: Any, acc: Any, weights: np.ndarray | None = None) -> None:
+        self._check_state(psi, (self.batch, self.dim))
+        self._check_state(acc, (self.dim, self.dim))
+        wptr = None
+        if weights is not None:
+            weights = np.ascontiguousarray(weights, dtype=np.float64)
+            assert weights.shape == (self.batch,)
+            wptr = weights.ctypes.data
+        _lib.check(
+            self.lib.ryd_outer_accumulate(
+                self._h, psi.data_ptr(), wptr, acc.data_ptr(), self._stream()
+            )
+        )
+
+    # -- introspection ----------------------------------------------------
+    def stats(self) -> dict[str, Any]:
+        s = RydStats()
+        _lib.check(self.lib.ryd_get_stats(self._h, C.byref(s)))
+        return {
+            "n_applications": int(s.n_applications),
+            "n_launches": int(s.n_launches),
+            "n_steps": int(s.n_steps),
+            "passes": int(s.passes),
+            "last_order": int(s.last_order),
+            "norm_bound": float(s.norm_bound),
+        }
+
+    def reset_stats(self) -> None:
+        _lib.check(self.lib.ryd_reset_stats(self._h))
+
+    def set_kernel_timing(self, enable: bool) -> None:
+        _lib.check(self.lib.ryd_set_kernel_timing(self._h, int(bool(enable))))
+
+    def kernel_timing(self) -> tuple[float, int]:
+        ms = C.c_double()
+        n = C.c_int64()
+        _lib.check(self.lib.ryd_get_kernel_timing(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
