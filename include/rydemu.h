@@ -88,8 +88,10 @@ typedef struct ryd_opts {
   int32_t taylor_order; /* 0 = choose from norm bound and `tol` */
   int32_t max_order;    /* cap for the automatic choice (default 24) */
   double tol;           /* per-exponential truncation bound (default 1e-12) */
-  double max_step;      /* us; 0 = one step per knot interval */
-  double reserved[4];
+  double max_step;      /* us; 0 = no cap (steps never straddle a spline knot) */
+  double magnus_tol;    /* per-interval Magnus error target driving the automatic
+                           sub-stepping next to waveform kinks (default 1e-10) */
+  double reserved[3];
 } ryd_opts;
 
 typedef struct ryd_stats {
@@ -140,6 +142,21 @@ int ryd_set_dissipator(ryd_handle* h, const double* S);
  * with the commutator-free 4th-order Magnus / Taylor stepper. */
 int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
                const ryd_opts* opts, void* stream);
+
+/* Replaces: the whole solver call qutip.sesolve/mesolve(H, state, tlist)
+ * (simulation.py:729-735, result.states at every evaluation time).  Advances
+ * `state_dev` in place through times[0..n_times-1] (us, non-decreasing) and, if
+ * `out_dev` is not NULL, stores the state reached at times[i] (i >= 1) in slot
+ * i-1 of out_dev, complex128[n_times-1][batch][dim].  For sesolve with N <= 12
+ * the whole call is ONE launch of the persistent LDS-resident trajectory kernel
+ * (one workgroup per batch entry); otherwise the tiled multi-pass kernels run
+ * once per Taylor stage. */
+int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
+              void* out_dev, const ryd_opts* opts, void* stream);
+
+/* Test/bench hook: force_generic != 0 disables the persistent kernel so that
+ * the tiled path can be exercised and timed at small N. */
+int ryd_set_path(ryd_handle* h, int32_t force_generic);
 
 /* Replaces: QobjEvo.__call__(t) applied to a state (used by
  * qutip_backend.py:259-264 and QutipOperator.apply_to, qutip_op.py:85-100).

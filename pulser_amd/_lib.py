@@ -55,7 +55,8 @@ class RydOpts(C.Structure):
         ("max_order", C.c_int32),
         ("tol", C.c_double),
         ("max_step", C.c_double),
-        ("reserved", C.c_double * 4),
+        ("magnus_tol", C.c_double),
+        ("reserved", C.c_double * 3),
     ]
 
 
@@ -80,6 +81,8 @@ SYMBOLS = {
     "ryd_set_interaction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "ryd_set_dissipator": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ryd_evolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.POINTER(RydOpts), C.c_void_p]),
+    "ryd_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RydOpts), C.c_void_p]),
+    "ryd_set_path": (C.c_int, [C.c_void_p, C.c_int32]),
     "ryd_apply_generator": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "ryd_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ryd_occupations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

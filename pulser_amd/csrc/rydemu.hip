@@ -410,6 +410,228 @@ __global__ void k_outer_acc(const cplx* __restrict__ psi, int N, int B,
 }
 
 // ---------------------------------------------------------------------------
+// Persistent trajectory kernel (sesolve, N <= 12)
+// ---------------------------------------------------------------------------
+// One workgroup evolves one state vector through a whole schedule of CF4 steps
+// in a single launch: psi lives in registers (thread t owns amplitudes
+// t + j*NT), the Horner iterate lives in LDS for the flip-partner reads, and
+// HBM is touched only for the initial load, the snapshots and the final store.
+// Flip partners of the high index bits (>= log2 NT) are register-to-register.
+struct StepDesc {
+  double h, u1, u2;
+  double shift_a, shift_b;
+  int idx;
+  int order_a, order_b;
+  int snap;  // snapshot slot written after this step, or -1
+  int pad;
+};
+
+struct TrajArgs {
+  cplx* state;         // [B][2^N] in/out
+  cplx* snaps;         // [n_slots][B][2^N] or null
+  const cplx* pp;      // [n_series][n_int][4]
+  const ryd_qdesc* desc;
+  const double* e0;
+  long long e0_stride;
+  const StepDesc* steps;
+  int n_int, n_steps, B;
+  double a1, a2;
+};
+
+// wave-uniform double -> scalar registers
+__device__ __forceinline__ double uniform_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// MODEL 0: per-atom complex drive coefficients (local addressing, noise).
+// MODEL 1: one real drive coefficient shared by the driven atoms of the
+//          trajectory (global channel with constant zero phase; bad atoms are
+//          masked out) - the flip partners are summed first, 2 DADD each.
+template <int N, int NTT, int MODEL>
+__global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
+  constexpr int D = 1 << N;
+  constexpr int R = D / NTT > 0 ? D / NTT : 1;
+  constexpr int LOGNT = NTT == 1024 ? 10 : (NTT == 512 ? 9 : (NTT == 256 ? 8 : (NTT == 128 ? 7 : 6)));
+  constexpr int NLDS = N < LOGNT ? N : LOGNT;  // bits whose partner is read from LDS
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx* ws0 = reinterpret_cast<cplx*>(smem);      // two buffers: the Horner iterate
+  cplx* ws1 = ws0 + D;                            // ping-pongs, one barrier per stage
+  double* cfA = reinterpret_cast<double*>(ws1 + D);  // [16][4]: cr, ci, delta, 0 for exp A
+  double* cfB = cfA + 64;                            // same for exp B
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const bool active = tid < D;
+  cplx* st = A.state + (size_t)b * D;
+  const double* e0g = A.e0 + (size_t)b * A.e0_stride;
+
+  cplx psi[R];
+  double e0r[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int l = tid + j * NTT;
+    psi[j] = active ? st[l] : make_double2(0.0, 0.0);
+    e0r[j] = active ? e0g[l] : 0.0;
+  }
+
+  for (int s = 0; s < A.n_steps; ++s) {
+    const StepDesc sd = A.steps[s];
+    if (tid < N) {
+      const ryd_qdesc d = A.desc[(size_t)b * N + tid];
+      auto val = [&](int ser, double u) -> cplx {
+        const cplx* p = A.pp + ((size_t)ser * A.n_int + sd.idx) * 4;
+        cplx r = p[0];
+        r = make_double2(fma(r.x, u, p[1].x), fma(r.y, u, p[1].y));
+        r = make_double2(fma(r.x, u, p[2].x), fma(r.y, u, p[2].y));
+        r = make_double2(fma(r.x, u, p[3].x), fma(r.y, u, p[3].y));
+        return r;
+      };
+      // same arithmetic as k_eval_coefs (w1 * val(t1) + w2 * val(t2))
+      double c1r = 0, c1i = 0, c2r = 0, c2i = 0, dlA = 0, dlB = 0;
+      if (d.drive_series >= 0) {
+        const cplx v1 = val(d.drive_series, sd.u1), v2 = val(d.drive_series, sd.u2);
+        c1r = v1.x; c1i = v1.y; c2r = v2.x; c2i = v2.y;
+      }
+      if (d.det_series >= 0) {
+        const double d1 = val(d.det_series, sd.u1).x, d2 = val(d.det_series, sd.u2).x;
+        dlA += d.det_scale * (A.a1 * d1 + A.a2 * d2);
+        dlB += d.det_scale * (A.a2 * d1 + A.a1 * d2);
+      }
+      if (d.off_series >= 0) {
+        const double o1 = val(d.off_series, sd.u1).x, o2 = val(d.off_series, sd.u2).x;
+        dlA += d.off_scale * (A.a1 * o1 + A.a2 * o2);
+        dlB += d.off_scale * (A.a2 * o1 + A.a1 * o2);
+      }
+      cfA[4 * tid + 0] = d.drive_scale * (A.a1 * c1r + A.a2 * c2r);
+      cfA[4 * tid + 1] = d.drive_scale * (A.a1 * c1i + A.a2 * c2i);
+      cfA[4 * tid + 2] = dlA;
+      cfA[4 * tid + 3] = d.drive_series >= 0 ? 1.0 : 0.0;
+      cfB[4 * tid + 0] = d.drive_scale * (A.a2 * c1r + A.a1 * c2r);
+      cfB[4 * tid + 1] = d.drive_scale * (A.a2 * c1i + A.a1 * c2i);
+      cfB[4 * tid + 2] = dlB;
+      cfB[4 * tid + 3] = d.drive_series >= 0 ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int ex = 0; ex < 2; ++ex) {
+      const double* cf = ex ? cfB : cfA;
+      const int order = ex ? sd.order_b : sd.order_a;
+      const double shift = ex ? sd.shift_b : sd.shift_a;
+      const double wmix = A.a1 + A.a2;
+      // all per-atom values of this exponential in one batch of LDS reads
+      // (bit q <-> atom N-1-q), then wave-uniform ones -> scalar registers
+      double craw[N], ciraw[N], draw[N], mraw[N];
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const double2 a = *reinterpret_cast<const double2*>(cf + 4 * (N - 1 - q));
+        const double2 c = *reinterpret_cast<const double2*>(cf + 4 * (N - 1 - q) + 2);
+        craw[q] = a.x; ciraw[q] = a.y; draw[q] = c.x; mraw[q] = c.y;
+      }
+      double cr[MODEL == 0 ? N : 1], ci[MODEL == 0 ? N : 1];
+      double mq[MODEL == 1 ? N : 1];  // 1.0 for driven atoms, 0.0 otherwise
+      double cuni = 0.0;
+      if (MODEL == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          cr[q] = uniform_d(craw[q]);
+          ci[q] = uniform_d(ciraw[q]);
+        }
+      } else {
+        double cv = 0.0;
+#pragma unroll
+        for (int q = 0; q < N; ++q) cv = mraw[q] != 0.0 ? craw[q] : cv;
+        cuni = uniform_d(cv);
+#pragma unroll
+        for (int q = 0; q < N; ++q) mq[q] = uniform_d(mraw[q]);
+      }
+      double eg[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int l = tid + j * NTT;
+        double sdet = 0.0;
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+          if (!((l >> q) & 1)) sdet -= draw[q];
+        eg[j] = sdet + (wmix * e0r[j] - shift);
+      }
+      cplx w[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        w[j] = psi[j];
+        if (active) ws0[tid + j * NTT] = w[j];
+      }
+      __syncthreads();
+      const cplx* rd = ws0;
+      cplx* wr = ws1;
+      for (int jj = order; jj >= 1; --jj) {
+        const double sc = sd.h / jj;
+        cplx acc[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int l = tid + j * NTT;
+          // issue every LDS partner read of this element before using any
+          cplx xv[NLDS > 0 ? NLDS : 1];
+#pragma unroll
+          for (int q = 0; q < NLDS; ++q) xv[q] = rd[(l ^ (1 << q)) & (D - 1)];
+          if (MODEL == 0) {
+            cplx a = make_double2(eg[j] * w[j].y, -eg[j] * w[j].x);  // -i e x
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+              const int rb = q >= LOGNT ? q - LOGNT : 0;
+              const cplx x = q < NLDS ? xv[q < NLDS ? q : 0] : w[(j ^ (1 << rb)) & (R - 1)];
+              // coefficient -i c (output bit 1) or -i conj(c) (output bit 0)
+              const double sgi = ((l >> q) & 1) ? ci[q] : -ci[q];
+              a = cfma(make_double2(sgi, -cr[q]), x, a);
+            }
+            acc[j] = a;
+          } else {
+            double s0x = 0.0, s0y = 0.0, s1x = 0.0, s1y = 0.0;  // two chains
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+              const int rb = q >= LOGNT ? q - LOGNT : 0;
+              const cplx x = q < NLDS ? xv[q < NLDS ? q : 0] : w[(j ^ (1 << rb)) & (R - 1)];
+              if (q & 1) { s1x = fma(mq[q], x.x, s1x); s1y = fma(mq[q], x.y, s1y); }
+              else { s0x = fma(mq[q], x.x, s0x); s0y = fma(mq[q], x.y, s0y); }
+            }
+            const double sx = s0x + s1x, sy = s0y + s1y;
+            // -i (e w + c sum)
+            acc[j] = make_double2(fma(cuni, sy, eg[j] * w[j].y), -fma(cuni, sx, eg[j] * w[j].x));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+          w[j] = make_double2(fma(sc, acc[j].x, psi[j].x), fma(sc, acc[j].y, psi[j].y));
+        if (jj > 1) {
+#pragma unroll
+          for (int j = 0; j < R; ++j)
+            if (active) wr[tid + j * NTT] = w[j];
+          __syncthreads();  // one barrier per stage: reads of `rd` done, `wr` visible
+          const cplx* t = rd;
+          rd = wr;
+          wr = const_cast<cplx*>(t);
+        }
+      }
+      const cplx post = make_double2(cos(sd.h * shift), -sin(sd.h * shift));
+#pragma unroll
+      for (int j = 0; j < R; ++j) psi[j] = cmul(post, w[j]);
+      __syncthreads();  // last-stage reads done before ws0 / cf are rewritten
+    }
+    if (sd.snap >= 0 && A.snaps && active) {
+      cplx* o = A.snaps + ((size_t)sd.snap * A.B + b) * D;
+#pragma unroll
+      for (int j = 0; j < R; ++j) o[tid + j * NTT] = psi[j];
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) st[tid + j * NTT] = psi[j];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 struct Pass {
@@ -430,10 +652,12 @@ struct ryd_handle {
   std::vector<double> tknots;
   std::vector<std::complex<double>> pp_host;  // [series][int][4]
   std::vector<double> s_abs, s_pos, s_neg;    // per series, per interval bounds
+  std::vector<double> s_curv;                 // |quadratic| dt^2 + |cubic| dt^3 per interval
   cplx* pp_dev = nullptr;
   std::vector<ryd_qdesc> desc_host;
   ryd_qdesc* desc_dev = nullptr;
   std::vector<double> bd_drive, bd_pos, bd_neg;  // per interval, max over batch
+  std::vector<double> bd_curv;                   // per interval: non-linearity of H(t)
   bool bounds_valid = false;
   double* e0_dev = nullptr;
   int e0_mats = 0;
@@ -446,6 +670,10 @@ struct ryd_handle {
   cplx *wA = nullptr, *wB = nullptr, *kbuf = nullptr;
   std::vector<Pass> passes;
   bool passes_valid = false;
+  StepDesc* sched_dev = nullptr;
+  size_t sched_cap = 0;
+  bool force_generic = false;
+  bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
   ryd_stats stats{};
   // timing
   bool timing = false;
@@ -624,6 +852,7 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->e0_dev);
   hipFree(h->pp_dev);
   hipFree(h->desc_dev);
+  hipFree(h->sched_dev);
   for (auto& p : h->ev_used) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   delete h;
@@ -648,6 +877,7 @@ extern "C" int ryd_set_series(ryd_handle* h, int32_t n_series, int32_t n_knots,
   h->s_abs.assign((size_t)n_series * n_int, 0.0);
   h->s_pos.assign((size_t)n_series * n_int, 0.0);
   h->s_neg.assign((size_t)n_series * n_int, 0.0);
+  h->s_curv.assign((size_t)n_series * n_int, 0.0);
   for (int s = 0; s < n_series; ++s)
     for (int i = 0; i < n_int; ++i) {
       const std::complex<double>* p = &h->pp_host[((size_t)s * n_int + i) * 4];
@@ -657,6 +887,7 @@ extern "C" int ryd_set_series(ryd_handle* h, int32_t n_series, int32_t n_knots,
       h->s_abs[(size_t)s * n_int + i] = std::abs(p[3]) + dev;
       h->s_pos[(size_t)s * n_int + i] = std::max(p[3].real() + dev, 0.0);
       h->s_neg[(size_t)s * n_int + i] = std::max(-p[3].real() + dev, 0.0);
+      h->s_curv[(size_t)s * n_int + i] = std::abs(p[1]) * dt * dt + std::abs(p[0]) * dt * dt * dt;
     }
   if (h->pp_dev) hipFree(h->pp_dev);
   h->pp_dev = nullptr;
@@ -689,22 +920,28 @@ static void compute_bounds(ryd_handle* h) {
   h->bd_drive.assign(n_int, 0.0);
   h->bd_pos.assign(n_int, 0.0);
   h->bd_neg.assign(n_int, 0.0);
-  std::vector<double> dr(n_int), po(n_int), ne(n_int);
+  h->bd_curv.assign(n_int, 0.0);
+  std::vector<double> dr(n_int), po(n_int), ne(n_int), cu(n_int);
   for (int b = 0; b < h->B; ++b) {
     std::fill(dr.begin(), dr.end(), 0.0);
     std::fill(po.begin(), po.end(), 0.0);
     std::fill(ne.begin(), ne.end(), 0.0);
+    std::fill(cu.begin(), cu.end(), 0.0);
     for (int k = 0; k < h->N; ++k) {
       const ryd_qdesc& d = h->desc_host[(size_t)b * h->N + k];
       if (d.drive_series >= 0) {
         const double* a = &h->s_abs[(size_t)d.drive_series * n_int];
         const double sc = std::fabs(d.drive_scale);
         for (int i = 0; i < n_int; ++i) dr[i] += sc * a[i];
+        const double* cv = &h->s_curv[(size_t)d.drive_series * n_int];
+        for (int i = 0; i < n_int; ++i) cu[i] += sc * cv[i];
       }
       auto add_det = [&](int s, double sc) {
         if (s < 0 || sc == 0.0) return;
         const double* P = &h->s_pos[(size_t)s * n_int];
         const double* M = &h->s_neg[(size_t)s * n_int];
+        const double* cv = &h->s_curv[(size_t)s * n_int];
+        for (int i = 0; i < n_int; ++i) cu[i] += std::fabs(sc) * cv[i];
         for (int i = 0; i < n_int; ++i) {
           if (sc > 0) { po[i] += sc * P[i]; ne[i] += sc * M[i]; }
           else { po[i] += -sc * M[i]; ne[i] += -sc * P[i]; }
@@ -717,8 +954,29 @@ static void compute_bounds(ryd_handle* h) {
       h->bd_drive[i] = std::max(h->bd_drive[i], dr[i]);
       h->bd_pos[i] = std::max(h->bd_pos[i], po[i]);
       h->bd_neg[i] = std::max(h->bd_neg[i], ne[i]);
+      h->bd_curv[i] = std::max(h->bd_curv[i], cu[i]);
     }
   }
+  // MODEL 1 of the persistent kernel: inside every trajectory all driven atoms
+  // share (series, scale) and that series is real-valued
+  const int n_int2 = h->n_knots - 1;
+  std::vector<char> series_real(h->n_series, 1);
+  for (int sidx = 0; sidx < h->n_series; ++sidx)
+    for (size_t i = 0; i < (size_t)n_int2 * 4; ++i)
+      if (h->pp_host[(size_t)sidx * n_int2 * 4 + i].imag() != 0.0) { series_real[sidx] = 0; break; }
+  bool uni = true;
+  for (int b = 0; b < h->B && uni; ++b) {
+    int ser = -2;
+    double sc = 0.0;
+    for (int k = 0; k < h->N; ++k) {
+      const ryd_qdesc& d = h->desc_host[(size_t)b * h->N + k];
+      if (d.drive_series < 0) continue;
+      if (ser == -2) { ser = d.drive_series; sc = d.drive_scale; }
+      else if (ser != d.drive_series || sc != d.drive_scale) { uni = false; break; }
+      if (!series_real[d.drive_series]) { uni = false; break; }
+    }
+  }
+  h->uniform_real_drive = uni;
   h->bounds_valid = true;
 }
 
@@ -915,21 +1173,24 @@ extern "C" int ryd_apply_generator(ryd_handle* h, const void* in_dev, void* out_
                          make_double2(1.0, 0.0), st);
 }
 
-// One exponential  state <- exp(h * G~) state,  G~ = w1 G(t1) + w2 G(t2).
-static int exp_step(ryd_handle* h, cplx* state, double hstep, const MixPoint& m,
-                    const ryd_opts& o, hipStream_t st) {
-  int rc;
-  if ((rc = launch_eval(h, m, st))) return rc;
-  const double wmix = m.w1 + m.w2;
-  // spectral bounds of H~ (sesolve shifts the spectrum to its midpoint)
-  const int i1 = m.idx1, i2 = m.idx2;
-  const double drive = m.w1 * h->bd_drive[i1] + m.w2 * h->bd_drive[i2];
-  const double dpos = m.w1 * h->bd_pos[i1] + m.w2 * h->bd_pos[i2];
-  const double dneg = m.w1 * h->bd_neg[i1] + m.w2 * h->bd_neg[i2];
+// ---------------------------------------------------------------------------
+// stepping: schedule (host) -> generic multi-launch path or persistent kernel
+// ---------------------------------------------------------------------------
+static const double kS3 = 1.7320508075688772;
+static const double kC1 = 0.5 - kS3 / 6.0, kC2 = 0.5 + kS3 / 6.0;  // Gauss nodes
+static const double kA1 = 0.25 + kS3 / 6.0, kA2 = 0.25 - kS3 / 6.0;  // CF4 weights
+
+// Taylor order and spectral shift of one exponential exp(h (w1 G(t1) + w2 G(t2)))
+// with both Gauss points inside knot interval `idx`.
+static void plan_exp(ryd_handle* h, int idx, double hstep, double w1, double w2,
+                     const ryd_opts& o, int* order_out, double* shift_out) {
+  const double wmix = w1 + w2;
+  const double drive = wmix * h->bd_drive[idx];
+  const double dpos = wmix * h->bd_pos[idx], dneg = wmix * h->bd_neg[idx];
   const double lo = wmix * h->e0_min - dpos, hi = wmix * h->e0_max + dneg;
   double bound, shift = 0.0;
   if (h->cfg.mode == RYD_SESOLVE) {
-    shift = 0.5 * (lo + hi);
+    shift = 0.5 * (lo + hi);  // H' = H - shift: halves the spectral radius
     bound = 0.5 * (hi - lo) + drive;
   } else {
     bound = 2.0 * (0.5 * (hi - lo) + drive) + wmix * h->diss_norm;
@@ -950,6 +1211,63 @@ static int exp_step(ryd_handle* h, cplx* state, double hstep, const MixPoint& m,
   }
   if (order < 2) order = 2;
   h->stats.last_order = order;
+  *order_out = order;
+  *shift_out = shift;
+}
+
+// CF4 steps covering [t0, t1]: never straddling a spline knot (inside a knot
+// interval every coefficient is a single cubic), optionally capped by max_step.
+static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& o,
+                           std::vector<StepDesc>& out) {
+  const double eps = 1e-12;
+  double t = t0;
+  while (t < t1 - eps) {
+    const int idx = find_interval(h, t + eps);
+    double tend = t1;  // the last interval extends to t1 (extrapolation, as scipy does)
+    if (idx < h->n_knots - 2) tend = std::min(t1, h->tknots[idx + 1]);
+    if (tend <= t + eps) tend = t1;
+    const double len = tend - t;
+    int nsub = 1;
+    if (o.max_step > 0) nsub = std::max(1, (int)std::ceil(len / o.max_step - 1e-9));
+    {
+      // The local error of the 4th-order Magnus step is dominated by the
+      // non-linear (quadratic + cubic) part of the spline inside the interval -
+      // large only where it rings next to a kink of the waveform.  Calibrated
+      // against converged references: err ~ 1e-5 * h * curvature,
+      // and it falls as n^-4 with n equal sub-steps.
+      const double dtk = h->tknots[idx + 1] - h->tknots[idx];
+      const double frac = dtk > 0 ? std::min(1.0, len / dtk) : 1.0;
+      const double est = 1e-5 * len * h->bd_curv[idx] * frac * frac;
+      const double mtol = o.magnus_tol > 0 ? o.magnus_tol : 1e-10;
+      if (est > mtol) {
+        const int nm = (int)std::ceil(std::pow(est / mtol, 0.25));
+        nsub = std::max(nsub, std::min(nm, 256));
+      }
+    }
+    const double hs = len / nsub;
+    for (int s = 0; s < nsub; ++s) {
+      const double ta = t + s * hs;
+      StepDesc d;
+      std::memset(&d, 0, sizeof d);
+      d.h = hs;
+      d.idx = idx;
+      d.u1 = ta + kC1 * hs - h->tknots[idx];
+      d.u2 = ta + kC2 * hs - h->tknots[idx];
+      plan_exp(h, idx, hs, kA1, kA2, o, &d.order_a, &d.shift_a);
+      plan_exp(h, idx, hs, kA2, kA1, o, &d.order_b, &d.shift_b);
+      d.snap = -1;
+      out.push_back(d);
+    }
+    t = tend;
+  }
+}
+
+// One exponential  state <- exp(h * G~) state  on the generic multi-launch path.
+static int exp_step(ryd_handle* h, cplx* state, double hstep, const MixPoint& m, int order,
+                    double shift, hipStream_t st) {
+  int rc;
+  if ((rc = launch_eval(h, m, st))) return rc;
+  const double wmix = m.w1 + m.w2;
   // Horner: w_m = psi; w_{j-1} = psi + (h/j) G' w_j; result w_0, times e^{-i h shift}
   const cplx one = make_double2(1.0, 0.0);
   const cplx* in = state;
@@ -965,12 +1283,119 @@ static int exp_step(ryd_handle* h, cplx* state, double hstep, const MixPoint& m,
   return RYD_OK;
 }
 
-extern "C" int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
-                          const ryd_opts* opts, void* stream) {
+static int run_generic(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched,
+                       cplx* snaps, hipStream_t st) {
+  int rc;
+  const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  for (const StepDesc& d : sched) {
+    MixPoint m;
+    m.idx1 = m.idx2 = d.idx;
+    m.u1 = d.u1;
+    m.u2 = d.u2;
+    m.w1 = kA1; m.w2 = kA2;
+    if ((rc = exp_step(h, state, d.h, m, d.order_a, d.shift_a, st))) return rc;
+    m.w1 = kA2; m.w2 = kA1;
+    if ((rc = exp_step(h, state, d.h, m, d.order_b, d.shift_b, st))) return rc;
+    h->stats.n_steps++;
+    if (d.snap >= 0 && snaps)
+      HIPCHK(hipMemcpyAsync(snaps + (size_t)d.snap * h->dim * h->B, state, bytes,
+                            hipMemcpyDeviceToDevice, st));
+  }
+  return RYD_OK;
+}
+
+template <int N, int MODEL>
+static int launch_traj2(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
+  constexpr int D = 1 << N;
+  constexpr int NTT = D < 64 ? 64 : (N >= 11 ? 1024 : (D > 512 ? 512 : D));
+  const size_t lds = 2 * (size_t)D * sizeof(cplx) + 4 * 16 * sizeof(double) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_traj<N, NTT, MODEL>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_traj<N, NTT, MODEL>), dim3(h->B), dim3(NTT), lds, st, A);
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
+}
+
+template <int N>
+static int launch_traj(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
+  return h->uniform_real_drive ? launch_traj2<N, 1>(h, A, st) : launch_traj2<N, 0>(h, A, st);
+}
+
+// Persistent path (sesolve, N <= 12): one workgroup per trajectory keeps its
+// state vector in LDS/registers for the whole schedule; one launch.
+static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched,
+                          cplx* snaps, hipStream_t st) {
+  if (sched.empty()) return RYD_OK;
+  const size_t bytes = sched.size() * sizeof(StepDesc);
+  if (h->sched_cap < sched.size()) {
+    if (h->sched_dev) hipFree(h->sched_dev);
+    h->sched_dev = nullptr;
+    h->sched_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->sched_dev, bytes * 2));
+    h->sched_cap = sched.size() * 2;
+  }
+  // the schedule buffer may still be read by an earlier launch on `st`
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMemcpyAsync(h->sched_dev, sched.data(), bytes, hipMemcpyHostToDevice, st));
+  TrajArgs A;
+  A.state = state;
+  A.snaps = snaps;
+  A.pp = h->pp_dev;
+  A.n_int = h->n_knots - 1;
+  A.desc = h->desc_dev;
+  A.e0 = h->e0_dev;
+  A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << h->N);
+  A.steps = h->sched_dev;
+  A.n_steps = (int)sched.size();
+  A.B = h->B;
+  A.a1 = kA1;
+  A.a2 = kA2;
+  int rc = RYD_ERR_INVALID;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+  switch (h->N) {
+    case 1: rc = launch_traj<1>(h, A, st); break;
+    case 2: rc = launch_traj<2>(h, A, st); break;
+    case 3: rc = launch_traj<3>(h, A, st); break;
+    case 4: rc = launch_traj<4>(h, A, st); break;
+    case 5: rc = launch_traj<5>(h, A, st); break;
+    case 6: rc = launch_traj<6>(h, A, st); break;
+    case 7: rc = launch_traj<7>(h, A, st); break;
+    case 8: rc = launch_traj<8>(h, A, st); break;
+    case 9: rc = launch_traj<9>(h, A, st); break;
+    case 10: rc = launch_traj<10>(h, A, st); break;
+    case 11: rc = launch_traj<11>(h, A, st); break;
+    case 12: rc = launch_traj<12>(h, A, st); break;
+    default: return fail(RYD_ERR_INVALID, "persistent path needs N <= 12");
+  }
+  if (rc) return rc;
+  if (h->timing) {
+    HIPCHK(hipEventRecord(ev.second, st));
+    h->ev_used.push_back(ev);
+  }
+  for (const StepDesc& d : sched) {
+    h->stats.n_applications += d.order_a + d.order_b;
+    h->stats.n_steps++;
+  }
+  h->stats.n_launches++;
+  return RYD_OK;
+}
+
+static bool use_persistent(const ryd_handle* h) {
+  return h->cfg.mode == RYD_SESOLVE && h->N <= 12 && !h->force_generic;
+}
+
+extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
+                         void* out_dev, const ryd_opts* opts, void* stream) {
   int rc = check_ready(h);
   if (rc) return rc;
-  if (!state_dev) return fail(RYD_ERR_INVALID, "null state");
-  if (!(t1 >= t0)) return fail(RYD_ERR_INVALID, "t1 < t0");
+  if (!state_dev || !times || n_times < 2) return fail(RYD_ERR_INVALID, "need a state and >= 2 times");
+  for (int i = 1; i < n_times; ++i)
+    if (!(times[i] >= times[i - 1])) return fail(RYD_ERR_INVALID, "times must be non-decreasing");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (!h->bounds_valid) compute_bounds(h);
   ryd_opts o;
@@ -978,36 +1403,46 @@ extern "C" int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
   if (opts) o = *opts;
   hipStream_t st = (hipStream_t)stream;
   cplx* state = (cplx*)state_dev;
-  const double s3 = std::sqrt(3.0);
-  const double c1 = 0.5 - s3 / 6.0, c2 = 0.5 + s3 / 6.0;
-  const double a1 = 0.25 + s3 / 6.0, a2 = 0.25 - s3 / 6.0;
-  const double eps = 1e-12;
-  double t = t0;
-  while (t < t1 - eps) {
-    // step to the next knot (the spline is a single cubic inside) or to t1;
-    // the last interval extends to t1 (polynomial extrapolation, as scipy does)
-    const int idx = find_interval(h, t + eps);
-    double tend = t1;
-    if (idx < h->n_knots - 2) tend = std::min(t1, h->tknots[idx + 1]);
-    if (tend <= t + eps) tend = t1;
-    double len = tend - t;
-    int nsub = 1;
-    if (o.max_step > 0) nsub = std::max(1, (int)std::ceil(len / o.max_step - 1e-9));
-    const double hs = len / nsub;
-    for (int s = 0; s < nsub; ++s) {
-      const double ta = t + s * hs;
-      MixPoint m;
-      m.idx1 = m.idx2 = idx;
-      m.u1 = ta + c1 * hs - h->tknots[idx];
-      m.u2 = ta + c2 * hs - h->tknots[idx];
-      m.w1 = a1; m.w2 = a2;
-      if ((rc = exp_step(h, state, hs, m, o, st))) return rc;
-      m.w1 = a2; m.w2 = a1;
-      if ((rc = exp_step(h, state, hs, m, o, st))) return rc;
-      h->stats.n_steps++;
+  cplx* snaps = (cplx*)out_dev;
+  const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  std::vector<StepDesc> sched;
+  // snapshot slot i-1 receives the state at times[i]
+  for (int i = 1; i < n_times; ++i) {
+    const size_t before = sched.size();
+    build_schedule(h, times[i - 1], times[i], o, sched);
+    if (snaps) {
+      if (sched.size() > before) {
+        sched.back().snap = i - 1;
+      } else {  // zero-length interval: the state is unchanged
+        if (before == 0) {
+          HIPCHK(hipMemcpyAsync(snaps + (size_t)(i - 1) * h->dim * h->B, state, bytes,
+                                hipMemcpyDeviceToDevice, st));
+        } else {
+          // duplicate time after at least one step: flush what we have, copy, continue
+          if ((rc = use_persistent(h) ? run_persistent(h, state, sched, snaps, st)
+                                      : run_generic(h, state, sched, snaps, st)))
+            return rc;
+          sched.clear();
+          HIPCHK(hipMemcpyAsync(snaps + (size_t)(i - 1) * h->dim * h->B, state, bytes,
+                                hipMemcpyDeviceToDevice, st));
+        }
+      }
     }
-    t = tend;
   }
+  return use_persistent(h) ? run_persistent(h, state, sched, snaps, st)
+                           : run_generic(h, state, sched, snaps, st);
+}
+
+extern "C" int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
+                          const ryd_opts* opts, void* stream) {
+  if (!(t1 >= t0)) return fail(RYD_ERR_INVALID, "t1 < t0");
+  const double times[2] = {t0, t1};
+  return ryd_solve(h, state_dev, 2, times, nullptr, opts, stream);
+}
+
+extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
+  if (!h) return fail(RYD_ERR_INVALID, "null handle");
+  h->force_generic = force_generic != 0;
   return RYD_OK;
 }
 

@@ -166,6 +166,7 @@ class Engine:
         tol: float = 0.0,
         max_step: float = 0.0,
         max_order: int = 0,
+        magnus_tol: float = 0.0,
     ) -> None:
         """In place: ``state <- U(t1, t0) state`` (times in us)."""
         self._check_state(state)
@@ -174,12 +175,63 @@ class Engine:
             max_order=int(max_order),
             tol=float(tol),
             max_step=float(max_step),
+            magnus_tol=float(magnus_tol),
         )
         _lib.check(
             self.lib.ryd_evolve(
                 self._h, state.data_ptr(), float(t0), float(t1), C.byref(opts), self._stream()
             )
         )
+
+    def solve(
+        self,
+        state: Any,
+        times: Sequence[float],
+        store: bool = True,
+        taylor_order: int = 0,
+        tol: float = 0.0,
+        max_step: float = 0.0,
+        max_order: int = 0,
+        magnus_tol: float = 0.0,
+    ) -> Any:
+        """Advance ``state`` in place through ``times`` (us); with ``store``
+        return complex128[len(times)-1, B, dim...] = the states at times[1:]
+        (``result.states[1:]`` of the reference's solver call,
+        simulation.py:729-748)."""
+        self._check_state(state)
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        if t.ndim != 1 or len(t) < 2:
+            raise ValueError("times must hold at least two values")
+        out = None
+        if store:
+            out = self.torch.empty(
+                (len(t) - 1,) + self.state_shape,
+                dtype=self.torch.complex128,
+                device=self.device,
+            )
+        opts = RydOpts(
+            taylor_order=int(taylor_order),
+            max_order=int(max_order),
+            tol=float(tol),
+            max_step=float(max_step),
+            magnus_tol=float(magnus_tol),
+        )
+        _lib.check(
+            self.lib.ryd_solve(
+                self._h,
+                state.data_ptr(),
+                len(t),
+                t.ctypes.data,
+                out.data_ptr() if out is not None else None,
+                C.byref(opts),
+                self._stream(),
+            )
+        )
+        return out
+
+    def set_path(self, force_generic: bool) -> None:
+        """Disable (True) / enable (False) the persistent small-N kernel."""
+        _lib.check(self.lib.ryd_set_path(self._h, int(bool(force_generic))))
 
     def apply_generator(self, x: Any, t: float) -> Any:
         """``G(t) x`` with ``G = -iH`` (sesolve) or the Lindbladian (mesolve)."""

@@ -188,3 +188,41 @@ def test_ket_to_dm_and_outer_accumulate():
     eng.outer_accumulate(_to_dev(eng, xs), acc, w)
     ref = sum(w[b] * np.outer(xs[b], xs[b].conj()) for b in range(3))
     assert np.max(np.abs(acc.cpu().numpy() - ref)) < 1e-15
+
+
+@pytest.mark.parametrize("n", [1, 3, 6, 8, 9, 10, 11, 12])
+def test_persistent_kernel_matches_generic_and_oracle(n):
+    """The LDS-resident trajectory kernel (one launch) against the tiled path
+    (one launch per Taylor stage) and the oracle, with per-qubit coefficients."""
+    from oracle import qutip_path as qp
+
+    probs = [local_problem(n, seed=s, duration=61) for s in range(2)]
+    times = np.array([0.0, 0.0105, 0.0105, 0.03, 0.06])
+    outs = {}
+    for force in (False, True):
+        eng = _engine(probs)
+        eng.set_path(force)
+        st = eng.new_state()
+        snaps = eng.solve(st, times).cpu().numpy()
+        assert np.array_equal(snaps[-1], st.cpu().numpy())
+        outs[force] = snaps
+        if not force:
+            assert eng.stats()["n_launches"] == 2  # split at the duplicated time
+    assert np.max(np.abs(outs[False] - outs[True])) < 1e-13
+    assert np.array_equal(outs[False][0], outs[False][1])
+    for b, p in enumerate(probs):
+        ham = qp.build_hamiltonian(p)
+        ref = qp.sesolve(ham, qp.all_ground_state(n, p["eigenbasis"]), times[[0, 1, 3, 4]], max_step=1e-3, **qp.TIGHT)
+        for i, j in ((0, 1), (2, 2), (3, 3)):
+            assert np.max(np.abs(outs[False][i][b] - ref[j])) < AMP_TOL
+
+
+def test_persistent_kernel_cfg2_chain12_snapshots():
+    prob, extra = load_fixture("cfg2_chain12_anneal.npz")
+    eng = _engine([with_anneal_samples(prob)])
+    st = eng.new_state()
+    snaps = eng.solve(st, np.asarray(extra["eval_times"])).cpu().numpy()
+    ref = np.asarray(extra["oracle_states_tight"])
+    assert eng.stats()["n_launches"] == 1
+    for i in range(1, len(ref)):
+        assert np.max(np.abs(snaps[i - 1][0] - ref[i])) < AMP_TOL

@@ -27,6 +27,12 @@ def run(n, mode, t1, batch=1, order=0, tol=0.0, tile_bits=0):
     eng.close()
 
 if __name__ == "__main__":
+    run(12, "sesolve", 3.1)
+    run(12, "sesolve", 0.502, batch=256)
+    run(12, "sesolve", 0.302, batch=1024)
+    run(10, "sesolve", 3.1)
+    run(8, "sesolve", 3.1)
+    sys.exit(0)
     run(12, "sesolve", 0.302)
     run(12, "sesolve", 0.102, batch=256)
     run(12, "sesolve", 0.052, batch=1024)
