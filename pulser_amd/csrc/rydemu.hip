@@ -1244,6 +1244,15 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
         nsub = std::max(nsub, std::min(nm, 256));
       }
     }
+    {
+      // keep the Taylor argument rho = h * ||G~|| near 1: beyond that the
+      // polynomial degree grows faster than the step (and cancellation sets in)
+      int ord;
+      double sh;
+      plan_exp(h, idx, len / nsub, kA1, kA2, o, &ord, &sh);
+      const double rho = (len / nsub) * h->stats.norm_bound * (kA1 + kA2);
+      if (rho > 1.5) nsub *= (int)std::ceil(rho / 1.0);
+    }
     const double hs = len / nsub;
     for (int s = 0; s < nsub; ++s) {
       const double ta = t + s * hs;

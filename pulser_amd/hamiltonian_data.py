@@ -1,0 +1,458 @@
+"""Backend-agnostic inputs of the hot path and their noise trajectories.
+
+Restates, for Ising (ground-rydberg / digital) sequences without a DMM, what
+``pulser._hamiltonian_data.HamiltonianData`` does between the sampler and the
+Hamiltonian (pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py):
+
+* ``SequenceInputs``   - the plain-array stand-in of ``SequenceSamples`` +
+  register + device numbers;
+* ``to_nested_dict``   - sampler/samples.py:524-621;
+* ``HamiltonianData``  - noise-trajectory draws in the reference's exact order
+  on the GLOBAL ``np.random`` stream (:782-911), SPAM-only dedup with
+  ``Counter.most_common()`` (:795-835), noisy samples (:408-534), interaction
+  matrix (:562-652), collapse-operator specs (:654-739).
+
+Outputs are the problem bundles of ``pulser_amd.problem``.
+"""
+
+from __future__ import annotations
+
+from collections import Counter
+from dataclasses import dataclass, field, replace
+from typing import Any, Iterator, Sequence
+
+import numpy as np
+
+from .noise_model import (NoiseModel, doppler_sigma,
+                          has_shot_to_shot_except_spam, register_sigma_xy_z)
+from .problem import COORD_PRECISION
+
+STATES_RANK = ["u", "d", "r", "g", "h", "x"]  # pulser/channels/base_channel.py
+EIGENSTATES = {"ground-rydberg": ["r", "g"], "digital": ["g", "h"], "XY": ["u", "d"]}
+
+SUPPORTED_NOISES = {
+    "ising": {"amplitude", "detuning", "dephasing", "relaxation", "depolarizing",
+              "doppler", "eff_noise", "SPAM", "leakage", "register", "dmm_sigma",
+              "dmm_crosstalk"},
+    "XY": {"dephasing", "depolarizing", "eff_noise", "SPAM", "leakage", "register"},
+}
+
+
+@dataclass
+class Slot:
+    """``_PulseTargetSlot`` (sampler/samples.py): samples [ti, tf) hit targets."""
+
+    ti: int
+    tf: int
+    targets: tuple[int, ...]  # qubit indices
+
+
+@dataclass
+class ChannelInput:
+    """One channel's samples (``ChannelSamples``, sampler/samples.py:95-246)."""
+
+    name: str
+    addressing: str  # "Global" | "Local"
+    basis: str  # "ground-rydberg" | "digital" | "XY"
+    amp: np.ndarray
+    det: np.ndarray
+    phase: np.ndarray
+    slots: list[Slot] = field(default_factory=list)
+    propagation_dir: tuple[float, float, float] | None = None
+
+    @property
+    def duration(self) -> int:
+        return len(self.amp)
+
+    def extend_duration(self, new_duration: int) -> "ChannelInput":
+        """``ChannelSamples.extend_duration`` (samples.py:152-200): pad amp and
+        det with zeros, phase with its last value ('edge')."""
+        extra = new_duration - self.duration
+        if extra < 0:
+            raise ValueError("Can't extend samples to a lower duration.")
+        if extra == 0:
+            return self
+        pad = lambda a, mode: np.pad(np.asarray(a, float), (0, extra), mode=mode)  # noqa: E731
+        phase = (
+            pad(self.phase, "edge") if self.duration > 0 else np.zeros(new_duration)
+        )
+        return replace(self, amp=pad(self.amp, "constant"), det=pad(self.det, "constant"), phase=phase)
+
+
+@dataclass
+class SequenceInputs:
+    """Everything the path needs from sequence + register + device."""
+
+    coords: np.ndarray  # float[N, 2 or 3], register order = tensor order
+    qubit_ids: tuple[str, ...]
+    channels: list[ChannelInput]
+    interaction_coeff: float  # C6 (rad.um^6/us), devices/_device_datacls.py:382
+    measurement: str | None = None
+    slm_end: int = 0
+    slm_targets: tuple[int, ...] = ()
+
+    @property
+    def n_qudits(self) -> int:
+        return len(self.qubit_ids)
+
+    @property
+    def max_duration(self) -> int:
+        return max(ch.duration for ch in self.channels)
+
+    @property
+    def used_bases(self) -> set[str]:
+        """``SequenceSamples.used_bases`` (samples.py:486-495): bases of the
+        channels whose amplitude or detuning samples are not all zero."""
+        return {ch.basis for ch in self.channels if not _is_empty(ch)}
+
+    @property
+    def in_xy(self) -> bool:
+        return any(ch.basis == "XY" for ch in self.channels)
+
+    def extend_duration(self, new_duration: int) -> "SequenceInputs":
+        return replace(self, channels=[c.extend_duration(new_duration) for c in self.channels])
+
+    def to_nested_dict(self, all_local: bool = False) -> dict[str, Any]:
+        """sampler/samples.py:524-621 without DMM channels / XY SLM masks."""
+        T = self.max_duration
+        d: dict[str, Any] = {"Global": {}, "Local": {}}
+
+        def entry() -> dict[str, np.ndarray]:
+            return {"amp": np.zeros(T), "det": np.zeros(T), "phase": np.zeros(T)}
+
+        for ch in self.channels:
+            cs = ch.extend_duration(T)
+            if ch.addressing == "Global" and not all_local:
+                g = d["Global"].setdefault(ch.basis, entry())
+                g["amp"] += cs.amp
+                g["det"] += cs.det
+                g["phase"] += cs.phase
+            else:
+                loc = d["Local"].setdefault(ch.basis, {})
+                for s in cs.slots:
+                    for t in s.targets:
+                        e = loc.setdefault(t, entry())
+                        sl = slice(s.ti, s.tf)
+                        e["amp"][sl] += cs.amp[sl]
+                        e["det"][sl] += cs.det[sl]
+                        e["phase"][sl] += cs.phase[sl]
+        return d
+
+
+def _is_empty(ch: ChannelInput) -> bool:
+    """``ChannelSamples.is_empty`` (samples.py:202-214)."""
+    return (np.count_nonzero(ch.amp) + np.count_nonzero(ch.det)) == 0
+
+
+def single_global_channel(
+    coords: np.ndarray,
+    samples: dict[str, np.ndarray],
+    interaction_coeff: float,
+    basis: str = "ground-rydberg",
+    name: str = "ising_global",
+    prefix: str = "q",
+    extended: bool = True,
+) -> SequenceInputs:
+    """Convenience: one global channel whose single pulse block spans the
+    whole (un-extended) duration; ``samples`` already hold the extra trailing
+    sample of simulation.py:173 when ``extended``."""
+    n = len(coords)
+    dur = len(samples["amp"]) - (1 if extended else 0)
+    ch = ChannelInput(
+        name, "Global", basis,
+        np.asarray(samples["amp"], float), np.asarray(samples["det"], float),
+        np.asarray(samples["phase"], float),
+        slots=[Slot(0, dur, tuple(range(n)))],
+    )
+    return SequenceInputs(
+        np.asarray(coords, float), tuple(f"{prefix}{i}" for i in range(n)), [ch],
+        float(interaction_coeff),
+    )
+
+
+@dataclass
+class NoiseTrajectory:
+    """pulser/_hamiltonian_data/noise_trajectory.py:25-60."""
+
+    bad_atoms: np.ndarray  # bool[N]
+    doppler_detune: np.ndarray  # float[N]
+    amp_fluctuations: dict[str, float]
+    det_fluctuations: dict[str, float]
+    det_phases: dict[str, np.ndarray]
+    coords: np.ndarray
+    interaction_matrix: np.ndarray
+    reps: int = 1
+
+
+def generate_detuning_fluctuations(
+    nm: Any, det_cst_term: float, phases: np.ndarray, times: np.ndarray
+) -> np.ndarray:
+    """hamiltonian_data.py:132-169: delta_hf(t) + delta_sigma, times in ns."""
+    det_hf = np.zeros_like(times, dtype=float)
+    if nm.detuning_hf_psd:
+        t = np.asarray(times) * 1e-3
+        freqs = np.asarray(nm.detuning_hf_omegas)[1:]
+        psd = np.asarray(nm.detuning_hf_psd)[1:]
+        df = np.diff(nm.detuning_hf_omegas)
+        amp = np.sqrt(2.0 * df * psd)
+        arg = freqs[:, None] * t[None, :] + phases[:, None]
+        det_hf = (amp[:, None] * np.cos(arg)).sum(axis=0)
+    return det_cst_term + det_hf
+
+
+def distances(coords: np.ndarray) -> np.ndarray:
+    """hamiltonian_data.py:172-189 (cdist rounded to COORD_PRECISION)."""
+    c = np.asarray(coords, float)
+    diff = c[:, None, :] - c[None, :, :]
+    return np.round(np.sqrt((diff**2).sum(-1)), COORD_PRECISION)
+
+
+def finite_waist_amp_fraction(
+    coords: Sequence[float], propagation_dir: Sequence[float], laser_waist: float
+) -> float:
+    """hamiltonian_data.py:758-780."""
+    pos = np.zeros(3)
+    pos[: len(coords)] = np.array(coords, float)
+    u = np.array(propagation_dir, float)
+    u = u / np.linalg.norm(u)
+    dist = np.linalg.norm(pos - np.dot(pos, u) * u)
+    return float(np.exp(-((dist / laser_waist) ** 2)))
+
+
+class HamiltonianData:
+    """Noise trajectories of one sequence (hamiltonian_data.py:192-943)."""
+
+    def __init__(
+        self,
+        samples: SequenceInputs,
+        noise_model: Any | None,
+        n_trajectories: int | None,
+    ) -> None:
+        if samples.max_duration == 0:
+            raise ValueError("SequenceSamples is empty.")
+        self.samples = samples
+        self.noise_model = noise_model if noise_model is not None else NoiseModel()
+        self._check_noise_model()
+        if n_trajectories is None:
+            n_trajectories = 1
+        nm = self.noise_model
+        self.local_noises = True  # hamiltonian_data.py:259-273
+        if set(nm.noise_types).issubset(
+            {"dephasing", "relaxation", "SPAM", "depolarizing", "eff_noise", "leakage"}
+        ):
+            self.local_noises = "SPAM" in nm.noise_types and nm.state_prep_error > 0
+        self.noise_trajectories = self._create_noise_trajectories(n_trajectories)
+
+    # -- basis -------------------------------------------------------------
+    @property
+    def n_qudits(self) -> int:
+        return self.samples.n_qudits
+
+    @property
+    def interaction_type(self) -> str:
+        return "XY" if self.samples.in_xy else "ising"
+
+    @property
+    def basis_name(self) -> str:
+        """hamiltonian_data.py:913-924."""
+        used = self.samples.used_bases
+        if len(used) == 0:
+            name = "XY" if self.samples.in_xy else "ground-rydberg"
+        elif len(used) == 1:
+            name = list(used)[0]
+        else:
+            name = "all"
+        if self.noise_model.with_leakage:
+            name += "_with_error"
+        return name
+
+    @property
+    def eigenbasis(self) -> list[str]:
+        """hamiltonian_data.py:926-931 + SequenceSamples.eigenbasis."""
+        used = self.samples.used_bases
+        if len(used) == 0:
+            used = {"XY" if self.samples.in_xy else "ground-rydberg"}
+        states = set()
+        for b in used:
+            states.update(EIGENSTATES[b])
+        if self.noise_model.with_leakage:
+            states.add("x")
+        return [s for s in STATES_RANK if s in states]
+
+    def _check_noise_model(self) -> None:
+        not_supported = set(self.noise_model.noise_types) - SUPPORTED_NOISES[self.interaction_type]
+        if not_supported:
+            raise NotImplementedError(
+                f"Interaction mode '{self.interaction_type}' does not support "
+                f"simulation of noise types: {', '.join(not_supported)}."
+            )
+
+    # -- collapse operators (hamiltonian_data.py:654-739) ---------------------
+    def collapse_ops(self) -> tuple[list, dict]:
+        nm = self.noise_model
+        eigenbasis = self.eigenbasis
+        names = ["I"] + [f"sigma_{a}{b}" for a in eigenbasis for b in eigenbasis]
+        ops: list[tuple[Any, Any]] = []
+        paulis: dict[str, list[tuple[complex, str]]] = {}
+        if "dephasing" in nm.noise_types:
+            rates = {"d": nm.dephasing_rate, "r": nm.dephasing_rate, "h": nm.hyperfine_dephasing_rate}
+            for state in eigenbasis:
+                if state in rates:
+                    ops.append((np.sqrt(2 * rates[state]), f"sigma_{state}{state}"))
+        if "relaxation" in nm.noise_types:
+            if "sigma_gr" not in names:
+                raise ValueError(
+                    "'relaxation' noise requires addressing of the 'ground-rydberg' basis."
+                )
+            ops.append((np.sqrt(nm.relaxation_rate), "sigma_gr"))
+        if "depolarizing" in nm.noise_types:
+            if "all" in self.basis_name:
+                raise NotImplementedError("Cannot include depolarizing noise in all-basis.")
+            b, a = eigenbasis[:2]
+            paulis["x"] = [(1, f"sigma_{a}{b}"), (1, f"sigma_{b}{a}")]
+            paulis["y"] = [(1j, f"sigma_{a}{b}"), (-1j, f"sigma_{b}{a}")]
+            paulis["z"] = [(1, f"sigma_{b}{b}"), (-1, f"sigma_{a}{a}")]
+            coeff = np.sqrt(nm.depolarizing_rate / 4)
+            for label in paulis:
+                ops.append((coeff, label))
+        if "eff_noise" in nm.noise_types:
+            d = len(eigenbasis)
+            for id_, rate in enumerate(nm.eff_noise_rates):
+                op = np.array(nm.eff_noise_opers[id_])
+                if op.shape != (d, d):
+                    raise ValueError(
+                        f"Incompatible shape for effective noise operator n°{id_}. "
+                        f"Operator {op} should be of shape {(d, d)}."
+                    )
+                ops.append((np.sqrt(rate), op))
+        return ops, paulis
+
+    # -- interaction (hamiltonian_data.py:562-652) ------------------------------
+    def interaction_matrix(self, coords: np.ndarray, bad_atoms: np.ndarray) -> np.ndarray:
+        n = self.n_qudits
+        d = distances(coords)
+        inter = np.zeros((1, n, n))
+        for i in range(n):
+            for j in range(i + 1, n):
+                inter[0, i, j] = inter[0, j, i] = self.samples.interaction_coeff / d[i, j] ** 6
+        bad = np.asarray(bad_atoms, bool)
+        inter[:, bad.reshape(1, -1) | bad.reshape(-1, 1)] = 0.0
+        return inter
+
+    # -- trajectories (hamiltonian_data.py:782-911) -----------------------------
+    def _create_noise_trajectories(self, ntrajs: int) -> list[NoiseTrajectory]:
+        nm = self.noise_model
+        n = self.n_qudits
+        chans = [c.name for c in self.samples.channels]
+        out: list[NoiseTrajectory] = []
+        if not has_shot_to_shot_except_spam(nm):
+            configs = Counter(
+                "".join(
+                    (np.random.uniform(size=n) < nm.state_prep_error).astype(int).astype(str)
+                )
+                for _ in range(ntrajs)
+            ).most_common()
+            for bool_string, reps in configs:
+                bad = np.array([c == "1" for c in bool_string])
+                out.append(
+                    NoiseTrajectory(
+                        bad, np.zeros(n),
+                        {c: 1.0 for c in chans}, {c: 0.0 for c in chans},
+                        {c: np.array(0.0) for c in chans},
+                        self.samples.coords, self.interaction_matrix(self.samples.coords, bad),
+                        reps,
+                    )
+                )
+            return out
+        for _ in range(ntrajs):
+            amp_f: dict[str, float] = {}
+            det_f: dict[str, float] = {}
+            det_ph: dict[str, np.ndarray] = {}
+            coords = self.samples.coords
+            if "SPAM" in nm.noise_types and nm.state_prep_error > 0:
+                bad = np.random.uniform(size=n) < nm.state_prep_error
+            else:
+                bad = np.zeros(n, bool)
+            if "doppler" in nm.noise_types:
+                dop = np.random.normal(0, doppler_sigma(nm.temperature * 1e-6), size=n)
+            else:
+                dop = np.zeros(n)
+            for c in chans:
+                amp_f[c] = max(0, np.random.normal(1.0, nm.amp_sigma))
+                det_f[c] = np.random.normal(0.0, nm.detuning_sigma) if nm.detuning_sigma else 0.0
+                if nm.detuning_hf_omegas:
+                    det_ph[c] = np.random.uniform(0.0, 2 * np.pi, size=len(nm.detuning_hf_omegas) - 1)
+                else:
+                    det_ph[c] = np.array(0.0)
+            if "register" in nm.noise_types:
+                sxy, sz = register_sigma_xy_z(nm.temperature, nm.trap_waist, float(nm.trap_depth))
+                pos = np.asarray(coords, float)
+                if pos.shape[1] == 2:
+                    pos = np.column_stack((pos, np.zeros(n)))
+                narr_xy = np.random.normal(0, sxy, (n, 2))
+                narr_z = np.random.normal(0, sz, n)
+                coords = pos + np.column_stack((narr_xy, narr_z))
+            out.append(
+                NoiseTrajectory(bad, dop, amp_f, det_f, det_ph, coords,
+                                self.interaction_matrix(coords, bad), 1)
+            )
+        return out
+
+    # -- noisy samples (hamiltonian_data.py:408-534) ----------------------------
+    def nested_samples(self, traj: NoiseTrajectory) -> dict[str, Any]:
+        nm = self.noise_model
+        d = self.samples.to_nested_dict(all_local=self.local_noises)
+        if not self.local_noises:
+            return d
+        T = self.samples.max_duration
+        for ch in self.samples.channels:
+            loc = d["Local"][ch.basis]
+            det_fl = generate_detuning_fluctuations(
+                nm, traj.det_fluctuations[ch.name], traj.det_phases[ch.name], np.arange(0, T, 1)
+            )
+            for slot in ch.slots:
+                for q in slot.targets:
+                    sl = slice(slot.ti, slot.tf)
+                    if "doppler" in nm.noise_types:
+                        loc[q]["det"][sl] += traj.doppler_detune[q]
+                    if "amplitude" in nm.noise_types:
+                        frac = traj.amp_fluctuations[ch.name]
+                        if nm.laser_waist is not None and ch.addressing == "Global":
+                            prop = ch.propagation_dir or (0.0, 1.0, 0.0)
+                            frac *= finite_waist_amp_fraction(
+                                tuple(traj.coords[q]), tuple(prop), nm.laser_waist
+                            )
+                        loc[q]["amp"][sl] *= frac
+                    if "detuning" in nm.noise_types:
+                        loc[q]["det"][sl] += det_fl[sl]
+        for basis in d["Local"]:  # badly prepared atoms: everything zeroed (:507-509)
+            for q, vals in d["Local"][basis].items():
+                if traj.bad_atoms[q]:
+                    for qty in ("amp", "det", "phase"):
+                        vals[qty] *= 0.0
+        return d
+
+    def problem(self, traj: NoiseTrajectory, sampling_rate: float) -> dict[str, Any]:
+        ops, paulis = self.collapse_ops()
+        return {
+            "n_qudits": self.n_qudits,
+            "qubit_ids": tuple(self.samples.qubit_ids),
+            "coords": np.asarray(traj.coords, float),
+            "eigenbasis": self.eigenbasis,
+            "basis_name": self.basis_name,
+            "interaction_type": self.interaction_type,
+            "duration": int(self.samples.max_duration),
+            "sampling_rate": float(sampling_rate),
+            "samples": self.nested_samples(traj),
+            "interaction_matrix": traj.interaction_matrix,
+            "bad_atoms": np.asarray(traj.bad_atoms, bool),
+            "collapse_ops": ops,
+            "depolarizing_pauli_2ds": paulis,
+            "slm_end": int(self.samples.slm_end),
+            "slm_targets": tuple(self.samples.slm_targets),
+            "reps": int(traj.reps),
+        }
+
+    def problems(self, sampling_rate: float) -> Iterator[dict[str, Any]]:
+        for traj in self.noise_trajectories:
+            yield self.problem(traj, sampling_rate)

@@ -1,0 +1,178 @@
+"""Numeric restatement of ``pulser.NoiseModel`` (the fields the hot path reads).
+
+Mirrors pulser-core/pulser/noise_model.py:175-520: same field names, defaults
+and noise-type inference (``noise_types`` = the noise families whose
+parameters are truthy, :401-405, minus doppler when ``disable_doppler``).  Any
+object exposing these attributes (e.g. a real ``pulser.NoiseModel``) can be
+passed wherever a NoiseModel is expected - only attribute access is used.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field, fields
+from typing import Any
+
+import numpy as np
+
+# pulser-core/pulser/constants.py:18-23 (env-overridable there; fixed here)
+TRAP_WAVELENGTH = 0.85  # um
+MASS = 1.45e-25  # kg
+KB = 1.38e-23  # J/K
+KEFF = 8.7  # um^-1
+
+_NOISE_TYPE_PARAMS: dict[str, tuple[str, ...]] = {
+    "leakage": ("with_leakage",),
+    "doppler": ("temperature",),
+    "register": ("trap_waist", "trap_depth"),
+    "amplitude": ("laser_waist", "amp_sigma"),
+    "detuning": ("detuning_sigma", "detuning_hf_psd", "detuning_hf_omegas"),
+    "SPAM": ("p_false_pos", "p_false_neg", "state_prep_error"),
+    "dephasing": ("dephasing_rate", "hyperfine_dephasing_rate"),
+    "relaxation": ("relaxation_rate",),
+    "depolarizing": ("depolarizing_rate",),
+    "eff_noise": ("eff_noise_rates", "eff_noise_opers"),
+    "dmm_sigma": ("dmm_sigma",),
+    "dmm_crosstalk": ("detuning_map_spot_waist",),
+}
+_PARAM_TO_NOISE_TYPE = {
+    p: nt for nt, params in _NOISE_TYPE_PARAMS.items() for p in params
+}
+
+# pulser-core/pulser/noise_model.py:101-114
+LEGACY_DEFAULTS = {
+    "runs": 15,
+    "samples_per_run": 5,
+    "state_prep_error": 0.005,
+    "p_false_pos": 0.01,
+    "p_false_neg": 0.05,
+    "temperature": 50.0,
+    "laser_waist": 175.0,
+    "amp_sigma": 5e-2,
+    "relaxation_rate": 0.01,
+    "dephasing_rate": 0.05,
+    "hyperfine_dephasing_rate": 1e-3,
+    "depolarizing_rate": 0.05,
+}
+
+
+def doppler_sigma(temperature: float) -> float:
+    """noise_model.py:127-133 (temperature in K)."""
+    return KEFF * math.sqrt(KB * temperature / MASS)
+
+
+def register_sigma_xy_z(
+    temperature: float, trap_waist: float, trap_depth: float
+) -> tuple[float, float]:
+    """noise_model.py:136-171."""
+    sxy = math.sqrt(temperature * trap_waist**2 / (4 * trap_depth))
+    sz = math.pi / TRAP_WAVELENGTH * math.sqrt(2) * trap_waist * sxy
+    return sxy, sz
+
+
+def _to_tuple(obj: Any) -> Any:
+    if isinstance(obj, np.ndarray):
+        return tuple(_to_tuple(el) for el in obj)
+    if isinstance(obj, (tuple, list)):
+        return tuple(_to_tuple(el) for el in obj)
+    return obj
+
+
+@dataclass(frozen=True)
+class NoiseModel:
+    noise_types: tuple[str, ...] = field(init=False, default=())
+    runs: int | None = None
+    samples_per_run: int = 1
+    state_prep_error: float = 0.0
+    p_false_pos: float = 0.0
+    p_false_neg: float = 0.0
+    temperature: float = 0.0
+    laser_waist: float | None = None
+    amp_sigma: float = 0.0
+    detuning_sigma: float = 0.0
+    detuning_hf_psd: tuple = ()
+    detuning_hf_omegas: tuple = ()
+    relaxation_rate: float = 0.0
+    dephasing_rate: float = 0.0
+    trap_waist: float = 0.0
+    trap_depth: float | None = None
+    hyperfine_dephasing_rate: float = 0.0
+    depolarizing_rate: float = 0.0
+    eff_noise_rates: tuple = ()
+    eff_noise_opers: tuple = ()
+    with_leakage: bool = False
+    disable_doppler: bool = False
+    dmm_sigma: float = 0.0
+    detuning_map_spot_waist: float | None = None
+
+    def __post_init__(self) -> None:
+        vals = {f.name: getattr(self, f.name) for f in fields(self) if f.init}
+        for key in ("eff_noise_rates", "eff_noise_opers", "detuning_hf_psd", "detuning_hf_omegas"):
+            vals[key] = _to_tuple(vals[key])
+            object.__setattr__(self, key, vals[key])
+
+        def truthy(v: Any) -> bool:
+            if isinstance(v, tuple):
+                return len(v) > 0
+            return bool(v)
+
+        types = {
+            _PARAM_TO_NOISE_TYPE[p]
+            for p, v in vals.items()
+            if p in _PARAM_TO_NOISE_TYPE and truthy(v)
+        }
+        if "leakage" in types and "eff_noise" not in types:
+            raise ValueError(
+                "At least one effective noise operator must be defined to "
+                "simulate leakage."
+            )
+        if len(vals["eff_noise_rates"]) != len(vals["eff_noise_opers"]):
+            raise ValueError(
+                "The operators list length must be equal to the rates list length."
+            )
+        if len(vals["detuning_hf_psd"]) != len(vals["detuning_hf_omegas"]):
+            raise ValueError(
+                "'detuning_hf_psd' and 'detuning_hf_omegas' must have the same length."
+            )
+        for p in ("state_prep_error", "p_false_pos", "p_false_neg", "amp_sigma", "dmm_sigma"):
+            if not (0.0 <= float(vals[p]) <= 1.0):
+                raise ValueError(f"'{p}' must be greater than or equal to zero and smaller than or equal to one, not {vals[p]}.")
+        for p in ("dephasing_rate", "hyperfine_dephasing_rate", "relaxation_rate",
+                  "depolarizing_rate", "temperature", "detuning_sigma", "trap_waist"):
+            if float(vals[p]) < 0:
+                raise ValueError(f"'{p}' must be greater than or equal to zero, not {vals[p]}.")
+        if "register" in types and (
+            vals["trap_waist"] == 0.0 or vals["trap_depth"] is None or vals["temperature"] == 0.0
+        ):
+            raise ValueError(
+                "trap_waist, trap_depth, and temperature must be defined in "
+                "order to simulate register noise."
+            )
+        if vals["disable_doppler"]:
+            types.discard("doppler")
+        object.__setattr__(self, "noise_types", tuple(sorted(types)))
+
+    def __repr__(self) -> str:
+        shown = {f.name: getattr(self, f.name) for f in fields(self)
+                 if f.init and getattr(self, f.name) not in (None, 0, 0.0, (), False)
+                 or f.name == "samples_per_run"}
+        args = ", ".join(f"{k}={v!r}" for k, v in shown.items())
+        return f"NoiseModel(noise_types={self.noise_types!r}, {args})"
+
+
+def has_shot_to_shot_except_spam(nm: Any) -> bool:
+    """pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py:89-104."""
+    return (
+        "doppler" in nm.noise_types
+        or ("amplitude" in nm.noise_types and nm.amp_sigma != 0.0)
+        or "detuning" in nm.noise_types
+        or "register" in nm.noise_types
+        or "dmm_sigma" in nm.noise_types
+    )
+
+
+def has_stochastic_noise(nm: Any) -> bool:
+    """pulser-simulation/pulser_simulation/simulation.py:61-64."""
+    return has_shot_to_shot_except_spam(nm) or (
+        "SPAM" in nm.noise_types and nm.state_prep_error != 0
+    )

@@ -89,3 +89,60 @@ def channel_amp_det(samples_obj: Any) -> list[tuple[np.ndarray, np.ndarray]]:
     """(amp, det) per channel of a ``SequenceSamples`` - the input of the
     default ``max_step`` rule (simulation.py:663-687, 768-776)."""
     return [(_np(cs.amp), _np(cs.det)) for cs in samples_obj.samples_list]
+
+
+def sequence_inputs_from_pulser(samples: Any, register: Any, device: Any) -> Any:
+    """``pulser.sampler.SequenceSamples`` + register + device ->
+    ``pulser_amd.hamiltonian_data.SequenceInputs`` (plain arrays).
+
+    Follows ``HamiltonianData.__init__`` / ``_delocalize_samples``
+    (pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py:208-303): global
+    channels target every qubit of the register; local targets must exist.
+    """
+    from .hamiltonian_data import ChannelInput, SequenceInputs, Slot
+
+    if register is None or device is None:
+        raise TypeError("A register and a device are required with SequenceSamples.")
+    device.validate_register(register)
+    if samples._slm_mask.end > 0 and not device.supports_slm_mask:
+        raise ValueError("Samples use SLM mask but device does not have one.")
+    if not samples.used_bases <= device.supported_bases:
+        raise ValueError("Bases used in samples should be supported by device.")
+    qids = list(register.qubits)
+    index = {q: i for i, q in enumerate(qids)}
+    if not samples._slm_mask.targets <= set(qids):
+        raise ValueError(
+            "The ids of qubits targeted in SLM mask should be defined in register."
+        )
+    channels = []
+    for name, cs in samples.channel_samples.items():
+        ch_obj = samples._ch_objs[name]
+        if type(cs).__name__ == "DMMSamples":
+            raise NotImplementedError("DMM channels are not supported by the MI355X backend yet.")
+        if ch_obj.basis == "XY":
+            raise NotImplementedError("XY mode is not supported by the MI355X backend yet.")
+        slots = []
+        for s in cs.slots:
+            if ch_obj.addressing == "Global":
+                targets = tuple(range(len(qids)))
+            else:
+                if not set(s.targets) <= set(qids):
+                    raise ValueError(
+                        "The ids of qubits targeted in Local channels"
+                        " should be defined in register."
+                    )
+                targets = tuple(sorted(index[t] for t in s.targets))
+            slots.append(Slot(int(s.ti), int(s.tf), targets))
+        channels.append(
+            ChannelInput(
+                str(name), ch_obj.addressing, ch_obj.basis, _np(cs.amp).astype(float),
+                _np(cs.det).astype(float), _np(cs.phase).astype(float), slots,
+                getattr(ch_obj, "propagation_dir", None),
+            )
+        )
+    coords = np.array([_np(register.qubits[q]) for q in qids], dtype=float)
+    return SequenceInputs(
+        coords, tuple(str(q) for q in qids), channels, float(device.interaction_coeff),
+        samples._measurement, int(samples._slm_mask.end),
+        tuple(index[q] for q in samples._slm_mask.targets),
+    )

@@ -1,0 +1,433 @@
+"""Result marshalling and bitstring sampling (host side, NumPy replay).
+
+Mirrors ``pulser_simulation.qutip_result.QutipResult``,
+``pulser.result.Result/SampledResult`` and
+``pulser_simulation.simresults.{SimulationResults,CoherentResults,NoisyResults}``.
+States come back from the GPU as NumPy arrays; the sampling replays the
+reference's exact NumPy call sequence on the global ``np.random`` stream, which
+is what makes sampled bitstring indices bit-exact:
+
+* weights: ``np.abs(state)**2`` (or ``|diag rho|``), reversed for ground-rydberg,
+  normalised by a sequential sum (pulser_simulation/qutip_result.py:101-158);
+* ``multinomial``: ``rand(n)`` then ``searchsorted(cumsum(p))``
+  (pulser-core/pulser/math/multinomial.py:18-36);
+* SPAM measurement flips (pulser_simulation/simresults.py:537-568);
+* first-match time lookup (simresults.py:176-190).
+"""
+
+from __future__ import annotations
+
+import collections.abc
+from collections import Counter
+from dataclasses import dataclass
+from functools import lru_cache
+from typing import Any, Mapping, Optional, Sequence, Union
+
+import numpy as np
+
+EIGENSTATES = {"ground-rydberg": ["r", "g"], "digital": ["g", "h"], "XY": ["u", "d"]}
+_ONE_STATE = {"ground-rydberg": "r", "digital": "h", "XY": "d"}
+
+
+class QState(np.ndarray):
+    """A ket (shape (D, 1)) or density matrix (D, D) with the few ``qutip.Qobj``
+    accessors user code of the reference relies on (``full``, ``isket``,
+    ``norm``, ``unit``, ``overlap``, ``dag``, ``diag``, ``tr``)."""
+
+    def __new__(cls, data: Any) -> "QState":
+        arr = np.asarray(data, dtype=complex)
+        if arr.ndim == 1:
+            arr = arr.reshape(-1, 1)
+        return arr.view(cls)
+
+    @property
+    def isket(self) -> bool:
+        return self.shape[1] == 1 and self.shape[0] > 1 or self.shape == (1, 1)
+
+    @property
+    def isoper(self) -> bool:
+        return not self.isket
+
+    def full(self) -> np.ndarray:
+        return np.array(self)
+
+    def dag(self) -> "QState":
+        return QState(np.conj(np.asarray(self)).T)
+
+    def diag(self) -> np.ndarray:
+        return np.diag(np.asarray(self))
+
+    def tr(self) -> complex:
+        return complex(np.trace(np.asarray(self)))
+
+    def norm(self) -> float:
+        a = np.asarray(self)
+        if self.isket:
+            return float(np.linalg.norm(a))
+        return float(np.sum(np.linalg.svd(a, compute_uv=False)))
+
+    def unit(self) -> "QState":
+        return QState(np.asarray(self) / self.norm())
+
+    def overlap(self, other: Any) -> complex:
+        a, b = np.asarray(self), np.asarray(QState(other))
+        if self.isket and b.shape[1] == 1:
+            return complex(np.vdot(a, b))
+        return complex(np.trace(a.conj().T @ b))
+
+
+def multinomial(n_samples: int, probabilities: np.ndarray) -> np.ndarray:
+    """pulser-core/pulser/math/multinomial.py:18-36."""
+    rnd = np.random.rand(n_samples)
+    cumsums = np.cumsum(probabilities)
+    return np.searchsorted(cumsums, rnd)
+
+
+class Result:
+    """``pulser.result.Result`` (pulser-core/pulser/result.py:34-168)."""
+
+    atom_order: tuple
+    meas_basis: str
+
+    @property
+    def _size(self) -> int:
+        return len(self.atom_order)
+
+    def _weights(self) -> np.ndarray:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    @property
+    def sampling_dist(self) -> dict[str, float]:
+        """Sampling distribution of the measured bitstring (result.py:70-86)."""
+        weights = self._weights()
+        nonzero = np.argwhere(weights != 0.0).flatten()
+        return {np.binary_repr(i, self._size): float(weights[i]) for i in nonzero}
+
+    def get_samples(self, n_samples: int) -> Counter:
+        """result.py:103-115 - insertion order = order of first occurrence."""
+        return Counter(
+            np.binary_repr(i, self._size)
+            for i in multinomial(n_samples, self._weights())
+        )
+
+
+@dataclass
+class SampledResult(Result):
+    """``pulser.result.SampledResult`` (result.py:171-242)."""
+
+    atom_order: tuple
+    meas_basis: str
+    bitstring_counts: Mapping[str, int]
+    evaluation_time: float = 1.0
+
+    def __post_init__(self) -> None:
+        self.n_samples = sum(self.bitstring_counts.values())
+
+    def _weights(self) -> np.ndarray:
+        weights = np.zeros(2**self._size)
+        for bitstr, counts in self.bitstring_counts.items():
+            weights[int(bitstr, base=2)] = counts / self.n_samples
+        return weights / sum(weights)
+
+
+@dataclass
+class StateResult(Result):
+    """``pulser_simulation.qutip_result.QutipResult`` with a NumPy state."""
+
+    atom_order: tuple
+    meas_basis: str
+    state: QState
+    matching_meas_basis: bool
+    evaluation_time: float = 1.0
+
+    @property
+    def _dim(self) -> int:
+        full = self.state.shape[0]
+        return int(np.rint(full ** (1 / self._size)).astype(int))
+
+    @property
+    def _basis_name(self) -> str:  # qutip_result.py:66-90
+        if self.meas_basis == "XY":
+            return "XY_with_error" if self._dim == 3 else "XY"
+        if self._dim == 4:
+            return "all_with_error"
+        if self._dim == 3:
+            return self.meas_basis + "_with_error" if self.matching_meas_basis else "all"
+        if not self.matching_meas_basis:
+            return "digital" if self.meas_basis == "ground-rydberg" else "ground-rydberg"
+        return self.meas_basis
+
+    @property
+    def _eigenbasis(self) -> list[str]:
+        bases = self._basis_name.split("_with_error")
+        names = ["ground-rydberg", "digital"] if bases[0] == "all" else [bases[0]]
+        rank = ["u", "d", "r", "g", "h", "x"]
+        states = {s for b in names for s in EIGENSTATES[b]}
+        out = [s for s in rank if s in states]
+        return out + (["x"] if len(bases) == 2 else [])
+
+    def _weights(self) -> np.ndarray:
+        """qutip_result.py:101-158."""
+        size = self._size
+        if not self.state.isket:
+            probs = np.abs(self.state.diag())
+        else:
+            probs = (np.abs(self.state.full()) ** 2).flatten()
+        if self._dim == 2:
+            if self.matching_meas_basis:
+                weights = probs[::-1] if self.meas_basis == "ground-rydberg" else probs
+            else:
+                weights = np.zeros(probs.size)
+                weights[0] = 1.0
+        elif self._dim in (3, 4):
+            if self.meas_basis not in _ONE_STATE:
+                raise RuntimeError(f"Unknown measurement basis '{self.meas_basis}'.")
+            one = self._eigenbasis.index(_ONE_STATE[self.meas_basis])
+            ex_one = [i for i in range(self._dim) if i != one]
+            probs = probs.reshape([self._dim] * size)
+            weights = np.zeros(2**size)
+            for dec_val in range(2**size):
+                ind = [ex_one if v == "0" else [one] for v in np.binary_repr(dec_val, width=size)]
+                weights[dec_val] = np.sum(probs[np.ix_(*ind)])
+        else:
+            raise NotImplementedError(
+                "Cannot sample system with single-atom state vectors of dimension > 4."
+            )
+        # builtin sum() = sequential left-to-right fp64 accumulation; the last
+        # element of cumsum is the same sequence of additions, in C
+        return weights / np.cumsum(weights)[-1]
+
+    def get_state(
+        self,
+        reduce_to_basis: str | None = None,
+        ignore_global_phase: bool = True,
+        tol: float = 1e-6,
+        normalize: bool = True,
+    ) -> QState:
+        """qutip_result.py:160-242 (``reduce_to_basis`` only for 2-level)."""
+        state = QState(self.state.copy())
+        if ignore_global_phase and state.isket:
+            full = state.full()
+            global_ph = float(np.angle(full[np.argmax(np.abs(full))])[0])
+            state = QState(full * np.exp(-1j * global_ph))
+        if self._dim == 2:
+            if reduce_to_basis not in [None, self._basis_name]:
+                raise TypeError(
+                    f"Can't reduce a system in {self._basis_name}"
+                    + f" to the {reduce_to_basis} basis."
+                )
+        elif reduce_to_basis is not None:
+            raise NotImplementedError(
+                "reduce_to_basis for multi-level bases is not supported by the MI355X backend yet."
+            )
+        arr = np.asarray(state).copy()
+        arr[np.abs(arr) < 1e-12] = 0  # Qobj.tidyup default atol
+        return QState(arr)
+
+
+class SimulationResults(collections.abc.Sequence):
+    """simresults.py:37-229."""
+
+    _use_pseudo_dens: bool = False
+
+    def __init__(self, size: int, basis_name: str, sim_times: np.ndarray) -> None:
+        self._size = size
+        bases = ["ground-rydberg", "digital", "all", "XY"]
+        bases += [b + "_with_error" for b in bases]
+        if basis_name not in bases:
+            raise ValueError(f"`basis_name` must be in {bases}")
+        self._basis_name = basis_name
+        self._dim = 3 if self._basis_name == "all" else 2
+        if "_with_error" in self._basis_name:
+            self._dim += 1
+        self._sim_times = sim_times
+        self._results_seq: tuple = ()
+
+    def __getitem__(self, i: Any) -> Any:
+        return self._results_seq[i]
+
+    def __len__(self) -> int:
+        return len(self._results_seq)
+
+    @property
+    def states(self) -> list:
+        raise NotImplementedError
+
+    def expect(self, obs_list: Sequence[np.ndarray]) -> list:
+        """simresults.py:89-132 (``qutip.expect`` of dense observables)."""
+        if not isinstance(obs_list, (list, np.ndarray)):
+            raise TypeError("`obs_list` must be a list of operators.")
+        dim = self._dim if not self._use_pseudo_dens else 2
+        legal_shape = (dim**self._size, dim**self._size)
+        mats = []
+        for obs in obs_list:
+            if not isinstance(obs, np.ndarray):
+                raise TypeError(
+                    f"Incompatible type {type(obs)} of observable. "
+                    "Type must be ArrayLike or qutip.Qobj."
+                )
+            if obs.shape != legal_shape:
+                raise ValueError(
+                    "Incompatible shape of observable."
+                    + f"Expected {legal_shape}, got {obs.shape}."
+                )
+            if self._use_pseudo_dens and np.count_nonzero(obs - np.diag(np.diagonal(obs))):
+                raise ValueError(f"Observable {obs!r} is non-diagonal.")
+            mats.append(np.asarray(obs))
+        if self._use_pseudo_dens:
+            states = [self._calc_pseudo_density(i) for i in range(len(self))]
+        else:
+            states = self.states
+        out = []
+        for m in mats:
+            herm = np.allclose(m, m.conj().T)
+            vals = []
+            for s in states:
+                a = np.asarray(s)
+                v = np.vdot(a, m @ a) if a.shape[1] == 1 and a.shape[0] > 1 else np.trace(m @ a)
+                vals.append(v.real if herm else v)
+            out.append(np.array(vals))
+        return out
+
+    def sample_state(self, t: float, n_samples: int = 1000, t_tol: float = 1.0e-3) -> Counter:
+        t_index = self._get_index_from_time(t, t_tol)
+        return self[t_index].get_samples(n_samples)
+
+    def sample_final_state(self, N_samples: int = 1000) -> Counter:
+        return self.sample_state(self._sim_times[-1], N_samples)
+
+    def _get_index_from_time(self, t_float: float, tol: float = 1.0e-3) -> int:
+        """simresults.py:176-190 - the FIRST index within tol."""
+        try:
+            return int(np.where(abs(t_float - self._sim_times) < tol)[0][0])
+        except IndexError:
+            raise IndexError(
+                f"Given time {t_float} is absent from simulation times within"
+                + f" tolerance {tol}."
+            )
+
+    def _meas_projector(self, state_n: int) -> np.ndarray:
+        p = np.zeros((2, 2))
+        good = 1 - state_n if self._basis_name == "ground-rydberg" else state_n
+        p[good, good] = 1.0
+        return p
+
+    @lru_cache(maxsize=None)
+    def _calc_pseudo_density(self, t_index: int) -> QState:
+        """simresults.py:192-217: diagonal matrix of post-measurement weights."""
+        w = self[t_index]._weights()
+        D = 2**self._size
+        diag = np.zeros(D)
+        for i in np.nonzero(w)[0]:
+            bits = np.binary_repr(i, width=self._size)
+            d = np.array([1.0])
+            for c in bits:
+                d = np.kron(d, np.diag(self._meas_projector(int(c))))
+            diag += w[i] * d
+        return QState(np.diag(diag).astype(complex))
+
+
+class NoisyResults(SimulationResults):
+    """simresults.py:232-360."""
+
+    _use_pseudo_dens = True
+
+    def __init__(self, run_output: Sequence[SampledResult], size: int, basis_name: str,
+                 sim_times: np.ndarray, n_measures: int) -> None:
+        basis = basis_name.replace("_with_error", "")
+        super().__init__(size, "digital" if basis == "all" else basis, sim_times)
+        self.n_measures = n_measures
+        self._results_seq = tuple(run_output)
+
+    @property
+    def states(self) -> list:
+        return [self.get_state(t) for t in self._sim_times]
+
+    @property
+    def results(self) -> list[Counter]:
+        return [Counter(res.sampling_dist) for res in self]
+
+    def get_state(self, t: float, t_tol: float = 1.0e-3) -> QState:
+        return self._calc_pseudo_density(self._get_index_from_time(t, t_tol))
+
+    def get_final_state(self) -> QState:
+        return self.get_state(self._sim_times[-1])
+
+
+class CoherentResults(SimulationResults):
+    """simresults.py:363-568."""
+
+    def __init__(self, run_output: Sequence[StateResult], size: int, basis_name: str,
+                 sim_times: np.ndarray, meas_basis: str,
+                 meas_errors: Optional[Mapping[str, float]] = None) -> None:
+        super().__init__(size, basis_name, sim_times)
+        if "all" in self._basis_name:
+            if meas_basis not in {"ground-rydberg", "digital"}:
+                raise ValueError("`meas_basis` must be 'ground-rydberg' or 'digital'.")
+        else:
+            expected = self._basis_name.replace("_with_error", "")
+            if meas_basis != expected:
+                raise ValueError(
+                    f"`meas_basis` associated to basis_name '"
+                    f"{self._basis_name}' must be '{expected}'."
+                )
+        self._meas_basis = meas_basis
+        self._results_seq = tuple(run_output)
+        if meas_errors is not None:
+            if set(meas_errors) != {"epsilon", "epsilon_prime"}:
+                raise ValueError(
+                    "When defining measurement errors, only values of "
+                    "'epsilon' and 'epsilon_prime' must be given."
+                )
+            self._use_pseudo_dens = True
+        self._meas_errors = meas_errors
+
+    @property
+    def states(self) -> list[QState]:
+        return [res.state for res in self]
+
+    def get_state(self, t: float, reduce_to_basis: Optional[str] = None,
+                  ignore_global_phase: bool = True, tol: float = 1e-6,
+                  normalize: bool = True, t_tol: float = 1.0e-3) -> QState:
+        t_index = self._get_index_from_time(t, t_tol)
+        return self[t_index].get_state(reduce_to_basis, ignore_global_phase, tol, normalize)
+
+    def get_final_state(self, reduce_to_basis: Optional[str] = None,
+                        ignore_global_phase: bool = True, tol: float = 1e-6,
+                        normalize: bool = True) -> QState:
+        return self.get_state(self._sim_times[-1], reduce_to_basis, ignore_global_phase,
+                              tol, normalize)
+
+    def _meas_projector(self, state_n: int) -> np.ndarray:
+        if self._meas_errors:  # simresults.py:500-520
+            err = self._meas_errors["epsilon"] if state_n == 0 else self._meas_errors["epsilon_prime"]
+            good = 1 - state_n if "ground-rydberg" in self._basis_name else state_n
+            p = np.zeros((2, 2))
+            p[good, good] = 1 - err
+            p[1 - good, 1 - good] = err
+            return p
+        return super()._meas_projector(state_n)
+
+    def sample_state(self, t: float, n_samples: int = 1000, t_tol: float = 1.0e-3) -> Counter:
+        """simresults.py:522-568."""
+        sampled_state = super().sample_state(t, n_samples, t_tol)
+        if self._meas_errors is None or (
+            self._meas_errors["epsilon"] == 0.0 and self._meas_errors["epsilon_prime"] == 0
+        ):
+            return sampled_state
+        return spam_flips(sampled_state, self._meas_errors["epsilon"],
+                          self._meas_errors["epsilon_prime"])
+
+
+def spam_flips(sampled_state: Counter, eps: float, eps_p: float) -> Counter:
+    """Per-shot per-bit measurement flips (simresults.py:537-568)."""
+    shots = list(sampled_state.keys())
+    n_detects_list = list(sampled_state.values())
+    shot_arr = np.array([list(shot) for shot in shots], dtype=int)
+    flip_probs = np.where(shot_arr == 1, eps_p, eps)
+    flip_probs_repeated = np.repeat(flip_probs, n_detects_list, axis=0)
+    random_matrix = np.random.uniform(size=(np.sum(n_detects_list), len(shot_arr[0])))
+    flips = random_matrix < flip_probs_repeated
+    new_shots = shot_arr.repeat(n_detects_list, axis=0) ^ flips
+    detected: Counter = Counter(map(tuple, new_shots))
+    return Counter({"".join(map(str, k)): v for k, v in detected.items()})

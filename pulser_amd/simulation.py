@@ -1,0 +1,601 @@
+"""``QutipEmulator``-compatible front-end of the MI355X emulation backend.
+
+Same constructor / ``from_sequence`` / ``run`` / setters / properties, same
+exceptions and warnings as ``pulser_simulation.simulation.QutipEmulator``
+(pulser-simulation/pulser_simulation/simulation.py:84-1051), with the solver
+call (``qutip.sesolve/mesolve``, :729-735) replaced by the HIP engine.  The
+RNG call order on the global ``np.random`` stream is preserved: noise
+trajectories at construction (:208), the hidden noiseless ``HamiltonianData``
+behind ``set_evaluation_times`` (:266-297), then sampling.
+
+Inputs: a ``pulser_amd.hamiltonian_data.SequenceInputs`` (plain arrays; works
+without pulser installed) or, when the user has pulser, a
+``pulser.sampler.SequenceSamples`` + register + device / a ``pulser.Sequence``.
+"""
+
+from __future__ import annotations
+
+import math
+import warnings
+from collections import Counter
+from dataclasses import dataclass, field
+from enum import Enum
+from functools import lru_cache
+from typing import Any, Iterator, Optional, Union, cast
+
+import numpy as np
+
+from .hamiltonian_data import HamiltonianData, SequenceInputs
+from .noise_model import (LEGACY_DEFAULTS, NoiseModel, _NOISE_TYPE_PARAMS,
+                          has_stochastic_noise)
+from .results import (CoherentResults, NoisyResults, QState, SampledResult,
+                      SimulationResults, StateResult)
+from .terms import sampling_times
+
+__all__ = ["QutipEmulator", "Solver", "SimConfig", "NoiseModel"]
+
+
+class Solver(str, Enum):
+    """simulation.py:67-81.  The Monte-Carlo wavefunction solver is not part
+    of this backend; requesting it raises ``NotImplementedError``."""
+
+    DEFAULT = "default"
+    MESOLVER = "MasterEquation"
+    MCSOLVER = "MonteCarlo"
+
+
+_DIFF_NOISE_PARAMS = {
+    "noise_types": "noise",
+    "state_prep_error": "eta",
+    "p_false_pos": "epsilon",
+    "p_false_neg": "epsilon_prime",
+}
+
+
+def _find_relevant_params(noise_types, state_prep_error, amp_sigma, laser_waist) -> set[str]:
+    """pulser-core/pulser/noise_model.py:497-520."""
+    relevant: set[str] = set()
+    for nt in noise_types:
+        relevant.update(_NOISE_TYPE_PARAMS[nt])
+        if nt == "register":
+            relevant.add("temperature")
+        if (nt in ("doppler", "detuning", "register", "dmm_sigma")
+                or (nt == "amplitude" and amp_sigma != 0.0)
+                or (nt == "SPAM" and state_prep_error != 0.0)):
+            relevant.update(("runs", "samples_per_run"))
+    if laser_waist is None:
+        relevant.discard("laser_waist")
+    return relevant
+
+
+@dataclass(frozen=True)
+class SimConfig:
+    """Deprecated configuration shim (pulser_simulation/simconfig.py:42-157):
+    converts to / from a ``NoiseModel``."""
+
+    noise: Union[str, tuple] = ()
+    runs: int = LEGACY_DEFAULTS["runs"]
+    samples_per_run: int = LEGACY_DEFAULTS["samples_per_run"]
+    temperature: float = LEGACY_DEFAULTS["temperature"]
+    laser_waist: float = LEGACY_DEFAULTS["laser_waist"]
+    amp_sigma: float = LEGACY_DEFAULTS["amp_sigma"]
+    detuning_sigma: float = 0.0
+    eta: float = LEGACY_DEFAULTS["state_prep_error"]
+    epsilon: float = LEGACY_DEFAULTS["p_false_pos"]
+    epsilon_prime: float = LEGACY_DEFAULTS["p_false_neg"]
+    relaxation_rate: float = LEGACY_DEFAULTS["relaxation_rate"]
+    dephasing_rate: float = LEGACY_DEFAULTS["dephasing_rate"]
+    hyperfine_dephasing_rate: float = LEGACY_DEFAULTS["hyperfine_dephasing_rate"]
+    depolarizing_rate: float = LEGACY_DEFAULTS["depolarizing_rate"]
+    eff_noise_rates: list = field(default_factory=list, repr=False)
+    eff_noise_opers: list = field(default_factory=list, repr=False)
+    solver_options: dict | None = None
+
+    def __post_init__(self) -> None:
+        warnings.warn(
+            "'SimConfig' has been deprecated since v1.6 and will be removed in a "
+            "future version. Please use 'NoiseModel' instead.",
+            DeprecationWarning,
+            stacklevel=3,
+        )
+        noise = (self.noise,) if isinstance(self.noise, str) else tuple(self.noise)
+        object.__setattr__(self, "noise", noise)
+        # temperature is given in uK and stored in K (simconfig.py)
+        object.__setattr__(self, "temperature", self.temperature * 1e-6)
+
+    @classmethod
+    def from_noise_model(cls, noise_model: Any) -> "SimConfig":
+        kwargs: dict[str, Any] = dict(noise=noise_model.noise_types)
+        for param in _find_relevant_params(noise_model.noise_types, noise_model.state_prep_error,
+                                           noise_model.amp_sigma, noise_model.laser_waist):
+            kwargs[_DIFF_NOISE_PARAMS.get(param, param)] = getattr(noise_model, param)
+        if "amplitude" in noise_model.noise_types:
+            kwargs.setdefault("laser_waist", float("inf"))
+        kwargs.pop("with_leakage", None)
+        if kwargs.get("runs", 0) is None:
+            kwargs.pop("runs")
+        for k in ("detuning_hf_psd", "detuning_hf_omegas", "trap_waist", "trap_depth",
+                  "dmm_sigma", "detuning_map_spot_waist"):
+            kwargs.pop(k, None)
+        if "eff_noise_opers" in kwargs:
+            kwargs["eff_noise_opers"] = [np.array(o) for o in kwargs["eff_noise_opers"]]
+            kwargs["eff_noise_rates"] = list(kwargs.get("eff_noise_rates", []))
+        return cls(**kwargs)
+
+    def to_noise_model(self) -> NoiseModel:
+        laser_waist_ = None if math.isinf(self.laser_waist) else self.laser_waist
+        kwargs = {}
+        for param in _find_relevant_params(self.noise, self.eta, self.amp_sigma, laser_waist_):
+            kwargs[param] = getattr(self, _DIFF_NOISE_PARAMS.get(param, param))
+        if "temperature" in kwargs:
+            kwargs["temperature"] *= 1e6
+        if "eff_noise_opers" in kwargs:
+            kwargs["eff_noise_opers"] = tuple(np.array(o) for o in kwargs["eff_noise_opers"])
+            kwargs["eff_noise_rates"] = tuple(kwargs["eff_noise_rates"])
+        return NoiseModel(**kwargs)
+
+
+def _as_inputs(sampled_seq: Any, register: Any, device: Any) -> SequenceInputs:
+    if isinstance(sampled_seq, SequenceInputs):
+        return sampled_seq
+    if hasattr(sampled_seq, "samples_list") and hasattr(sampled_seq, "channels"):
+        from .pulser_adapter import sequence_inputs_from_pulser
+
+        return sequence_inputs_from_pulser(sampled_seq, register, device)
+    raise TypeError("The provided sequence has to be a valid SequenceSamples instance.")
+
+
+class QutipEmulator:
+    """Emulator of a pulse sequence on MI355X (drop-in for
+    ``pulser_simulation.QutipEmulator``; arguments as simulation.py:130-141)."""
+
+    def __init__(
+        self,
+        sampled_seq: Any,
+        register: Any = None,
+        device: Any = None,
+        sampling_rate: float = 1.0,
+        config: Optional[SimConfig] = None,
+        evaluation_times: Union[float, str, Any] = "Full",
+        noise_model: Any = None,
+        solver: Solver = Solver.DEFAULT,
+        n_trajectories: int | None = None,
+    ) -> None:
+        samples = _as_inputs(sampled_seq, register, device)
+        if samples.max_duration == 0:
+            raise ValueError("SequenceSamples is empty.")
+        self._sampling_rate = sampling_rate
+        self.solver = Solver(solver)
+        self._tot_duration = samples.max_duration
+        self.samples_obj = samples.extend_duration(self._tot_duration + 1)  # :173
+        self._n_trajectories = n_trajectories
+        if not (0 < sampling_rate <= 1.0):
+            raise ValueError(
+                "The sampling rate (`sampling_rate` = "
+                f"{sampling_rate}) must be greater than 0 and "
+                "less than or equal to 1."
+            )
+        if int(self._tot_duration * sampling_rate) < 4:
+            raise ValueError("`sampling_rate` is too small, less than 4 data points.")
+        if noise_model is not None and config is not None:
+            raise ValueError(
+                "'noise_model' and 'config' cannot both be provided to "
+                "'QutipEmulator'. Please provide just a 'noise_model'."
+            )
+        if config is not None:
+            warnings.warn(
+                "Supplying a 'SimConfig' to QutipEmulator has been "
+                "deprecated. Please instantiate with a 'NoiseModel' instead.",
+                DeprecationWarning,
+                stacklevel=2,
+            )
+            noise_model = config.to_noise_model()
+        if not noise_model:
+            noise_model = NoiseModel()
+        self._noise_trajectories_used = False
+        self._hamiltonian_data = HamiltonianData(
+            self.samples_obj, noise_model,
+            self._get_n_trajectories(noise_model, check_value=True),
+        )
+        self._problems = self._build_problems()
+        self._current_problem = self._problems[0]
+        self._eval_times_array: np.ndarray
+        self.set_evaluation_times(evaluation_times)
+        if self.samples_obj.measurement:
+            self._meas_basis = self.samples_obj.measurement
+        elif "all" in self.basis_name:
+            self._meas_basis = "digital"
+        else:
+            self._meas_basis = self.basis_name.replace("_with_error", "")
+        self.set_initial_state("all-ground")
+        self._engine_opts: dict[str, Any] = {}
+        self.last_engine_stats: dict[str, Any] = {}
+
+    # ------------------------------------------------------------------ setup
+    def _build_problems(self) -> list[dict[str, Any]]:
+        return list(self._hamiltonian_data.problems(self._sampling_rate))
+
+    def _get_n_trajectories(self, noise_model: Any, check_value: bool) -> int | None:
+        n = self._n_trajectories if self._n_trajectories is not None else noise_model.runs
+        if check_value and has_stochastic_noise(noise_model) and n is None:
+            raise ValueError(
+                "'n_trajectories' must be defined when the NoiseModel contains"
+                " stochastic noise, which is the case for the given noise "
+                f"model: {noise_model!r}"
+            )
+        return n
+
+    @property
+    def n_trajectories(self) -> int | None:
+        return self._get_n_trajectories(self.noise_model, check_value=False)
+
+    @lru_cache(maxsize=2)
+    def _get_noiseless_data(self, leakage: bool) -> HamiltonianData:
+        """simulation.py:266-297: a second HamiltonianData (draws RNG once)."""
+        if leakage:
+            noise = NoiseModel(eff_noise_opers=(np.zeros((3, 3)),), eff_noise_rates=(0.0,),
+                               with_leakage=True)
+        else:
+            noise = NoiseModel()
+        return HamiltonianData(self.samples_obj, noise, n_trajectories=1)
+
+    @property
+    def _noiseless_problem(self) -> dict[str, Any]:
+        hd = self._get_noiseless_data(False)
+        return hd.problem(hd.noise_trajectories[0], self._sampling_rate)
+
+    @property
+    def sampling_times(self) -> np.ndarray:
+        self._get_noiseless_data(False)
+        return sampling_times(self.samples_obj.max_duration, self._sampling_rate)
+
+    @property
+    def dim(self) -> int:
+        return len(self._hamiltonian_data.eigenbasis)
+
+    @property
+    def basis_name(self) -> str:
+        return self._hamiltonian_data.basis_name
+
+    @property
+    def basis(self) -> dict[str, QState]:
+        eb = self._hamiltonian_data.eigenbasis
+        return {s: QState(np.eye(len(eb))[i]) for i, s in enumerate(eb)}
+
+    @property
+    def noise_model(self) -> Any:
+        return self._hamiltonian_data.noise_model
+
+    @property
+    def config(self) -> SimConfig:
+        return SimConfig.from_noise_model(self._hamiltonian_data.noise_model)
+
+    @property
+    def total_duration_ns(self) -> int:
+        return self._tot_duration
+
+    @property
+    def initial_state(self) -> QState:
+        return self._initial_state
+
+    def _all_ground(self) -> QState:
+        eb = self._hamiltonian_data.eigenbasis
+        v = "u" if self._hamiltonian_data.interaction_type == "XY" else "g"
+        loc = eb.index(v)
+        idx = 0
+        for _ in range(self._hamiltonian_data.n_qudits):
+            idx = idx * len(eb) + loc
+        psi = np.zeros(len(eb) ** self._hamiltonian_data.n_qudits, dtype=complex)
+        psi[idx] = 1.0
+        return QState(psi)
+
+    def set_initial_state(self, state: Any) -> None:
+        """simulation.py:484-525."""
+        if isinstance(state, str) and state == "all-ground":
+            self._initial_state = self._all_ground()
+            self._initial_is_ground = True
+            return
+        arr = np.asarray(state)
+        shape = arr.shape[0]
+        legal_shape = self.dim ** self._hamiltonian_data.n_qudits
+        if shape != legal_shape:
+            raise ValueError(
+                "Incompatible shape of initial state."
+                + f"Expected {legal_shape}, got {shape}."
+            )
+        self._initial_state = QState(arr.reshape(-1)).unit()
+        self._initial_is_ground = bool(
+            np.array_equal(np.asarray(self._initial_state), np.asarray(self._all_ground()))
+        )
+
+    @property
+    def evaluation_times(self) -> np.ndarray:
+        return np.array(self._eval_times_array)
+
+    def set_evaluation_times(self, value: Any) -> None:
+        """simulation.py:532-599."""
+        st = self.sampling_times
+        if isinstance(value, str):
+            if value == "Full":
+                eval_times = np.copy(st)
+            elif value == "Minimal":
+                eval_times = np.array([])
+            else:
+                raise ValueError(
+                    "Wrong evaluation time label. It should "
+                    "be `Full`, `Minimal`, an array of times or"
+                    + " a float between 0 and 1."
+                )
+        elif isinstance(value, float):
+            if value > 1 or value <= 0:
+                raise ValueError("evaluation_times float must be between 0 and 1.")
+            indices = np.linspace(0, len(st) - 1, int(value * len(st)), dtype=int)
+            eval_times = st[indices]
+        elif isinstance(value, (list, tuple, np.ndarray)):
+            if np.max(value, initial=0) > self._tot_duration * 1e-3:
+                raise ValueError(
+                    "Provided evaluation-time list extends further than sequence duration."
+                )
+            if np.min(value, initial=0) < 0:
+                raise ValueError("Provided evaluation-time list contains negative values.")
+            eval_times = np.array(value)
+        else:
+            raise ValueError(
+                "Wrong evaluation time label. It should "
+                "be `Full`, `Minimal`, an array of times or a "
+                + "float between 0 and 1."
+            )
+        self._eval_times_array = np.union1d(eval_times, [0.0, self._tot_duration * 1e-3])
+        self._eval_times_instruction = value
+
+    # --------------------------------------------------------------- operators
+    def build_operator(self, operations: Union[list, tuple]) -> np.ndarray:
+        """Dense operator from ``[(op, qubits), ...]`` (hamiltonian.py:145-200)."""
+        eb = self._hamiltonian_data.eigenbasis
+        d, n = len(eb), self._hamiltonian_data.n_qudits
+        ops = {"I": np.eye(d, dtype=complex)}
+        for i, a in enumerate(eb):
+            for j, b in enumerate(eb):
+                m = np.zeros((d, d), dtype=complex)
+                m[i, j] = 1
+                ops["sigma_" + a + b] = m
+        if not isinstance(operations, list):
+            operations = [operations]
+        qids = list(self.samples_obj.qubit_ids)
+        op_list = [ops["I"]] * n
+        for operator, qubits in operations:
+            if isinstance(operator, str):
+                if operator not in ops:
+                    raise ValueError(f"{operator} is not a valid operator")
+                operator = ops[operator]
+            operator = np.asarray(operator, dtype=complex)
+            if qubits == "global":
+                return sum(self.build_operator([(operator, [q])]) for q in qids)
+            if len(set(qubits)) < len(qubits):
+                raise ValueError("Duplicate atom ids in argument list.")
+            if not set(qubits).issubset(qids):
+                raise ValueError("Invalid qubit names: " f"{set(qubits) - set(qids)}")
+            for q in qubits:
+                op_list[qids.index(q)] = operator
+        out = np.eye(1, dtype=complex)
+        for m in op_list:
+            out = np.kron(out, m)
+        return out
+
+    def get_hamiltonian(self, time: float, noiseless: bool = False) -> np.ndarray:
+        """Dense H(t) in rad/us at ``time`` ns (simulation.py:625-661); built by
+        applying the device generator to the identity (small registers only)."""
+        if time > self._tot_duration:
+            raise ValueError(
+                f"Provided time (`time` = {time}) must be "
+                "less than or equal to the sequence duration "
+                f"({self._tot_duration})."
+            )
+        if time < 0:
+            raise ValueError(
+                f"Provided time (`time` = {time}) must be greater than or equal to 0."
+            )
+        from .engine import Engine
+
+        prob = dict(self._noiseless_problem if noiseless else self._current_problem)
+        prob["collapse_ops"] = []
+        n = prob["n_qudits"]
+        if n > 12:
+            raise ValueError("get_hamiltonian materialises a dense matrix; N <= 12 only.")
+        D = 2**n
+        cols = np.zeros((D, D), dtype=complex)
+        with Engine.from_problems([prob], mode="sesolve") as eng:
+            import torch
+
+            for j in range(D):
+                e = torch.zeros((1, D), dtype=torch.complex128, device=eng.device)
+                e[0, j] = 1.0
+                cols[:, j] = eng.apply_generator(e, time / 1000).cpu().numpy()[0]
+        return QState(1j * cols)  # G = -iH, column j = G e_j
+
+    # --------------------------------------------------------------------- run
+    def _validate_options(self, options: dict[str, Any]) -> None:
+        """simulation.py:768-797."""
+        from .hamiltonian_data import ChannelInput  # noqa: F401
+
+        def min_variation(ch: Any) -> int:  # simulation.py:663-687
+            end_point = ch.duration - 1
+            mins = []
+            for sample in (np.asarray(ch.amp), np.asarray(ch.det)):
+                mins.append(int(np.min(np.diff(np.nonzero(np.diff(sample)), prepend=-1,
+                                               append=end_point))))
+            return min(mins)
+
+        options.setdefault(
+            "max_step", min(min_variation(ch) for ch in self.samples_obj.channels) / 1000
+        )
+        options.setdefault("nsteps", max(1000, self._tot_duration // options["max_step"]))
+        if "SPAM" in self.noise_model.noise_types:
+            if self.noise_model.state_prep_error > 0 and not self._initial_is_ground:
+                raise NotImplementedError(
+                    "Can't combine state preparation errors with an initial "
+                    "state different from the ground."
+                )
+
+    def _solver_mode(self, problem: dict[str, Any]) -> str:
+        """simulation.py:705-718."""
+        if len(problem["collapse_ops"]) == 0:
+            return "sesolve"
+        if self.solver == Solver.DEFAULT:
+            mode = "mcsolve" if has_stochastic_noise(self.noise_model) else "mesolve"
+        else:
+            mode = {Solver.MCSOLVER: "mcsolve", Solver.MESOLVER: "mesolve"}[self.solver]
+        if mode == "mcsolve":
+            raise NotImplementedError(
+                "The Monte-Carlo wavefunction solver (qutip.mcsolve) is not part of "
+                "the MI355X backend; pass solver=Solver.MESOLVER to integrate the "
+                "master equation for every noise trajectory instead."
+            )
+        return mode
+
+    def _engine_kwargs(self, options: dict[str, Any]) -> dict[str, Any]:
+        kw = {}
+        for k in ("tol", "taylor_order", "max_order", "magnus_tol"):
+            if k in options:
+                kw[k] = options[k]
+        if options.get("max_step"):
+            kw["max_step"] = float(options["max_step"])
+        return kw
+
+    def _solve_batch(self, problems: list[dict[str, Any]], progress_bar: Any,
+                     options: dict[str, Any]) -> list[CoherentResults]:
+        """The solver call of ``_run_solver`` (simulation.py:689-766) for a batch
+        of trajectories in ONE engine (one GPU launch sequence)."""
+        if progress_bar not in (True, False, None):
+            raise ValueError("`progress_bar` must be a bool.")
+        from .engine import Engine
+
+        mode = self._solver_mode(problems[0])
+        times = self._eval_times_array
+        with Engine.from_problems(problems, mode=mode) as eng:
+            state = eng.new_state(np.asarray(self._initial_state).reshape(1, -1))
+            first = state.cpu().numpy()
+            snaps = eng.solve(state, times, store=True, **self._engine_kwargs(options))
+            host = snaps.cpu().numpy()
+            self.last_engine_stats = eng.stats()
+        meas_errors = (
+            {"epsilon": self.noise_model.p_false_pos, "epsilon_prime": self.noise_model.p_false_neg}
+            if "SPAM" in self.noise_model.noise_types else None
+        )
+        qids = tuple(self.samples_obj.qubit_ids)
+        n = self._hamiltonian_data.n_qudits
+        out = []
+        for b in range(len(problems)):
+            results = []
+            for i, t in enumerate(times):
+                st = first[b] if i == 0 else host[i - 1][b]
+                results.append(
+                    StateResult(qids, self._meas_basis, QState(st),
+                                self._meas_basis in self.basis_name,
+                                evaluation_time=float(t / (self._tot_duration * 1e-3)))
+                )
+            out.append(CoherentResults(results, n, self.basis_name, times, self._meas_basis,
+                                       meas_errors))
+        return out
+
+    def run(self, progress_bar: bool = False, print_progress: bool = False,
+            **options: Any) -> SimulationResults:
+        """simulation.py:800-883.  ``options`` accepts QuTiP's ``max_step`` (an
+        upper bound on the step, us) plus the engine's ``tol``,
+        ``taylor_order``, ``magnus_tol``; QuTiP-only keys are ignored."""
+        warnings.warn(
+            "QutipEmulator is deprecated as of pulser 1.9. Please use QutipBackendV2 instead.",
+            DeprecationWarning,
+            stacklevel=2,
+        )
+        self._validate_options(options)
+        if not has_stochastic_noise(self.noise_model):
+            if print_progress:
+                print("Emulating Trajectory 1/1")
+            return self._solve_batch([self._current_problem], progress_bar, options)[0]
+
+        total_count = np.array([Counter() for _ in self._eval_times_array])
+        for res, reps in self._noisy_runs(progress_bar, print_progress, **options):
+            total_count += np.array(
+                [
+                    res.sample_state(t, n_samples=self.noise_model.samples_per_run * reps)
+                    for t in self._eval_times_array
+                ]
+            )
+        n_measures = cast(int, self.n_trajectories) * self.noise_model.samples_per_run
+        qids = tuple(self.samples_obj.qubit_ids)
+        results = [
+            SampledResult(qids, self._meas_basis, total_count[ind],
+                          evaluation_time=float(t / (self._tot_duration * 1e-3)))
+            for ind, t in enumerate(self._eval_times_array)
+        ]
+        return NoisyResults(results, self._hamiltonian_data.n_qudits, self.basis_name,
+                            self._eval_times_array, n_measures)
+
+    def _noisy_runs(self, progress_bar: Any, print_progress: bool = False,
+                    batch: int | None = None, **options: Any
+                    ) -> Iterator[tuple[CoherentResults, int]]:
+        """simulation.py:885-915; trajectories are solved in GPU batches but
+        yielded (and therefore sampled) in the reference's serial order."""
+        n_trajectories = self.n_trajectories
+        if self._noise_trajectories_used:  # fresh draws on every further run (:892-900)
+            nm = self._hamiltonian_data.noise_model
+            self._hamiltonian_data = HamiltonianData(
+                self.samples_obj, nm, self._get_n_trajectories(nm, check_value=True))
+            self._problems = self._build_problems()
+        self._noise_trajectories_used = True
+        probs = self._problems
+        n_eval = len(self._eval_times_array)
+        dim_bytes = 16 * (2 ** self._hamiltonian_data.n_qudits) ** (
+            2 if len(probs[0]["collapse_ops"]) else 1)
+        if batch is None:  # keep the snapshot tensor under ~8 GB
+            batch = int(max(1, min(256, (8 << 30) // max(1, dim_bytes * n_eval))))
+        traj_nb = 0
+        for start in range(0, len(probs), batch):
+            chunk = probs[start:start + batch]
+            solved = self._solve_batch(chunk, progress_bar, options)
+            for prob, res in zip(chunk, solved):
+                reps = prob["reps"]
+                if print_progress:
+                    if reps == 1:
+                        print(f"Emulating Trajectory {traj_nb+1}/{n_trajectories}")
+                    else:
+                        print("Emulating Trajectories "
+                              f"[{traj_nb+1} - {traj_nb+reps}]/{n_trajectories}")
+                self._current_problem = prob
+                traj_nb += reps
+                yield res, reps
+
+    @classmethod
+    def from_sequence(cls, sequence: Any, sampling_rate: float = 1.0,
+                      config: Optional[SimConfig] = None,
+                      evaluation_times: Union[float, str, Any] = "Full",
+                      with_modulation: bool = False, noise_model: Any = None,
+                      solver: Solver = Solver.DEFAULT,
+                      n_trajectories: int | None = None) -> "QutipEmulator":
+        """simulation.py:955-1051 - needs ``pulser`` for the sampler."""
+        if not (hasattr(sequence, "is_parametrized") and hasattr(sequence, "_schedule")):
+            raise TypeError("The provided sequence has to be a valid pulser.Sequence instance.")
+        if sequence.is_parametrized() or sequence.is_register_mappable():
+            raise ValueError(
+                "The provided sequence needs to be built to be simulated. Call"
+                " `Sequence.build()` with the necessary parameters."
+            )
+        if not sequence._schedule:
+            raise ValueError("The provided sequence has no declared channels.")
+        if all(sequence._schedule[x][-1].tf == 0 for x in sequence.declared_channels):
+            raise ValueError("No instructions given for the channels in the sequence.")
+        if with_modulation and sequence._slm_mask_targets:
+            raise NotImplementedError(
+                "Simulation of sequences combining an SLM mask and output "
+                "modulation is not supported."
+            )
+        from pulser.sampler import sampler  # user-side dependency
+
+        samples = sampler.sample(
+            sequence, modulation=with_modulation,
+            extended_duration=sequence.get_duration(include_fall_time=with_modulation),
+        )
+        return cls(samples, sequence.register, sequence.device, sampling_rate, config,
+                   evaluation_times, noise_model=noise_model, solver=solver,
+                   n_trajectories=n_trajectories)

@@ -1,0 +1,413 @@
+"""CPU tests of the host-side logic (no GPU, no pulser needed).
+
+* the oracle against the reference's golden vectors (known answers);
+* the product's restated HamiltonianData / results / sampling against fixtures
+  captured from the real pulser-core (tests/golden/make_fixtures.py) and
+  against the reference's seeded golden Counters, with the solver call replaced
+  by the fixture's stored states (the HIP solver itself is covered by -m gpu);
+* the C-ABI library loads and exports every symbol include/rydemu.h declares.
+"""
+import os
+import re
+from collections import Counter
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_fixture, with_anneal_samples
+
+import pulser_amd
+from pulser_amd import problem as P
+from pulser_amd.hamiltonian_data import (ChannelInput, HamiltonianData,
+                                         SequenceInputs, Slot, single_global_channel)
+from pulser_amd.noise_model import NoiseModel, LEGACY_DEFAULTS
+from pulser_amd.results import (CoherentResults, QState, StateResult, multinomial,
+                                spam_flips)
+from pulser_amd.simulation import QutipEmulator, SimConfig, Solver
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --------------------------------------------------------------------- oracle
+@pytest.mark.parametrize("k", range(7))
+def test_oracle_reproduces_reference_golden_counters_rydberg(k):
+    """tests/pulser_simulation/test_simulation.py:978-1040 (seed 123)."""
+    from oracle import qutip_path as qp, sampling as osamp
+
+    prob, extra = load_fixture(f"noises_rydberg_{k}.npz")
+    aux = extra["aux"]
+    ham = qp.build_hamiltonian(prob)
+    assert len(ham.collapse) == extra["n_collapse_ops"] * prob["n_qudits"]
+    psi0 = qp.all_ground_state(prob["n_qudits"], prob["eigenbasis"])
+    states = qp.mesolve(ham, psi0, aux["eval_times"], **aux["options"])
+    assert np.max(np.abs(states[-1] - extra["oracle_final_state_default"])) < 1e-12
+    # replay the RNG: constructor draws (first + hidden noiseless HamiltonianData)
+    np.random.seed(123)
+    n = prob["n_qudits"]
+    ntraj = LEGACY_DEFAULTS["runs"] if False else 1
+    np.random.uniform(size=n * ntraj)
+    np.random.uniform(size=n)
+    c = osamp.sample_state(states, aux["eval_times"], aux["eval_times"][-1], 1000, n,
+                           prob["eigenbasis"], aux["meas_basis"], aux["matching_meas_basis"])
+    assert dict(c) == extra["reference_golden_counter"]
+    rho = states[-1]
+    tr2 = np.trace(rho @ rho).real
+    assert tr2 < 1 and not np.isclose(tr2, 1)  # test_simulation.py:1033-1034
+
+
+def test_oracle_three_atom_state_and_lookup_quirk():
+    """test_simulation.py:2156-2190 + SURVEY F5 (penultimate sample lookup)."""
+    prob, extra = load_fixture("three_atom_state.npz")
+    idx = int(extra["oracle_lookup_index"])
+    assert idx == 3999  # first index within 1e-3 of 4.0 us, not the last one
+    st = np.asarray(extra["oracle_states_default"])[2]
+    st = st * np.exp(-1j * np.angle(st[np.argmax(np.abs(st))]))
+    assert np.all(np.isclose(st, extra["reference_golden_state"], 1e-2))
+
+
+def test_oracle_liouvillian_matches_matrix_free_rhs():
+    from oracle import qutip_path as qp
+    from helpers import DEPOL_PAULIS, local_problem
+
+    ops = [(np.sqrt(0.1), "sigma_rr"), (np.sqrt(0.07), "sigma_gr")] + [(np.sqrt(0.0125), p) for p in "xyz"]
+    prob = local_problem(2, seed=2, collapse_ops=ops, paulis=DEPOL_PAULIS)
+    ham = qp.build_hamiltonian(prob)
+    rng = np.random.default_rng(0)
+    rho = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4))
+    L = qp.liouvillian(ham, 0.123)
+    ref = (L @ rho.ravel(order="F")).reshape(4, 4, order="F")  # column stacking
+    got = qp.lindblad_rhs(ham)(0.123, rho.ravel()).reshape(4, 4)
+    assert np.max(np.abs(ref - got)) < 1e-12
+
+
+# ----------------------------------------------------------- synthetic inputs
+def test_synthetic_generators_match_pulser_fixtures():
+    prob, extra = load_fixture("cfg1_square4_pi.npz")
+    coords = P.register_coords(P.square_rect(2, 2), 5.0)
+    assert np.array_equal(coords, prob["coords"])
+    amp = np.concatenate([P.blackman_samples(1000, np.pi), [0.0]])
+    assert np.array_equal(amp, prob["samples"]["Global"]["ground-rydberg"]["amp"])
+    assert np.array_equal(P.interaction_matrix(coords, P.C6_LEVEL70), prob["interaction_matrix"])
+    prob, extra = load_fixture("cfg2_chain12_anneal.npz")
+    rb = float(extra["blockade_radius"])
+    assert abs(rb - 8.692) < 1e-3
+    assert np.allclose(P.register_coords(P.square_rect(1, 12), rb), prob["coords"], atol=1e-12)
+    s = P.anneal_samples()
+    assert len(s["amp"]) == 3101 and s["amp"][-1] == 0.0 and s["det"][-1] == 0.0
+    prob, extra = load_fixture("cfg3_tri6_dephasing.npz")
+    assert np.allclose(P.register_coords(P.triangular_rect(2, 3), float(extra["blockade_radius"])),
+                       prob["coords"], atol=1e-12)
+
+
+def test_problem_roundtrip(tmp_path):
+    from helpers import DEPOL_PAULIS, local_problem
+
+    prob = local_problem(3, collapse_ops=[(0.1, "x"), (0.2 + 0.1j, np.eye(2))], paulis=DEPOL_PAULIS)
+    path = str(tmp_path / "p.npz")
+    P.save_problem(path, prob, note="x", arr=np.arange(3))
+    back, extra = P.load_problem(path)
+    assert back["qubit_ids"] == prob["qubit_ids"] and extra["note"] == "x"
+    assert np.array_equal(back["samples"]["Local"]["ground-rydberg"][2]["amp"],
+                          prob["samples"]["Local"]["ground-rydberg"][2]["amp"])
+    assert back["collapse_ops"][1][0] == 0.2 + 0.1j
+
+
+# ------------------------------------------------- restated HamiltonianData
+def _chain12_inputs(extra):
+    coords = P.register_coords(P.square_rect(1, 12), float(extra["blockade_radius"]))
+    s = P.anneal_samples()
+    un = {k: v[:-1] for k, v in s.items()}  # un-extended, as the sampler hands it over
+    return single_global_channel(coords, un, P.C6_LEVEL70, extended=False)
+
+
+def test_noise_trajectories_follow_reference_rng_order():
+    """cfg4: doppler + amplitude + SPAM, seed 0, 1024 trajectories - every draw
+    must equal what pulser-core's HamiltonianData drew (fixture)."""
+    prob0, extra = load_fixture("cfg4_chain12_noise.npz")
+    nm = NoiseModel(**extra["noise_model"])
+    assert set(nm.noise_types) == {"SPAM", "amplitude", "doppler"}
+    inputs = _chain12_inputs(extra).extend_duration(3101)
+    np.random.seed(0)
+    hd = HamiltonianData(inputs, nm, int(extra["n_trajectories"]))
+    assert np.array_equal(np.random.get_state()[1][:4], extra["rng_probe_after_ctor"])
+    trajs = hd.noise_trajectories
+    assert len(trajs) == 1024
+    assert np.array_equal(np.array([t.bad_atoms for t in trajs]), extra["traj_bad_atoms"])
+    assert np.array_equal(np.array([t.doppler_detune for t in trajs]), extra["traj_doppler"])
+    assert np.array_equal(np.array([t.amp_fluctuations["ising_global"] for t in trajs]),
+                          extra["traj_amp_fluctuation"])
+    p = hd.problem(trajs[0], 1.0)
+    for q in range(12):
+        for key in ("amp", "det", "phase"):
+            assert np.array_equal(p["samples"]["Local"]["ground-rydberg"][q][key],
+                                  prob0["samples"]["Local"]["ground-rydberg"][q][key]), (q, key)
+    assert np.array_equal(p["interaction_matrix"], prob0["interaction_matrix"])
+    for i in range(3):
+        pi = hd.problem(trajs[i], 1.0)
+        det = np.stack([pi["samples"]["Local"]["ground-rydberg"][q]["det"] for q in range(12)])
+        amp = np.stack([pi["samples"]["Local"]["ground-rydberg"][q]["amp"] for q in range(12)])
+        assert np.array_equal(det[:, ::100], extra["kept_det"][i])
+        assert np.array_equal(amp[:, ::100], extra["kept_amp"][i])
+        assert np.array_equal(pi["interaction_matrix"], extra["kept_interaction"][i])
+
+
+def test_spam_only_trajectories_are_deduplicated():
+    """hamiltonian_data.py:795-835: Counter(...).most_common() -> (config, reps)."""
+    _, extra = load_fixture("cfg4_chain12_noise.npz")
+    inputs = _chain12_inputs(extra).extend_duration(3101)
+    np.random.seed(0)
+    hd = HamiltonianData(inputs, NoiseModel(state_prep_error=0.005, dephasing_rate=0.05), 1024)
+    reps = [t.reps for t in hd.noise_trajectories]
+    assert sum(reps) == 1024 and reps == sorted(reps, reverse=True)
+    assert not hd.noise_trajectories[0].bad_atoms.any()
+    assert hd.local_noises and hd.collapse_ops()[0] == [(np.sqrt(0.1), "sigma_rr")]
+
+
+# ---------------------------------- emulator front-end with the solver stubbed
+class _FakeSolve:
+    """Stands in for the HIP solver call: returns the fixture's stored state at
+    every evaluation time (only the looked-up one matters for sampling)."""
+
+    def __init__(self, emu, state):
+        self.emu, self.state = emu, state
+
+    def __call__(self, problems, progress_bar, options):
+        emu = self.emu
+        qids = tuple(emu.samples_obj.qubit_ids)
+        me = ({"epsilon": emu.noise_model.p_false_pos, "epsilon_prime": emu.noise_model.p_false_neg}
+              if "SPAM" in emu.noise_model.noise_types else None)
+        res = [StateResult(qids, emu._meas_basis, QState(self.state),
+                           emu._meas_basis in emu.basis_name)
+               for _ in emu._eval_times_array]
+        return [CoherentResults(res, len(qids), emu.basis_name, emu._eval_times_array,
+                                emu._meas_basis, me) for _ in problems]
+
+
+def _inputs_from_problem(prob, basis, c6=P.C6_LEVEL70):
+    n = prob["n_qudits"]
+    chans = []
+    if prob["samples"]["Global"]:
+        s = prob["samples"]["Global"][basis]
+        T = len(s["amp"]) - 1
+        chans.append(ChannelInput("g", "Global", basis, s["amp"][:-1], s["det"][:-1],
+                                  s["phase"][:-1], [Slot(0, T, tuple(range(n)))]))
+    for q, s in prob["samples"]["Local"].get(basis, {}).items():
+        T = len(s["amp"]) - 1
+        chans.append(ChannelInput(f"l{q}", "Local", basis, s["amp"][:-1], s["det"][:-1],
+                                  s["phase"][:-1], [Slot(0, T, (int(q),))]))
+    return SequenceInputs(prob["coords"], prob["qubit_ids"], chans, c6)
+
+
+@pytest.mark.parametrize("k", range(7))
+def test_emulator_golden_counters_rydberg(k, monkeypatch):
+    """test_simulation.py:978-1040 through the product's front-end: NoiseModel
+    -> collapse specs, RNG order (constructor draws), weights, multinomial."""
+    prob, extra = load_fixture(f"noises_rydberg_{k}.npz")
+    noise = tuple(extra["noise"])
+    params = {}
+    if "dephasing" in noise:
+        params.update(dephasing_rate=0.05, hyperfine_dephasing_rate=1e-3)
+    if "relaxation" in noise:
+        params.update(relaxation_rate=0.01)
+    if "depolarizing" in noise:
+        params.update(depolarizing_rate=0.05)
+    leak = "leakage" in noise
+    if leak or "eff_noise" in noise:
+        params["eff_noise_opers"] = [np.diag([1.0, 0, 0]).astype(complex) if leak
+                                     else np.diag([1.0, -1.0]).astype(complex)]
+        params["eff_noise_rates"] = [0.1 if leak else 0.025]
+    np.random.seed(123)
+    emu = QutipEmulator(_inputs_from_problem(prob, "ground-rydberg"), sampling_rate=0.01,
+                        noise_model=NoiseModel(with_leakage=leak, **params))
+    assert set(emu.noise_model.noise_types) == set(noise)
+    p = emu._current_problem
+    assert p["basis_name"] == prob["basis_name"] and p["eigenbasis"] == list(prob["eigenbasis"])
+    assert len(p["collapse_ops"]) == extra["n_collapse_ops"]
+    for (c1, o1), (c2, o2) in zip(p["collapse_ops"], prob["collapse_ops"]):
+        assert np.isclose(c1, c2) and (o1 == o2 if isinstance(o1, str) else np.array_equal(o1, o2))
+    assert np.array_equal(emu.evaluation_times, extra["aux"]["eval_times"])
+    opts = {}
+    emu._validate_options(opts)
+    assert opts["max_step"] == extra["aux"]["options"]["max_step"]
+    assert opts["nsteps"] == extra["aux"]["options"]["nsteps"]
+    monkeypatch.setattr(emu, "_solve_batch", _FakeSolve(emu, extra["oracle_lookup_state_default"]))
+    with pytest.warns(DeprecationWarning, match="QutipEmulator is deprecated as of pulser 1.9"):
+        res = emu.run()
+    assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
+
+
+@pytest.mark.parametrize("k", range(7))
+def test_emulator_golden_counters_digital(k, monkeypatch):
+    """test_simulation.py:1079-1160 (3 atoms, digital basis, d = 2 or 3)."""
+    prob, extra = load_fixture(f"noises_digital_{k}.npz")
+    noise = tuple(extra["noise"])
+    params = {}
+    if "dephasing" in noise:
+        params.update(dephasing_rate=0.05, hyperfine_dephasing_rate=0.05)
+    if "depolarizing" in noise:
+        params.update(depolarizing_rate=0.05)
+    leak = "leakage" in noise
+    if leak or "eff_noise" in noise:
+        params["eff_noise_opers"] = [np.diag([0, 1.0, 0]).astype(complex) if leak
+                                     else np.diag([1.0, -1.0]).astype(complex)]
+        params["eff_noise_rates"] = [0.1 if leak else 0.025]
+    np.random.seed(123)
+    emu = QutipEmulator(_inputs_from_problem(prob, "digital"), sampling_rate=0.01,
+                        noise_model=NoiseModel(with_leakage=leak, **params))
+    assert emu.basis_name == prob["basis_name"] and emu._meas_basis == "digital"
+    assert emu._current_problem["eigenbasis"] == list(prob["eigenbasis"])
+    monkeypatch.setattr(emu, "_solve_batch", _FakeSolve(emu, extra["oracle_lookup_state_default"]))
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
+
+
+def test_emulator_validation_messages_and_defaults():
+    _, extra = load_fixture("cfg4_chain12_noise.npz")
+    inputs = _chain12_inputs(extra)
+    with pytest.raises(ValueError, match="must be greater than 0 and less than or equal to 1"):
+        QutipEmulator(inputs, sampling_rate=0.0)
+    with pytest.raises(ValueError, match="`sampling_rate` is too small, less than 4 data points."):
+        QutipEmulator(inputs, sampling_rate=0.001)
+    with pytest.raises(ValueError, match="'n_trajectories' must be defined"):
+        QutipEmulator(inputs, noise_model=NoiseModel(temperature=50.0))
+    with pytest.raises(TypeError, match="valid SequenceSamples instance"):
+        QutipEmulator("nope")
+    emu = QutipEmulator(inputs, evaluation_times="Minimal")
+    assert np.array_equal(emu.evaluation_times, [0.0, 3.1])
+    assert emu.total_duration_ns == 3100 and emu.dim == 2 and emu.basis_name == "ground-rydberg"
+    assert len(emu.sampling_times) == 3101
+    emu.set_evaluation_times(0.5)
+    assert len(emu.evaluation_times) == 1550  # int(0.5 * 3101) knots, ends included
+    with pytest.raises(ValueError, match="extends further than sequence duration"):
+        emu.set_evaluation_times([0.0, 5.0])
+    with pytest.raises(ValueError, match="Wrong evaluation time label"):
+        emu.set_evaluation_times("Best")
+    with pytest.raises(ValueError, match="Incompatible shape of initial state.Expected 4096, got 3"):
+        emu.set_initial_state(np.ones(3))
+    assert np.asarray(emu.initial_state)[-1, 0] == 1.0
+    opts = {}
+    emu._validate_options(opts)
+    assert opts == {"max_step": 0.001, "nsteps": 3100 // 0.001}  # = 3099999.0, as simulation.py:778-780 computes it
+    with pytest.raises(NotImplementedError, match="Monte-Carlo"):
+        QutipEmulator(inputs, noise_model=NoiseModel(temperature=50.0, dephasing_rate=0.1),
+                      n_trajectories=2)._solver_mode({"collapse_ops": [1]})
+    op = emu.build_operator([("sigma_rr", ["q0", "q11"])])
+    assert op.shape == (4096, 4096) and op[0, 0] == 1 and op[1, 1] == 0
+    with pytest.raises(ValueError, match="Duplicate atom ids"):
+        emu.build_operator([("sigma_rr", ["q0", "q0"])])
+
+
+def test_simconfig_noise_model_roundtrip():
+    with pytest.warns(DeprecationWarning, match="'SimConfig' has been deprecated"):
+        cfg = SimConfig(noise=("SPAM", "doppler", "dephasing"), eta=0.02, temperature=30.0, runs=7)
+    nm = cfg.to_noise_model()
+    assert set(nm.noise_types) == {"SPAM", "doppler", "dephasing"}
+    assert nm.state_prep_error == 0.02 and abs(nm.temperature - 30.0) < 1e-9 and nm.runs == 7
+    with pytest.warns(DeprecationWarning):
+        back = SimConfig.from_noise_model(nm)
+    assert set(back.noise) == set(nm.noise_types) and back.eta == 0.02
+
+
+# ------------------------------------------------------------ results/sampling
+def test_weights_multinomial_and_flips_match_oracle():
+    from oracle import sampling as osamp
+
+    rng = np.random.default_rng(3)
+    n = 5
+    psi = rng.normal(size=32) + 1j * rng.normal(size=32)
+    psi /= np.linalg.norm(psi)
+    res = StateResult(tuple(range(n)), "ground-rydberg", QState(psi), True)
+    w = res._weights()
+    assert np.array_equal(w, osamp.weights(psi, n, ["r", "g"], "ground-rydberg"))
+    assert np.array_equal(w, (np.abs(psi) ** 2)[::-1] / sum((np.abs(psi) ** 2)[::-1]))
+    np.random.seed(5)
+    a = res.get_samples(500)
+    np.random.seed(5)
+    b = osamp.get_samples(w, 500, n)
+    assert a == b and list(a) == list(b)  # same insertion order
+    np.random.seed(9)
+    fa = spam_flips(a, 0.01, 0.05)
+    np.random.seed(9)
+    fb = osamp.spam_flips(b, 0.01, 0.05)
+    assert fa == fb
+    rho = np.outer(psi, psi.conj())
+    assert np.allclose(StateResult(tuple(range(n)), "ground-rydberg", QState(rho), True)._weights(), w)
+    # reference's own multinomial test (tests/math/test_multinomial.py:19-37)
+    np.random.seed(1337)
+    probs = np.array([0.2, 0.5, 0.3])
+    idx = multinomial(10000, probs)
+    assert np.allclose(np.bincount(idx) / 10000, probs, atol=0.02)
+
+
+def test_cfg3_counters_with_spam_flips():
+    """Product sampling (weights + multinomial + flips) against the oracle's
+    Counters for the cfg3 physics at N = 6 (seed 123)."""
+    prob, extra = load_fixture("cfg3_tri6_dephasing.npz")
+    states = np.asarray(extra["oracle_states_default"])
+    times = np.asarray(extra["eval_times"])
+    qids = tuple(prob["qubit_ids"])
+    res = [StateResult(qids, "ground-rydberg", QState(s), True) for s in states]
+    cr = CoherentResults(res, 6, "ground-rydberg", times, "ground-rydberg",
+                         dict(extra["meas_errors"]))
+    assert cr._get_index_from_time(3.1) == 4  # first match: the 3.099 us sample
+    np.random.seed(123)
+    c = cr.sample_state(3.099, 1000)
+    assert c == Counter(extra["oracle_counter_t3099_spam"])
+    dens = cr._calc_pseudo_density(5)
+    assert abs(np.trace(np.asarray(dens)) - 1) < 1e-12
+    nk = np.diag(1.0 - ((np.arange(64) >> 5) & 1)).astype(complex)
+    e = cr.expect([nk])[0]
+    assert e.shape == (6,) and 0 <= e[-1] <= 1
+
+
+# ------------------------------------------------------------------ lowering
+def test_lowering_matches_oracle_terms():
+    from oracle import qutip_path as qp
+    from pulser_amd.terms import lower
+
+    prob, _ = load_fixture("cfg2_chain12_anneal.npz")
+    prob = with_anneal_samples(prob)
+    t = lower([prob])
+    ham = qp.build_hamiltonian(prob)
+    assert np.array_equal(t.tknots, ham.tlist) and t.pp.shape == (2, 3100, 4)
+    labels = [x.label for x in ham.terms]
+    assert labels == ["int", "G:ground-rydberg:sigma_gr", "G:ground-rydberg:sigma_rr"]
+    d = t.desc[0, 0]
+    for tt in (0.0, 0.4999, 0.5003, 1.7, 3.0999):
+        i = min(int(np.searchsorted(t.tknots, tt, side="right")) - 1, 3099)
+        u = tt - t.tknots[i]
+        val = lambda s: np.polyval(t.pp[s, i], u)  # noqa: E731
+        c_or = ham.splines[0](tt)
+        det_or = -2 * ham.splines[1](tt).real
+        assert abs(val(d["drive_series"]) - c_or) < 1e-12
+        assert abs(val(d["det_series"]).real - det_or) < 1e-11
+    assert np.array_equal(t.interaction[0], prob["interaction_matrix"][0])
+    with pytest.raises(NotImplementedError, match="not supported by the MI355X backend"):
+        lower([load_fixture("noises_digital_5.npz")[0]])
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from pulser_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "rydemu.h")).read()
+    declared = set(re.findall(r"\b(ryd_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.ryd_abi_version() == _lib.RYD_ABI_VERSION
+    assert f"#define RYD_ABI_VERSION {_lib.RYD_ABI_VERSION}" in header
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pulser_amd.engine import Engine
+
+    prob, _ = load_fixture("cfg1_square4_pi.npz")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine.from_problems([prob])
