@@ -1,0 +1,138 @@
+"""GPU end-to-end: the QutipEmulator-compatible front-end on the HIP engine
+against the reference's seeded golden values and the oracle's Counters.
+
+Bit-exact bitstring Counters (sampling indices) for given seeds; states within
+1e-7 of the tight oracle; the reference's own state golden at its rtol 1e-2.
+"""
+from collections import Counter
+
+import numpy as np
+import pytest
+
+from helpers import load_fixture, with_anneal_samples
+from test_host_logic import _chain12_inputs, _inputs_from_problem
+
+from pulser_amd import NoiseModel, QutipEmulator, Solver
+from pulser_amd import problem as P
+from pulser_amd.hamiltonian_data import single_global_channel
+
+pytestmark = pytest.mark.gpu
+
+SUPPORTED_RYDBERG = [0, 1, 2, 3, 4, 5]  # index 6 = leakage (3-level): not built yet
+
+
+@pytest.mark.parametrize("k", SUPPORTED_RYDBERG)
+def test_reference_golden_counters_rydberg_end_to_end(k):
+    """tests/pulser_simulation/test_simulation.py:978-1040 with the real solver."""
+    prob, extra = load_fixture(f"noises_rydberg_{k}.npz")
+    noise = tuple(extra["noise"])
+    params = {}
+    if "dephasing" in noise:
+        params.update(dephasing_rate=0.05, hyperfine_dephasing_rate=1e-3)
+    if "relaxation" in noise:
+        params.update(relaxation_rate=0.01)
+    if "depolarizing" in noise:
+        params.update(depolarizing_rate=0.05)
+    if "eff_noise" in noise:
+        params.update(eff_noise_opers=[np.diag([1.0, -1.0]).astype(complex)], eff_noise_rates=[0.025])
+    np.random.seed(123)
+    emu = QutipEmulator(_inputs_from_problem(prob, "ground-rydberg"), sampling_rate=0.01,
+                        noise_model=NoiseModel(**params))
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
+    final = np.asarray(res.states[-1])
+    assert np.max(np.abs(final - extra["oracle_final_state_tight"])) < 1e-7
+    tr2 = np.trace(final @ final).real
+    assert tr2 < 1 and not np.isclose(tr2, 1)
+
+
+def test_leakage_is_refused_loudly():
+    prob, extra = load_fixture("noises_rydberg_6.npz")
+    np.random.seed(123)
+    emu = QutipEmulator(
+        _inputs_from_problem(prob, "ground-rydberg"), sampling_rate=0.01,
+        noise_model=NoiseModel(with_leakage=True, eff_noise_opers=[np.diag([1.0, 0, 0])],
+                               eff_noise_rates=[0.1]))
+    with pytest.warns(DeprecationWarning), pytest.raises(NotImplementedError, match="not supported"):
+        emu.run()
+
+
+def test_cfg1_plumbing_and_three_atom_golden_state():
+    prob, extra = load_fixture("cfg1_square4_pi.npz")
+    coords = P.register_coords(P.square_rect(2, 2), 5.0)
+    amp = P.blackman_samples(1000, np.pi)
+    inputs = single_global_channel(coords, {"amp": amp, "det": 0 * amp, "phase": 0 * amp},
+                                   P.C6_LEVEL70, extended=False)
+    emu = QutipEmulator(inputs)
+    assert len(emu.evaluation_times) == 1001
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    idx = np.asarray(extra["oracle_state_indices"])
+    ref = np.asarray(extra["oracle_states_tight"])
+    for j, i in enumerate(idx):
+        assert np.max(np.abs(np.asarray(res.states[i])[:, 0] - ref[j])) < 1e-7
+    np.random.seed(123)
+    assert res.sample_final_state(1000) == Counter(extra["oracle_counter_default"])
+    h0 = np.asarray(emu.get_hamiltonian(500))
+    assert np.allclose(h0, h0.conj().T) and abs(h0[0, 0] - prob["interaction_matrix"][0][np.triu_indices(4, 1)].sum()) < 1e-9
+
+    # test_simulation.py:2156-2190
+    prob, extra = load_fixture("three_atom_state.npz")
+    emu = QutipEmulator(_inputs_from_problem(prob, "ground-rydberg", c6=P.C6_LEVEL60))
+    emu.set_initial_state(np.ones(8))
+    np.random.seed(123)
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    final = np.asarray(res.get_final_state())[:, 0]
+    assert np.all(np.isclose(final, extra["reference_golden_state"], 1e-2))
+    assert res._get_index_from_time(4.0) == 3999
+
+
+def test_spam_state_prep_trajectories_mesolve_counts():
+    """SPAM state-prep errors + dephasing with Solver.MESOLVER: deduplicated
+    trajectories, batched on the GPU, sampled in the reference's serial order."""
+    prob, extra = load_fixture("cfg3_tri4_dephasing.npz")
+    prob = with_anneal_samples(prob)
+    inputs = _inputs_from_problem(prob, "ground-rydberg")
+    nm = NoiseModel(dephasing_rate=0.05, state_prep_error=0.1, p_false_pos=0.01,
+                    p_false_neg=0.05, samples_per_run=5)
+    np.random.seed(11)
+    with pytest.raises(NotImplementedError, match="Monte-Carlo"):
+        with pytest.warns(DeprecationWarning):
+            QutipEmulator(inputs, noise_model=nm, n_trajectories=12,
+                          evaluation_times="Minimal").run()
+    np.random.seed(11)
+    emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=12, solver=Solver.MESOLVER,
+                        evaluation_times="Minimal")
+    reps = [p["reps"] for p in emu._problems]
+    assert sum(reps) == 12 and len(reps) > 1
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    assert res.n_measures == 60
+    assert sum(res[-1].bitstring_counts.values()) == 60
+    # same seed, same counts (deterministic RNG order), and a fresh draw on re-run
+    np.random.seed(11)
+    emu2 = QutipEmulator(inputs, noise_model=nm, n_trajectories=12, solver=Solver.MESOLVER,
+                         evaluation_times="Minimal")
+    with pytest.warns(DeprecationWarning):
+        res2 = emu2.run()
+    assert res2[-1].bitstring_counts == res[-1].bitstring_counts
+
+
+def test_noisy_doppler_amplitude_trajectories_against_oracle():
+    """cfg4 physics, 3 trajectories: every trajectory state equals the oracle's
+    tight solution of the noisy problem captured from pulser-core."""
+    prob0, extra = load_fixture("cfg4_chain12_noise.npz")
+    nm = NoiseModel(**extra["noise_model"])
+    np.random.seed(0)
+    emu = QutipEmulator(_chain12_inputs(extra), noise_model=nm, n_trajectories=1024,
+                        evaluation_times=list(extra["eval_times"]))
+    assert len(emu._problems) == 1024
+    emu._problems = emu._problems[:3]
+    ref = np.asarray(extra["oracle_states_tight"])
+    got = emu._solve_batch(emu._problems, False, {})
+    for b in range(3):
+        for i in range(len(extra["eval_times"])):
+            assert np.max(np.abs(np.asarray(got[b].states[i])[:, 0] - ref[b][i])) < 1e-7
+    assert emu.last_engine_stats["n_launches"] == 1  # one persistent launch for the batch
