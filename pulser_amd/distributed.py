@@ -1,0 +1,196 @@
+"""Trajectory sharding over the GPUs of one node (one process per GPU).
+
+The reference runs noise trajectories in a serial Python loop
+(pulser-simulation/pulser_simulation/simulation.py:850-861, 903-915).  Each
+iteration is independent once its random parameters are drawn, so the
+(trajectory, reps) list is split into contiguous blocks balanced by reps, one
+block per rank, with NO data-path collective.  What keeps results identical to
+the serial reference - and independent of the world size - is that every random
+number is drawn on rank 0 from the global ``np.random`` stream in the
+reference's order:
+
+1. noise-trajectory parameters at construction (hamiltonian_data.py:782-911),
+2. per (trajectory, evaluation time): ``rand(n)`` for the multinomial draw
+   (math/multinomial.py:32) and, with SPAM measurement errors,
+   ``uniform(size=(n, N))`` for the bit flips (simresults.py:556-558),
+
+and broadcast.  The only collective on the result path is one all-reduce (sum)
+of the per-rank accumulators: bitstring histograms int64[n_eval, 2^N]
+(BAG_UNION of Counters == sum) and reps-weighted occupation sums
+float64[n_eval, N+1].  Backend: ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo``
+in the CPU tests.
+"""
+
+from __future__ import annotations
+
+import os
+from collections import Counter
+from typing import Any, Callable, Sequence
+
+import numpy as np
+
+
+def env_world() -> tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: str | None = None) -> Any:
+    """Initialise ``torch.distributed`` (no-op for a single process)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, local_rank, world = env_world()
+    if world == 1:
+        return None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return dist
+
+
+def partition(reps: Sequence[int], world: int) -> list[tuple[int, int]]:
+    """Contiguous [start, stop) blocks of the trajectory list, balanced by the
+    cumulative number of repetitions."""
+    reps = np.asarray(reps, dtype=np.int64)
+    total = int(reps.sum())
+    cum = np.concatenate([[0], np.cumsum(reps)])
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        i = int(np.searchsorted(cum, target, side="left"))
+        bounds.append(min(max(i, bounds[-1]), len(reps)))
+    bounds.append(len(reps))
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def sample_with(rnd: np.ndarray, weights: np.ndarray) -> np.ndarray:
+    """``multinomial`` with pre-drawn uniforms (math/multinomial.py:32-36)."""
+    return np.searchsorted(np.cumsum(weights), rnd)
+
+
+def flips_with(indices: np.ndarray, n_qudits: int, rnd_matrix: np.ndarray | None,
+               eps: float, eps_p: float) -> np.ndarray:
+    """Measurement flips of simresults.py:537-568 with a pre-drawn matrix.
+
+    The reference groups identical shots (Counter, first-occurrence order) and
+    repeats each group; the random matrix rows are consumed in that order."""
+    if rnd_matrix is None or (eps == 0.0 and eps_p == 0):
+        return indices
+    counter = Counter(int(i) for i in indices)  # insertion order = first occurrence
+    shots = np.array(list(counter.keys()), dtype=np.int64)
+    counts = np.array(list(counter.values()), dtype=np.int64)
+    bits = (shots[:, None] >> (n_qudits - 1 - np.arange(n_qudits))[None, :]) & 1
+    flip_probs = np.where(bits == 1, eps_p, eps)
+    flips = rnd_matrix < np.repeat(flip_probs, counts, axis=0)
+    new_bits = np.repeat(bits, counts, axis=0) ^ flips
+    weights = 1 << (n_qudits - 1 - np.arange(n_qudits))
+    return (new_bits * weights[None, :]).sum(axis=1)
+
+
+def predraw_sampling(reps: Sequence[int], n_eval: int, samples_per_run: int, n_qudits: int,
+                     with_meas_errors: bool) -> list[list[tuple[np.ndarray, np.ndarray | None]]]:
+    """Rank 0: all sampling random numbers in the reference's order
+    (trajectory-major, evaluation-time-minor; simulation.py:853-861)."""
+    out = []
+    for r in reps:
+        n = samples_per_run * int(r)
+        per_t = []
+        for _ in range(n_eval):
+            rnd = np.random.rand(n)
+            mat = np.random.uniform(size=(n, n_qudits)) if with_meas_errors else None
+            per_t.append((rnd, mat))
+        out.append(per_t)
+    return out
+
+
+def run_ensemble(
+    emulator: Any,
+    solve_fn: Callable[[list[dict[str, Any]]], np.ndarray] | None = None,
+    dist: Any = None,
+    batch: int = 128,
+) -> dict[str, Any]:
+    """Sharded equivalent of the stochastic branch of ``QutipEmulator.run``
+    (simulation.py:847-883).
+
+    ``emulator`` must have been constructed identically on every rank *with the
+    same seed* or - preferably - its trajectories are taken from rank 0 (done
+    here by broadcasting ``noise_trajectories``).  ``solve_fn(problems)`` returns
+    host states complex[len(problems), n_eval, dim] (default: the HIP engine).
+    Returns on every rank the total histograms int64[n_eval, 2^N], the Counters
+    and the reps-weighted mean occupations.
+    """
+    import torch
+
+    rank, _, world = env_world()
+    if dist is None:
+        world, rank = 1, 0
+    hd = emulator._hamiltonian_data
+    nm = emulator.noise_model
+    n = hd.n_qudits
+    times = emulator._eval_times_array
+    n_eval = len(times)
+    meas_err = "SPAM" in nm.noise_types and not (nm.p_false_pos == 0.0 and nm.p_false_neg == 0)
+    # -- rank 0 owns every random draw ------------------------------------
+    payload: list[Any] = [None]
+    if rank == 0:
+        trajs = hd.noise_trajectories
+        rnd = predraw_sampling([t.reps for t in trajs], n_eval, nm.samples_per_run, n, meas_err)
+        payload = [(trajs, rnd)]
+    if dist is not None:
+        dist.broadcast_object_list(payload, src=0)
+    trajs, rnd = payload[0]
+    lo, hi = partition([t.reps for t in trajs], world)[rank]
+    hist = np.zeros((n_eval, 2**n), dtype=np.int64)
+    occ_sum = np.zeros((n_eval, n + 1), dtype=np.float64)
+    if solve_fn is None:
+        def solve_fn(problems: list[dict[str, Any]]) -> np.ndarray:
+            res = emulator._solve_batch(problems, False, {})
+            return np.stack([[np.asarray(s) for s in r.states] for r in res])
+    from .results import QState, StateResult
+
+    qids = tuple(emulator.samples_obj.qubit_ids)
+    idx_bits = 1 - ((np.arange(2**n)[:, None] >> (n - 1 - np.arange(n))[None, :]) & 1)
+    for start in range(lo, hi, batch):
+        block = list(range(start, min(hi, start + batch)))
+        problems = [hd.problem(trajs[i], emulator._sampling_rate) for i in block]
+        states = solve_fn(problems)
+        for j, i in enumerate(block):
+            for ti in range(n_eval):
+                st = QState(states[j][ti])
+                w = StateResult(qids, emulator._meas_basis, st,
+                                emulator._meas_basis in emulator.basis_name)._weights()
+                r, mat = rnd[i][ti]
+                ind = sample_with(r, w)
+                ind = flips_with(ind, n, mat, nm.p_false_pos, nm.p_false_neg)
+                hist[ti] += np.bincount(ind, minlength=2**n)
+                p = np.abs(np.asarray(st)[:, 0]) ** 2 if st.isket else np.abs(st.diag())
+                occ_sum[ti, :n] += trajs[i].reps * (p @ idx_bits)
+                occ_sum[ti, n] += trajs[i].reps * p.sum()
+    # -- the one collective: sum of the per-rank accumulators -----------------
+    if dist is not None:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        th = torch.from_numpy(hist).to(dev)
+        to = torch.from_numpy(occ_sum).to(dev)
+        dist.all_reduce(th)
+        dist.all_reduce(to)
+        hist, occ_sum = th.cpu().numpy(), to.cpu().numpy()
+    n_traj = sum(t.reps for t in trajs)
+    counters = [
+        Counter({np.binary_repr(i, n): int(c) for i, c in enumerate(h) if c})
+        for h in hist
+    ]
+    return {
+        "histograms": hist,
+        "counters": counters,
+        "mean_occupations": occ_sum[:, :n] / n_traj,
+        "mean_norm": occ_sum[:, n] / n_traj,
+        "n_measures": n_traj * nm.samples_per_run,
+        "block": (lo, hi),
+    }
