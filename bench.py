@@ -99,7 +99,24 @@ def timed_run(eng, state_fn, t0, t1, steps, warmup, dist=None, torch=None):
     return dt / steps, eng.stats(), kms, kl, occ
 
 
-def roofline(nb, batch, stats, kernel_ms, launches, kernel_name):
+def measured_traffic(key):
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes of this
+    round (tools/profile.sh -> profiles/*_traffic.json); None if not measured."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if key in d:
+            return {"bytes_per_launch": d[key]["total_bytes_per_launch"],
+                    "source": os.path.relpath(path, ROOT),
+                    "method": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes"}
+    return None
+
+
+def roofline(nb, batch, stats, kernel_ms, launches, kernel_name, traffic_key=None):
     """Algorithmic bytes = 32 B x 2^nb per generator application."""
     apps = stats["n_applications"]
     bytes_total = 32.0 * (2.0**nb) * batch * apps
@@ -112,7 +129,7 @@ def roofline(nb, batch, stats, kernel_ms, launches, kernel_name):
         "peak": HBM_PEAK / 1e9,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK,
-        "traffic": None,
+        "traffic": measured_traffic(traffic_key) if traffic_key else None,
         "launches": launches,
         "avg_launch_ms": kernel_ms / max(launches, 1),
         "applications": apps,
@@ -158,6 +175,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="independent sequences per GPU")
     ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--slice-ns", type=int, default=2, help="cfg3/cfg5: simulated ns per step")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -184,6 +202,9 @@ def main() -> None:
 
     n_gpus = max(world, 1)
     out = {}
+    common = {"n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "f64", "data": "synthetic", "unit": "sim-us/s"}
     if args.workload == "cfg2":
         n, B = 12, args.batch
         eng = Engine.from_problems([chain_problem(n)] * B, mode="sesolve")
@@ -193,16 +214,8 @@ def main() -> None:
         out = {
             "metric": "sim-us/sec, 12-atom Rydberg anneal sequence, sesolve fp64 (aggregate over sequences)",
             "value": value,
-            "unit": "sim-us/s",
-            "n_gpus": n_gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            **common,
             "ms_per_step": sec * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: 12-atom chain at the blockade radius, analog Ising "
                             "anneal 3100 ns, sesolve complex128; batch of independent sequences per GPU",
@@ -214,13 +227,36 @@ def main() -> None:
                 "generator_applications_per_sequence": stats["n_applications"] // max(args.steps, 1),
                 "parallelism": f"dp{n_gpus} (independent sequences, all-reduce of ensemble sums only)",
             },
-            "roofline": roofline(n, B, stats, kms, kl, "k_traj<12,1024,1> (persistent, LDS-resident)"),
+            "roofline": roofline(n, B, stats, kms, kl, "k_traj<12,1024,1> (persistent, LDS-resident)",
+                                 "cfg2:k_traj"),
         }
         out["roofline"]["note"] = (
             "state vectors stay in LDS/registers for the whole sequence, so the algorithmic 32 B/amp/"
             "application never reaches HBM; frac > 1 is on-chip reuse, not an HBM measurement"
         )
         eng.close()
+    elif args.workload in ("cfg3", "cfg5"):
+        # HBM-streaming workloads as the primary line (used for the rocprofv3 passes)
+        if args.workload == "cfg3":
+            ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
+            eng = Engine.from_problems([tri_problem(2, 7, ops)], mode="mesolve")
+            t0, t1, nb, kname = 1.0, 1.0 + 1e-3 * args.slice_ns, 28, "k_apply<mesolve> (tiled, multi-pass)"
+            wl = f"BASELINE configs[2]: 14-atom triangular register, dephasing mesolve (rho = 4.29 GB), {args.slice_ns} ns slice at t = 1 us"
+        else:
+            eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")
+            t0, t1, nb, kname = 1.0, 1.0 + 1e-3 * args.slice_ns, 20, "k_apply<sesolve> (tiled, multi-pass)"
+            wl = f"BASELINE configs[4]: 20-atom 4x5 register, sesolve, {args.slice_ns} ns slice at t = 1 us"
+        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, t0, t1, args.steps, args.warmup, dist, torch)
+        out = {"metric": "sim-us/sec", "value": n_gpus * (t1 - t0) / sec, **common,
+               "ms_per_step": sec * 1e3,
+               "config": {"workload": wl, "passes_per_application": stats["passes"],
+                          "taylor_order": stats["last_order"],
+                          "parallelism": f"replicas x{n_gpus} (a single state does not shard)"},
+               "roofline": roofline(nb, 1, stats, kms, kl, kname,
+                                    "cfg3:k_apply" if args.workload == "cfg3" else None)}
+        eng.close()
+        args.no_extras = True
+        args.no_cpu = True
     else:
         raise SystemExit(f"unknown workload {args.workload}")
 
@@ -242,7 +278,8 @@ def main() -> None:
                      "value": (t1 - t0) / sec, "unit": "sim-us/s", "ms_per_sim_ns": sec * 1e3 / 2,
                      "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
                      "trace": float(occ[-1].item()),
-                     "roofline": roofline(28, 1, stats, kms, kl, "k_apply<mesolve> (tiled, multi-pass)")})
+                     "roofline": roofline(28, 1, stats, kms, kl, "k_apply<mesolve> (tiled, multi-pass)",
+                                          "cfg3:k_apply")})
         eng.close()
         # cfg5: 20-atom sesolve slice
         eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")
