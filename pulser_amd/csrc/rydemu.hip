@@ -35,6 +35,7 @@
 #include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -91,6 +92,13 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 __device__ __forceinline__ cplx cfma(cplx a, cplx b, cplx c) {  // a*b + c
   return make_double2(fma(a.x, b.x, fma(-a.y, b.y, c.x)),
                       fma(a.x, b.y, fma(a.y, b.x, c.y)));
+}
+
+// wave-uniform double -> scalar registers
+__device__ __forceinline__ double uniform_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
 }
 
 #define MAXF 16  // flips per pass (<= tile bits)
@@ -275,6 +283,185 @@ __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_apply12: the T = 12 specialisation of k_apply (single flips only).
+// Same arithmetic, restructured for the memory system: every global load of a
+// phase is issued before any of them is consumed (x and E0 up front; the
+// partial sums and the Horner base together, after the flip phase), each
+// thread keeps its 8 amplitudes in registers (flips of tile bits 9-11 are
+// register moves), LDS partner reads of one amplitude are issued as one batch,
+// and the wave-uniform flip coefficients live in scalar registers.
+// ---------------------------------------------------------------------------
+template <int MODE, int Q0>
+__global__ __launch_bounds__(512, 4) void k_apply12(const PassArgs A) {
+  constexpr int T = 12, NTT = 512, R = 8, LOGNT = 9, TL = 6;
+  constexpr int NFMAX = T - Q0;  // flips are the tile-local bits Q0 .. Q0 + n_flip - 1
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx* xs = reinterpret_cast<cplx*>(smem);
+  double* tabLo = reinterpret_cast<double*>(xs + (1 << T));
+  double* tabHi = tabLo + (1 << TL);
+  double* cft = tabHi + (1 << TL);  // [MAXF][2]: cr, ci of every flip
+
+  const int tid = threadIdx.x;
+  const int N = A.N;
+  const int b = blockIdx.y;
+  const unsigned long long base_idx = deposit((unsigned long long)blockIdx.x, A.outer);
+  const size_t boff = (size_t)b << A.nb;
+  const double* __restrict__ cf = A.coefs + (size_t)b * N * 4;
+  const cplx* __restrict__ xin = A.in + boff;
+  const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride;
+  const unsigned Dm1 = (MODE == RYD_MESOLVE) ? ((1u << N) - 1u) : 0u;
+  constexpr int q0 = Q0;
+  const int nf = A.n_flip;
+
+  // ---- phase A: all loads of x (and the E0 entries) in flight at once ----
+  cplx x[R];
+  double e0v[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    x[j] = xin[base_idx | deposit((unsigned long long)(tid + j * NTT), A.tile)];
+  if (A.include_diag) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const unsigned long long g = base_idx | deposit((unsigned long long)(tid + j * NTT), A.tile);
+      if (MODE == RYD_SESOLVE) {
+        e0v[j] = e0[g];
+      } else {
+        const unsigned a = (unsigned)(g >> N), bb = (unsigned)g & Dm1;
+        e0v[j] = e0[a] - e0[bb];
+      }
+    }
+  }
+  if (tid < nf) {
+    const int p = tile_bit_pos(A.tile, q0 + tid);
+    const int k = (MODE == RYD_SESOLVE || p < N) ? N - 1 - p : 2 * N - 1 - p;
+    cft[2 * tid] = cf[4 * k];
+    cft[2 * tid + 1] = cf[4 * k + 1];
+  }
+  double eOuter = 0.0;
+  if (A.include_diag) {
+    for (int e = tid; e < 2 * (1 << TL); e += NTT) {
+      const bool hiHalf = e >= (1 << TL);
+      const int v = hiHalf ? e - (1 << TL) : e;
+      const int qb = hiHalf ? TL : 0;
+      double s = 0.0;
+      for (int q = 0; q < TL; ++q) {
+        const int p = tile_bit_pos(A.tile, qb + q);
+        double sg;
+        int k;
+        if (MODE == RYD_SESOLVE) { k = N - 1 - p; sg = -1.0; }
+        else if (p >= N) { k = 2 * N - 1 - p; sg = -1.0; }
+        else { k = N - 1 - p; sg = 1.0; }
+        if (!((v >> q) & 1)) s += sg * cf[4 * k + 2];
+      }
+      (hiHalf ? tabHi : tabLo)[v] = s;
+    }
+    for (int i = 0; i < 3; ++i)
+      for (int jj = 0; jj < A.outer.len[i]; ++jj) {
+        const int p = A.outer.lo[i] + jj;
+        double sg;
+        int k;
+        if (MODE == RYD_SESOLVE) { k = N - 1 - p; sg = -1.0; }
+        else if (p >= N) { k = 2 * N - 1 - p; sg = -1.0; }
+        else { k = N - 1 - p; sg = 1.0; }
+        if (!((base_idx >> p) & 1ull)) eOuter += sg * cf[4 * k + 2];
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) xs[tid + j * NTT] = x[j];
+  __syncthreads();
+
+  // wave-uniform flip coefficients -> scalar registers.  The coefficient of a
+  // flip is (sgn * ci, s2 * cr): sgn = +1 / -1 for output bit 1 / 0, s2 = -1 for
+  // -iH (sesolve, row bits) and +1 for +i rho H (column bits).
+  double fcr[NFMAX], fci[NFMAX];
+#pragma unroll
+  for (int f = 0; f < NFMAX; ++f) {
+    const bool on = f < nf;
+    const double cr = on ? cft[2 * f] : 0.0, ci = on ? cft[2 * f + 1] : 0.0;
+    double s2 = -1.0;
+    if (MODE == RYD_MESOLVE && on && tile_bit_pos(A.tile, q0 + f) < N) s2 = 1.0;
+    fcr[f] = uniform_d(s2 * cr);
+    fci[f] = uniform_d(ci);
+  }
+
+  // ---- phase B: diagonal first (frees the E0 registers), then the flips ----
+  cplx acc[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int l = tid + j * NTT;
+    cplx a = make_double2(0.0, 0.0);
+    if (A.include_diag) {
+      double e = tabLo[l & ((1 << TL) - 1)] + tabHi[l >> TL] + eOuter;
+      if (MODE == RYD_SESOLVE) {
+        e += A.wmix * e0v[j] - A.shift;
+        a = make_double2(e * x[j].y, -e * x[j].x);
+      } else {
+        const unsigned long long g = base_idx | deposit((unsigned long long)l, A.tile);
+        const unsigned aa = (unsigned)(g >> N), bb = (unsigned)g & Dm1;
+        e += A.wmix * e0v[j];
+        const int n11 = __popc(aa & bb), n10 = __popc(aa & ~bb & Dm1),
+                  n01 = __popc(~aa & bb & Dm1), n00 = N - n11 - n10 - n01;
+        const double dr = A.wmix * (A.Sd[0].x * n00 + A.Sd[1].x * n01 +
+                                    A.Sd[2].x * n10 + A.Sd[3].x * n11);
+        const double di = A.wmix * (A.Sd[0].y * n00 + A.Sd[1].y * n01 +
+                                    A.Sd[2].y * n10 + A.Sd[3].y * n11) - e;
+        a = make_double2(dr * x[j].x - di * x[j].y, dr * x[j].y + di * x[j].x);
+      }
+    }
+    acc[j] = a;
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int l = tid + j * NTT;
+    cplx a = acc[j];
+    constexpr int NX = LOGNT > Q0 ? LOGNT - Q0 : 1;  // partners read from LDS
+    cplx xv[NX];
+#pragma unroll
+    for (int f = 0; f < NX; ++f)
+      if (Q0 + f < LOGNT && f < nf) xv[f] = xs[l ^ (1 << (Q0 + f))];
+#pragma unroll
+    for (int f = 0; f < NFMAX; ++f) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int q = Q0 + f;
+      if (f >= nf) continue;  // wave-uniform
+      const cplx p = q < LOGNT ? xv[f < NX ? f : 0]
+                               : x[(j ^ (1 << (q >= LOGNT ? q - LOGNT : 0))) & (R - 1)];
+      const double sgi = ((l >> q) & 1) ? fci[f] : -fci[f];
+      a = cfma(make_double2(sgi, fcr[f]), p, a);
+    }
+    acc[j] = a;
+  }
+
+  // ---- phase C: partial sums / Horner base, again as one batch of loads ----
+  if (A.final_pass) {
+    cplx kv[R], bv[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const size_t g = boff + (base_idx | deposit((unsigned long long)(tid + j * NTT), A.tile));
+      kv[j] = A.kin ? A.kin[g] : make_double2(0.0, 0.0);
+      bv[j] = A.base ? A.base[g] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const cplx r = make_double2(fma(A.scale, acc[j].x + kv[j].x, bv[j].x),
+                                  fma(A.scale, acc[j].y + kv[j].y, bv[j].y));
+      A.out[boff + (base_idx | deposit((unsigned long long)(tid + j * NTT), A.tile))] = cmul(A.post, r);
+    }
+  } else {
+    cplx kv[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      kv[j] = A.kin ? A.kin[boff + (base_idx | deposit((unsigned long long)(tid + j * NTT), A.tile))]
+                    : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      A.kout[boff + (base_idx | deposit((unsigned long long)(tid + j * NTT), A.tile))] =
+          make_double2(acc[j].x + kv[j].x, acc[j].y + kv[j].y);
+  }
+}
+
 // coefs[b][k] = w1 * val(t1) + w2 * val(t2) for the drive (complex) and the
 // detuning (real) of atom k of trajectory b.  pp: [n_series][n_int][4] complex.
 __global__ void k_eval_coefs(const cplx* __restrict__ pp, int n_int,
@@ -437,13 +624,6 @@ struct TrajArgs {
   int n_int, n_steps, B;
   double a1, a2;
 };
-
-// wave-uniform double -> scalar registers
-__device__ __forceinline__ double uniform_d(double v) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
 
 // MODEL 0: per-atom complex drive coefficients (local addressing, noise).
 // MODEL 1: one real drive coefficient shared by the driven atoms of the
@@ -673,6 +853,7 @@ struct ryd_handle {
   StepDesc* sched_dev = nullptr;
   size_t sched_cap = 0;
   bool force_generic = false;
+  bool no_fast_apply = false;  // test hook: use the generic k_apply for T = 12 too
   bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
   ryd_stats stats{};
   // timing
@@ -812,6 +993,10 @@ extern "C" int ryd_create(const ryd_config* cfg, ryd_handle** out) {
   h->B = cfg->batch;
   h->T = T;
   h->dim = (size_t)1 << nb;
+  // k_apply12 (register-resident tile kernel) measured 8-14 % slower than the
+  // generic kernel on MI355X in round 1 (profiles/r01): opt-in until it wins.
+  h->no_fast_apply = true;
+  if (const char* ev = std::getenv("RYD_FAST_APPLY")) h->no_fast_apply = ev[0] != '1';
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
   hipError_t e;
   if ((e = hipMalloc((void**)&h->wA, bytes)) != hipSuccess ||
@@ -834,6 +1019,14 @@ extern "C" int ryd_create(const ryd_config* cfg, ryd_handle** out) {
   if ((e = hipFuncSetAttribute((const void*)k_apply<RYD_SESOLVE>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
       (e = hipFuncSetAttribute((const void*)k_apply<RYD_MESOLVE>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply12<RYD_SESOLVE, 0>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply12<RYD_MESOLVE, 0>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply12<RYD_SESOLVE, 4>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply12<RYD_MESOLVE, 4>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) {
     ryd_destroy(h);
     return fail(RYD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
@@ -1133,7 +1326,22 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
     dim3 grid((unsigned)(1ull << p.n_outer_bits), h->B);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->timing) { int rc = timing_begin(h, st, ev); if (rc) return rc; }
-    if (h->cfg.mode == RYD_SESOLVE)
+    // contiguous single-flip range on a full 2^12 tile -> specialised kernel
+    bool fast = p.T == 12 && A.n_dbl == 0 && A.n_flip >= 1 && !h->no_fast_apply &&
+                (A.flip_q[0] == 0 || A.flip_q[0] == 4);
+    for (int i = 1; i < A.n_flip && fast; ++i) fast = A.flip_q[i] == A.flip_q[0] + i;
+    if (fast) {
+      const size_t lds12 = ((size_t)1 << 12) * sizeof(cplx) + 2 * 64 * sizeof(double) +
+                           2 * MAXF * sizeof(double);
+      const bool se = h->cfg.mode == RYD_SESOLVE;
+      if (A.flip_q[0] == 0) {
+        if (se) hipLaunchKernelGGL((k_apply12<RYD_SESOLVE, 0>), grid, dim3(512), lds12, st, A);
+        else hipLaunchKernelGGL((k_apply12<RYD_MESOLVE, 0>), grid, dim3(512), lds12, st, A);
+      } else {
+        if (se) hipLaunchKernelGGL((k_apply12<RYD_SESOLVE, 4>), grid, dim3(512), lds12, st, A);
+        else hipLaunchKernelGGL((k_apply12<RYD_MESOLVE, 4>), grid, dim3(512), lds12, st, A);
+      }
+    } else if (h->cfg.mode == RYD_SESOLVE)
       hipLaunchKernelGGL(k_apply<RYD_SESOLVE>, grid, dim3(NT), lds, st, A);
     else
       hipLaunchKernelGGL(k_apply<RYD_MESOLVE>, grid, dim3(NT), lds, st, A);
@@ -1451,7 +1659,8 @@ extern "C" int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
 
 extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
   if (!h) return fail(RYD_ERR_INVALID, "null handle");
-  h->force_generic = force_generic != 0;
+  h->force_generic = (force_generic & 1) != 0;
+  h->no_fast_apply = (force_generic & 2) != 0;
   return RYD_OK;
 }
 

@@ -229,9 +229,10 @@ class Engine:
         )
         return out
 
-    def set_path(self, force_generic: bool) -> None:
-        """Disable (True) / enable (False) the persistent small-N kernel."""
-        _lib.check(self.lib.ryd_set_path(self._h, int(bool(force_generic))))
+    def set_path(self, force_generic: bool, no_fast_apply: bool = False) -> None:
+        """Test/bench hook: disable the persistent small-N kernel and/or the
+        specialised T = 12 tile kernel (the generic ones are used instead)."""
+        _lib.check(self.lib.ryd_set_path(self._h, int(bool(force_generic)) | (2 if no_fast_apply else 0)))
 
     def apply_generator(self, x: Any, t: float) -> Any:
         """``G(t) x`` with ``G = -iH`` (sesolve) or the Lindbladian (mesolve)."""

@@ -456,3 +456,107 @@ class HamiltonianData:
     def problems(self, sampling_rate: float) -> Iterator[dict[str, Any]]:
         for traj in self.noise_trajectories:
             yield self.problem(traj, sampling_rate)
+
+
+    # -- factored lowering: trajectories -> device tables without arrays ------
+    def factorable(self) -> bool:
+        """True when every trajectory's noisy samples are the shared channel
+        samples scaled / offset per (trajectory, atom): each atom driven by one
+        channel only, no high-frequency detuning noise, 2-level basis."""
+        if len(self.eigenbasis) != 2 or self.interaction_type != "ising":
+            return False
+        if self.noise_model.detuning_hf_psd:
+            return False
+        seen: set[tuple[str, int]] = set()
+        for ch in self.samples.channels:
+            targets = {t for s in ch.slots for t in s.targets}
+            for t in targets:
+                if (ch.basis, t) in seen:
+                    return False
+                seen.add((ch.basis, t))
+        return True
+
+    def device_tables(self, trajs: Sequence[NoiseTrajectory], sampling_rate: float) -> Any:
+        """``pulser_amd.terms.DeviceTables`` for a batch of trajectories.
+
+        Mathematically identical to lowering ``self.problem(traj)`` for every
+        trajectory (splines are linear in their knots), but the per-trajectory
+        noise of hamiltonian_data.py:408-534 is kept in factored form: the
+        spline tables hold the shared (channel, target-mask) series once and each
+        (trajectory, atom) descriptor carries the amplitude factor, the doppler /
+        detuning offset (times the slot mask) and the bad-atom zeroing.
+        """
+        from .terms import (DESC_DTYPE, DeviceTables, _SeriesPool, adapt_to_sampling_rate,
+                            local_dissipator, lower, sampling_times)
+        from scipy.interpolate import CubicSpline
+
+        if not self.factorable():
+            return lower([self.problem(t, sampling_rate) for t in trajs])
+        nm = self.noise_model
+        n, T = self.n_qudits, self.samples.max_duration
+        basis_name = self.basis_name
+        tknots = sampling_times(T, sampling_rate)
+        pool = _SeriesPool()
+        # per atom: (channel, drive series, det series, mask series)
+        per_atom: dict[int, tuple[Any, int, int, int]] = {}
+        for ch in self.samples.channels:
+            cs = ch.extend_duration(T)
+            masks: dict[int, np.ndarray] = {}
+            for s in cs.slots:
+                for t in s.targets:
+                    masks.setdefault(t, np.zeros(T))[s.ti:s.tf] = 1.0
+            for t, m in masks.items():
+                c = 0.5 * (m * cs.amp) * np.exp(-1j * (m * cs.phase))
+                di = pool.add(adapt_to_sampling_rate(c, sampling_rate, T))
+                ti = pool.add(adapt_to_sampling_rate(m * cs.det, sampling_rate, T))
+                mi = pool.add(adapt_to_sampling_rate(m, sampling_rate, T))
+                per_atom[t] = (ch, di, ti, mi)
+        desc = np.zeros((len(trajs), n), dtype=DESC_DTYPE)
+        desc["drive_series"] = desc["det_series"] = desc["off_series"] = -1
+        mats = []
+        local = self.local_noises
+        for b, tr in enumerate(trajs):
+            for k, (ch, di, ti, mi) in per_atom.items():
+                if local and tr.bad_atoms[k]:
+                    continue  # amp, det and phase zeroed (:507-509)
+                frac, off = 1.0, 0.0
+                if local:
+                    if "amplitude" in nm.noise_types:
+                        frac = tr.amp_fluctuations[ch.name]
+                        if nm.laser_waist is not None and ch.addressing == "Global":
+                            prop = ch.propagation_dir or (0.0, 1.0, 0.0)
+                            frac *= finite_waist_amp_fraction(tuple(tr.coords[k]), tuple(prop),
+                                                              nm.laser_waist)
+                    if "doppler" in nm.noise_types:
+                        off += tr.doppler_detune[k]
+                    if "detuning" in nm.noise_types:
+                        off += float(tr.det_fluctuations[ch.name])
+                d = desc[b, k]
+                if di >= 0 and frac != 0.0:
+                    d["drive_series"], d["drive_scale"] = di, frac
+                if ti >= 0:
+                    d["det_series"], d["det_scale"] = ti, 1.0
+                if off != 0.0 and mi >= 0:
+                    d["off_series"], d["off_scale"] = mi, off
+            bad = np.asarray(tr.bad_atoms, bool)
+            u = np.array(tr.interaction_matrix, dtype=float)[-1].copy()
+            np.fill_diagonal(u, 0.0)
+            if "digital" in basis_name or (n - int(bad.sum())) <= 1:
+                u[:] = 0.0
+            u[bad, :] = 0.0
+            u[:, bad] = 0.0
+            mats.append(u)
+        if not pool.arrays:
+            pool.arrays.append(np.zeros(len(tknots), dtype=np.complex128))
+        pp = np.empty((len(pool.arrays), len(tknots) - 1, 4), dtype=np.complex128)
+        for i, knots in enumerate(pool.arrays):
+            pp[i] = np.transpose(CubicSpline(tknots, knots, bc_type="not-a-knot").c, (1, 0))
+        shared = all(np.array_equal(mats[0], m) for m in mats[1:])
+        ops, paulis = self.collapse_ops()
+        return DeviceTables(
+            n_qubits=n, batch=len(trajs),
+            tknots=np.ascontiguousarray(tknots, dtype=np.float64), pp=np.ascontiguousarray(pp),
+            desc=desc, interaction=np.ascontiguousarray(np.stack(mats[:1] if shared else mats)),
+            dissipator=local_dissipator(ops, self.eigenbasis, paulis),
+            series_knots=pool.arrays,
+        )

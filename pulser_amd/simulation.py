@@ -197,8 +197,9 @@ class QutipEmulator:
             self.samples_obj, noise_model,
             self._get_n_trajectories(noise_model, check_value=True),
         )
-        self._problems = self._build_problems()
-        self._current_problem = self._problems[0]
+        self._problems_cache: list[dict[str, Any]] | None = None
+        self._current_problem = self._hamiltonian_data.problem(
+            self._hamiltonian_data.noise_trajectories[0], self._sampling_rate)
         self._eval_times_array: np.ndarray
         self.set_evaluation_times(evaluation_times)
         if self.samples_obj.measurement:
@@ -212,8 +213,17 @@ class QutipEmulator:
         self.last_engine_stats: dict[str, Any] = {}
 
     # ------------------------------------------------------------------ setup
-    def _build_problems(self) -> list[dict[str, Any]]:
-        return list(self._hamiltonian_data.problems(self._sampling_rate))
+    @property
+    def _problems(self) -> list[dict[str, Any]]:
+        """Problem bundles of every trajectory (materialised on first use; the
+        stochastic run path lowers trajectories in factored form instead)."""
+        if self._problems_cache is None:
+            self._problems_cache = list(self._hamiltonian_data.problems(self._sampling_rate))
+        return self._problems_cache
+
+    @_problems.setter
+    def _problems(self, value: list[dict[str, Any]]) -> None:
+        self._problems_cache = value
 
     def _get_n_trajectories(self, noise_model: Any, check_value: bool) -> int | None:
         n = self._n_trajectories if self._n_trajectories is not None else noise_model.runs
@@ -463,16 +473,24 @@ class QutipEmulator:
         return kw
 
     def _solve_batch(self, problems: list[dict[str, Any]], progress_bar: Any,
-                     options: dict[str, Any]) -> list[CoherentResults]:
+                     options: dict[str, Any], tables: Any = None) -> list[CoherentResults]:
         """The solver call of ``_run_solver`` (simulation.py:689-766) for a batch
-        of trajectories in ONE engine (one GPU launch sequence)."""
+        of trajectories in ONE engine (one GPU launch sequence).  ``tables``:
+        pre-lowered device tables for the batch (factored noise) instead of
+        ``problems``."""
         if progress_bar not in (True, False, None):
             raise ValueError("`progress_bar` must be a bool.")
         from .engine import Engine
+        from .terms import lower
 
-        mode = self._solver_mode(problems[0])
+        if tables is None:
+            mode = self._solver_mode(problems[0])
+            tables = lower(problems)
+        else:
+            mode = self._solver_mode({"collapse_ops": [1] if tables.dissipator is not None else []})
+        n_batch = tables.batch
         times = self._eval_times_array
-        with Engine.from_problems(problems, mode=mode) as eng:
+        with Engine(tables, mode=mode) as eng:
             state = eng.new_state(np.asarray(self._initial_state).reshape(1, -1))
             first = state.cpu().numpy()
             snaps = eng.solve(state, times, store=True, **self._engine_kwargs(options))
@@ -485,7 +503,7 @@ class QutipEmulator:
         qids = tuple(self.samples_obj.qubit_ids)
         n = self._hamiltonian_data.n_qudits
         out = []
-        for b in range(len(problems)):
+        for b in range(n_batch):
             results = []
             for i, t in enumerate(times):
                 st = first[b] if i == 0 else host[i - 1][b]
@@ -542,27 +560,30 @@ class QutipEmulator:
             nm = self._hamiltonian_data.noise_model
             self._hamiltonian_data = HamiltonianData(
                 self.samples_obj, nm, self._get_n_trajectories(nm, check_value=True))
-            self._problems = self._build_problems()
+            self._problems_cache = None
         self._noise_trajectories_used = True
-        probs = self._problems
+        hd = self._hamiltonian_data
+        trajs = hd.noise_trajectories
+        if self._problems_cache is not None:  # an explicit (possibly trimmed) list wins
+            trajs = trajs[: len(self._problems_cache)]
         n_eval = len(self._eval_times_array)
-        dim_bytes = 16 * (2 ** self._hamiltonian_data.n_qudits) ** (
-            2 if len(probs[0]["collapse_ops"]) else 1)
+        is_me = len(self._current_problem["collapse_ops"]) > 0
+        dim_bytes = 16 * (2 ** hd.n_qudits) ** (2 if is_me else 1)
         if batch is None:  # keep the snapshot tensor under ~8 GB
             batch = int(max(1, min(256, (8 << 30) // max(1, dim_bytes * n_eval))))
         traj_nb = 0
-        for start in range(0, len(probs), batch):
-            chunk = probs[start:start + batch]
-            solved = self._solve_batch(chunk, progress_bar, options)
-            for prob, res in zip(chunk, solved):
-                reps = prob["reps"]
+        for start in range(0, len(trajs), batch):
+            chunk = trajs[start:start + batch]
+            tables = hd.device_tables(chunk, self._sampling_rate)
+            solved = self._solve_batch([], progress_bar, options, tables=tables)
+            for tr, res in zip(chunk, solved):
+                reps = tr.reps
                 if print_progress:
                     if reps == 1:
                         print(f"Emulating Trajectory {traj_nb+1}/{n_trajectories}")
                     else:
                         print("Emulating Trajectories "
                               f"[{traj_nb+1} - {traj_nb+reps}]/{n_trajectories}")
-                self._current_problem = prob
                 traj_nb += reps
                 yield res, reps
 

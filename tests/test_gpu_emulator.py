@@ -136,3 +136,24 @@ def test_noisy_doppler_amplitude_trajectories_against_oracle():
         for i in range(len(extra["eval_times"])):
             assert np.max(np.abs(np.asarray(got[b].states[i])[:, 0] - ref[b][i])) < 1e-7
     assert emu.last_engine_stats["n_launches"] == 1  # one persistent launch for the batch
+
+
+def test_cfg4_noisy_run_factored_equals_general_path():
+    """Full stochastic run (doppler + amplitude + SPAM, 24 trajectories): the
+    factored lowering (shared spline tables + per-atom scales) and the general
+    lowering of every noisy problem give the same sampled Counters."""
+    _, extra = load_fixture("cfg4_chain12_noise.npz")
+    nm = NoiseModel(samples_per_run=10, **extra["noise_model"])
+    counts = []
+    for general in (False, True):
+        np.random.seed(5)
+        emu = QutipEmulator(_chain12_inputs(extra), noise_model=nm, n_trajectories=24,
+                            evaluation_times="Minimal")
+        if general:
+            emu._hamiltonian_data.factorable = lambda: False
+        with pytest.warns(DeprecationWarning):
+            res = emu.run()
+        assert res.n_measures == 240
+        counts.append([dict(r.bitstring_counts) for r in res])
+    assert counts[0] == counts[1]
+    assert sum(counts[0][-1].values()) == 240

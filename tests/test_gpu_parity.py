@@ -226,3 +226,27 @@ def test_persistent_kernel_cfg2_chain12_snapshots():
     assert eng.stats()["n_launches"] == 1
     for i in range(1, len(ref)):
         assert np.max(np.abs(snaps[i - 1][0] - ref[i])) < AMP_TOL
+
+
+@pytest.mark.parametrize("mode,n", [("sesolve", 12), ("sesolve", 17), ("mesolve", 6), ("mesolve", 9)])
+def test_specialised_tile_kernel_matches_generic(mode, n):
+    """k_apply12 (registers + batched loads) against the generic k_apply, for the
+    diagonal pass and the accumulation passes, and against the oracle at N = 12."""
+    ops = [(np.sqrt(0.1), "sigma_rr")] if mode == "mesolve" else None
+    probs = [local_problem(n, seed=s, duration=21, collapse_ops=ops) for s in range(2)]
+    eng = _engine(probs, mode=mode)
+    shape = eng.state_shape
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=shape) + 1j * rng.normal(size=shape)
+    dev = _to_dev(eng, x)
+    fast = eng.apply_generator(dev, 0.0123).cpu().numpy()
+    eng.set_path(True, no_fast_apply=True)
+    slow = eng.apply_generator(dev, 0.0123).cpu().numpy()
+    assert eng.stats()["passes"] == {12: 1, 17: 2, 6: 1, 9: 2}[n]
+    assert np.max(np.abs(fast - slow)) <= 1e-12 * np.max(np.abs(slow))
+    st_a = eng.new_state()
+    eng.evolve(st_a, 0.0, 0.004)
+    eng.set_path(True, no_fast_apply=False)
+    st_b = eng.new_state()
+    eng.evolve(st_b, 0.0, 0.004)
+    assert np.max(np.abs(st_a.cpu().numpy() - st_b.cpu().numpy())) < 1e-13

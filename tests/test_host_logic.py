@@ -411,3 +411,38 @@ def test_engine_fails_loudly_without_gpu():
     prob, _ = load_fixture("cfg1_square4_pi.npz")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Engine.from_problems([prob])
+
+
+def test_factored_trajectory_lowering_equals_general_lowering():
+    """HamiltonianData.device_tables (scales/offsets on shared series) must give
+    the same time-dependent coefficients as lowering every noisy problem."""
+    from pulser_amd.terms import lower
+
+    _, extra = load_fixture("cfg4_chain12_noise.npz")
+    nm = NoiseModel(temperature=50.0, amp_sigma=0.05, laser_waist=175.0, detuning_sigma=0.3,
+                    state_prep_error=0.2, p_false_pos=0.01)
+    inputs = _chain12_inputs(extra).extend_duration(3101)
+    np.random.seed(3)
+    hd = HamiltonianData(inputs, nm, 6)
+    assert hd.factorable()
+    trajs = hd.noise_trajectories
+    assert any(t.bad_atoms.any() for t in trajs)
+    fac = hd.device_tables(trajs, 1.0)
+    gen = lower([hd.problem(t, 1.0) for t in trajs])
+    assert fac.pp.shape[0] == 3 and gen.pp.shape[0] > 20
+    assert np.array_equal(fac.interaction, gen.interaction)
+
+    def coefs(tb, b, k, i, u):
+        d = tb.desc[b, k]
+        val = lambda s: np.polyval(tb.pp[s, i], u) if s >= 0 else 0.0  # noqa: E731
+        c = d["drive_scale"] * val(d["drive_series"])
+        dl = d["det_scale"] * np.real(val(d["det_series"])) + d["off_scale"] * np.real(val(d["off_series"]))
+        return c, dl
+
+    for b in range(len(trajs)):
+        for k in range(12):
+            for i, u in ((0, 0.0004), (499, 0.0009), (1700, 0.0005), (3099, 0.00099)):
+                cf, df = coefs(fac, b, k, i, u)
+                cg, dg = coefs(gen, b, k, i, u)
+                assert abs(cf - cg) < 1e-12 * max(1.0, abs(cg)), (b, k, i)
+                assert abs(df - dg) < 1e-11 * max(1.0, abs(dg)), (b, k, i)
