@@ -269,6 +269,24 @@ def main() -> None:
                      "unit": "sim-us/s", "ms_per_sequence": sec * 1e3,
                      "roofline": roofline(12, 1, stats, kms, kl, "k_traj (1 workgroup)")})
         eng.close()
+        # north-star target size, Schroedinger leg: one 14-atom triangular-register sequence
+        eng = Engine.from_problems([tri_problem(2, 7)], mode="sesolve")
+        t0, t1 = 1.0, 1.1
+        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, t0, t1, 2, 1, None, torch)
+        also.append({"workload": "14-atom triangular register, sesolve, single sequence, 100 ns slice at t = 1 us",
+                     "value": (t1 - t0) / sec, "unit": "sim-us/s",
+                     "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
+                     "roofline": roofline(14, 1, stats, kms, kl, "k_apply<sesolve> (tiled, 2 passes; 256 KiB state: launch-latency-bound)")})
+        eng.close()
+        # ... and a batch of 64 such sequences (state batch = 16 MiB): the streaming regime
+        eng = Engine.from_problems([tri_problem(2, 7)] * 64, mode="sesolve")
+        t0, t1 = 1.0, 1.05
+        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, t0, t1, 2, 1, None, torch)
+        also.append({"workload": "14-atom triangular register, sesolve, 64 sequences, 50 ns slice at t = 1 us",
+                     "value": 64 * (t1 - t0) / sec, "unit": "sim-us/s",
+                     "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
+                     "roofline": roofline(14, 64, stats, kms, kl, "k_apply<sesolve> (tiled, 2 passes)")})
+        eng.close()
         # cfg3: 14-atom triangular register, dephasing Lindblad, HBM-streaming tiled kernel
         ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
         eng = Engine.from_problems([tri_problem(2, 7, ops)], mode="mesolve")

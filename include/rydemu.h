@@ -154,6 +154,30 @@ int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
 int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
               void* out_dev, const ryd_opts* opts, void* stream);
 
+/* General path for everything the tuned 2-level Ising kernels do not cover: the
+ * 3-level "all" basis, leakage (d = 3/4), XY mode with its SLM-mask switching
+ * terms, arbitrary eff_noise collapse operators.  The generator is given as an
+ * explicit term list G(t) = sum_t coef_t(t) A_t with CSR matrices A_t over the
+ * evolved vector (psi, or row-major vec(rho) for the Liouvillian):
+ *   coef_t(t) = scale_t * S[series_t](t)   (conjugated when conj_t != 0), or the
+ *   constant scale_t when series_t == -1.
+ * Replaces the same reference interfaces as the tuned path (QobjEvo term list,
+ * hamiltonian.py:246-439; liouvillian built by qutip.mesolve from c_ops).
+ * Use ryd_set_series for the spline tables, then ryd_solve / ryd_evolve /
+ * ryd_apply_generator as usual; states are complex128[batch][dim]. */
+typedef struct ryd_general_config {
+  int32_t abi_version;
+  int32_t batch;
+  int32_t device;
+  int32_t reserved;
+  int64_t dim;
+} ryd_general_config;
+
+int ryd_general_create(const ryd_general_config* cfg, ryd_handle** out);
+int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+                         const double* val /* complex128[nnz] */, int32_t series, int32_t conj,
+                         double scale_re, double scale_im, double row_norm);
+
 /* Test/bench hook: force_generic != 0 disables the persistent kernel so that
  * the tiled path can be exercised and timed at small N. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);

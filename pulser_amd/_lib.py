@@ -37,6 +37,16 @@ class RydConfig(C.Structure):
     ]
 
 
+class RydGeneralConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("batch", C.c_int32),
+        ("device", C.c_int32),
+        ("reserved", C.c_int32),
+        ("dim", C.c_int64),
+    ]
+
+
 class RydQDesc(C.Structure):
     _fields_ = [
         ("drive_series", C.c_int32),
@@ -83,6 +93,9 @@ SYMBOLS = {
     "ryd_evolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.POINTER(RydOpts), C.c_void_p]),
     "ryd_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RydOpts), C.c_void_p]),
     "ryd_set_path": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ryd_general_create": (C.c_int, [C.POINTER(RydGeneralConfig), C.POINTER(C.c_void_p)]),
+    "ryd_general_add_term": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "ryd_apply_generator": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "ryd_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ryd_occupations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

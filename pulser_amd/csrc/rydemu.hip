@@ -812,6 +812,74 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
 }
 
 // ---------------------------------------------------------------------------
+// General path: G(t) = sum_t coef_t(t) A_t with explicit CSR terms (any local
+// dimension; small systems).  One thread per (row, batch entry).
+// ---------------------------------------------------------------------------
+struct GenTermDev {
+  const int* row_ptr;
+  const int* col;
+  const cplx* val;
+};
+
+#define MAX_GEN_TERMS 96
+
+struct GenArgs {
+  const cplx* in;
+  const cplx* base;
+  cplx* out;
+  const cplx* tcoef;  // [n_terms] time-mixed coefficients
+  const GenTermDev* terms;
+  long long dim;
+  int n_terms;
+  double scale;
+};
+
+__global__ void k_gen_coefs(const cplx* __restrict__ pp, int n_int, const int* __restrict__ series,
+                            const int* __restrict__ conjf, const cplx* __restrict__ scale,
+                            int n_terms, int idx, double u1, double w1, double u2, double w2,
+                            cplx* __restrict__ tcoef) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  cplx v = make_double2(w1 + w2, 0.0);
+  if (series[t] >= 0) {
+    auto val = [&](double u) -> cplx {
+      const cplx* p = pp + ((size_t)series[t] * n_int + idx) * 4;
+      cplx r = p[0];
+      r = make_double2(fma(r.x, u, p[1].x), fma(r.y, u, p[1].y));
+      r = make_double2(fma(r.x, u, p[2].x), fma(r.y, u, p[2].y));
+      r = make_double2(fma(r.x, u, p[3].x), fma(r.y, u, p[3].y));
+      return r;
+    };
+    const cplx a = val(u1), b = val(u2);
+    v = make_double2(w1 * a.x + w2 * b.x, w1 * a.y + w2 * b.y);
+    if (conjf[t]) v.y = -v.y;
+  }
+  tcoef[t] = cmul(scale[t], v);
+}
+
+__global__ __launch_bounds__(256) void k_gen_apply(const GenArgs A) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= A.dim) return;
+  const size_t boff = (size_t)blockIdx.y * A.dim;
+  const cplx* __restrict__ x = A.in + boff;
+  cplx acc = make_double2(0.0, 0.0);
+  for (int t = 0; t < A.n_terms; ++t) {
+    const GenTermDev T = A.terms[t];
+    const int lo = T.row_ptr[row], hi = T.row_ptr[row + 1];
+    cplx s = make_double2(0.0, 0.0);
+    for (int e = lo; e < hi; ++e) s = cfma(T.val[e], x[T.col[e]], s);
+    acc = cfma(A.tcoef[t], s, acc);
+  }
+  cplx r = make_double2(A.scale * acc.x, A.scale * acc.y);
+  if (A.base) {
+    const cplx b = A.base[boff + row];
+    r.x += b.x;
+    r.y += b.y;
+  }
+  A.out[boff + row] = r;
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 struct Pass {
@@ -821,6 +889,13 @@ struct Pass {
   std::vector<int> flip_q;
   std::vector<std::pair<int, int>> dbl;  // (qb, qa)
   bool include_diag = false;
+};
+
+struct GenTermHost {
+  GenTermDev dev{nullptr, nullptr, nullptr};
+  int series = -1, conj = 0;
+  std::complex<double> scale{1.0, 0.0};
+  double row_norm = 0.0;
 };
 
 struct ryd_handle {
@@ -852,6 +927,14 @@ struct ryd_handle {
   bool passes_valid = false;
   StepDesc* sched_dev = nullptr;
   size_t sched_cap = 0;
+  // general path (explicit CSR terms)
+  bool general = false;
+  std::vector<GenTermHost> gen_host;
+  cplx* gen_tcoef = nullptr;
+  GenTermDev* gen_terms_dev = nullptr;
+  int* gen_series_dev = nullptr;
+  int* gen_conj_dev = nullptr;
+  cplx* gen_scale_dev = nullptr;
   bool force_generic = false;
   bool no_fast_apply = false;  // test hook: use the generic k_apply for T = 12 too
   bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
@@ -1046,6 +1129,16 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->pp_dev);
   hipFree(h->desc_dev);
   hipFree(h->sched_dev);
+  hipFree(h->gen_tcoef);
+  hipFree(h->gen_terms_dev);
+  hipFree(h->gen_series_dev);
+  hipFree(h->gen_conj_dev);
+  hipFree(h->gen_scale_dev);
+  for (auto& t : h->gen_host) {
+    hipFree((void*)t.dev.row_ptr);
+    hipFree((void*)t.dev.col);
+    hipFree((void*)t.dev.val);
+  }
   for (auto& p : h->ev_used) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   delete h;
@@ -1359,9 +1452,18 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
 static int check_ready(const ryd_handle* h) {
   if (!h) return fail(RYD_ERR_INVALID, "null handle");
   if (!h->pp_dev) return fail(RYD_ERR_STATE, "ryd_set_series has not been called");
+  if (h->general) {
+    if (h->gen_host.empty()) return fail(RYD_ERR_STATE, "ryd_general_add_term has not been called");
+    return RYD_OK;
+  }
   if (!h->desc_dev) return fail(RYD_ERR_STATE, "ryd_set_qubit_desc has not been called");
   return RYD_OK;
 }
+
+struct MixPoint;
+static int launch_eval_general(ryd_handle* h, const MixPoint& m, hipStream_t st);
+static int apply_general(ryd_handle* h, const MixPoint& m, const cplx* in, const cplx* base,
+                         cplx* out, double scale, hipStream_t st);
 
 extern "C" int ryd_apply_generator(ryd_handle* h, const void* in_dev, void* out_dev, double t,
                                    void* stream) {
@@ -1376,9 +1478,152 @@ extern "C" int ryd_apply_generator(ryd_handle* h, const void* in_dev, void* out_
   m.u1 = m.u2 = t - h->tknots[m.idx1];
   m.w1 = 1.0;
   m.w2 = 0.0;
+  if (h->general) {
+    if ((rc = launch_eval_general(h, m, st))) return rc;
+    return apply_general(h, m, (const cplx*)in_dev, nullptr, (cplx*)out_dev, 1.0, st);
+  }
   if ((rc = launch_eval(h, m, st))) return rc;
   return apply_generator(h, (const cplx*)in_dev, nullptr, (cplx*)out_dev, 1.0, 1.0, 0.0,
                          make_double2(1.0, 0.0), st);
+}
+
+// ---------------------------------------------------------------------------
+// General path (explicit CSR terms) - host side
+// ---------------------------------------------------------------------------
+extern "C" int ryd_general_create(const ryd_general_config* cfg, ryd_handle** out) {
+  if (!cfg || !out) return fail(RYD_ERR_INVALID, "null argument");
+  if (cfg->abi_version != RYD_ABI_VERSION)
+    return fail(RYD_ERR_INVALID, "ABI version mismatch: caller %d, library %d", cfg->abi_version,
+                RYD_ABI_VERSION);
+  if (cfg->dim < 1 || cfg->dim > ((int64_t)1 << 26))
+    return fail(RYD_ERR_INVALID, "dim=%lld out of range", (long long)cfg->dim);
+  if (cfg->batch < 1 || cfg->batch > 65535) return fail(RYD_ERR_INVALID, "batch out of range");
+  HIPCHK(hipSetDevice(cfg->device));
+  ryd_handle* h = new ryd_handle();
+  h->general = true;
+  h->cfg.abi_version = cfg->abi_version;
+  h->cfg.device = cfg->device;
+  h->cfg.mode = RYD_SESOLVE;
+  h->cfg.batch = cfg->batch;
+  h->B = cfg->batch;
+  h->dim = (size_t)cfg->dim;
+  h->N = 0;
+  h->nb = 0;
+  const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  hipError_t e;
+  if ((e = hipMalloc((void**)&h->wA, bytes)) != hipSuccess ||
+      (e = hipMalloc((void**)&h->wB, bytes)) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_tcoef, MAX_GEN_TERMS * sizeof(cplx))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_terms_dev, MAX_GEN_TERMS * sizeof(GenTermDev))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_series_dev, MAX_GEN_TERMS * sizeof(int))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_conj_dev, MAX_GEN_TERMS * sizeof(int))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_scale_dev, MAX_GEN_TERMS * sizeof(cplx))) != hipSuccess) {
+    ryd_destroy(h);
+    return fail(RYD_ERR_HIP, "hipMalloc (general path) failed: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return RYD_OK;
+}
+
+extern "C" int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr,
+                                    const int32_t* col, const double* val, int32_t series,
+                                    int32_t conj, double scale_re, double scale_im,
+                                    double row_norm) {
+  if (!h || !h->general) return fail(RYD_ERR_INVALID, "not a general-path handle");
+  if (!row_ptr || (nnz > 0 && (!col || !val))) return fail(RYD_ERR_INVALID, "null argument");
+  if ((int)h->gen_host.size() >= MAX_GEN_TERMS)
+    return fail(RYD_ERR_INVALID, "too many terms (max %d)", MAX_GEN_TERMS);
+  if (series < -1 || series >= std::max(h->n_series, 1) || (series >= 0 && h->n_series == 0))
+    return fail(RYD_ERR_INVALID, "series index %d out of range (call ryd_set_series first)", series);
+  if (row_ptr[0] != 0 || row_ptr[h->dim] != nnz)
+    return fail(RYD_ERR_INVALID, "row_ptr does not describe %lld non-zeros", (long long)nnz);
+  for (int64_t e = 0; e < nnz; ++e)
+    if (col[e] < 0 || (size_t)col[e] >= h->dim)
+      return fail(RYD_ERR_INVALID, "column index out of range at entry %lld", (long long)e);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  GenTermHost t;
+  t.series = series;
+  t.conj = conj;
+  t.scale = std::complex<double>(scale_re, scale_im);
+  t.row_norm = row_norm;
+  HIPCHK(hipMalloc((void**)&t.dev.row_ptr, (h->dim + 1) * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t.dev.col, std::max<int64_t>(nnz, 1) * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t.dev.val, std::max<int64_t>(nnz, 1) * sizeof(cplx)));
+  HIPCHK(hipMemcpy((void*)t.dev.row_ptr, row_ptr, (h->dim + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    HIPCHK(hipMemcpy((void*)t.dev.col, col, nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy((void*)t.dev.val, val, nnz * sizeof(cplx), hipMemcpyHostToDevice));
+  }
+  h->gen_host.push_back(t);
+  const int n = (int)h->gen_host.size();
+  std::vector<GenTermDev> devs(n);
+  std::vector<int> ser(n), cj(n);
+  std::vector<cplx> sc(n);
+  for (int i = 0; i < n; ++i) {
+    devs[i] = h->gen_host[i].dev;
+    ser[i] = h->gen_host[i].series;
+    cj[i] = h->gen_host[i].conj;
+    sc[i] = make_double2(h->gen_host[i].scale.real(), h->gen_host[i].scale.imag());
+  }
+  HIPCHK(hipMemcpy(h->gen_terms_dev, devs.data(), n * sizeof(GenTermDev), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->gen_series_dev, ser.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->gen_conj_dev, cj.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->gen_scale_dev, sc.data(), n * sizeof(cplx), hipMemcpyHostToDevice));
+  h->bounds_valid = false;
+  return RYD_OK;
+}
+
+static void compute_bounds_general(ryd_handle* h) {
+  const int n_int = h->n_knots - 1;
+  h->bd_drive.assign(n_int, 0.0);
+  h->bd_pos.assign(n_int, 0.0);
+  h->bd_neg.assign(n_int, 0.0);
+  h->bd_curv.assign(n_int, 0.0);
+  for (const GenTermHost& t : h->gen_host) {
+    const double w = std::abs(t.scale) * t.row_norm;
+    for (int i = 0; i < n_int; ++i) {
+      if (t.series >= 0) {
+        h->bd_drive[i] += w * h->s_abs[(size_t)t.series * n_int + i];
+        h->bd_curv[i] += w * h->s_curv[(size_t)t.series * n_int + i];
+      } else {
+        h->bd_drive[i] += w;
+      }
+    }
+  }
+  h->e0_min = h->e0_max = 0.0;
+  h->uniform_real_drive = false;
+  h->bounds_valid = true;
+}
+
+static int apply_general(ryd_handle* h, const MixPoint& m, const cplx* in, const cplx* base,
+                         cplx* out, double scale, hipStream_t st) {
+  const int n = (int)h->gen_host.size();
+  if (n == 0) return fail(RYD_ERR_STATE, "no terms: call ryd_general_add_term first");
+  GenArgs A;
+  A.in = in;
+  A.base = base;
+  A.out = out;
+  A.tcoef = h->gen_tcoef;
+  A.terms = h->gen_terms_dev;
+  A.dim = (long long)h->dim;
+  A.n_terms = n;
+  A.scale = scale;
+  dim3 grid((unsigned)((h->dim + 255) / 256), h->B);
+  hipLaunchKernelGGL(k_gen_apply, grid, dim3(256), 0, st, A);
+  HIPCHK(hipGetLastError());
+  h->stats.n_launches++;
+  h->stats.n_applications++;
+  (void)m;
+  return RYD_OK;
+}
+
+static int launch_eval_general(ryd_handle* h, const MixPoint& m, hipStream_t st) {
+  const int n = (int)h->gen_host.size();
+  hipLaunchKernelGGL(k_gen_coefs, dim3((n + 63) / 64), dim3(64), 0, st, h->pp_dev, h->n_knots - 1,
+                     h->gen_series_dev, h->gen_conj_dev, h->gen_scale_dev, n, m.idx1, m.u1, m.w1,
+                     m.u2, m.w2, h->gen_tcoef);
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1397,7 +1642,9 @@ static void plan_exp(ryd_handle* h, int idx, double hstep, double w1, double w2,
   const double dpos = wmix * h->bd_pos[idx], dneg = wmix * h->bd_neg[idx];
   const double lo = wmix * h->e0_min - dpos, hi = wmix * h->e0_max + dneg;
   double bound, shift = 0.0;
-  if (h->cfg.mode == RYD_SESOLVE) {
+  if (h->general) {
+    bound = drive;  // sum_t |coef_t| ||A_t||_inf; no spectral shift
+  } else if (h->cfg.mode == RYD_SESOLVE) {
     shift = 0.5 * (lo + hi);  // H' = H - shift: halves the spectral radius
     bound = 0.5 * (hi - lo) + drive;
   } else {
@@ -1483,6 +1730,19 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
 static int exp_step(ryd_handle* h, cplx* state, double hstep, const MixPoint& m, int order,
                     double shift, hipStream_t st) {
   int rc;
+  if (h->general) {
+    if ((rc = launch_eval_general(h, m, st))) return rc;
+    const cplx* gin = state;
+    cplx* gbufs[2] = {h->wA, h->wB};
+    int gw = 0;
+    for (int j = order; j >= 1; --j) {
+      cplx* out = j == 1 ? state : gbufs[gw];
+      if ((rc = apply_general(h, m, gin, state, out, hstep / j, st))) return rc;
+      gin = out;
+      gw ^= 1;
+    }
+    return RYD_OK;
+  }
   if ((rc = launch_eval(h, m, st))) return rc;
   const double wmix = m.w1 + m.w2;
   // Horner: w_m = psi; w_{j-1} = psi + (h/j) G' w_j; result w_0, times e^{-i h shift}
@@ -1603,7 +1863,7 @@ static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc
 }
 
 static bool use_persistent(const ryd_handle* h) {
-  return h->cfg.mode == RYD_SESOLVE && h->N <= 12 && !h->force_generic;
+  return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 12 && !h->force_generic;
 }
 
 extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
@@ -1614,7 +1874,7 @@ extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const 
   for (int i = 1; i < n_times; ++i)
     if (!(times[i] >= times[i - 1])) return fail(RYD_ERR_INVALID, "times must be non-decreasing");
   HIPCHK(hipSetDevice(h->cfg.device));
-  if (!h->bounds_valid) compute_bounds(h);
+  if (!h->bounds_valid) { if (h->general) compute_bounds_general(h); else compute_bounds(h); }
   ryd_opts o;
   std::memset(&o, 0, sizeof o);
   if (opts) o = *opts;

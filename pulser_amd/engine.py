@@ -302,3 +302,90 @@ class Engine:
         n = C.c_int64()
         _lib.check(self.lib.ryd_get_kernel_timing(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
+
+
+class GeneralEngine:
+    """Explicit-term engine for the systems the tuned kernels do not cover
+    (multi-level bases, leakage, XY, arbitrary eff_noise); see
+    ``pulser_amd.general``.  One problem per engine, batch = 1."""
+
+    def __init__(self, tables: Any, device: int | None = None) -> None:
+        from ._lib import RydGeneralConfig
+
+        self.torch = _torch()
+        self.lib = _lib.load()
+        self.tables = tables
+        self.dim = int(tables.dim)
+        self.local_dim = int(tables.local_dim)
+        self.n = int(tables.n_qudits)
+        self.is_density = bool(tables.is_density)
+        self.batch = 1
+        self.device_index = self.torch.cuda.current_device() if device is None else int(device)
+        self.device = self.torch.device("cuda", self.device_index)
+        cfg = RydGeneralConfig(abi_version=_lib.RYD_ABI_VERSION, batch=1,
+                               device=self.device_index, reserved=0, dim=self.dim)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.ryd_general_create(C.byref(cfg), C.byref(self._h)))
+        tk = np.ascontiguousarray(tables.tknots, dtype=np.float64)
+        pp = np.ascontiguousarray(tables.pp, dtype=np.complex128)
+        _lib.check(self.lib.ryd_set_series(self._h, pp.shape[0], len(tk), tk.ctypes.data,
+                                           pp.ctypes.data))
+        for i in range(len(tables.values)):
+            rp, ci, va = tables.row_ptr[i], tables.col_idx[i], tables.values[i]
+            _lib.check(self.lib.ryd_general_add_term(
+                self._h, len(va), rp.ctypes.data, ci.ctypes.data if len(va) else None,
+                va.ctypes.data if len(va) else None, int(tables.series[i]), int(tables.conj[i]),
+                float(tables.scale[i].real), float(tables.scale[i].imag), float(tables.row_norm[i])))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ryd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self) -> "GeneralEngine":
+        return self
+
+    def __exit__(self, *exc: Any) -> None:
+        self.close()
+
+    def _stream(self) -> int:
+        return int(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def new_state(self, ket: np.ndarray) -> Any:
+        """Device vector from a host ket: psi, or row-major vec(|psi><psi|)."""
+        v = np.asarray(ket, dtype=np.complex128).reshape(-1)
+        if self.is_density:
+            v = np.outer(v, v.conj()).reshape(-1)
+        if v.size != self.dim:
+            raise ValueError(f"Incompatible shape of state. Expected {self.dim}, got {v.size}.")
+        return self.torch.from_numpy(np.ascontiguousarray(v[None, :])).to(self.device)
+
+    def solve(self, state: Any, times: Sequence[float], **opts: Any) -> Any:
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        out = self.torch.empty((len(t) - 1, 1, self.dim), dtype=self.torch.complex128,
+                               device=self.device)
+        o = RydOpts(taylor_order=int(opts.get("taylor_order", 0)), max_order=int(opts.get("max_order", 0)),
+                    tol=float(opts.get("tol", 0.0)), max_step=float(opts.get("max_step", 0.0)),
+                    magnus_tol=float(opts.get("magnus_tol", 0.0)))
+        _lib.check(self.lib.ryd_solve(self._h, state.data_ptr(), len(t), t.ctypes.data,
+                                      out.data_ptr(), C.byref(o), self._stream()))
+        return out
+
+    def apply_generator(self, x: Any, t: float) -> Any:
+        out = self.torch.empty_like(x)
+        _lib.check(self.lib.ryd_apply_generator(self._h, x.data_ptr(), out.data_ptr(), float(t),
+                                                self._stream()))
+        return out
+
+    def stats(self) -> dict[str, Any]:
+        s = RydStats()
+        _lib.check(self.lib.ryd_get_stats(self._h, C.byref(s)))
+        return {"n_applications": int(s.n_applications), "n_launches": int(s.n_launches),
+                "n_steps": int(s.n_steps), "passes": 1, "last_order": int(s.last_order),
+                "norm_bound": float(s.norm_bound)}

@@ -485,6 +485,8 @@ class QutipEmulator:
 
         if tables is None:
             mode = self._solver_mode(problems[0])
+            if not self._fast_path_ok(problems[0]):
+                return self._solve_general(problems, mode, options)
             tables = lower(problems)
         else:
             mode = self._solver_mode({"collapse_ops": [1] if tables.dissipator is not None else []})
@@ -512,6 +514,60 @@ class QutipEmulator:
                                 self._meas_basis in self.basis_name,
                                 evaluation_time=float(t / (self._tot_duration * 1e-3)))
                 )
+            out.append(CoherentResults(results, n, self.basis_name, times, self._meas_basis,
+                                       meas_errors))
+        return out
+
+    @staticmethod
+    def _fast_path_ok(problem: dict[str, Any]) -> bool:
+        """2-level ground-rydberg / digital problems whose dissipator has only
+        diagonal and double-flip entries run on the tuned matrix-free kernels;
+        everything else takes the explicit-term general path."""
+        from .terms import SUPPORTED_BASES, local_dissipator
+
+        if problem["basis_name"] not in SUPPORTED_BASES or len(problem["eigenbasis"]) != 2:
+            return False
+        if problem.get("interaction_type") == "XY":
+            return False
+        S = local_dissipator(problem.get("collapse_ops", []), problem["eigenbasis"],
+                             problem.get("depolarizing_pauli_2ds"))
+        if S is not None:
+            for r in range(4):
+                for c in range(4):
+                    if c not in (r, 3 - r) and S[r, c] != 0:
+                        return False
+        return True
+
+    def _solve_general(self, problems: list[dict[str, Any]], mode: str,
+                       options: dict[str, Any]) -> list[CoherentResults]:
+        from .engine import GeneralEngine
+        from .general import lower_general
+
+        times = self._eval_times_array
+        meas_errors = (
+            {"epsilon": self.noise_model.p_false_pos, "epsilon_prime": self.noise_model.p_false_neg}
+            if "SPAM" in self.noise_model.noise_types else None
+        )
+        qids = tuple(self.samples_obj.qubit_ids)
+        n = self._hamiltonian_data.n_qudits
+        out = []
+        for prob in problems:
+            tables = lower_general(prob, mesolve=(mode == "mesolve"))
+            with GeneralEngine(tables) as eng:
+                state = eng.new_state(np.asarray(self._initial_state).reshape(-1))
+                first = state.cpu().numpy()[0]
+                host = eng.solve(state, times, **self._engine_kwargs(options)).cpu().numpy()
+                self.last_engine_stats = eng.stats()
+            D = len(prob["eigenbasis"]) ** n
+            results = []
+            for i, t in enumerate(times):
+                st = first if i == 0 else host[i - 1][0]
+                if mode == "mesolve":
+                    st = st.reshape(D, D)
+                results.append(
+                    StateResult(qids, self._meas_basis, QState(st),
+                                self._meas_basis in self.basis_name,
+                                evaluation_time=float(t / (self._tot_duration * 1e-3))))
             out.append(CoherentResults(results, n, self.basis_name, times, self._meas_basis,
                                        meas_errors))
         return out
@@ -574,8 +630,12 @@ class QutipEmulator:
         traj_nb = 0
         for start in range(0, len(trajs), batch):
             chunk = trajs[start:start + batch]
-            tables = hd.device_tables(chunk, self._sampling_rate)
-            solved = self._solve_batch([], progress_bar, options, tables=tables)
+            if self._fast_path_ok(self._current_problem):
+                tables = hd.device_tables(chunk, self._sampling_rate)
+                solved = self._solve_batch([], progress_bar, options, tables=tables)
+            else:
+                solved = self._solve_batch([hd.problem(t, self._sampling_rate) for t in chunk],
+                                           progress_bar, options)
             for tr, res in zip(chunk, solved):
                 reps = tr.reps
                 if print_progress:

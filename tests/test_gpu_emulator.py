@@ -18,7 +18,7 @@ from pulser_amd.hamiltonian_data import single_global_channel
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED_RYDBERG = [0, 1, 2, 3, 4, 5]  # index 6 = leakage (3-level): not built yet
+SUPPORTED_RYDBERG = list(range(7))  # index 6 = leakage (3-level): explicit-term general path
 
 
 @pytest.mark.parametrize("k", SUPPORTED_RYDBERG)
@@ -33,11 +33,14 @@ def test_reference_golden_counters_rydberg_end_to_end(k):
         params.update(relaxation_rate=0.01)
     if "depolarizing" in noise:
         params.update(depolarizing_rate=0.05)
-    if "eff_noise" in noise:
-        params.update(eff_noise_opers=[np.diag([1.0, -1.0]).astype(complex)], eff_noise_rates=[0.025])
+    leak = "leakage" in noise
+    if leak or "eff_noise" in noise:
+        params.update(eff_noise_opers=[np.diag([1.0, 0, 0]).astype(complex) if leak
+                                       else np.diag([1.0, -1.0]).astype(complex)],
+                      eff_noise_rates=[0.1 if leak else 0.025])
     np.random.seed(123)
     emu = QutipEmulator(_inputs_from_problem(prob, "ground-rydberg"), sampling_rate=0.01,
-                        noise_model=NoiseModel(**params))
+                        noise_model=NoiseModel(with_leakage=leak, **params))
     with pytest.warns(DeprecationWarning):
         res = emu.run()
     assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
@@ -45,17 +48,6 @@ def test_reference_golden_counters_rydberg_end_to_end(k):
     assert np.max(np.abs(final - extra["oracle_final_state_tight"])) < 1e-7
     tr2 = np.trace(final @ final).real
     assert tr2 < 1 and not np.isclose(tr2, 1)
-
-
-def test_leakage_is_refused_loudly():
-    prob, extra = load_fixture("noises_rydberg_6.npz")
-    np.random.seed(123)
-    emu = QutipEmulator(
-        _inputs_from_problem(prob, "ground-rydberg"), sampling_rate=0.01,
-        noise_model=NoiseModel(with_leakage=True, eff_noise_opers=[np.diag([1.0, 0, 0])],
-                               eff_noise_rates=[0.1]))
-    with pytest.warns(DeprecationWarning), pytest.raises(NotImplementedError, match="not supported"):
-        emu.run()
 
 
 def test_cfg1_plumbing_and_three_atom_golden_state():
@@ -157,3 +149,71 @@ def test_cfg4_noisy_run_factored_equals_general_path():
         counts.append([dict(r.bitstring_counts) for r in res])
     assert counts[0] == counts[1]
     assert sum(counts[0][-1].values()) == 240
+
+
+@pytest.mark.parametrize("k", range(7))
+def test_reference_golden_counters_digital_end_to_end(k):
+    """tests/pulser_simulation/test_simulation.py:1079-1160 with the real solver:
+    digital basis, local Raman pulses, 2-level (tuned kernels) and 3-level with
+    leakage / general eff_noise (explicit-term general path)."""
+    prob, extra = load_fixture(f"noises_digital_{k}.npz")
+    noise = tuple(extra["noise"])
+    params = {}
+    if "dephasing" in noise:
+        params.update(dephasing_rate=0.05, hyperfine_dephasing_rate=0.05)
+    if "depolarizing" in noise:
+        params.update(depolarizing_rate=0.05)
+    leak = "leakage" in noise
+    if leak or "eff_noise" in noise:
+        params["eff_noise_opers"] = [np.diag([0, 1.0, 0]).astype(complex) if leak
+                                     else np.diag([1.0, -1.0]).astype(complex)]
+        params["eff_noise_rates"] = [0.1 if leak else 0.025]
+    np.random.seed(123)
+    emu = QutipEmulator(_inputs_from_problem(prob, "digital"), sampling_rate=0.01,
+                        noise_model=NoiseModel(with_leakage=leak, **params))
+    assert emu._fast_path_ok(emu._current_problem) == (not leak)
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
+    final = np.asarray(res.states[-1])
+    assert np.max(np.abs(final - extra["oracle_final_state_tight"])) < 1e-7
+    if leak:  # test_simulation.py:1036-1039: nothing leaks into the error state
+        st = np.asarray(res.get_final_state())
+        assert st.shape == (27, 27)
+
+
+def test_general_path_matches_tuned_kernels_and_oracle_generator():
+    """The explicit-term path against the matrix-free kernels (2-level problem
+    forced through it) and against the oracle's Lindblad RHS for a non-diagonal
+    eff_noise operator that only the general path supports."""
+    from helpers import local_problem
+    from oracle import qutip_path as qp
+    from pulser_amd.engine import Engine, GeneralEngine
+    from pulser_amd.general import lower_general
+    import torch
+
+    prob = local_problem(4, seed=2, duration=41)
+    times = np.array([0.0, 0.013, 0.04])
+    with Engine.from_problems([prob]) as eng:
+        st = eng.new_state()
+        ref = eng.solve(st, times).cpu().numpy()[:, 0]
+    with GeneralEngine(lower_general(prob, mesolve=False)) as g:
+        psi0 = np.zeros(16, complex); psi0[-1] = 1
+        got = g.solve(g.new_state(psi0), times).cpu().numpy()[:, 0]
+    assert np.max(np.abs(got - ref)) < 1e-8  # different norm bounds -> different step/order choices
+    # general eff_noise: C = sqrt(rate) * (X + 0.3 Z) has pair-dependent single flips
+    op = np.array([[0.3, 1.0], [1.0, -0.3]], dtype=complex)
+    prob = local_problem(3, seed=5, duration=41, collapse_ops=[(np.sqrt(0.2), op)])
+    assert not QutipEmulator._fast_path_ok(prob)
+    ham = qp.build_hamiltonian(prob)
+    rhs = qp.lindblad_rhs(ham)
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(8, 8)) + 1j * rng.normal(size=(8, 8))
+    with GeneralEngine(lower_general(prob, mesolve=True)) as g:
+        dev = torch.from_numpy(x.reshape(1, -1).copy()).to(g.device)
+        out = g.apply_generator(dev, 0.0123).cpu().numpy()[0].reshape(8, 8)
+        assert np.max(np.abs(out - rhs(0.0123, x.ravel()).reshape(8, 8))) < 1e-11
+        psi0 = np.zeros(8, complex); psi0[-1] = 1
+        rho = g.solve(g.new_state(psi0), np.array([0.0, 0.04])).cpu().numpy()[-1, 0].reshape(8, 8)
+    ref = qp.mesolve(ham, psi0, np.array([0.0, 0.04]), max_step=1e-3, **qp.TIGHT)[-1]
+    assert np.max(np.abs(rho - ref)) < 1e-7
