@@ -247,6 +247,87 @@ def gen_noises_digital():
         )
 
 
+
+# ---------------------------------------------------------------------------
+# 2b. test_simulation.py:1179-1300 (3 atoms, "all" basis = digital + rydberg)
+# ---------------------------------------------------------------------------
+
+ALL_CASES = [
+    (("dephasing",), {"111": 961, "101": 15, "110": 14, "011": 9, "001": 1}, 2),
+    (("eff_noise",), {"111": 961, "101": 15, "110": 14, "011": 9, "001": 1}, 2),
+    (("relaxation",), {"000": 459, "010": 202, "001": 168, "100": 167, "101": 4}, 1),
+    (("dephasing", "relaxation"), {"000": 451, "010": 205, "001": 170, "100": 168, "101": 6}, 3),
+    (("eff_noise", "dephasing"), {"111": 932, "101": 28, "011": 24, "110": 15, "001": 1}, 4),
+    (("eff_noise", "leakage"), {"111": 961, "101": 15, "110": 14, "011": 9, "001": 1}, 2),
+]
+
+
+def seq_all():
+    """The CCZ sequence fixture `seq` of test_simulation.py:76-96."""
+    pi_pulse = Pulse.ConstantDetuning(BlackmanWaveform(1000, np.pi), 0.0, 0)
+    twopi_pulse = Pulse.ConstantDetuning(BlackmanWaveform(1000, 2 * np.pi), 0.0, 0)
+    seq = seq_digital()
+    seq.declare_channel("ryd", "rydberg_local", "control1")
+    seq.add(pi_pulse, "ryd", protocol="wait-for-all")
+    seq.target("control2", "ryd")
+    seq.add(pi_pulse, "ryd")
+    seq.target("target", "ryd")
+    seq.add(twopi_pulse, "ryd")
+    seq.target("control2", "ryd")
+    seq.add(pi_pulse, "ryd")
+    seq.target("control1", "ryd")
+    seq.add(pi_pulse, "ryd")
+    seq.add(Pulse.ConstantPulse(1000, 1, 0, 0), "ryd")
+    return seq
+
+
+def gen_noises_all():
+    pi_y = Pulse.ConstantDetuning(BlackmanWaveform(1000, np.pi), 0.0, -np.pi / 2)
+    twopi_pulse = Pulse.ConstantDetuning(BlackmanWaveform(1000, 2 * np.pi), 0.0, 0)
+    for k, (noise, golden, n_ops) in enumerate(ALL_CASES):
+        seq = seq_all()
+        params = {}
+        if "relaxation" in noise:
+            seq.target("control1", "raman")
+            seq.add(pi_y, "raman")
+            seq.target("target", "raman")
+            seq.add(pi_y, "raman")
+            seq.target("control2", "raman")
+            seq.add(pi_y, "raman")
+            seq.declare_channel("ryd_glob", "rydberg_global")
+            seq.add(twopi_pulse, "ryd_glob")
+            seq.measure()
+            params["relaxation_rate"] = 1.0
+        leak = "leakage" in noise
+        dd = 4 if leak else 3
+        deph_op = np.zeros((dd, dd), dtype=complex); deph_op[0, 0] = 1
+        hyp_op = np.zeros((dd, dd), dtype=complex); hyp_op[2, 2] = 1
+        if "dephasing" in noise:
+            params["hyperfine_dephasing_rate"] = 0.1
+            params["dephasing_rate"] = 0.1
+        if leak or "eff_noise" in noise:
+            params["eff_noise_opers"] = [deph_op, hyp_op]
+            params["eff_noise_rates"] = [0.2, 0.2]
+        problems, aux, _ = capture(seq, NoiseModel(with_leakage=leak, **params), 0.01)
+        states = solve(problems[0], aux)
+        np.random.seed(123)  # the reference seeds right before run()
+        counter = osamp.sample_state(
+            states, aux["eval_times"], aux["eval_times"][-1], 1000,
+            problems[0]["n_qudits"], problems[0]["eigenbasis"],
+            aux["meas_basis"], aux["matching_meas_basis"],
+        )
+        ok = dict(counter) == golden
+        print(f"noises_all[{k}] {noise}: {'OK' if ok else 'MISMATCH'} {dict(counter)} meas={aux['meas_basis']}")
+        tight = solve(problems[0], aux, tight=True)
+        idx = osamp.index_from_time(aux["eval_times"], aux["eval_times"][-1])
+        P.save_problem(
+            os.path.join(HERE, f"noises_all_{k}.npz"), problems[0], aux=aux, seed=123,
+            noise=list(noise), n_collapse_ops=n_ops, reference_golden_counter=golden,
+            reference_cite="tests/pulser_simulation/test_simulation.py:1179-1300",
+            oracle_final_state_default=states[-1], oracle_final_state_tight=tight[-1],
+            oracle_lookup_index=idx, oracle_lookup_state_default=states[idx],
+        )
+
 # ---------------------------------------------------------------------------
 # 3. test_simulation.py:2156-2190 (3 atoms, custom initial state, golden state)
 # ---------------------------------------------------------------------------
@@ -484,6 +565,8 @@ if __name__ == "__main__":
         gen_noises_rydberg()
     if "digital" in which:
         gen_noises_digital()
+    if "all" in which:
+        gen_noises_all()
     if "three" in which:
         gen_three_atom_state()
     if "cfg1" in which:

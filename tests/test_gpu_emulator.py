@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from helpers import load_fixture, with_anneal_samples
-from test_host_logic import _chain12_inputs, _inputs_from_problem
+from test_host_logic import _all_basis_emulator, _chain12_inputs, _inputs_from_problem
 
 from pulser_amd import NoiseModel, QutipEmulator, Solver
 from pulser_amd import problem as P
@@ -217,3 +217,20 @@ def test_general_path_matches_tuned_kernels_and_oracle_generator():
         rho = g.solve(g.new_state(psi0), np.array([0.0, 0.04])).cpu().numpy()[-1, 0].reshape(8, 8)
     ref = qp.mesolve(ham, psi0, np.array([0.0, 0.04]), max_step=1e-3, **qp.TIGHT)[-1]
     assert np.max(np.abs(rho - ref)) < 1e-7
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_reference_golden_counters_all_basis_end_to_end(k):
+    """test_simulation.py:1179-1300 with the real solver: 3-level "all" basis
+    (and 4-level with leakage), local + global channels, dephasing / relaxation /
+    eff_noise - explicit-term general path."""
+    emu, prob, extra = _all_basis_emulator(k)
+    assert not emu._fast_path_ok(emu._current_problem)
+    np.random.seed(123)
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
+    final = np.asarray(res.states[-1])
+    assert np.max(np.abs(final - extra["oracle_final_state_tight"])) < 1e-7
+    tr2 = np.trace(final @ final).real
+    assert tr2 < 1 and not np.isclose(tr2, 1)

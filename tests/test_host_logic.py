@@ -183,19 +183,69 @@ class _FakeSolve:
                                 emu._meas_basis, me) for _ in problems]
 
 
-def _inputs_from_problem(prob, basis, c6=P.C6_LEVEL70):
+def _inputs_from_problem(prob, basis=None, c6=P.C6_LEVEL70, measurement=None):
+    """SequenceInputs equivalent to a captured (noiseless-sample) problem: one
+    Global channel per global basis entry, one Local channel per (basis, atom)."""
     n = prob["n_qudits"]
     chans = []
-    if prob["samples"]["Global"]:
-        s = prob["samples"]["Global"][basis]
+    for b, s in prob["samples"]["Global"].items():
+        if basis is not None and b != basis:
+            continue
         T = len(s["amp"]) - 1
-        chans.append(ChannelInput("g", "Global", basis, s["amp"][:-1], s["det"][:-1],
+        chans.append(ChannelInput(f"g_{b}", "Global", b, s["amp"][:-1], s["det"][:-1],
                                   s["phase"][:-1], [Slot(0, T, tuple(range(n)))]))
-    for q, s in prob["samples"]["Local"].get(basis, {}).items():
-        T = len(s["amp"]) - 1
-        chans.append(ChannelInput(f"l{q}", "Local", basis, s["amp"][:-1], s["det"][:-1],
-                                  s["phase"][:-1], [Slot(0, T, (int(q),))]))
-    return SequenceInputs(prob["coords"], prob["qubit_ids"], chans, c6)
+    for b, per_q in prob["samples"]["Local"].items():
+        if basis is not None and b != basis:
+            continue
+        for q, s in per_q.items():
+            T = len(s["amp"]) - 1
+            chans.append(ChannelInput(f"l_{b}_{q}", "Local", b, s["amp"][:-1], s["det"][:-1],
+                                      s["phase"][:-1], [Slot(0, T, (int(q),))]))
+    return SequenceInputs(prob["coords"], prob["qubit_ids"], chans, c6, measurement=measurement)
+
+
+def _all_basis_emulator(k):
+    """Emulator for case k of test_simulation.py:1179-1300 ("all" basis)."""
+    prob, extra = load_fixture(f"noises_all_{k}.npz")
+    noise = tuple(extra["noise"])
+    leak = "leakage" in noise
+    dd = 4 if leak else 3
+    params = {}
+    if "relaxation" in noise:
+        params["relaxation_rate"] = 1.0
+    if "dephasing" in noise:
+        params.update(hyperfine_dephasing_rate=0.1, dephasing_rate=0.1)
+    if leak or "eff_noise" in noise:
+        a = np.zeros((dd, dd), dtype=complex); a[0, 0] = 1
+        b = np.zeros((dd, dd), dtype=complex); b[2, 2] = 1
+        params.update(eff_noise_opers=[a, b], eff_noise_rates=[0.2, 0.2])
+    meas = extra["aux"]["meas_basis"]
+    emu = QutipEmulator(
+        _inputs_from_problem(prob, measurement=meas if meas != "digital" else None),
+        sampling_rate=0.01, noise_model=NoiseModel(with_leakage=leak, **params))
+    return emu, prob, extra
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_emulator_golden_counters_all_basis(k, monkeypatch):
+    """test_simulation.py:1179-1300 (3 atoms, digital + rydberg channels, d = 3/4)."""
+    emu, prob, extra = _all_basis_emulator(k)
+    assert set(emu.noise_model.noise_types) == set(extra["noise"])
+    assert emu.basis_name == prob["basis_name"] and emu._meas_basis == extra["aux"]["meas_basis"]
+    p = emu._current_problem
+    assert p["eigenbasis"] == list(prob["eigenbasis"])
+    assert len(p["collapse_ops"]) == extra["n_collapse_ops"]
+    assert np.array_equal(emu.evaluation_times, extra["aux"]["eval_times"])
+    monkeypatch.setattr(emu, "_solve_batch", _FakeSolve(emu, extra["oracle_lookup_state_default"]))
+    np.random.seed(123)  # the reference seeds right before run()
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
+    with pytest.raises(NotImplementedError, match="Cannot include depolarizing noise in all-basis."):
+        QutipEmulator(_inputs_from_problem(prob), noise_model=NoiseModel(depolarizing_rate=1.0))
+    with pytest.raises(ValueError, match="Incompatible shape for effective noise operator n°0."):
+        QutipEmulator(_inputs_from_problem(prob), noise_model=NoiseModel(
+            eff_noise_opers=[np.diag([1.0, -1.0])], eff_noise_rates=[1.0]))
 
 
 @pytest.mark.parametrize("k", range(7))
