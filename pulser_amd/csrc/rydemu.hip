@@ -462,6 +462,211 @@ __global__ __launch_bounds__(512, 4) void k_apply12(const PassArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_apply14: 2^14-amplitude tiles held in REGISTERS (16 per thread, 1024
+// threads); LDS only exchanges the 10 low tile bits, slice by slice (a slice
+// = the 1024 amplitudes with equal register index, closed under flips of bits
+// 0-9); flips of tile bits 10-13 are register moves.  Covers the whole state
+// of a 14-atom sesolve in one pass and every column-bit flip of a 14-atom
+// density-matrix row in one pass.  Tile = index bits [0, 14); flips are the
+// bits 0 .. n_flip-1; blockIdx.x = the higher index bits, blockIdx.y = batch.
+// ---------------------------------------------------------------------------
+struct Apply14Args {
+  const cplx* in;
+  const cplx* base;   // Horner base (final form) or null
+  cplx* out;          // final form: post * (base + scale * acc)
+  cplx* kout;         // partial form (no base, no scale) when not null
+  const double* coefs;
+  const double* e0;
+  long long e0_stride;
+  double wmix, diag_scale, scale, shift;
+  cplx post;
+  cplx Sd[4];
+  int N, nb, n_flip;
+};
+
+template <int MODE, bool REAL>
+__global__ __launch_bounds__(1024) void k_apply14(const Apply14Args A) {
+  constexpr int T = 14, NTT = 1024, R = 16, LOGNT = 10, TL = 7, GS = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx* xs = reinterpret_cast<cplx*>(smem);            // GS slices of 1024
+  double* tabLo = reinterpret_cast<double*>(xs + GS * NTT);
+  double* tabHi = tabLo + (1 << TL);
+  double* cft = tabHi + (1 << TL);                     // [T][2]
+
+  const int tid = threadIdx.x;
+  const int N = A.N;
+  const int nf = A.n_flip;
+  const size_t boff = (size_t)blockIdx.y << A.nb;
+  const unsigned long long base_idx = (unsigned long long)blockIdx.x << T;
+  const double* __restrict__ cf = A.coefs + (size_t)blockIdx.y * N * 4;
+  const double* __restrict__ e0 = A.e0 + (size_t)blockIdx.y * A.e0_stride;
+  const cplx* __restrict__ xin = A.in + boff + base_idx;
+  const unsigned Dm1 = (MODE == RYD_MESOLVE) ? ((1u << N) - 1u) : 0u;
+
+  cplx x[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) x[j] = xin[tid + j * NTT];
+
+  if (tid < nf) {
+    const int p = tid;  // tile-local bit = global bit
+    const int k = (MODE == RYD_SESOLVE || p < N) ? N - 1 - p : 2 * N - 1 - p;
+    cft[2 * tid] = cf[4 * k];
+    cft[2 * tid + 1] = cf[4 * k + 1];
+  }
+  // detuning part of the diagonal: two 128-entry tables + the outer bits
+  for (int e = tid; e < 2 * (1 << TL); e += NTT) {
+    const bool hiHalf = e >= (1 << TL);
+    const int v = hiHalf ? e - (1 << TL) : e;
+    const int qb = hiHalf ? TL : 0;
+    double s = 0.0;
+    for (int q = 0; q < TL; ++q) {
+      const int p = qb + q;
+      if (p >= A.nb) continue;
+      double sg;
+      int k;
+      if (MODE == RYD_SESOLVE) { k = N - 1 - p; sg = -1.0; }
+      else if (p >= N) { k = 2 * N - 1 - p; sg = -1.0; }
+      else { k = N - 1 - p; sg = 1.0; }
+      if (!((v >> q) & 1)) s += sg * cf[4 * k + 2];
+    }
+    (hiHalf ? tabHi : tabLo)[v] = s;
+  }
+  double eOuter = 0.0;
+  for (int p = T; p < A.nb; ++p) {
+    double sg;
+    int k;
+    if (MODE == RYD_SESOLVE) { k = N - 1 - p; sg = -1.0; }
+    else if (p >= N) { k = 2 * N - 1 - p; sg = -1.0; }
+    else { k = N - 1 - p; sg = 1.0; }
+    if (!((base_idx >> p) & 1ull)) eOuter += sg * cf[4 * k + 2];
+  }
+  __syncthreads();
+
+  // flip coefficient (sgn * ci, s2 * cr), wave-uniform -> scalar registers
+  double fcr[T], fci[T];
+#pragma unroll
+  for (int f = 0; f < T; ++f) {
+    const bool on = f < nf;
+    const double cr = on ? cft[2 * f] : 0.0, ci = on ? cft[2 * f + 1] : 0.0;
+    const double s2 = (MODE == RYD_MESOLVE && f < N) ? 1.0 : -1.0;
+    fcr[f] = uniform_d(s2 * cr);
+    fci[f] = REAL ? 0.0 : uniform_d(ci);
+  }
+
+#pragma unroll
+  for (int g0 = 0; g0 < R; g0 += GS) {
+    if (g0) __syncthreads();  // previous group's partner reads are done
+#pragma unroll
+    for (int jj = 0; jj < GS; ++jj) xs[jj * NTT + tid] = x[(g0 + jj) & (R - 1)];
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < GS; ++jj) {
+      const int j = g0 + jj;  // compile-time after unrolling
+      const int l = tid + j * NTT;
+      const unsigned long long gi = base_idx | (unsigned long long)l;
+      cplx bv = make_double2(0.0, 0.0);
+      if (!A.kout && A.base) bv = A.base[boff + gi];
+      cplx xv[LOGNT];
+#pragma unroll
+      for (int q = 0; q < LOGNT; ++q)
+        if (q < nf) xv[q] = xs[jj * NTT + (tid ^ (1 << q))];
+      const cplx xo = x[j];
+      // diagonal
+      double e = tabLo[l & ((1 << TL) - 1)] + tabHi[l >> TL] + eOuter;
+      cplx a;
+      if (MODE == RYD_SESOLVE) {
+        e = A.diag_scale * (e + A.wmix * e0[gi]) - A.shift;
+        a = make_double2(e * xo.y, -e * xo.x);
+      } else {
+        const unsigned aa = (unsigned)(gi >> N), bb = (unsigned)gi & Dm1;
+        e += A.wmix * (e0[aa] - e0[bb]);
+        const int n11 = __popc(aa & bb), n10 = __popc(aa & ~bb & Dm1),
+                  n01 = __popc(~aa & bb & Dm1), n00 = N - n11 - n10 - n01;
+        const double dr = A.diag_scale * A.wmix * (A.Sd[0].x * n00 + A.Sd[1].x * n01 +
+                                                   A.Sd[2].x * n10 + A.Sd[3].x * n11);
+        const double di = A.diag_scale * (A.wmix * (A.Sd[0].y * n00 + A.Sd[1].y * n01 +
+                                                    A.Sd[2].y * n10 + A.Sd[3].y * n11) - e);
+        a = make_double2(dr * xo.x - di * xo.y, dr * xo.y + di * xo.x);
+      }
+#pragma unroll
+      for (int f = 0; f < T; ++f) {
+        if (f >= nf) continue;  // wave-uniform
+        cplx p;
+        if (f < LOGNT) {
+          p = xv[f];
+        } else {
+          p = x[(j ^ (1 << (f >= LOGNT ? f - LOGNT : 0))) & (R - 1)];
+        }
+        if (REAL) {
+          a = make_double2(fma(-fcr[f], p.y, a.x), fma(fcr[f], p.x, a.y));
+        } else {
+          const double sgi = ((l >> f) & 1) ? fci[f] : -fci[f];
+          a = cfma(make_double2(sgi, fcr[f]), p, a);
+        }
+      }
+      if (A.kout) {
+        A.kout[boff + gi] = a;
+      } else {
+        const cplx r = make_double2(fma(A.scale, a.x, bv.x), fma(A.scale, a.y, bv.y));
+        A.out[boff + gi] = cmul(A.post, r);
+      }
+    }
+  }
+}
+
+// out = base + scale * (P + P^dagger) for Hermitian-preserving generators:
+// 32 x 32 tile pairs (A <= B); both mirror tiles are written (coalesced, via an
+// LDS transpose), only the upper one is read from `base`.
+struct SymmArgs {
+  const cplx* P;
+  const cplx* base;
+  cplx* out;
+  double scale;
+  int N;
+};
+
+__global__ __launch_bounds__(256) void k_symm(const SymmArgs A) {
+  __shared__ cplx tAB[32][33];
+  __shared__ cplx tBA[32][33];
+  const int TA = blockIdx.y, TB = blockIdx.x;
+  if (TA > TB) return;
+  const size_t D = (size_t)1 << A.N;
+  const size_t boff = (size_t)blockIdx.z * D * D;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // ty: 0..7
+  const cplx* __restrict__ P = A.P + boff;
+  const cplx* __restrict__ base = A.base + boff;
+  cplx* __restrict__ out = A.out + boff;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = ty + 8 * r;
+    tAB[i][tx] = P[((size_t)TA * 32 + i) * D + (size_t)TB * 32 + tx];
+    tBA[i][tx] = P[((size_t)TB * 32 + i) * D + (size_t)TA * 32 + tx];
+  }
+  __syncthreads();
+  cplx v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = ty + 8 * r;
+    const cplx pab = tAB[i][tx], pba = tBA[tx][i];
+    const size_t g = ((size_t)TA * 32 + i) * D + (size_t)TB * 32 + tx;
+    const cplx b = base[g];
+    v[r] = make_double2(fma(A.scale, pab.x + pba.x, b.x), fma(A.scale, pab.y - pba.y, b.y));
+    out[g] = v[r];
+  }
+  if (TA == TB) return;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tAB[ty + 8 * r][tx] = v[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = ty + 8 * r;
+    const cplx w = tAB[tx][i];
+    out[((size_t)TB * 32 + i) * D + (size_t)TA * 32 + tx] = make_double2(w.x, -w.y);
+  }
+}
+
 // coefs[b][k] = w1 * val(t1) + w2 * val(t2) for the drive (complex) and the
 // detuning (real) of atom k of trajectory b.  pp: [n_series][n_int][4] complex.
 __global__ void k_eval_coefs(const cplx* __restrict__ pp, int n_int,
@@ -889,6 +1094,7 @@ struct Pass {
   std::vector<int> flip_q;
   std::vector<std::pair<int, int>> dbl;  // (qb, qa)
   bool include_diag = false;
+  bool use14 = false;  // pass 0 on 2^14 register tiles (k_apply14)
 };
 
 struct GenTermHost {
@@ -937,6 +1143,8 @@ struct ryd_handle {
   cplx* gen_scale_dev = nullptr;
   bool force_generic = false;
   bool no_fast_apply = false;  // test hook: use the generic k_apply for T = 12 too
+  bool no_tile14 = false;      // test hook: disable k_apply14 / the Hermitian mesolve path
+  bool drive_real = false;     // every drive series is real-valued
   bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
   ryd_stats stats{};
   // timing
@@ -1033,7 +1241,13 @@ static void plan_passes(ryd_handle* h) {
       Pass p;
       if (first) {
         g = T;
-        p = make_pass(nb, {{0, g}});
+        if (h->T == 12 && nb >= 14 && !h->no_tile14) {
+          g = 14;
+          p = make_pass(nb, {{0, g}});
+          p.use14 = true;
+        } else {
+          p = make_pass(nb, {{0, g}});
+        }
       } else {
         const int c = std::max(0, std::min(std::min(C, done), T - 1));
         g = std::max(1, std::min(nb - done, T - c));
@@ -1102,6 +1316,14 @@ extern "C" int ryd_create(const ryd_config* cfg, ryd_handle** out) {
   if ((e = hipFuncSetAttribute((const void*)k_apply<RYD_SESOLVE>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
       (e = hipFuncSetAttribute((const void*)k_apply<RYD_MESOLVE>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
       (e = hipFuncSetAttribute((const void*)k_apply12<RYD_SESOLVE, 0>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
@@ -1263,6 +1485,10 @@ static void compute_bounds(ryd_handle* h) {
     }
   }
   h->uniform_real_drive = uni;
+  bool dreal = true;
+  for (const ryd_qdesc& d : h->desc_host)
+    if (d.drive_series >= 0 && !series_real[d.drive_series]) { dreal = false; break; }
+  h->drive_real = dreal;
   h->bounds_valid = true;
 }
 
@@ -1375,6 +1601,21 @@ static int timing_begin(ryd_handle* h, hipStream_t st, std::pair<hipEvent_t, hip
   return RYD_OK;
 }
 
+static int launch_apply14(ryd_handle* h, const Apply14Args& B, hipStream_t st) {
+  const size_t lds = (size_t)8 * 1024 * sizeof(cplx) + 2 * 128 * sizeof(double) + 2 * 16 * sizeof(double);
+  dim3 grid((unsigned)(1ull << (h->nb - 14)), h->B);
+  const bool se = h->cfg.mode == RYD_SESOLVE;
+  if (h->drive_real) {
+    if (se) hipLaunchKernelGGL((k_apply14<RYD_SESOLVE, true>), grid, dim3(1024), lds, st, B);
+    else hipLaunchKernelGGL((k_apply14<RYD_MESOLVE, true>), grid, dim3(1024), lds, st, B);
+  } else {
+    if (se) hipLaunchKernelGGL((k_apply14<RYD_SESOLVE, false>), grid, dim3(1024), lds, st, B);
+    else hipLaunchKernelGGL((k_apply14<RYD_MESOLVE, false>), grid, dim3(1024), lds, st, B);
+  }
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
+}
+
 // out = post * (base + scale * G~ in); all passes.  `in` must differ from `out`
 // unless single-element hazards are impossible (never used in place here).
 static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx* out,
@@ -1419,6 +1660,34 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
     dim3 grid((unsigned)(1ull << p.n_outer_bits), h->B);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->timing) { int rc = timing_begin(h, st, ev); if (rc) return rc; }
+    if (p.use14) {
+      Apply14Args B;
+      std::memset(&B, 0, sizeof B);
+      B.in = in;
+      B.base = A.final_pass ? base : nullptr;
+      B.out = out;
+      B.kout = A.final_pass ? nullptr : h->kbuf;
+      B.coefs = h->coefs_dev;
+      B.e0 = h->e0_dev;
+      B.e0_stride = A.e0_stride;
+      B.wmix = wmix;
+      B.diag_scale = 1.0;
+      B.scale = scale;
+      B.shift = shift;
+      B.post = post;
+      for (int i = 0; i < 4; ++i) B.Sd[i] = h->Sd[i];
+      B.N = h->N;
+      B.nb = h->nb;
+      B.n_flip = std::min(14, h->nb);
+      int rc14 = launch_apply14(h, B, st);
+      if (rc14) return rc14;
+      if (h->timing) {
+        HIPCHK(hipEventRecord(ev.second, st));
+        h->ev_used.push_back(ev);
+      }
+      h->stats.n_launches++;
+      continue;
+    }
     // contiguous single-flip range on a full 2^12 tile -> specialised kernel
     bool fast = p.T == 12 && A.n_dbl == 0 && A.n_flip >= 1 && !h->no_fast_apply &&
                 (A.flip_q[0] == 0 || A.flip_q[0] == 4);
@@ -1726,6 +1995,11 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
   }
 }
 
+static bool hermitian_path(const ryd_handle* h) {
+  return !h->general && h->cfg.mode == RYD_MESOLVE && !h->has_dbl && h->N >= 7 && h->N <= 14 &&
+         h->T == 12 && !h->no_tile14;
+}
+
 // One exponential  state <- exp(h * G~) state  on the generic multi-launch path.
 static int exp_step(ryd_handle* h, cplx* state, double hstep, const MixPoint& m, int order,
                     double shift, hipStream_t st) {
@@ -1745,6 +2019,52 @@ static int exp_step(ryd_handle* h, cplx* state, double hstep, const MixPoint& m,
   }
   if ((rc = launch_eval(h, m, st))) return rc;
   const double wmix = m.w1 + m.w2;
+  if (hermitian_path(h)) {
+    // rho stays Hermitian, so G rho = P + P^dagger with P = (1/2) D.rho + the
+    // column-bit flips only: one register-tile pass over rows + one tile-pair
+    // symmetrisation instead of three tiled passes.
+    const cplx* hin = state;
+    cplx* hb[2] = {h->wA, h->wB};
+    int hw = 0;
+    for (int j = order; j >= 1; --j) {
+      cplx* out = j == 1 ? state : hb[hw];
+      Apply14Args B;
+      std::memset(&B, 0, sizeof B);
+      B.in = hin;
+      B.kout = h->kbuf;
+      B.coefs = h->coefs_dev;
+      B.e0 = h->e0_dev;
+      B.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << h->N);
+      B.wmix = wmix;
+      B.diag_scale = 0.5;
+      B.scale = 1.0;
+      B.post = make_double2(1.0, 0.0);
+      for (int i = 0; i < 4; ++i) B.Sd[i] = h->Sd[i];
+      B.N = h->N;
+      B.nb = h->nb;
+      B.n_flip = h->N;
+      std::pair<hipEvent_t, hipEvent_t> ev;
+      if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+      if ((rc = launch_apply14(h, B, st))) return rc;
+      if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
+      SymmArgs S;
+      S.P = h->kbuf;
+      S.base = state;
+      S.out = out;
+      S.scale = hstep / j;
+      S.N = h->N;
+      const unsigned nt = 1u << (h->N - 5);
+      if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+      hipLaunchKernelGGL(k_symm, dim3(nt, nt, h->B), dim3(256), 0, st, S);
+      HIPCHK(hipGetLastError());
+      if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
+      h->stats.n_launches += 2;
+      h->stats.n_applications++;
+      hin = out;
+      hw ^= 1;
+    }
+    return RYD_OK;
+  }
   // Horner: w_m = psi; w_{j-1} = psi + (h/j) G' w_j; result w_0, times e^{-i h shift}
   const cplx one = make_double2(1.0, 0.0);
   const cplx* in = state;
@@ -1921,6 +2241,10 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
   if (!h) return fail(RYD_ERR_INVALID, "null handle");
   h->force_generic = (force_generic & 1) != 0;
   h->no_fast_apply = (force_generic & 2) != 0;
+  {
+    const bool nt = (force_generic & 4) != 0;
+    if (nt != h->no_tile14) { h->no_tile14 = nt; plan_passes(h); }
+  }
   return RYD_OK;
 }
 

@@ -250,3 +250,47 @@ def test_specialised_tile_kernel_matches_generic(mode, n):
     st_b = eng.new_state()
     eng.evolve(st_b, 0.0, 0.004)
     assert np.max(np.abs(st_a.cpu().numpy() - st_b.cpu().numpy())) < 1e-13
+
+
+@pytest.mark.parametrize("n", [7, 8, 9])
+def test_hermitian_mesolve_path_matches_generic_passes_and_oracle(n):
+    """mesolve with a diagonal dissipator on N >= 7: the register-tile row pass
+    + Hermitian symmetrisation (2 launches per application) against the generic
+    3-pass tiling, and against the tight oracle at N = 7."""
+    from oracle import qutip_path as qp
+
+    ops = [(np.sqrt(0.1), "sigma_rr")]
+    probs = [local_problem(n, seed=s, duration=31, collapse_ops=ops) for s in range(2)]
+    times = np.array([0.0, 0.011, 0.03])
+    outs = {}
+    for no14 in (False, True):
+        eng = _engine(probs, mode="mesolve")
+        eng.set_path(False, no_tile14=no14)
+        st = eng.new_state()
+        outs[no14] = eng.solve(st, times).cpu().numpy()
+        s = eng.stats()
+        assert s["n_launches"] == (2 if not no14 else s["passes"]) * s["n_applications"]
+    assert np.max(np.abs(outs[False] - outs[True])) < 1e-12
+    rho = outs[False][-1]
+    assert np.max(np.abs(rho - np.conj(np.swapaxes(rho, 1, 2)))) == 0.0  # exactly Hermitian
+    if n == 7:
+        for b, p in enumerate(probs):
+            ham = qp.build_hamiltonian(p)
+            ref = qp.mesolve(ham, qp.all_ground_state(n, p["eigenbasis"]), times[[0, 2]],
+                             max_step=1e-3, **qp.TIGHT)[-1]
+            assert np.max(np.abs(rho[b] - ref)) < AMP_TOL
+
+
+def test_register_tile_kernel_sesolve_14_and_16_atoms():
+    """k_apply14 as pass 0 (N = 14: the only pass) against the generic tiling."""
+    for n in (14, 16):
+        probs = [local_problem(n, seed=4, duration=21)]
+        res = {}
+        for no14 in (False, True):
+            eng = _engine(probs)
+            eng.set_path(False, no_tile14=no14)
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 0.003)
+            res[no14] = st.cpu().numpy()
+            assert eng.stats()["passes"] == ({14: 1, 16: 2}[n] if not no14 else 2)
+        assert np.max(np.abs(res[False] - res[True])) < 1e-13
