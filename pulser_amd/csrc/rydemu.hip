@@ -1144,6 +1144,7 @@ struct ryd_handle {
   bool force_generic = false;
   bool no_fast_apply = false;  // test hook: use the generic k_apply for T = 12 too
   bool no_tile14 = false;      // test hook: disable k_apply14 / the Hermitian mesolve path
+  bool force_tile14 = false;   // test hook: use them even when too few tiles fill the GPU
   bool drive_real = false;     // every drive series is real-valued
   bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
   ryd_stats stats{};
@@ -1202,6 +1203,19 @@ static int local_of(const Segs& s, int p) {
   return -1;
 }
 
+// A 2^14 register tile keeps one whole CU busy per 16384 amplitudes; it only
+// pays when the launch has enough tiles for the 256 CUs (measured: 64 tiles of a
+// 20-atom ket are 1.4x slower than 256 LDS tiles of 2^12).
+static bool tile14_pays(const ryd_handle* h) {
+  if (h->no_tile14 || h->nb < 14) return false;
+  if (h->force_tile14) return true;
+  const long long tiles = (long long)h->B << (h->nb - 14);
+  if (tiles >= 512) return true;
+  // fewer tiles: only when the bigger tile saves a whole pass (e.g. 14-atom kets)
+  const int p12 = 1 + (std::max(h->nb - 12, 0) + 7) / 8, p14 = 1 + (h->nb - 14 + 7) / 8;
+  return p14 < p12 && tiles >= 16;
+}
+
 static void plan_passes(ryd_handle* h) {
   h->passes.clear();
   const int nb = h->nb, N = h->N, T = std::min(h->T, nb);
@@ -1241,7 +1255,7 @@ static void plan_passes(ryd_handle* h) {
       Pass p;
       if (first) {
         g = T;
-        if (h->T == 12 && nb >= 14 && !h->no_tile14) {
+        if (h->T == 12 && nb >= 14 && tile14_pays(h)) {
           g = 14;
           p = make_pass(nb, {{0, g}});
           p.use14 = true;
@@ -1997,7 +2011,7 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
 
 static bool hermitian_path(const ryd_handle* h) {
   return !h->general && h->cfg.mode == RYD_MESOLVE && !h->has_dbl && h->N >= 7 && h->N <= 14 &&
-         h->T == 12 && !h->no_tile14;
+         h->T == 12 && tile14_pays(h);
 }
 
 // One exponential  state <- exp(h * G~) state  on the generic multi-launch path.
@@ -2242,8 +2256,12 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
   h->force_generic = (force_generic & 1) != 0;
   h->no_fast_apply = (force_generic & 2) != 0;
   {
-    const bool nt = (force_generic & 4) != 0;
-    if (nt != h->no_tile14) { h->no_tile14 = nt; plan_passes(h); }
+    const bool nt = (force_generic & 4) != 0, ft = (force_generic & 8) != 0;
+    if (nt != h->no_tile14 || ft != h->force_tile14) {
+      h->no_tile14 = nt;
+      h->force_tile14 = ft;
+      plan_passes(h);
+    }
   }
   return RYD_OK;
 }

@@ -265,7 +265,7 @@ def test_hermitian_mesolve_path_matches_generic_passes_and_oracle(n):
     outs = {}
     for no14 in (False, True):
         eng = _engine(probs, mode="mesolve")
-        eng.set_path(False, no_tile14=no14)
+        eng.set_path(False, no_tile14=no14, force_tile14=not no14)
         st = eng.new_state()
         outs[no14] = eng.solve(st, times).cpu().numpy()
         s = eng.stats()
@@ -288,7 +288,7 @@ def test_register_tile_kernel_sesolve_14_and_16_atoms():
         res = {}
         for no14 in (False, True):
             eng = _engine(probs)
-            eng.set_path(False, no_tile14=no14)
+            eng.set_path(False, no_tile14=no14, force_tile14=not no14)
             st = eng.new_state()
             eng.evolve(st, 0.0, 0.003)
             res[no14] = st.cpu().numpy()
