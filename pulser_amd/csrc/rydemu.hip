@@ -485,9 +485,10 @@ struct Apply14Args {
   int N, nb, n_flip;
 };
 
-template <int MODE, bool REAL>
+template <int MODE, bool REAL, bool FULL>
 __global__ __launch_bounds__(1024) void k_apply14(const Apply14Args A) {
-  constexpr int T = 14, NTT = 1024, R = 16, LOGNT = 10, TL = 7, GS = 8;
+  // FULL: all 14 tile bits are flipped (n_flip == 14) - no per-flip predicates.
+  constexpr int T = 14, NTT = 1024, R = 16, LOGNT = 10, TL = 7, GS = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx* xs = reinterpret_cast<cplx*>(smem);            // GS slices of 1024
   double* tabLo = reinterpret_cast<double*>(xs + GS * NTT);
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_apply14(const Apply14Args A) {
 
   const int tid = threadIdx.x;
   const int N = A.N;
-  const int nf = A.n_flip;
+  const int nf = FULL ? T : A.n_flip;
   const size_t boff = (size_t)blockIdx.y << A.nb;
   const unsigned long long base_idx = (unsigned long long)blockIdx.x << T;
   const double* __restrict__ cf = A.coefs + (size_t)blockIdx.y * N * 4;
@@ -508,11 +509,17 @@ __global__ __launch_bounds__(1024) void k_apply14(const Apply14Args A) {
 #pragma unroll
   for (int j = 0; j < R; ++j) x[j] = xin[tid + j * NTT];
 
-  if (tid < nf) {
-    const int p = tid;  // tile-local bit = global bit
-    const int k = (MODE == RYD_SESOLVE || p < N) ? N - 1 - p : 2 * N - 1 - p;
-    cft[2 * tid] = cf[4 * k];
-    cft[2 * tid + 1] = cf[4 * k + 1];
+  if (tid < T) {
+    double cr = 0.0, ci = 0.0;
+    if (tid < nf) {
+      const int p = tid;  // tile-local bit = global bit
+      const int k = (MODE == RYD_SESOLVE || p < N) ? N - 1 - p : 2 * N - 1 - p;
+      const double s2 = (MODE == RYD_MESOLVE && p < N) ? 1.0 : -1.0;
+      cr = s2 * cf[4 * k];
+      ci = cf[4 * k + 1];
+    }
+    cft[2 * tid] = cr;      // s2 * cr
+    cft[2 * tid + 1] = ci;
   }
   // detuning part of the diagonal: two 128-entry tables + the outer bits
   for (int e = tid; e < 2 * (1 << TL); e += NTT) {
@@ -541,75 +548,77 @@ __global__ __launch_bounds__(1024) void k_apply14(const Apply14Args A) {
     else { k = N - 1 - p; sg = 1.0; }
     if (!((base_idx >> p) & 1ull)) eOuter += sg * cf[4 * k + 2];
   }
-  __syncthreads();
-
-  // flip coefficient (sgn * ci, s2 * cr), wave-uniform -> scalar registers
-  double fcr[T], fci[T];
-#pragma unroll
-  for (int f = 0; f < T; ++f) {
-    const bool on = f < nf;
-    const double cr = on ? cft[2 * f] : 0.0, ci = on ? cft[2 * f + 1] : 0.0;
-    const double s2 = (MODE == RYD_MESOLVE && f < N) ? 1.0 : -1.0;
-    fcr[f] = uniform_d(s2 * cr);
-    fci[f] = REAL ? 0.0 : uniform_d(ci);
-  }
+  // mesolve: row-dependent part of the dissipator diagonal is tile-constant
+  const double dsw = A.diag_scale * A.wmix;
 
 #pragma unroll
   for (int g0 = 0; g0 < R; g0 += GS) {
-    if (g0) __syncthreads();  // previous group's partner reads are done
+    __syncthreads();  // tables ready / previous group's partner reads done
 #pragma unroll
-    for (int jj = 0; jj < GS; ++jj) xs[jj * NTT + tid] = x[(g0 + jj) & (R - 1)];
+    for (int jj = 0; jj < GS; ++jj) xs[jj * NTT + tid] = x[g0 + jj];
     __syncthreads();
+    // diagonal of the GS amplitudes of this group
+    cplx acc[GS];
 #pragma unroll
     for (int jj = 0; jj < GS; ++jj) {
-      const int j = g0 + jj;  // compile-time after unrolling
+      const int j = g0 + jj;
       const int l = tid + j * NTT;
       const unsigned long long gi = base_idx | (unsigned long long)l;
-      cplx bv = make_double2(0.0, 0.0);
-      if (!A.kout && A.base) bv = A.base[boff + gi];
-      cplx xv[LOGNT];
-#pragma unroll
-      for (int q = 0; q < LOGNT; ++q)
-        if (q < nf) xv[q] = xs[jj * NTT + (tid ^ (1 << q))];
       const cplx xo = x[j];
-      // diagonal
       double e = tabLo[l & ((1 << TL) - 1)] + tabHi[l >> TL] + eOuter;
-      cplx a;
       if (MODE == RYD_SESOLVE) {
         e = A.diag_scale * (e + A.wmix * e0[gi]) - A.shift;
-        a = make_double2(e * xo.y, -e * xo.x);
+        acc[jj] = make_double2(e * xo.y, -e * xo.x);
       } else {
         const unsigned aa = (unsigned)(gi >> N), bb = (unsigned)gi & Dm1;
         e += A.wmix * (e0[aa] - e0[bb]);
         const int n11 = __popc(aa & bb), n10 = __popc(aa & ~bb & Dm1),
                   n01 = __popc(~aa & bb & Dm1), n00 = N - n11 - n10 - n01;
-        const double dr = A.diag_scale * A.wmix * (A.Sd[0].x * n00 + A.Sd[1].x * n01 +
-                                                   A.Sd[2].x * n10 + A.Sd[3].x * n11);
-        const double di = A.diag_scale * (A.wmix * (A.Sd[0].y * n00 + A.Sd[1].y * n01 +
-                                                    A.Sd[2].y * n10 + A.Sd[3].y * n11) - e);
-        a = make_double2(dr * xo.x - di * xo.y, dr * xo.y + di * xo.x);
+        const double dr = dsw * (A.Sd[0].x * n00 + A.Sd[1].x * n01 + A.Sd[2].x * n10 + A.Sd[3].x * n11);
+        const double di = dsw * (A.Sd[0].y * n00 + A.Sd[1].y * n01 + A.Sd[2].y * n10 + A.Sd[3].y * n11) -
+                          A.diag_scale * e;
+        acc[jj] = make_double2(dr * xo.x - di * xo.y, dr * xo.y + di * xo.x);
+      }
+    }
+    // flips: one coefficient fetch per flip serves the GS amplitudes
+#pragma unroll
+    for (int f = 0; f < T; ++f) {
+      if (!FULL && f >= nf) continue;  // wave-uniform
+      const double fcr = cft[2 * f];   // LDS broadcast read
+      const double fci = REAL ? 0.0 : cft[2 * f + 1];
+      cplx pv[GS];
+#pragma unroll
+      for (int jj = 0; jj < GS; ++jj) {
+        const int j = g0 + jj;
+        if (f < LOGNT) pv[jj] = xs[jj * NTT + (tid ^ (1 << f))];
+        else pv[jj] = x[(j ^ (1 << (f >= LOGNT ? f - LOGNT : 0))) & (R - 1)];
       }
 #pragma unroll
-      for (int f = 0; f < T; ++f) {
-        if (f >= nf) continue;  // wave-uniform
-        cplx p;
-        if (f < LOGNT) {
-          p = xv[f];
-        } else {
-          p = x[(j ^ (1 << (f >= LOGNT ? f - LOGNT : 0))) & (R - 1)];
-        }
+      for (int jj = 0; jj < GS; ++jj) {
+        const int l = tid + (g0 + jj) * NTT;
         if (REAL) {
-          a = make_double2(fma(-fcr[f], p.y, a.x), fma(fcr[f], p.x, a.y));
+          acc[jj] = make_double2(fma(-fcr, pv[jj].y, acc[jj].x), fma(fcr, pv[jj].x, acc[jj].y));
         } else {
-          const double sgi = ((l >> f) & 1) ? fci[f] : -fci[f];
-          a = cfma(make_double2(sgi, fcr[f]), p, a);
+          const double sgi = ((l >> f) & 1) ? fci : -fci;
+          acc[jj] = cfma(make_double2(sgi, fcr), pv[jj], acc[jj]);
         }
       }
-      if (A.kout) {
-        A.kout[boff + gi] = a;
-      } else {
-        const cplx r = make_double2(fma(A.scale, a.x, bv.x), fma(A.scale, a.y, bv.y));
-        A.out[boff + gi] = cmul(A.post, r);
+    }
+    // epilogue of the group
+    if (A.kout) {
+#pragma unroll
+      for (int jj = 0; jj < GS; ++jj)
+        A.kout[boff + (base_idx | (unsigned long long)(tid + (g0 + jj) * NTT))] = acc[jj];
+    } else {
+      cplx bv[GS];
+#pragma unroll
+      for (int jj = 0; jj < GS; ++jj)
+        bv[jj] = A.base ? A.base[boff + (base_idx | (unsigned long long)(tid + (g0 + jj) * NTT))]
+                        : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int jj = 0; jj < GS; ++jj) {
+        const cplx r = make_double2(fma(A.scale, acc[jj].x, bv[jj].x), fma(A.scale, acc[jj].y, bv[jj].y));
+        A.out[boff + (base_idx | (unsigned long long)(tid + (g0 + jj) * NTT))] = cmul(A.post, r);
       }
     }
   }
@@ -1331,13 +1340,21 @@ extern "C" int ryd_create(const ryd_config* cfg, ryd_handle** out) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
       (e = hipFuncSetAttribute((const void*)k_apply<RYD_MESOLVE>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
-      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, false>,
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, false, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
-      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, true>,
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, false, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
-      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, false>,
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, true, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
-      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, true>,
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, false, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, false, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, true, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, true, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
       (e = hipFuncSetAttribute((const void*)k_apply12<RYD_SESOLVE, 0>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
@@ -1616,16 +1633,20 @@ static int timing_begin(ryd_handle* h, hipStream_t st, std::pair<hipEvent_t, hip
 }
 
 static int launch_apply14(ryd_handle* h, const Apply14Args& B, hipStream_t st) {
-  const size_t lds = (size_t)8 * 1024 * sizeof(cplx) + 2 * 128 * sizeof(double) + 2 * 16 * sizeof(double);
+  const size_t lds = (size_t)4 * 1024 * sizeof(cplx) + 2 * 128 * sizeof(double) + 2 * 16 * sizeof(double);
   dim3 grid((unsigned)(1ull << (h->nb - 14)), h->B);
   const bool se = h->cfg.mode == RYD_SESOLVE;
+  const bool full = B.n_flip == 14;
+#define RYD_LAUNCH14(M, RL, FL) \
+  hipLaunchKernelGGL((k_apply14<M, RL, FL>), grid, dim3(1024), lds, st, B)
   if (h->drive_real) {
-    if (se) hipLaunchKernelGGL((k_apply14<RYD_SESOLVE, true>), grid, dim3(1024), lds, st, B);
-    else hipLaunchKernelGGL((k_apply14<RYD_MESOLVE, true>), grid, dim3(1024), lds, st, B);
+    if (se) { if (full) RYD_LAUNCH14(RYD_SESOLVE, true, true); else RYD_LAUNCH14(RYD_SESOLVE, true, false); }
+    else { if (full) RYD_LAUNCH14(RYD_MESOLVE, true, true); else RYD_LAUNCH14(RYD_MESOLVE, true, false); }
   } else {
-    if (se) hipLaunchKernelGGL((k_apply14<RYD_SESOLVE, false>), grid, dim3(1024), lds, st, B);
-    else hipLaunchKernelGGL((k_apply14<RYD_MESOLVE, false>), grid, dim3(1024), lds, st, B);
+    if (se) { if (full) RYD_LAUNCH14(RYD_SESOLVE, false, true); else RYD_LAUNCH14(RYD_SESOLVE, false, false); }
+    else { if (full) RYD_LAUNCH14(RYD_MESOLVE, false, true); else RYD_LAUNCH14(RYD_MESOLVE, false, false); }
   }
+#undef RYD_LAUNCH14
   HIPCHK(hipGetLastError());
   return RYD_OK;
 }

@@ -40,7 +40,7 @@ for name in ("cfg2", "cfg3", "cfg5"):
         md += [text, ""]
     except FileNotFoundError:
         continue
-for name, kern_sub in (("cfg3", "k_apply"), ("cfg2", "k_traj")):
+for name, kern_sub in (("cfg3", "k_apply14"), ("cfg3", "k_symm"), ("cfg3", "k_apply<"), ("cfg2", "k_traj")):
     try:
         f = pmc(name, "FETCH_SIZE"); w = pmc(name, "WRITE_SIZE")
     except FileNotFoundError:
