@@ -125,3 +125,45 @@ def sample_state(
     if meas_errors is None:
         return c
     return spam_flips(c, meas_errors["epsilon"], meas_errors["epsilon_prime"])
+
+
+def v2_sample(
+    state: np.ndarray,
+    eigenstates: Sequence[str],
+    num_shots: int,
+    one_state: str,
+    p_false_pos: float = 0.0,
+    p_false_neg: float = 0.0,
+) -> Counter:
+    """``QutipState.sample`` of the V2 backend
+    (pulser_simulation/qutip_state.py:112-217): probabilities below
+    ``1/(1000*num_shots)`` are dropped and the rest renormalised with
+    ``np.sum``; bitstring probabilities are accumulated in basis-state order;
+    flips draw ``uniform(size=(num_shots, N))``."""
+    state = np.asarray(state)
+    d = len(eigenstates)
+    if state.ndim == 2 and state.shape[0] == state.shape[1] and state.shape[0] > 1:
+        probs = np.abs(np.diag(state)).real
+    else:
+        probs = (np.abs(state.reshape(-1, 1)) ** 2).flatten().real
+    n = int(round(np.log(probs.size) / np.log(d)))
+    cutoff = 1 / (1000 * num_shots)
+    non_zero = np.argwhere(probs > cutoff).flatten()
+    p = probs[non_zero]
+    p = p / np.sum(p)
+    bit_probs: dict[str, float] = {}
+    for idx, pv in zip(non_zero, p):
+        digits = np.base_repr(idx, base=d).zfill(n)
+        bits = "".join("1" if eigenstates[int(c)] == one_state else "0" for c in digits)
+        bit_probs[bits] = bit_probs.get(bits, 0.0) + pv
+    bitstrings = np.array(list(bit_probs))
+    pr = np.array(list(map(float, bit_probs.values())))
+    indices = multinomial(num_shots, pr)
+    if p_false_pos == 0.0 and p_false_neg == 0.0:
+        return Counter(bitstrings[indices].tolist())
+    arr = np.array([list(bs) for bs in bitstrings[indices]], dtype=int)
+    flip_probs = np.where(arr == 1, p_false_neg, p_false_pos)
+    rnd = np.random.uniform(size=flip_probs.shape)
+    new = arr ^ (rnd < flip_probs)
+    cnt = Counter(map(tuple, new))
+    return Counter({"".join(map(str, k)): v for k, v in cnt.items()})

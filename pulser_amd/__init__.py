@@ -12,6 +12,8 @@ from .noise_model import NoiseModel
 from .results import (CoherentResults, NoisyResults, QState, SampledResult,
                       SimulationResults, StateResult)
 from .simulation import QutipEmulator, SimConfig, Solver
+from . import backend
+from .backend import QutipBackendV2, QutipConfig, RydState, Results
 
 __version__ = "0.1.0"
 
@@ -19,4 +21,5 @@ __all__ = [
     "QutipEmulator", "Solver", "SimConfig", "NoiseModel", "CoherentResults",
     "NoisyResults", "SimulationResults", "StateResult", "SampledResult", "QState",
     "SequenceInputs", "ChannelInput", "Slot", "HamiltonianData", "single_global_channel",
+    "QutipBackendV2", "QutipConfig", "RydState", "Results", "backend",
 ]

@@ -1,0 +1,588 @@
+"""``QutipBackendV2``-style emulator backend on the MI355X engine.
+
+Mirrors the non-deprecated entry point of the reference,
+``pulser_simulation.QutipBackendV2`` (pulser-simulation/pulser_simulation/
+qutip_backend.py:121-325) with its config (``qutip_config.py:28-192``), state
+type (``qutip_state.py``), the default observables
+(pulser-core/pulser/backend/default_observables.py) and ``Results``
+(pulser-core/pulser/backend/results.py): per evaluation time the normalised
+state (``.unit()``, qutip_backend.py:257) and the *noiseless* Hamiltonian
+operator (``:259-264``) are handed to every observable; noisy trajectories
+produce one ``Results`` each and are aggregated (MEAN for numbers, BAG_UNION
+for Counters, mean of |psi><psi| for the state, ``:322-325``).
+
+The solver call is the HIP engine; observables that need ``H|psi>`` apply the
+matrix-free generator kernel on the device (``ryd_apply_generator``).
+"""
+
+from __future__ import annotations
+
+import uuid
+import warnings
+from collections import Counter, defaultdict
+from typing import Any, Callable, Mapping, Sequence
+
+import numpy as np
+
+from .noise_model import NoiseModel, has_stochastic_noise
+from .results import QState, multinomial
+from .simulation import QutipEmulator, Solver
+
+__all__ = [
+    "QutipBackendV2", "QutipConfig", "RydState", "Results", "Observable", "StateResult",
+    "BitStrings", "Fidelity", "Expectation", "CorrelationMatrix", "Occupation", "Energy",
+    "EnergyVariance", "EnergySecondMoment",
+]
+
+_ONE_STATE = {("r", "g"): "r", ("g", "h"): "h", ("u", "d"): "d"}
+
+
+# ------------------------------------------------------------------- state
+class RydState:
+    """``QutipState`` (pulser_simulation/qutip_state.py:38-281) on a NumPy state."""
+
+    def __init__(self, state: Any, *, eigenstates: Sequence[str]) -> None:
+        self.eigenstates = tuple(eigenstates)
+        self._state = QState(state)
+        d = len(self.eigenstates)
+        self._n = int(round(np.log(self._state.shape[0]) / np.log(d)))
+
+    @property
+    def n_qudits(self) -> int:
+        return self._n
+
+    @property
+    def qudit_dim(self) -> int:
+        return len(self.eigenstates)
+
+    def to_qobj(self) -> QState:
+        return self._state
+
+    def infer_one_state(self) -> str:
+        """pulser/backend/state.py: the eigenstate measured as 1."""
+        for pair, one in _ONE_STATE.items():
+            if set(pair) == set(self.eigenstates):
+                return one
+        raise RuntimeError(f"Failed to infer the 'one state' from the eigenstates: {self.eigenstates}")
+
+    def get_basis_state_from_index(self, index: int) -> str:
+        d = self.qudit_dim
+        digits = np.base_repr(index, base=d).zfill(self._n)
+        return "".join(self.eigenstates[int(c)] for c in digits)
+
+    def overlap(self, other: "RydState") -> float:
+        """qutip_state.py:86-110."""
+        if not isinstance(other, RydState):
+            raise TypeError(f"'RydState.overlap()' expects another 'RydState', not {type(other)}.")
+        ov = self._state.overlap(other._state)
+        if self._state.isket and other._state.isket:
+            ov = np.abs(ov) ** 2
+        return float(np.real(ov))
+
+    def probabilities(self, *, cutoff: float = 1e-12) -> dict[str, float]:
+        """qutip_state.py:112-141."""
+        if not self._state.isket:
+            probs = np.abs(self._state.diag()).real
+        else:
+            probs = (np.abs(self._state.full()) ** 2).flatten().real
+        non_zero = np.argwhere(probs > cutoff).flatten()
+        probs = probs[non_zero]
+        probs = probs / np.sum(probs)
+        return dict(zip(map(self.get_basis_state_from_index, non_zero), probs))
+
+    def bitstring_probabilities(self, *, one_state: str | None = None,
+                                cutoff: float = 1e-12) -> Mapping[str, float]:
+        """qutip_state.py:143-167."""
+        one_state = one_state or self.infer_one_state()
+        zero_states = set(self.eigenstates) - {one_state}
+        probs = self.probabilities(cutoff=cutoff)
+        out: dict[str, float] = defaultdict(float)
+        for state_str in probs:
+            bitstring = state_str.replace(one_state, "1")
+            for s_ in zero_states:
+                bitstring = bitstring.replace(s_, "0")
+            out[bitstring] += probs[state_str]
+        return dict(out)
+
+    def sample(self, *, num_shots: int, one_state: str | None = None,
+               p_false_pos: float = 0.0, p_false_neg: float = 0.0) -> Counter:
+        """qutip_state.py:169-217 (same NumPy call sequence)."""
+        bitstring_probs = self.bitstring_probabilities(one_state=one_state,
+                                                       cutoff=1 / (1000 * num_shots))
+        bitstrings = np.array(list(bitstring_probs))
+        probs = np.array(list(map(float, bitstring_probs.values())))
+        indices = multinomial(num_shots, probs)
+        if p_false_pos == 0.0 and p_false_neg == 0.0:
+            return Counter(bitstrings[indices].tolist())
+        bitstr_arr = np.array([list(bs) for bs in bitstrings[indices]], dtype=int)
+        flip_probs = np.where(bitstr_arr == 1, p_false_neg, p_false_pos)
+        random_matrix = np.random.uniform(size=flip_probs.shape)
+        new_bitstrings = bitstr_arr ^ (random_matrix < flip_probs)
+        new_counts: Counter = Counter(map(tuple, new_bitstrings))
+        return Counter({"".join(map(str, k)): v for k, v in new_counts.items()})
+
+    @classmethod
+    def from_state_amplitudes(cls, *, eigenstates: Sequence[str],
+                              amplitudes: Mapping[str, complex]) -> "RydState":
+        """pulser/backend/state.py:100-176: {"rgr": a, ...} -> normalised ket."""
+        n = len(next(iter(amplitudes)))
+        d = len(eigenstates)
+        vec = np.zeros(d**n, dtype=complex)
+        for key, amp in amplitudes.items():
+            idx = 0
+            for ch in key:
+                idx = idx * d + list(eigenstates).index(ch)
+            vec[idx] = amp
+        return cls(QState(vec).unit(), eigenstates=eigenstates)
+
+
+class HamiltonianOperator:
+    """The noiseless H(t) handed to observables (qutip_backend.py:259-264),
+    matrix-free: ``apply_to`` runs the device generator kernel."""
+
+    def __init__(self, engine: Any, t_us: float, eigenstates: Sequence[str]) -> None:
+        self._eng, self._t, self.eigenstates = engine, t_us, tuple(eigenstates)
+
+    def _h_on(self, arr: np.ndarray) -> np.ndarray:
+        """H @ arr for a ket (D,1) or a matrix (D,D) of column vectors."""
+        import torch
+
+        cols = np.ascontiguousarray(np.asarray(arr, dtype=complex).T)  # rows = kets
+        out = np.empty_like(cols)
+        for i in range(cols.shape[0]):
+            x = torch.from_numpy(cols[i:i + 1].copy()).to(self._eng.device)
+            out[i] = 1j * self._eng.apply_generator(x, self._t).cpu().numpy()[0]  # G = -iH
+        return out.T
+
+    def apply_to(self, state: RydState) -> RydState:
+        s = state.to_qobj()
+        if s.isket:
+            return RydState(self._h_on(s), eigenstates=state.eigenstates)
+        h_rho = self._h_on(np.asarray(s))
+        return RydState(self._h_on(h_rho.conj().T).conj().T, eigenstates=state.eigenstates)  # H rho H
+
+    def expect(self, state: RydState) -> float:
+        s = state.to_qobj()
+        if s.isket:
+            return float(np.real(np.vdot(np.asarray(s), self._h_on(s))))
+        return float(np.real(np.trace(self._h_on(np.asarray(s)))))
+
+
+# --------------------------------------------------------------- observables
+class Observable:
+    """pulser/backend/observable.py:60-215."""
+
+    default_aggregation = "mean"
+
+    def __init__(self, *, evaluation_times: Sequence[float] | None = None,
+                 tag_suffix: str | None = None) -> None:
+        if evaluation_times is not None:
+            ev = np.array(evaluation_times, dtype=float)
+            if ev.ndim != 1 or np.any(ev < 0) or np.any(ev > 1) or np.any(np.diff(ev) <= 0):
+                raise ValueError(
+                    "All evaluation times must be between 0. and 1., unique and sorted in ascending order."
+                )
+            self.evaluation_times: np.ndarray | None = ev
+        else:
+            self.evaluation_times = None
+        self._tag_suffix = tag_suffix
+        self._uuid = uuid.uuid4()
+
+    _base_tag = "observable"
+
+    @property
+    def tag(self) -> str:
+        return self._base_tag if self._tag_suffix is None else f"{self._base_tag}_{self._tag_suffix}"
+
+    def __call__(self, config: "QutipConfig", t: float, state: RydState,
+                 hamiltonian: HamiltonianOperator, result: "Results") -> None:
+        time_tol = (0.5 / result.total_duration) if result.total_duration else 1e-6
+        if (self.evaluation_times is not None
+                and config.is_time_in_evaluation_times(t, self.evaluation_times, tol=time_tol)) or (
+                self.evaluation_times is None and config.is_evaluation_time(t, tol=time_tol)):
+            result._store(observable=self, time=t,
+                          value=self.apply(config=config, state=state, hamiltonian=hamiltonian))
+
+    def apply(self, *, config: "QutipConfig", state: RydState,
+              hamiltonian: HamiltonianOperator) -> Any:  # pragma: no cover
+        raise NotImplementedError
+
+
+class StateResult(Observable):
+    _base_tag = "state"
+    default_aggregation = "density_matrix"
+
+    def apply(self, *, state: RydState, **kw: Any) -> RydState:
+        return RydState(np.array(state.to_qobj()), eigenstates=state.eigenstates)
+
+
+class BitStrings(Observable):
+    _base_tag = "bitstrings"
+    default_aggregation = "bag_union"
+
+    def __init__(self, *, evaluation_times: Sequence[float] | None = None,
+                 num_shots: int | None = None, one_state: str | None = None,
+                 tag_suffix: str | None = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+        if num_shots is not None and num_shots < 1:
+            raise ValueError(f"'num_shots' must be greater than or equal to 1, not {num_shots}.")
+        self._num_shots = None if num_shots is None else int(num_shots)
+        self.one_state = one_state
+
+    def apply(self, *, config: "QutipConfig", state: RydState, **kw: Any) -> Counter:
+        return state.sample(
+            num_shots=self._num_shots if self._num_shots is not None else config.default_num_shots,
+            one_state=self.one_state,
+            p_false_pos=config.noise_model.p_false_pos,
+            p_false_neg=config.noise_model.p_false_neg,
+        )
+
+
+class Fidelity(Observable):
+    _base_tag = "fidelity"
+
+    def __init__(self, state: RydState, *, evaluation_times: Sequence[float] | None = None,
+                 tag_suffix: str | None = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+        if not isinstance(state, RydState):
+            raise TypeError(f"'state' must be a RydState, not {type(state)}.")
+        self.state = state
+
+    def apply(self, *, state: RydState, **kw: Any) -> float:
+        return self.state.overlap(state)
+
+
+class Expectation(Observable):
+    """<O> of a dense operator (d^N x d^N array)."""
+
+    _base_tag = "expectation"
+
+    def __init__(self, operator: np.ndarray, *, evaluation_times: Sequence[float] | None = None,
+                 tag_suffix: str | None = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+        self.operator = np.asarray(operator, dtype=complex)
+
+    def apply(self, *, state: RydState, **kw: Any) -> Any:
+        s = np.asarray(state.to_qobj())
+        if s.shape[1] == 1:
+            return complex(np.vdot(s, self.operator @ s))
+        return complex(np.trace(self.operator @ s))
+
+
+def _probabilities(state: RydState) -> np.ndarray:
+    s = state.to_qobj()
+    return (np.abs(np.asarray(s)[:, 0]) ** 2) if s.isket else np.real(s.diag())
+
+
+def _one_mask(state: RydState, one_state: str | None) -> np.ndarray:
+    """bool[D, N]: atom k of basis state i is in the 'one' eigenstate."""
+    one = one_state or state.infer_one_state()
+    d, n = state.qudit_dim, state.n_qudits
+    idx = np.arange(d**n)
+    digits = np.stack([(idx // d ** (n - 1 - k)) % d for k in range(n)], axis=1)
+    return digits == list(state.eigenstates).index(one)
+
+
+class Occupation(Observable):
+    """<n_i> with n = |one><one| (default_observables.py:377-435)."""
+
+    _base_tag = "occupation"
+
+    def __init__(self, *, evaluation_times: Sequence[float] | None = None,
+                 one_state: str | None = None, tag_suffix: str | None = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+        self.one_state = one_state
+
+    def apply(self, *, state: RydState, **kw: Any) -> list:
+        p = _probabilities(state)
+        return [float(v) for v in p @ _one_mask(state, self.one_state)]
+
+
+class CorrelationMatrix(Observable):
+    """<n_i n_j> (default_observables.py:291-374)."""
+
+    _base_tag = "correlation_matrix"
+
+    def __init__(self, *, evaluation_times: Sequence[float] | None = None,
+                 one_state: str | None = None, tag_suffix: str | None = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+        self.one_state = one_state
+
+    def apply(self, *, state: RydState, **kw: Any) -> list[list]:
+        p = _probabilities(state)
+        m = _one_mask(state, self.one_state).astype(float)
+        return ((m * p[:, None]).T @ m).tolist()
+
+
+class Energy(Observable):
+    _base_tag = "energy"
+
+    def apply(self, *, state: RydState, hamiltonian: HamiltonianOperator, **kw: Any) -> float:
+        return hamiltonian.expect(state)
+
+
+class EnergySecondMoment(Observable):
+    """<H^2> through H|psi> (default_observables.py:532-580)."""
+
+    _base_tag = "energy_second_moment"
+
+    def apply(self, *, state: RydState, hamiltonian: HamiltonianOperator, **kw: Any) -> float:
+        s = state.to_qobj()
+        if s.isket:
+            hs = hamiltonian._h_on(s)
+            return float(np.real(np.vdot(hs, hs)))
+        return float(np.real(np.trace(np.asarray(hamiltonian.apply_to(state).to_qobj()))))
+
+
+class EnergyVariance(Observable):
+    _base_tag = "energy_variance"
+
+    def apply(self, *, state: RydState, hamiltonian: HamiltonianOperator, **kw: Any) -> float:
+        second = EnergySecondMoment.apply(self, state=state, hamiltonian=hamiltonian)  # type: ignore[arg-type]
+        return second - hamiltonian.expect(state) ** 2
+
+
+# ------------------------------------------------------------------- results
+class Results:
+    """pulser/backend/results.py:52-490 (storage, lookup, aggregation)."""
+
+    def __init__(self, atom_order: tuple, total_duration: int) -> None:
+        self.atom_order = tuple(atom_order)
+        self.total_duration = int(total_duration)
+        self._results: dict[uuid.UUID, list[Any]] = {}
+        self._times: dict[uuid.UUID, list[float]] = {}
+        self._tagmap: dict[str, uuid.UUID] = {}
+        self._aggregation: dict[uuid.UUID, str] = {}
+
+    def _store(self, *, observable: Observable, time: float, value: Any) -> None:
+        uid = observable._uuid
+        self._tagmap[observable.tag] = uid
+        self._aggregation[uid] = observable.default_aggregation
+        if uid not in self._results:
+            self._results[uid], self._times[uid] = [], []
+        if time in self._times[uid]:
+            raise RuntimeError(f"A value is already stored for observable '{observable.tag}' at time {time}.")
+        self._results[uid].append(value)
+        self._times[uid].append(time)
+
+    def _find_uuid(self, observable: Observable | str) -> uuid.UUID:
+        tag = observable.tag if isinstance(observable, Observable) else observable
+        if tag not in self._tagmap:
+            raise ValueError(f"{tag!r} is not an Observable instance nor a known observable tag in the results.")
+        return self._tagmap[tag]
+
+    def get_result_tags(self) -> list[str]:
+        return list(self._tagmap.keys())
+
+    def get_result_times(self, observable: Observable | str) -> list[float]:
+        return self._times[self._find_uuid(observable)]
+
+    def get_tagged_results(self) -> dict[str, list[Any]]:
+        return {tag: list(self._results[uid]) for tag, uid in self._tagmap.items()}
+
+    def get_result(self, observable: Observable | str, time: float) -> Any:
+        uid = self._find_uuid(observable)
+        tol = 0.5 / self.total_duration if self.total_duration else 1e-6
+        times = np.asarray(self._times[uid])
+        hit = np.where(np.abs(times - time) <= tol)[0]
+        if len(hit) == 0:
+            raise ValueError(f"{observable!r} is not available at time {time}.")
+        return self._results[uid][int(hit[0])]
+
+    def __getattr__(self, name: str) -> list[Any]:
+        if name.startswith("_") or name not in self.__dict__.get("_tagmap", {}):
+            raise AttributeError(f"{name!r} is not in the results.")
+        return list(self._results[self._tagmap[name]])
+
+    @property
+    def final_bitstrings(self) -> Counter:
+        """pulser/backend/results.py: the 'bitstrings' observable at t = 1."""
+        return self.get_result("bitstrings", 1.0)
+
+    @classmethod
+    def aggregate(cls, results: Sequence["Results"],
+                  **aggregators: Callable[[list[Any]], Any]) -> "Results":
+        """results.py:331-488 for the default aggregation kinds."""
+        if not results:
+            raise ValueError("no results to aggregate")
+        first = results[0]
+        out = cls(first.atom_order, first.total_duration)
+        for tag, uid in first._tagmap.items():
+            kind = first._aggregation[uid]
+            agg = aggregators.get(tag)
+            out._tagmap[tag] = uid
+            out._aggregation[uid] = kind
+            out._times[uid] = list(first._times[uid])
+            vals_t = []
+            for i in range(len(first._times[uid])):
+                vals = [r._results[r._tagmap[tag]][i] for r in results]
+                if agg is not None:
+                    vals_t.append(agg(vals))
+                elif kind == "bag_union":
+                    vals_t.append(sum(vals, Counter()))
+                elif kind == "density_matrix":
+                    vals_t.append(density_matrix_aggregator(vals))
+                elif isinstance(vals[0], (float, int)):
+                    vals_t.append(float(np.mean(vals)))
+                elif isinstance(vals[0], complex):
+                    vals_t.append(complex(np.mean(vals)))
+                elif isinstance(vals[0], np.ndarray):
+                    vals_t.append(np.stack(vals).mean(axis=0))
+                else:
+                    vals_t.append(np.mean(vals, axis=0).tolist())
+            out._results[uid] = vals_t
+        return out
+
+
+def density_matrix_aggregator(values: Sequence[RydState]) -> RydState:
+    """pulser_simulation/aggregators.py:20-37: mean of |psi><psi| (or of rho)."""
+    acc = None
+    for st in values:
+        s = st.to_qobj()
+        rho = np.outer(np.asarray(s)[:, 0], np.asarray(s)[:, 0].conj()) if s.isket else np.asarray(s)
+        acc = rho.copy() if acc is None else acc + rho
+    return RydState(acc / len(values), eigenstates=values[0].eigenstates)
+
+
+# -------------------------------------------------------------------- config
+class QutipConfig:
+    """``QutipConfig`` / ``EmulationConfig`` (qutip_config.py:28-192,
+    pulser/backend/config.py:151-470): the options this backend consumes."""
+
+    def __init__(self, *, observables: Sequence[Observable] = (), callbacks: Sequence[Callable] = (),
+                 default_evaluation_times: Any = (1.0,), initial_state: RydState | None = None,
+                 with_modulation: bool = False, noise_model: Any = None,
+                 prefer_device_noise_model: bool = False, n_trajectories: int | None = None,
+                 sampling_rate: float = 1.0, solver: Solver = Solver.DEFAULT,
+                 default_num_shots: int = 1000, progress_bar: bool = False,
+                 print_progress: bool = False, **backend_options: Any) -> None:
+        tags = [o.tag for o in observables]
+        if len(set(tags)) != len(tags):
+            raise ValueError("Some of the provided 'observables' share identical tags. Use 'tag_suffix' to make them unique.")
+        if not all(isinstance(o, Observable) for o in observables):
+            raise TypeError("All entries in 'observables' must be instances of Observable.")
+        self.observables = tuple(observables)
+        self.callbacks = tuple(callbacks)
+        if isinstance(default_evaluation_times, str):
+            if default_evaluation_times != "Full":
+                raise ValueError(f"'default_evaluation_times' must be 'Full' or a sequence of floats, not {default_evaluation_times!r}.")
+            self.default_evaluation_times: Any = "Full"
+        else:
+            ev = np.array(default_evaluation_times, dtype=float)
+            if ev.ndim != 1 or np.any(ev < 0) or np.any(ev > 1) or np.any(np.diff(ev) <= 0):
+                raise ValueError("All evaluation times must be between 0. and 1., unique and sorted in ascending order.")
+            self.default_evaluation_times = ev
+        self.initial_state = initial_state
+        self.with_modulation = bool(with_modulation)
+        self.noise_model = noise_model if noise_model is not None else NoiseModel()
+        self.prefer_device_noise_model = bool(prefer_device_noise_model)
+        self.n_trajectories = n_trajectories
+        if not (0 < sampling_rate <= 1.0):
+            raise ValueError(f"The sampling rate (`sampling_rate` = {sampling_rate}) must be greater than 0 and less than or equal to 1.")
+        self.sampling_rate = sampling_rate
+        self.solver = Solver(solver)
+        self.default_num_shots = int(default_num_shots)
+        self.progress_bar = progress_bar
+        self.print_progress = print_progress
+        self._extra = dict(backend_options)
+
+    def is_evaluation_time(self, t: float, tol: float = 1e-6) -> bool:
+        """config.py:419-427."""
+        if isinstance(self.default_evaluation_times, str):
+            return 0.0 <= t <= 1.0
+        return self.is_time_in_evaluation_times(t, self.default_evaluation_times, tol=tol)
+
+    @staticmethod
+    def is_time_in_evaluation_times(t: float, evaluation_times: Any, tol: float = 1e-6) -> bool:
+        """config.py:429-436."""
+        return 0.0 <= t <= 1.0 and bool(
+            np.any(np.abs(np.array(evaluation_times, dtype=float) - t) <= tol))
+
+    def _get_legacy_evaluation_times(self, total_duration_ns: int) -> Any:
+        """qutip_config.py:169-192."""
+        if self.callbacks:
+            return "Full"
+        extra: set[float] = set()
+        for obs in self.observables:
+            if obs.evaluation_times is not None:
+                extra.update(obs.evaluation_times)
+        rel = self.default_evaluation_times
+        if extra:
+            if isinstance(rel, str):
+                rel = np.linspace(0, total_duration_ns - 1,
+                                  int(self.sampling_rate * total_duration_ns), dtype=int) / total_duration_ns
+            rel = np.union1d(rel, list(extra))
+        return "Full" if isinstance(rel, str) else rel * total_duration_ns * 1e-3
+
+
+# ------------------------------------------------------------------- backend
+class QutipBackendV2:
+    """qutip_backend.py:121-325 on the MI355X engine.  ``sequence`` is a
+    ``pulser.Sequence`` (needs pulser) or a ``pulser_amd.SequenceInputs``."""
+
+    default_config = None  # built lazily (observables carry uuids)
+
+    def __init__(self, sequence: Any, *, config: QutipConfig | None = None,
+                 mimic_qpu: bool = False) -> None:
+        if config is not None and not isinstance(config, QutipConfig):
+            raise TypeError("'config' must be an instance of 'EmulationConfig'")
+        self._config = config or QutipConfig(observables=[BitStrings(evaluation_times=[1.0]),
+                                                          StateResult()])
+        cfg = self._config
+        nm = cfg.noise_model
+        if cfg.prefer_device_noise_model and getattr(getattr(sequence, "device", None), "noise_model", None):
+            nm = sequence.device.noise_model
+        kw = dict(sampling_rate=cfg.sampling_rate, noise_model=nm, solver=cfg.solver,
+                  n_trajectories=cfg.n_trajectories)
+        if hasattr(sequence, "_schedule"):
+            self._sim_obj = QutipEmulator.from_sequence(sequence, with_modulation=cfg.with_modulation, **kw)
+        else:
+            self._sim_obj = QutipEmulator(sequence, **kw)
+        self._sim_obj.set_evaluation_times(cfg._get_legacy_evaluation_times(self._sim_obj.total_duration_ns))
+        if cfg.initial_state:
+            self._sim_obj.set_initial_state(np.asarray(cfg.initial_state.to_qobj()).reshape(-1))
+        self._options = {"print_progress": cfg.print_progress, "progress_bar": cfg.progress_bar}
+        self._sim_obj._validate_options(dict(self._options))
+
+    def run(self) -> Results:
+        return self._run_raw(self._sim_obj, self._config, dict(self._options))
+
+    @staticmethod
+    def _run_raw(sim: QutipEmulator, config: QutipConfig, options: dict[str, Any]) -> Results:
+        from .engine import Engine
+
+        eigenstates = sim._hamiltonian_data.eigenbasis
+        noiseless = dict(sim._noiseless_problem)
+        noiseless["collapse_ops"] = []
+        if not sim._fast_path_ok(noiseless):
+            raise NotImplementedError(
+                "QutipBackendV2 observables need the matrix-free Hamiltonian; multi-level / XY "
+                "sequences are only available through QutipEmulator.run() for now.")
+        qids = tuple(sim.samples_obj.qubit_ids)
+        T = sim.total_duration_ns
+
+        def fill(res: Results, coherent: Any, ham_engine: Any) -> None:
+            for r in coherent:
+                t = r.evaluation_time
+                state = RydState(r.state.unit(), eigenstates=eigenstates)
+                ham = HamiltonianOperator(ham_engine, t * T / 1000, eigenstates)
+                for cb in config.callbacks:
+                    cb(config=config, t=float(t), state=state, hamiltonian=ham, result=res)
+                for obs in config.observables:
+                    obs(config=config, t=float(t), state=state, hamiltonian=ham, result=res)
+
+        with Engine.from_problems([noiseless], mode="sesolve") as ham_engine:
+            if not has_stochastic_noise(sim.noise_model):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore", DeprecationWarning)
+                    single = sim.run(**options)
+                res = Results(qids, T)
+                fill(res, single, ham_engine)
+                return res
+            results: list[Results] = []
+            for coherent, reps in sim._noisy_runs(**options):
+                for _ in range(reps):
+                    res = Results(qids, T)
+                    fill(res, coherent, ham_engine)
+                    results.append(res)
+            return Results.aggregate(results)

@@ -1,0 +1,114 @@
+"""GPU: the QutipBackendV2-style backend (observables engine) against oracle
+values, following tests/pulser_simulation/test_qutip_backend_v2.py."""
+from collections import Counter
+
+import numpy as np
+import pytest
+
+from helpers import blockade_radius
+
+from pulser_amd import NoiseModel
+from pulser_amd import problem as P
+from pulser_amd.backend import (BitStrings, CorrelationMatrix, Energy, EnergySecondMoment,
+                                EnergyVariance, Fidelity, Occupation, QutipBackendV2, QutipConfig,
+                                Results, RydState, StateResult)
+from pulser_amd.hamiltonian_data import single_global_channel
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(n=2):
+    coords = P.register_coords(P.square_rect(1, n), blockade_radius())
+    s = {k: v[:-1] for k, v in P.anneal_samples().items()}
+    return single_global_channel(coords, s, P.C6_LEVEL70, extended=False), coords
+
+
+def _oracle(n, times):
+    from oracle import qutip_path as qp
+
+    coords = P.register_coords(P.square_rect(1, n), blockade_radius())
+    prob = P.make_ising_problem(coords, P.anneal_samples())
+    ham = qp.build_hamiltonian(prob)
+    states = qp.sesolve(ham, qp.all_ground_state(n, prob["eigenbasis"]), times, max_step=1e-3, **qp.TIGHT)
+    return ham, states
+
+
+def test_backend_v2_observables_against_oracle(capfd):
+    """test_qutip_backend_v2.py:112-154 plus every default observable."""
+    from oracle import sampling as osamp
+
+    n = 3
+    inputs, _ = _inputs(n)
+    target = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rgr": 1.0})
+    rel = [0.0, 0.25, 0.5, 1.0]
+    config = QutipConfig(
+        default_evaluation_times=rel,
+        observables=[StateResult(), BitStrings(num_shots=200), Occupation(), CorrelationMatrix(),
+                     Energy(evaluation_times=[0.0, 0.5, 1.0]), EnergyVariance(), EnergySecondMoment(),
+                     Fidelity(target)],
+        print_progress=True,
+    )
+    with pytest.raises(TypeError, match="'config' must be an instance of 'EmulationConfig'"):
+        QutipBackendV2(inputs, config="tralala")
+    backend = QutipBackendV2(inputs, config=config)
+    np.random.seed(77)
+    results = backend.run()
+    out, _ = capfd.readouterr()
+    assert out == "Emulating Trajectory 1/1\n"
+    assert set(results.get_result_tags()) == {"state", "bitstrings", "occupation", "correlation_matrix",
+                                              "energy", "energy_variance", "energy_second_moment", "fidelity"}
+    assert results.get_result_times("state") == rel
+    assert results.get_result_times("energy") == [0.0, 0.5, 1.0]
+    times = np.array(rel) * 3.1
+    ham, ref = _oracle(n, times)
+    np.random.seed(77)
+    idx = np.arange(8)
+    for i, t in enumerate(rel):
+        psi = ref[i] / np.linalg.norm(ref[i])
+        got = np.asarray(results.get_result("state", t).to_qobj())[:, 0]
+        assert np.max(np.abs(got - psi)) < 1e-7
+        assert results.get_result("bitstrings", t) == osamp.v2_sample(got, ("r", "g"), 200, "r")
+        p = np.abs(psi) ** 2
+        occ = [float(np.sum(p * (1 - ((idx >> (n - 1 - k)) & 1)))) for k in range(n)]
+        assert np.allclose(results.get_result("occupation", t), occ, atol=1e-7)
+        corr = np.array(results.get_result("correlation_matrix", t))
+        assert np.allclose(np.diag(corr), occ, atol=1e-7) and np.allclose(corr, corr.T)
+        assert abs(results.get_result("fidelity", t) - abs(psi[0b010]) ** 2) < 1e-7
+        h = ham.matrix(times[i]).toarray()
+        e2 = np.vdot(h @ psi, h @ psi).real
+        e1 = np.vdot(psi, h @ psi).real
+        assert abs(results.get_result("energy_second_moment", t) - e2) < 1e-6 * max(1, abs(e2))
+        assert abs(results.get_result("energy_variance", t) - (e2 - e1 * e1)) < 1e-6 * max(1, abs(e2))
+        if t in (0.0, 0.5, 1.0):
+            assert abs(results.get_result("energy", t) - e1) < 1e-7 * max(1, abs(e1))
+    assert results.get_result("energy", 0.0) == results.energy[0] == pytest.approx(0.0)
+    assert results.final_bitstrings == results.bitstrings[-1]
+    with pytest.raises(ValueError, match="not available at time"):
+        results.get_result("energy", 0.25)
+
+
+def test_backend_v2_default_config_and_noisy_aggregation():
+    """Default config = final bitstrings + state; SPAM state-prep trajectories are
+    aggregated: mean occupation, union of Counters, mean of |psi><psi|."""
+    inputs, _ = _inputs(3)
+    np.random.seed(5)
+    res = QutipBackendV2(inputs).run()
+    assert set(res.get_result_tags()) == {"bitstrings", "state"}
+    assert sum(res.final_bitstrings.values()) == 1000
+    nm = NoiseModel(state_prep_error=0.3, p_false_pos=0.02, p_false_neg=0.03)
+    cfg = QutipConfig(noise_model=nm, n_trajectories=7,
+                      observables=[BitStrings(evaluation_times=[1.0], num_shots=50), Occupation(),
+                                   StateResult()])
+    np.random.seed(9)
+    backend = QutipBackendV2(inputs, config=cfg)
+    trajs = backend._sim_obj._hamiltonian_data.noise_trajectories
+    assert sum(t.reps for t in trajs) == 7 and len(trajs) > 1
+    res = backend.run()
+    assert sum(res.final_bitstrings.values()) == 7 * 50
+    rho = np.asarray(res.state[-1].to_qobj())
+    assert rho.shape == (8, 8) and abs(np.trace(rho) - 1) < 1e-9
+    # aggregated occupation = trace of the aggregated density matrix with n_k
+    idx = np.arange(8)
+    occ = [float(np.sum(np.real(np.diag(rho)) * (1 - ((idx >> (2 - k)) & 1)))) for k in range(3)]
+    assert np.allclose(res.occupation[-1], occ, atol=1e-9)
+    assert isinstance(Results.aggregate([res]), Results)
