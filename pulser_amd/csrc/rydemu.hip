@@ -1150,6 +1150,7 @@ struct ryd_handle {
   int* gen_series_dev = nullptr;
   int* gen_conj_dev = nullptr;
   cplx* gen_scale_dev = nullptr;
+  bool auto_tile = true;       // tile_bits == 0: tile size chosen by the library
   bool force_generic = false;
   bool no_fast_apply = false;  // test hook: use the generic k_apply for T = 12 too
   bool no_tile14 = false;      // test hook: disable k_apply14 / the Hermitian mesolve path
@@ -1163,6 +1164,8 @@ struct ryd_handle {
   double timing_ms = 0;
   int64_t timing_launches = 0;
 };
+
+static bool hermitian_path(const ryd_handle* h);
 
 static Segs make_segs(std::vector<std::pair<int, int>> v) {
   Segs s;
@@ -1264,7 +1267,7 @@ static void plan_passes(ryd_handle* h) {
       Pass p;
       if (first) {
         g = T;
-        if (h->T == 12 && nb >= 14 && tile14_pays(h)) {
+        if (h->auto_tile && nb >= 14 && tile14_pays(h)) {
           g = 14;
           p = make_pass(nb, {{0, g}});
           p.use14 = true;
@@ -1312,6 +1315,20 @@ extern "C" int ryd_create(const ryd_config* cfg, ryd_handle** out) {
   h->nb = nb;
   h->B = cfg->batch;
   h->T = T;
+  h->auto_tile = cfg->tile_bits == 0;
+  if (h->auto_tile) {
+    // Small states: the fewest passes first, then enough tiles to occupy the
+    // 256 CUs (a 2^12 tile keeps one CU busy for ~8 us; a 14-atom ket would
+    // run on 4 CUs).  passes(T) = 1 + ceil((nb - T) / (T - 4)).
+    auto passes = [&](int t) { return nb <= t ? 1 : 1 + (nb - t + (t - 5)) / (t - 4); };
+    int best = 12;
+    for (int t = 12; t >= 8; --t) {
+      if (passes(t) > passes(12)) break;
+      best = t;
+      if (((long long)cfg->batch << std::max(nb - t, 0)) >= 256) break;
+    }
+    h->T = best;
+  }
   h->dim = (size_t)1 << nb;
   // k_apply12 (register-resident tile kernel) measured 8-14 % slower than the
   // generic kernel on MI355X in round 1 (profiles/r01): opt-in until it wins.
@@ -2032,7 +2049,7 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
 
 static bool hermitian_path(const ryd_handle* h) {
   return !h->general && h->cfg.mode == RYD_MESOLVE && !h->has_dbl && h->N >= 7 && h->N <= 14 &&
-         h->T == 12 && tile14_pays(h);
+         h->auto_tile && tile14_pays(h);
 }
 
 // One exponential  state <- exp(h * G~) state  on the generic multi-launch path.
@@ -2352,6 +2369,7 @@ extern "C" int ryd_outer_accumulate(ryd_handle* h, const void* psi_dev, const do
 extern "C" int ryd_get_stats(const ryd_handle* h, ryd_stats* out) {
   if (!h || !out) return fail(RYD_ERR_INVALID, "null argument");
   *out = h->stats;
+  if (hermitian_path(h)) out->passes = 2;  // row pass + symmetrisation
   return RYD_OK;
 }
 
