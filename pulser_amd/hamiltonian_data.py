@@ -90,6 +90,42 @@ class SequenceInputs:
     measurement: str | None = None
     slm_end: int = 0
     slm_targets: tuple[int, ...] = ()
+    # XY mode (microwave channels): C3 coefficient and magnetic field
+    interaction_coeff_xy: float | None = None  # devices/_device_datacls.py:392
+    magnetic_field: tuple[float, float, float] | None = None
+
+    def to_dict(self) -> dict[str, Any]:
+        """Plain dict (arrays + scalars) for fixtures / IPC."""
+        return {
+            "coords": np.asarray(self.coords, float), "qubit_ids": tuple(self.qubit_ids),
+            "interaction_coeff": float(self.interaction_coeff),
+            "measurement": self.measurement or "", "slm_end": int(self.slm_end),
+            "slm_targets": tuple(int(t) for t in self.slm_targets),
+            "interaction_coeff_xy": -1.0 if self.interaction_coeff_xy is None else float(self.interaction_coeff_xy),
+            "magnetic_field": np.zeros(0) if self.magnetic_field is None else np.asarray(self.magnetic_field, float),
+            "channels": [
+                {"name": c.name, "addressing": c.addressing, "basis": c.basis,
+                 "amp": np.asarray(c.amp, float), "det": np.asarray(c.det, float),
+                 "phase": np.asarray(c.phase, float),
+                 "slots": [np.array([s.ti, s.tf] + list(s.targets), dtype=np.int64) for s in c.slots],
+                 "propagation_dir": np.zeros(0) if c.propagation_dir is None else np.asarray(c.propagation_dir, float)}
+                for c in self.channels
+            ],
+        }
+
+    @classmethod
+    def from_dict(cls, d: dict[str, Any]) -> "SequenceInputs":
+        chans = []
+        for c in d["channels"]:
+            slots = [Slot(int(a[0]), int(a[1]), tuple(int(x) for x in a[2:])) for a in c["slots"]]
+            pd = tuple(float(x) for x in c["propagation_dir"]) if len(c["propagation_dir"]) else None
+            chans.append(ChannelInput(c["name"], c["addressing"], c["basis"], np.asarray(c["amp"], float),
+                                      np.asarray(c["det"], float), np.asarray(c["phase"], float), slots, pd))
+        mf = tuple(float(x) for x in d["magnetic_field"]) if len(d["magnetic_field"]) else None
+        xy = None if d["interaction_coeff_xy"] < 0 else float(d["interaction_coeff_xy"])
+        return cls(np.asarray(d["coords"], float), tuple(d["qubit_ids"]), chans,
+                   float(d["interaction_coeff"]), d["measurement"] or None, int(d["slm_end"]),
+                   tuple(int(t) for t in d["slm_targets"]), xy, mf)
 
     @property
     def n_qudits(self) -> int:
@@ -113,26 +149,46 @@ class SequenceInputs:
         return replace(self, channels=[c.extend_duration(new_duration) for c in self.channels])
 
     def to_nested_dict(self, all_local: bool = False) -> dict[str, Any]:
-        """sampler/samples.py:524-621 without DMM channels / XY SLM masks."""
+        """sampler/samples.py:524-621 without DMM channels.  In XY mode a global
+        channel only reaches the SLM-masked atoms after ``slm_end``; before it the
+        unmasked atoms get the samples as local entries (:574-587, :594-596)."""
         T = self.max_duration
+        in_xy = self.in_xy
         d: dict[str, Any] = {"Global": {}, "Local": {}}
 
         def entry() -> dict[str, np.ndarray]:
             return {"amp": np.zeros(T), "det": np.zeros(T), "phase": np.zeros(T)}
 
+        if in_xy:  # _prepare_dict(in_xy=True): the XY entries always exist
+            d["Global"]["XY"] = entry()
+            d["Local"]["XY"] = {}
+        masked = set(self.slm_targets)
         for ch in self.channels:
             cs = ch.extend_duration(T)
+            xy = ch.basis == "XY"
             if ch.addressing == "Global" and not all_local:
                 g = d["Global"].setdefault(ch.basis, entry())
-                g["amp"] += cs.amp
-                g["det"] += cs.det
-                g["phase"] += cs.phase
+                start = self.slm_end if xy else 0
+                g["amp"][start:] += cs.amp[start:]
+                g["det"][start:] += cs.det[start:]
+                g["phase"][start:] += cs.phase[start:]
+                if start == 0:
+                    continue
+                loc = d["Local"].setdefault(ch.basis, {})
+                for t in (set(cs.slots[0].targets) - masked if cs.slots else set()):
+                    e = loc.setdefault(t, entry())
+                    e["amp"][:start] += cs.amp[:start]
+                    e["det"][:start] += cs.det[:start]
+                    e["phase"][:start] += cs.phase[:start]
             else:
                 loc = d["Local"].setdefault(ch.basis, {})
                 for s in cs.slots:
                     for t in s.targets:
+                        ti = s.ti
+                        if xy and t in masked:
+                            ti = max(ti, self.slm_end)
                         e = loc.setdefault(t, entry())
-                        sl = slice(s.ti, s.tf)
+                        sl = slice(ti, s.tf)
                         e["amp"][sl] += cs.amp[sl]
                         e["det"][sl] += cs.det[sl]
                         e["phase"][sl] += cs.phase[sl]
@@ -331,10 +387,27 @@ class HamiltonianData:
     def interaction_matrix(self, coords: np.ndarray, bad_atoms: np.ndarray) -> np.ndarray:
         n = self.n_qudits
         d = distances(coords)
-        inter = np.zeros((1, n, n))
+        is_xy = self.interaction_type == "XY"
+        inter = np.zeros((2 if is_xy else 1, n, n))
+        if is_xy:  # C3 (1 - 3 cos^2 theta) / r^3 with theta to the magnetic field (:589-611)
+            if self.samples.magnetic_field is None or self.samples.interaction_coeff_xy is None:
+                raise ValueError("XY mode needs 'magnetic_field' and 'interaction_coeff_xy'.")
+            mag = np.asarray(self.samples.magnetic_field, float)
+            mag_norm = np.linalg.norm(mag)
+            assert mag_norm > 0, "There must be a magnetic field in XY mode."
+            pos = np.asarray(coords, float)
+            if pos.shape[1] == 2:
+                pos = np.column_stack((pos, np.zeros(n)))
+            for i in range(n):
+                for j in range(i + 1, n):
+                    diff = pos[i] - pos[j]
+                    cosine = np.dot(diff, mag) / (np.linalg.norm(diff) * mag_norm)
+                    inter[0, i, j] = inter[0, j, i] = (
+                        self.samples.interaction_coeff_xy * (1 - 3 * cosine**2) / d[i, j] ** 3
+                    )
         for i in range(n):
             for j in range(i + 1, n):
-                inter[0, i, j] = inter[0, j, i] = self.samples.interaction_coeff / d[i, j] ** 6
+                inter[-1, i, j] = inter[-1, j, i] = self.samples.interaction_coeff / d[i, j] ** 6
         bad = np.asarray(bad_atoms, bool)
         inter[:, bad.reshape(1, -1) | bad.reshape(-1, 1)] = 0.0
         return inter

@@ -119,8 +119,6 @@ def sequence_inputs_from_pulser(samples: Any, register: Any, device: Any) -> Any
         ch_obj = samples._ch_objs[name]
         if type(cs).__name__ == "DMMSamples":
             raise NotImplementedError("DMM channels are not supported by the MI355X backend yet.")
-        if ch_obj.basis == "XY":
-            raise NotImplementedError("XY mode is not supported by the MI355X backend yet.")
         slots = []
         for s in cs.slots:
             if ch_obj.addressing == "Global":
@@ -141,8 +139,12 @@ def sequence_inputs_from_pulser(samples: Any, register: Any, device: Any) -> Any
             )
         )
     coords = np.array([_np(register.qubits[q]) for q in qids], dtype=float)
+    in_xy = any(c.basis == "XY" for c in channels)
+    mag = samples._magnetic_field
     return SequenceInputs(
         coords, tuple(str(q) for q in qids), channels, float(device.interaction_coeff),
         samples._measurement, int(samples._slm_mask.end),
-        tuple(index[q] for q in samples._slm_mask.targets),
+        tuple(sorted(index[q] for q in samples._slm_mask.targets)),
+        float(device.interaction_coeff_xy) if in_xy else None,
+        tuple(float(x) for x in np.asarray(mag, float)) if (in_xy and mag is not None) else None,
     )

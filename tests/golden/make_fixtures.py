@@ -328,6 +328,86 @@ def gen_noises_all():
             oracle_lookup_index=idx, oracle_lookup_state_default=states[idx],
         )
 
+
+# ---------------------------------------------------------------------------
+# 2c. test_simulation.py:1536-1690 (XY mode, SLM mask, SPAM trajectories, mesolve)
+# ---------------------------------------------------------------------------
+
+XY_CASES = [
+    (None, "dephasing", {"0000": 830, "0001": 21, "0010": 3, "0100": 80, "1000": 66}, 1),
+    (None, "eff_noise", {"0000": 851, "0001": 23, "0010": 8, "0100": 57, "1000": 61}, 1),
+    (None, "leakage", {"0000": 851, "0001": 23, "0010": 8, "0100": 57, "1000": 61}, 1),
+    (None, "depolarizing", {"0000": 791, "0001": 39, "0010": 10, "0100": 81, "0110": 2, "1000": 67, "1010": 10}, 3),
+    ("atom0", "dephasing", {"0000": 804, "0001": 105, "0010": 12, "0100": 54, "0101": 8, "1000": 17}, 1),
+    ("atom1", "dephasing", {"0000": 575, "0001": 334, "0011": 12, "0100": 13, "1000": 56, "1001": 10}, 1),
+]
+
+
+def gen_noisy_xy():
+    from collections import Counter
+    from pulser_amd.pulser_adapter import sequence_inputs_from_pulser, problem_from_trajectory
+
+    seed = 15092021
+    for k, (masked, noise, golden, n_ops) in enumerate(XY_CASES):
+        np.random.seed(seed)
+        reg = Register.square(2, prefix="atom")
+        seq = Sequence(reg, MockDevice)
+        seq.declare_channel("ch0", "mw_global")
+        if masked is not None:
+            seq.config_slm_mask([masked])
+        seq.add(Pulse.ConstantPulse(1000, 3.0, 1.0, 0.0), "ch0")
+        leak = noise == "leakage"
+        if leak or noise == "eff_noise":
+            op = np.diag([1.0, -1.0, 0.0]).astype(complex) if leak else np.diag([1.0, -1.0]).astype(complex)
+            params = dict(eff_noise_opers=[op], eff_noise_rates=[1.0])
+        else:
+            params = {f"{noise}_rate": _LEGACY_DEFAULTS[f"{noise}_rate"]}
+        nm = NoiseModel(samples_per_run=10, with_leakage=leak, state_prep_error=0.4,
+                        p_false_pos=0.01, p_false_neg=0.05, **params)
+        samples = sampler.sample(seq, extended_duration=seq.get_duration())
+        inputs = sequence_inputs_from_pulser(samples, seq.register, seq.device)
+        T = samples.max_duration
+        ext = samples.extend_duration(T + 1)
+        hd = HamiltonianData(ext, seq.register, seq.device, nm, 15)
+        HamiltonianData(ext, seq.register, seq.device, NoiseModel(), 1)  # hidden noiseless draw
+        rate = 0.1
+        tlist = qp.sampling_times(T + 1, rate)
+        eval_times = np.union1d(tlist, [0.0, T * 1e-3])
+        opts = qp.default_options(channel_amp_det(ext), T)
+        total = [Counter() for _ in eval_times]
+        finals, reps_list, bad_list = [], [], []
+        for traj, noisy, reps in hd.noisy_samples:
+            prob = problem_from_trajectory(hd, traj, noisy, reps, rate)
+            ham = qp.build_hamiltonian(prob)
+            psi0 = qp.all_ground_state(4, prob["eigenbasis"], xy=True)
+            states = qp.mesolve(ham, psi0, eval_times, **opts)
+            for i, t in enumerate(eval_times):
+                total[i] += osamp.sample_state(
+                    states, eval_times, t, 10 * reps, 4, prob["eigenbasis"], "XY", True,
+                    {"epsilon": 0.01, "epsilon_prime": 0.05})
+            idx = osamp.index_from_time(eval_times, eval_times[-1])
+            finals.append(states[idx]); reps_list.append(reps)
+            bad_list.append(prob["bad_atoms"])
+        # NoisyResults.sample_final_state: resample the final SampledResult (result.py:171-242)
+        idx = osamp.index_from_time(eval_times, eval_times[-1])
+        w = np.zeros(16)
+        n_meas = sum(total[idx].values())
+        for bs, c in total[idx].items():
+            w[int(bs, 2)] = c / n_meas
+        w = w / sum(w)
+        final = osamp.get_samples(w, 1000, 4)
+        ok = dict(final) == golden
+        print(f"noisy_xy[{k}] masked={masked} {noise}: {'OK' if ok else 'MISMATCH'} {dict(final)}")
+        P.save_problem(
+            os.path.join(HERE, f"noisy_xy_{k}.npz"), {"inputs": inputs.to_dict()},
+            seed=seed, masked=masked or "", noise=noise, n_collapse_ops=n_ops,
+            reference_golden_counter=golden,
+            reference_cite="tests/pulser_simulation/test_simulation.py:1536-1690 (MESOLVER cases)",
+            eval_times=eval_times, traj_reps=np.array(reps_list), traj_bad_atoms=np.array(bad_list),
+            oracle_traj_lookup_states=np.stack(finals),
+            oracle_total_final_counter=dict(total[idx]),
+        )
+
 # ---------------------------------------------------------------------------
 # 3. test_simulation.py:2156-2190 (3 atoms, custom initial state, golden state)
 # ---------------------------------------------------------------------------
@@ -565,6 +645,8 @@ if __name__ == "__main__":
         gen_noises_rydberg()
     if "digital" in which:
         gen_noises_digital()
+    if "xy" in which:
+        gen_noisy_xy()
     if "all" in which:
         gen_noises_all()
     if "three" in which:

@@ -234,3 +234,16 @@ def test_reference_golden_counters_all_basis_end_to_end(k):
     assert np.max(np.abs(final - extra["oracle_final_state_tight"])) < 1e-7
     tr2 = np.trace(final @ final).real
     assert tr2 < 1 and not np.isclose(tr2, 1)
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_reference_golden_counters_xy_end_to_end(k):
+    """test_simulation.py:1536-1690 (MESOLVER cases) with the real solver: XY
+    exchange interaction, SLM-mask switching terms, SPAM trajectories, 2- and
+    3-level (leakage) - explicit-term general path."""
+    from test_host_logic import _xy_emulator
+
+    emu, extra = _xy_emulator(k)
+    with pytest.warns(DeprecationWarning):
+        r = emu.run()
+    assert r.sample_final_state() == Counter(extra["reference_golden_counter"])

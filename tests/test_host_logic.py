@@ -496,3 +496,63 @@ def test_factored_trajectory_lowering_equals_general_lowering():
                 cg, dg = coefs(gen, b, k, i, u)
                 assert abs(cf - cg) < 1e-12 * max(1.0, abs(cg)), (b, k, i)
                 assert abs(df - dg) < 1e-11 * max(1.0, abs(dg)), (b, k, i)
+
+
+# ------------------------------------------------------------------ XY mode
+def _xy_emulator(k, solver=Solver.MESOLVER):
+    """Emulator for MESOLVER case k of test_simulation.py:1536-1690 (XY mode)."""
+    prob, extra = load_fixture(f"noisy_xy_{k}.npz")
+    inputs = SequenceInputs.from_dict(prob["inputs"])
+    noise = extra["noise"]
+    leak = noise == "leakage"
+    if leak or noise == "eff_noise":
+        op = np.diag([1.0, -1.0, 0.0]).astype(complex) if leak else np.diag([1.0, -1.0]).astype(complex)
+        params = dict(eff_noise_opers=[op], eff_noise_rates=[1.0])
+    else:
+        params = {f"{noise}_rate": LEGACY_DEFAULTS[f"{noise}_rate"]}
+    nm = NoiseModel(samples_per_run=10, with_leakage=leak, state_prep_error=0.4,
+                    p_false_pos=0.01, p_false_neg=0.05, **params)
+    np.random.seed(int(extra["seed"]))
+    emu = QutipEmulator(inputs, sampling_rate=0.1, noise_model=nm, n_trajectories=15, solver=solver)
+    return emu, extra
+
+
+class _FakeSolvePerTrajectory:
+    def __init__(self, emu, states):
+        self.emu, self.states, self.k = emu, list(states), 0
+
+    def __call__(self, problems, progress_bar, options, tables=None):
+        out = []
+        for _ in problems:
+            out += _FakeSolve(self.emu, self.states[self.k])([None], progress_bar, options)
+            self.k += 1
+        return out
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_emulator_golden_counters_xy(k, monkeypatch):
+    """XY mode, SLM mask, SPAM state-preparation trajectories (deduplicated),
+    per-evaluation-time sampling with measurement flips, final resampling of
+    the NoisyResults: the reference's golden Counters with the solver stubbed."""
+    emu, extra = _xy_emulator(k)
+    noise = extra["noise"]
+    assert set(emu.noise_model.noise_types) == ({"SPAM", noise} if noise != "leakage"
+                                                 else {"SPAM", "leakage", "eff_noise"})
+    assert emu.basis_name == ("XY_with_error" if noise == "leakage" else "XY")
+    trajs = emu._hamiltonian_data.noise_trajectories
+    assert list(trajs[0].bad_atoms) == [True, False, True, False]  # test_simulation.py:1669-1674
+    assert np.array_equal([t.reps for t in trajs], extra["traj_reps"])
+    assert np.array_equal(np.array([t.bad_atoms for t in trajs]), extra["traj_bad_atoms"])
+    assert len(emu._current_problem["collapse_ops"]) == extra["n_collapse_ops"]
+    assert np.array_equal(emu.evaluation_times, extra["eval_times"])
+    assert emu._current_problem["interaction_matrix"].shape == (2, 4, 4)
+    monkeypatch.setattr(emu, "_solve_batch",
+                        _FakeSolvePerTrajectory(emu, extra["oracle_traj_lookup_states"]))
+    with pytest.warns(DeprecationWarning):
+        r = emu.run()
+    idx = r._get_index_from_time(emu._eval_times_array[-1])
+    assert dict(r[idx].bitstring_counts) == extra["oracle_total_final_counter"]
+    assert r.sample_final_state() == Counter(extra["reference_golden_counter"])
+    with pytest.raises(NotImplementedError, match="mode 'XY' does not support simulation of"):
+        QutipEmulator(SequenceInputs.from_dict(load_fixture(f"noisy_xy_{k}.npz")[0]["inputs"]),
+                      noise_model=NoiseModel(temperature=50), n_trajectories=1)
