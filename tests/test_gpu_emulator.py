@@ -247,3 +247,45 @@ def test_reference_golden_counters_xy_end_to_end(k):
     with pytest.warns(DeprecationWarning):
         r = emu.run()
     assert r.sample_final_state() == Counter(extra["reference_golden_counter"])
+
+
+def test_get_hamiltonian_reference_goldens():
+    """tests/pulser_simulation/test_simulation.py:477-600: H(t) entries for the
+    noiseless case, doppler noise (seed 123) and doppler + register noise (seed
+    456) - pins the RNG draw order, the sign conventions, the noisy interaction
+    matrix and the spline evaluation through the device generator kernel."""
+    coords = np.array([[10.0, 0.0], [0.0, 0.0]])
+    coords = coords - coords.mean(axis=0)  # Register.from_coordinates(center=True)
+    amp = P.ramp_samples(1500, 0.0, 2.0)
+    inputs = single_global_channel(coords, {"amp": amp, "det": np.full(1500, 1.0), "phase": 0 * amp},
+                                   P.C6_LEVEL70, extended=False, prefix="atom")
+    sim = QutipEmulator(inputs, sampling_rate=0.01)
+    with pytest.raises(ValueError, match="less than or equal to"):
+        sim.get_hamiltonian(1650)
+    with pytest.raises(ValueError, match="greater than or equal to"):
+        sim.get_hamiltonian(-10)
+    ham = np.asarray(sim.get_hamiltonian(143))
+    assert np.isclose(ham[0, 0], P.C6_LEVEL70 / 10**6 - 2 * 1.0)
+
+    np.random.seed(123)
+    noisy = QutipEmulator(inputs, noise_model=NoiseModel(samples_per_run=1, temperature=20000),
+                          n_trajectories=15)
+    np.testing.assert_allclose(
+        np.asarray(noisy.get_hamiltonian(144)),
+        np.array([[4.47984523, 0.09606404, 0.09606404, 0.0],
+                  [0.09606404, 12.03082372, 0.0, 0.09606404],
+                  [0.09606404, 0.0, -12.97113702, 0.09606404],
+                  [0.0, 0.09606404, 0.09606404, 0.0]], dtype=complex), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.asarray(noisy.get_hamiltonian(144, noiseless=True)),
+                               np.asarray(QutipEmulator(inputs).get_hamiltonian(144)), atol=1e-12)
+
+    np.random.seed(456)
+    noisy = QutipEmulator(
+        inputs, noise_model=NoiseModel(samples_per_run=1, temperature=50.0, trap_depth=150.0,
+                                       trap_waist=1.0), n_trajectories=1)
+    np.testing.assert_allclose(
+        np.asarray(noisy.get_hamiltonian(144)),
+        np.array([[4.92294305, 0.09606404, 0.09606404, 0.0],
+                  [0.09606404, -0.59902269, 0.0, 0.09606404],
+                  [0.09606404, 0.0, -0.70099956, 0.09606404],
+                  [0.0, 0.09606404, 0.09606404, 0.0]], dtype=complex), rtol=1e-7, atol=1e-9)
