@@ -154,6 +154,39 @@ int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
 int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
               void* out_dev, const ryd_opts* opts, void* stream);
 
+/* Replaces: the c_ops argument of qutip.mcsolve (simulation.py:705-727: with
+ * collapse operators and stochastic noise Solver.DEFAULT picks qutip.mcsolve;
+ * Solver.MCSOLVER forces it) - the local 2x2 collapse operators that
+ * Hamiltonian._build_collapse_operators (hamiltonian.py:97-124) places on every
+ * atom.  ops: complex128[n_ops][2][2] row-major, interleaved (host), local index
+ * 0 = r (or h), 1 = g; n_ops <= 16.  Only for RYD_SESOLVE handles.  From then on
+ * the handle evolves kets under H_eff = H - (i/2) sum_atoms sum_k C_k^dag C_k
+ * (ryd_solve / ryd_evolve: the no-jump evolution, norm not conserved), and
+ * ryd_mc_solve runs quantum-jump trajectories.  sum_k C_k^dag C_k must be
+ * diagonal (true for dephasing, relaxation, depolarizing and diagonal / ladder
+ * eff_noise operators); otherwise RYD_ERR_UNSUPPORTED.  n_ops = 0 removes them. */
+int ryd_set_collapse(ryd_handle* h, int32_t n_ops, const double* ops);
+
+/* Replaces: qutip.mcsolve(H, psi0, tlist, c_ops, ntraj=1) for every batch entry
+ * (simulation.py:729-735 with solver_fn = qutip.mcsolve).  Same arguments as
+ * ryd_solve plus one 64-bit seed per batch entry (host, uint64[batch]).  Each
+ * batch entry is ONE Monte-Carlo wavefunction trajectory: the ket evolves under
+ * H_eff until its squared norm falls below a uniform threshold; then one local
+ * collapse (atom, operator) is drawn with weights ||C psi||^2, applied, and the
+ * ket renormalised.  Jumps are taken at the end of the integrator step in which
+ * the threshold is crossed (steps never exceed one sample interval, see
+ * ryd_opts.max_step).  Stored states and the final state are normalised.
+ * Random numbers: Philox4x32-10, key = seed, counter = jump index; a trajectory
+ * is a function of (seed, Hamiltonian) only.  qutip.mcsolve seeds its own
+ * generators, so parity with the reference is statistical: the trajectory
+ * average converges to the qutip.mesolve state. */
+int ryd_mc_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
+                 void* out_dev, const uint64_t* seeds, const ryd_opts* opts, void* stream);
+
+/* Number of collapses of every batch entry in the last ryd_mc_solve
+ * (McResult.col_times lengths); synchronises `stream`.  counts: int32[batch] (host). */
+int ryd_mc_get_jumps(ryd_handle* h, int32_t* counts, void* stream);
+
 /* General path for everything the tuned 2-level Ising kernels do not cover: the
  * 3-level "all" basis, leakage (d = 3/4), XY mode with its SLM-mask switching
  * terms, arbitrary eff_noise collapse operators.  The generator is given as an

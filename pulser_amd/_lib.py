@@ -92,6 +92,10 @@ SYMBOLS = {
     "ryd_set_dissipator": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ryd_evolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.POINTER(RydOpts), C.c_void_p]),
     "ryd_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(RydOpts), C.c_void_p]),
+    "ryd_set_collapse": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ryd_mc_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(RydOpts), C.c_void_p]),
+    "ryd_mc_get_jumps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ryd_set_path": (C.c_int, [C.c_void_p, C.c_int32]),
     "ryd_general_create": (C.c_int, [C.POINTER(RydGeneralConfig), C.POINTER(C.c_void_p)]),
     "ryd_general_add_term": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -116,6 +116,7 @@ struct PassArgs {
   double wmix;          // weight of the static parts (w1 + w2)
   double scale;         // h / j
   double shift;         // spectral shift of H (sesolve)
+  double dec_a, dec_b;  // Monte-Carlo wavefunction: real diagonal dec_a + dec_b * popc(i) (sesolve)
   cplx post;            // final multiplier
   cplx Sd[4];           // mesolve: dissipator diagonal, index 2*a_k + b_k
   cplx J[4];            // mesolve: double-flip coefficient, by output pair
@@ -236,6 +237,11 @@ __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
       if (MODE == RYD_SESOLVE) {
         e += A.wmix * e0[gi] - A.shift;
         acc = make_double2(e * x.y, -e * x.x);  // -i e x
+        if (A.dec_a != 0.0 || A.dec_b != 0.0) {  // -(1/2) sum C^dag C of H_eff (diagonal)
+          const double dr = fma(A.dec_b, (double)__popcll(gi), A.dec_a);
+          acc.x = fma(dr, x.x, acc.x);
+          acc.y = fma(dr, x.y, acc.y);
+        }
       } else {
         const unsigned a = (unsigned)(gi >> N), bb = (unsigned)gi & Dm1;
         e += A.wmix * (e0[a] - e0[bb]);
@@ -480,6 +486,7 @@ struct Apply14Args {
   const double* e0;
   long long e0_stride;
   double wmix, diag_scale, scale, shift;
+  double dec_a, dec_b;  // see PassArgs
   cplx post;
   cplx Sd[4];
   int N, nb, n_flip;
@@ -569,6 +576,11 @@ __global__ __launch_bounds__(1024) void k_apply14(const Apply14Args A) {
       if (MODE == RYD_SESOLVE) {
         e = A.diag_scale * (e + A.wmix * e0[gi]) - A.shift;
         acc[jj] = make_double2(e * xo.y, -e * xo.x);
+        if (A.dec_a != 0.0 || A.dec_b != 0.0) {
+          const double dr = fma(A.dec_b, (double)__popcll(gi), A.dec_a);
+          acc[jj].x = fma(dr, xo.x, acc[jj].x);
+          acc[jj].y = fma(dr, xo.y, acc[jj].y);
+        }
       } else {
         const unsigned aa = (unsigned)(gi >> N), bb = (unsigned)gi & Dm1;
         e += A.wmix * (e0[aa] - e0[bb]);
@@ -808,6 +820,225 @@ __global__ void k_outer_acc(const cplx* __restrict__ psi, int N, int B,
   }
   acc[i].x += sr;
   acc[i].y += si;
+}
+
+// ---------------------------------------------------------------------------
+// Monte-Carlo wavefunction (quantum-jump) kernels - the work qutip.mcsolve does
+// between and at the collapses (pulser-simulation/pulser_simulation/
+// simulation.py:705-735: solver_fn = qutip.mcsolve, c_ops = one local operator
+// per (spec, atom), hamiltonian.py:97-124).  The unnormalised ket evolves under
+// H_eff = H - (i/2) sum C^dag C; when its squared norm has dropped below a
+// uniform threshold, a collapse operator is drawn with weights ||C psi||^2,
+// applied, and the ket renormalised.  Everything runs on the device without
+// host synchronisation: one norm reduction per step, and - only for the
+// trajectories that jump - the single-atom reduced density matrices, the
+// selection and the 2x2 local update.  Random numbers: Philox4x32-10 keyed by a
+// per-trajectory 64-bit seed, counter = jump index, so a trajectory's history
+// does not depend on how the batch is split over launches or GPUs.
+// ---------------------------------------------------------------------------
+#define MC_MAX_OPS 16
+
+__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+// (threshold uniform, selection uniform) of jump number j: 53-bit doubles in [0, 1)
+__device__ __forceinline__ void mc_uniforms(unsigned long long seed, unsigned j, double* ut,
+                                            double* us) {
+  unsigned c[4] = {j, 0u, 0u, 0u};
+  philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+  *ut = ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) * (1.0 / 9007199254740992.0);
+  *us = ((double)(c[2] >> 5) * 67108864.0 + (double)(c[3] >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+struct McState {
+  double* norm2;     // [2][B] squared norms (slot = step parity), zero between uses
+  double* red;       // [B][N][4]: rho_rr, rho_gg, Re rho_rg, Im rho_rg of each atom
+  double* target;    // [B] current threshold uniform
+  double* refnorm;   // [B] squared norm right after the last jump (or at the start)
+  double* lastnorm;  // [B] squared norm after the last completed step
+  double* scale;     // [B] 1 / ||C psi|| of the selected collapse
+  int* flag;         // [B] this step jumps
+  int* sel;          // [B] atom * MC_MAX_OPS + op
+  int* count;        // [B] jumps so far
+  const unsigned long long* seeds;  // [B]
+  const cplx* ops;   // [n_ops][4] local collapse operators, row-major (index 0 = r)
+  int n_ops;
+};
+
+__device__ __forceinline__ double block_sum256(double v, double* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void k_mc_norm(const cplx* __restrict__ st, int nb,
+                                                 double* __restrict__ norm2) {
+  __shared__ double sh[4];
+  const size_t D = (size_t)1 << nb;
+  const int b = blockIdx.y;
+  const cplx* __restrict__ x = st + ((size_t)b << nb);
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < D; i += (size_t)gridDim.x * 256) {
+    const cplx v = x[i];
+    s = fma(v.x, v.x, fma(v.y, v.y, s));
+  }
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) atomicAdd(&norm2[b], s);
+}
+
+// start of a Monte-Carlo solve: thresholds of jump 0, reference norms
+__global__ void k_mc_init(McState M, int B, int N) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double ut, us;
+  mc_uniforms(M.seeds[b], 0u, &ut, &us);
+  M.target[b] = ut;
+  M.refnorm[b] = M.norm2[b];  // slot 0 holds the initial squared norm
+  M.lastnorm[b] = M.norm2[b];
+  M.norm2[b] = 0.0;
+  M.norm2[B + b] = 0.0;
+  M.count[b] = 0;
+  M.flag[b] = 0;
+  for (int i = 0; i < 4 * N; ++i) M.red[(size_t)b * 4 * N + i] = 0.0;
+}
+
+// reduced single-atom density matrices of the trajectories that jump this step
+__global__ __launch_bounds__(256) void k_mc_reduced(const cplx* __restrict__ st, int N,
+                                                    McState M, int B, int slot) {
+  __shared__ double sh[4];
+  const int b = blockIdx.y;
+  if (!(M.norm2[(size_t)slot * B + b] <= M.target[b] * M.refnorm[b])) return;  // block-uniform
+  const size_t D = (size_t)1 << N;
+  const cplx* __restrict__ x = st + ((size_t)b << N);
+  for (int a = 0; a < N; ++a) {
+    const size_t bit = (size_t)1 << (N - 1 - a);
+    double rr = 0.0, gg = 0.0, cr = 0.0, ci = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < D; i += (size_t)gridDim.x * 256) {
+      const cplx v = x[i];
+      const double m = v.x * v.x + v.y * v.y;
+      if (i & bit) {
+        gg += m;
+      } else {
+        const cplx w = x[i | bit];
+        rr += m;
+        cr += v.x * w.x + v.y * w.y;  // psi_r conj(psi_g)
+        ci += v.y * w.x - v.x * w.y;
+      }
+    }
+    rr = block_sum256(rr, sh);
+    gg = block_sum256(gg, sh);
+    cr = block_sum256(cr, sh);
+    ci = block_sum256(ci, sh);
+    if (threadIdx.x == 0) {
+      double* r = M.red + ((size_t)b * N + a) * 4;
+      atomicAdd(r + 0, rr);
+      atomicAdd(r + 1, gg);
+      atomicAdd(r + 2, cr);
+      atomicAdd(r + 3, ci);
+    }
+  }
+}
+
+// ||C psi||^2 = Tr(C rho_atom C^dag) for a local 2x2 operator
+__device__ __forceinline__ double mc_weight(const cplx* C, const double* r) {
+  double p = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const cplx c0 = C[2 * i], c1 = C[2 * i + 1];
+    // c0 conj(c1) rho_rg
+    const double xr = c0.x * c1.x + c0.y * c1.y, xi = c0.y * c1.x - c0.x * c1.y;
+    p += (c0.x * c0.x + c0.y * c0.y) * r[0] + (c1.x * c1.x + c1.y * c1.y) * r[1] +
+         2.0 * (xr * r[2] - xi * r[3]);
+  }
+  return p;
+}
+
+__global__ void k_mc_select(McState M, int B, int N, int slot) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double n2 = M.norm2[(size_t)slot * B + b];
+  M.norm2[(size_t)(slot ^ 1) * B + b] = 0.0;  // the next step accumulates there
+  M.norm2[(size_t)slot * B + b] = 0.0;
+  int flag = 0;
+  double last = n2;
+  if (n2 <= M.target[b] * M.refnorm[b]) {
+    double* red = M.red + (size_t)b * N * 4;
+    double total = 0.0;
+    for (int a = 0; a < N; ++a)
+      for (int k = 0; k < M.n_ops; ++k) total += fmax(mc_weight(M.ops + 4 * k, red + 4 * a), 0.0);
+    if (total > 0.0) {
+      const unsigned j = (unsigned)M.count[b];
+      double ut, us;
+      mc_uniforms(M.seeds[b], j, &ut, &us);
+      const double x = us * total;
+      double cum = 0.0, psel = 0.0, plast = 0.0;
+      int sel = -1, lastpos = -1;
+      for (int a = 0; a < N; ++a)
+        for (int k = 0; k < M.n_ops; ++k) {
+          const double p = fmax(mc_weight(M.ops + 4 * k, red + 4 * a), 0.0);
+          cum += p;
+          if (p > 0.0) { lastpos = a * MC_MAX_OPS + k; plast = p; }
+          if (sel < 0 && p > 0.0 && cum > x) { sel = a * MC_MAX_OPS + k; psel = p; }
+        }
+      if (sel < 0) { sel = lastpos; psel = plast; }  // rounding left x >= cum
+      M.sel[b] = sel;
+      M.scale[b] = 1.0 / sqrt(psel);
+      M.count[b] = (int)j + 1;
+      mc_uniforms(M.seeds[b], j + 1u, &ut, &us);
+      M.target[b] = ut;
+      M.refnorm[b] = 1.0;
+      last = 1.0;
+      flag = 1;
+    }
+    for (int i = 0; i < 4 * N; ++i) red[i] = 0.0;
+  }
+  M.flag[b] = flag;
+  M.lastnorm[b] = last;
+}
+
+// psi <- C_k^(atom) psi / ||C psi|| for the flagged trajectories (in place, by pairs)
+__global__ __launch_bounds__(256) void k_mc_jump(cplx* __restrict__ st, int N, McState M) {
+  const int b = blockIdx.y;
+  if (!M.flag[b]) return;
+  const int sel = M.sel[b];
+  const int p = N - 1 - sel / MC_MAX_OPS;
+  const cplx* C = M.ops + 4 * (sel % MC_MAX_OPS);
+  const cplx c00 = C[0], c01 = C[1], c10 = C[2], c11 = C[3];
+  const double s = M.scale[b];
+  const size_t half = (size_t)1 << (N - 1), bit = (size_t)1 << p;
+  cplx* __restrict__ x = st + ((size_t)b << N);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += (size_t)gridDim.x * 256) {
+    const size_t l0 = ((i >> p) << (p + 1)) | (i & (bit - 1)), l1 = l0 | bit;
+    const cplx v0 = x[l0], v1 = x[l1];
+    const cplx o0 = cfma(c00, v0, cmul(c01, v1)), o1 = cfma(c10, v0, cmul(c11, v1));
+    x[l0] = make_double2(s * o0.x, s * o0.y);
+    x[l1] = make_double2(s * o1.x, s * o1.y);
+  }
+}
+
+// dst = src / ||src|| using the norm recorded after the last step (dst may be src)
+__global__ __launch_bounds__(256) void k_mc_normalize(const cplx* __restrict__ src,
+                                                      cplx* __restrict__ dst, int nb,
+                                                      const double* __restrict__ lastnorm) {
+  const size_t D = (size_t)1 << nb;
+  const int b = blockIdx.y;
+  const double s = rsqrt(lastnorm[b]);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < D; i += (size_t)gridDim.x * 256) {
+    const cplx v = src[((size_t)b << nb) + i];
+    dst[((size_t)b << nb) + i] = make_double2(s * v.x, s * v.y);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1164,6 +1395,16 @@ struct ryd_handle {
   bool force_tile14 = false;   // test hook: use them even when too few tiles fill the GPU
   bool drive_real = false;     // every drive series is real-valued
   bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
+  // Monte-Carlo wavefunction mode (sesolve handles with ryd_set_collapse)
+  bool mc = false;         // collapse operators set: H_eff carries -(i/2) sum C^dag C
+  bool mc_active = false;  // inside ryd_mc_solve: jump bookkeeping after every step
+  int mc_n_ops = 0;
+  double mc_a = 0.0, mc_b = 0.0;  // real diagonal of G_eff: mc_a + mc_b * popc(index)
+  void* mc_pool = nullptr;        // one allocation behind McState
+  McState mcs{};
+  unsigned long long* mc_seeds_dev = nullptr;
+  cplx* mc_ops_dev = nullptr;
+  int mc_slot = 0;
   ryd_stats stats{};
   // timing
   bool timing = false;
@@ -1411,6 +1652,7 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->gen_series_dev);
   hipFree(h->gen_conj_dev);
   hipFree(h->gen_scale_dev);
+  hipFree(h->mc_pool);
   for (auto& t : h->gen_host) {
     hipFree((void*)t.dev.row_ptr);
     hipFree((void*)t.dev.col);
@@ -1679,8 +1921,12 @@ static int launch_apply14(ryd_handle* h, const Apply14Args& B, hipStream_t st) {
 // unless single-element hazards are impossible (never used in place here).
 static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx* out,
                            double wmix, double scale, double shift, cplx post,
-                           hipStream_t st) {
+                           hipStream_t st, bool with_decay = false) {
   if (!h->passes_valid) plan_passes(h);
+  // Monte-Carlo H_eff: real diagonal, centred (the centre is a scalar factor
+  // of the exponential, applied by exp_step through `post`)
+  const double dec_b = with_decay ? wmix * h->mc_b : 0.0;
+  const double dec_a = -0.5 * h->N * dec_b;
   const int np = (int)h->passes.size();
   for (int pi = 0; pi < np; ++pi) {
     const Pass& p = h->passes[pi];
@@ -1698,6 +1944,8 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
     A.wmix = wmix;
     A.scale = scale;
     A.shift = shift;
+    A.dec_a = dec_a;
+    A.dec_b = dec_b;
     A.post = post;
     for (int i = 0; i < 4; ++i) { A.Sd[i] = h->Sd[i]; A.J[i] = h->J[i]; }
     A.tile = p.tile;
@@ -1733,6 +1981,8 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
       B.diag_scale = 1.0;
       B.scale = scale;
       B.shift = shift;
+      B.dec_a = dec_a;
+      B.dec_b = dec_b;
       B.post = post;
       for (int i = 0; i < 4; ++i) B.Sd[i] = h->Sd[i];
       B.N = h->N;
@@ -1748,7 +1998,7 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
       continue;
     }
     // contiguous single-flip range on a full 2^12 tile -> specialised kernel
-    bool fast = p.T == 12 && A.n_dbl == 0 && A.n_flip >= 1 && !h->no_fast_apply &&
+    bool fast = p.T == 12 && A.n_dbl == 0 && A.n_flip >= 1 && !h->no_fast_apply && !with_decay &&
                 (A.flip_q[0] == 0 || A.flip_q[0] == 4);
     for (int i = 1; i < A.n_flip && fast; ++i) fast = A.flip_q[i] == A.flip_q[0] + i;
     if (fast) {
@@ -1975,6 +2225,7 @@ static void plan_exp(ryd_handle* h, int idx, double hstep, double w1, double w2,
   } else if (h->cfg.mode == RYD_SESOLVE) {
     shift = 0.5 * (lo + hi);  // H' = H - shift: halves the spectral radius
     bound = 0.5 * (hi - lo) + drive;
+    if (h->mc) bound += wmix * std::fabs(h->mc_b) * 0.5 * h->N;  // centred decay diagonal
   } else {
     bound = 2.0 * (0.5 * (hi - lo) + drive) + wmix * h->diss_norm;
   }
@@ -2132,11 +2383,44 @@ static int exp_step(ryd_handle* h, cplx* state, double hstep, const MixPoint& m,
   int which = 0;
   for (int j = order; j >= 1; --j) {
     cplx* out = j == 1 ? state : bufs[which];
-    const cplx post = j == 1 ? make_double2(std::cos(hstep * shift), -std::sin(hstep * shift)) : one;
-    if ((rc = apply_generator(h, in, state, out, wmix, hstep / j, shift, post, st))) return rc;
+    cplx post = one;
+    if (j == 1) {
+      // e^{-i h shift}, and for H_eff the centre of the decay diagonal
+      const double mag = h->mc ? std::exp(hstep * wmix * (h->mc_a + 0.5 * h->N * h->mc_b)) : 1.0;
+      post = make_double2(mag * std::cos(hstep * shift), -mag * std::sin(hstep * shift));
+    }
+    if ((rc = apply_generator(h, in, state, out, wmix, hstep / j, shift, post, st, h->mc))) return rc;
     in = out;
     which ^= 1;
   }
+  return RYD_OK;
+}
+
+static unsigned mc_blocks(const ryd_handle* h) {
+  return (unsigned)std::min<size_t>(std::max<size_t>(h->dim >> 10, 1), 128);
+}
+
+// Jump bookkeeping after one CF4 step of a Monte-Carlo solve (all on `st`).
+static int mc_after_step(ryd_handle* h, cplx* state, hipStream_t st) {
+  const unsigned nblk = mc_blocks(h);
+  hipLaunchKernelGGL(k_mc_norm, dim3(nblk, h->B), dim3(256), 0, st, state, h->nb, h->mcs.norm2);
+  hipLaunchKernelGGL(k_mc_reduced, dim3(nblk, h->B), dim3(256), 0, st, state, h->N, h->mcs, h->B, 0);
+  hipLaunchKernelGGL(k_mc_select, dim3((h->B + 127) / 128), dim3(128), 0, st, h->mcs, h->B, h->N, 0);
+  hipLaunchKernelGGL(k_mc_jump, dim3(nblk, h->B), dim3(256), 0, st, state, h->N, h->mcs);
+  HIPCHK(hipGetLastError());
+  h->stats.n_launches += 4;
+  return RYD_OK;
+}
+
+// Snapshot of the state: a plain copy, or the normalised ket in a Monte-Carlo solve.
+static int snapshot_copy(ryd_handle* h, const cplx* state, cplx* dst, hipStream_t st) {
+  if (h->mc_active) {
+    hipLaunchKernelGGL(k_mc_normalize, dim3(mc_blocks(h), h->B), dim3(256), 0, st, state, dst, h->nb,
+                       h->mcs.lastnorm);
+    HIPCHK(hipGetLastError());
+    return RYD_OK;
+  }
+  HIPCHK(hipMemcpyAsync(dst, state, h->dim * (size_t)h->B * sizeof(cplx), hipMemcpyDeviceToDevice, st));
   return RYD_OK;
 }
 
@@ -2154,10 +2438,11 @@ static int run_generic(ryd_handle* h, cplx* state, const std::vector<StepDesc>& 
     m.w1 = kA2; m.w2 = kA1;
     if ((rc = exp_step(h, state, d.h, m, d.order_b, d.shift_b, st))) return rc;
     h->stats.n_steps++;
-    if (d.snap >= 0 && snaps)
-      HIPCHK(hipMemcpyAsync(snaps + (size_t)d.snap * h->dim * h->B, state, bytes,
-                            hipMemcpyDeviceToDevice, st));
+    if (h->mc_active && (rc = mc_after_step(h, state, st))) return rc;
+    if (d.snap >= 0 && snaps && (rc = snapshot_copy(h, state, snaps + (size_t)d.snap * h->dim * h->B, st)))
+      return rc;
   }
+  (void)bytes;
   return RYD_OK;
 }
 
@@ -2243,7 +2528,7 @@ static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc
 }
 
 static bool use_persistent(const ryd_handle* h) {
-  return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 12 && !h->force_generic;
+  return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 12 && !h->force_generic && !h->mc;
 }
 
 extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
@@ -2272,16 +2557,14 @@ extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const 
         sched.back().snap = i - 1;
       } else {  // zero-length interval: the state is unchanged
         if (before == 0) {
-          HIPCHK(hipMemcpyAsync(snaps + (size_t)(i - 1) * h->dim * h->B, state, bytes,
-                                hipMemcpyDeviceToDevice, st));
+          if ((rc = snapshot_copy(h, state, snaps + (size_t)(i - 1) * h->dim * h->B, st))) return rc;
         } else {
           // duplicate time after at least one step: flush what we have, copy, continue
           if ((rc = use_persistent(h) ? run_persistent(h, state, sched, snaps, st)
                                       : run_generic(h, state, sched, snaps, st)))
             return rc;
           sched.clear();
-          HIPCHK(hipMemcpyAsync(snaps + (size_t)(i - 1) * h->dim * h->B, state, bytes,
-                                hipMemcpyDeviceToDevice, st));
+          if ((rc = snapshot_copy(h, state, snaps + (size_t)(i - 1) * h->dim * h->B, st))) return rc;
         }
       }
     }
@@ -2295,6 +2578,97 @@ extern "C" int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
   if (!(t1 >= t0)) return fail(RYD_ERR_INVALID, "t1 < t0");
   const double times[2] = {t0, t1};
   return ryd_solve(h, state_dev, 2, times, nullptr, opts, stream);
+}
+
+extern "C" int ryd_set_collapse(ryd_handle* h, int32_t n_ops, const double* ops) {
+  if (!h) return fail(RYD_ERR_INVALID, "null handle");
+  if (h->general || h->cfg.mode != RYD_SESOLVE)
+    return fail(RYD_ERR_INVALID, "collapse operators need a ket (sesolve) handle of the tuned path");
+  if (n_ops < 0 || n_ops > MC_MAX_OPS || (n_ops > 0 && !ops))
+    return fail(RYD_ERR_INVALID, "n_ops=%d out of range [0, %d]", n_ops, MC_MAX_OPS);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (n_ops == 0) {
+    h->mc = false;
+    h->mc_n_ops = 0;
+    h->mc_a = h->mc_b = 0.0;
+    return RYD_OK;
+  }
+  // M = sum C^dag C must be diagonal: H_eff then only gains a real diagonal
+  double m00 = 0, m11 = 0, m01r = 0, m01i = 0;
+  for (int k = 0; k < n_ops; ++k) {
+    const std::complex<double> c00(ops[8 * k + 0], ops[8 * k + 1]), c01(ops[8 * k + 2], ops[8 * k + 3]),
+        c10(ops[8 * k + 4], ops[8 * k + 5]), c11(ops[8 * k + 6], ops[8 * k + 7]);
+    m00 += std::norm(c00) + std::norm(c10);
+    m11 += std::norm(c01) + std::norm(c11);
+    const std::complex<double> x = std::conj(c00) * c01 + std::conj(c10) * c11;
+    m01r += x.real();
+    m01i += x.imag();
+  }
+  if (std::hypot(m01r, m01i) > 1e-13 * std::max(std::max(m00, m11), 1e-300))
+    return fail(RYD_ERR_UNSUPPORTED,
+                "sum C^dag C of the local collapse operators is not diagonal; use the "
+                "master-equation solver for this noise model");
+  const size_t B = (size_t)h->B, N = (size_t)h->N;
+  const size_t n_dbl = 2 * B + 4 * N * B + 4 * B;
+  const size_t bytes = n_dbl * sizeof(double) + B * sizeof(unsigned long long) +
+                       MC_MAX_OPS * 4 * sizeof(cplx) + 3 * B * sizeof(int);
+  if (!h->mc_pool) {
+    HIPCHK(hipMalloc(&h->mc_pool, bytes));
+    HIPCHK(hipMemset(h->mc_pool, 0, bytes));
+    char* p = (char*)h->mc_pool;
+    h->mcs.norm2 = (double*)p;    p += 2 * B * sizeof(double);
+    h->mcs.red = (double*)p;      p += 4 * N * B * sizeof(double);
+    h->mcs.target = (double*)p;   p += B * sizeof(double);
+    h->mcs.refnorm = (double*)p;  p += B * sizeof(double);
+    h->mcs.lastnorm = (double*)p; p += B * sizeof(double);
+    h->mcs.scale = (double*)p;    p += B * sizeof(double);
+    h->mc_seeds_dev = (unsigned long long*)p; p += B * sizeof(unsigned long long);
+    h->mc_ops_dev = (cplx*)p;     p += MC_MAX_OPS * 4 * sizeof(cplx);
+    h->mcs.flag = (int*)p;        p += B * sizeof(int);
+    h->mcs.sel = (int*)p;         p += B * sizeof(int);
+    h->mcs.count = (int*)p;
+    h->mcs.seeds = h->mc_seeds_dev;
+    h->mcs.ops = h->mc_ops_dev;
+  }
+  HIPCHK(hipMemcpy(h->mc_ops_dev, ops, (size_t)n_ops * 4 * sizeof(cplx), hipMemcpyHostToDevice));
+  h->mcs.n_ops = n_ops;
+  h->mc_n_ops = n_ops;
+  h->mc_a = -0.5 * m00 * h->N;
+  h->mc_b = 0.5 * (m00 - m11);
+  h->mc = true;
+  return RYD_OK;
+}
+
+extern "C" int ryd_mc_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
+                            void* out_dev, const uint64_t* seeds, const ryd_opts* opts,
+                            void* stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!h->mc) return fail(RYD_ERR_STATE, "ryd_set_collapse has not been called");
+  if (!state_dev || !seeds) return fail(RYD_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(h->mc_seeds_dev, seeds, (size_t)h->B * sizeof(unsigned long long),
+                        hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(h->mcs.norm2, 0, 2 * (size_t)h->B * sizeof(double), st));
+  hipLaunchKernelGGL(k_mc_norm, dim3(mc_blocks(h), h->B), dim3(256), 0, st, (const cplx*)state_dev,
+                     h->nb, h->mcs.norm2);
+  hipLaunchKernelGGL(k_mc_init, dim3((h->B + 127) / 128), dim3(128), 0, st, h->mcs, h->B, h->N);
+  HIPCHK(hipGetLastError());
+  h->mc_active = true;
+  rc = ryd_solve(h, state_dev, n_times, times, out_dev, opts, stream);
+  if (rc == RYD_OK) rc = snapshot_copy(h, (const cplx*)state_dev, (cplx*)state_dev, st);
+  h->mc_active = false;
+  return rc;
+}
+
+extern "C" int ryd_mc_get_jumps(ryd_handle* h, int32_t* counts, void* stream) {
+  if (!h || !counts) return fail(RYD_ERR_INVALID, "null argument");
+  if (!h->mc) return fail(RYD_ERR_STATE, "ryd_set_collapse has not been called");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipMemcpy(counts, h->mcs.count, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost));
+  return RYD_OK;
 }
 
 extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {

@@ -47,7 +47,10 @@ class Engine:
         self.tables = tables
         self.n = tables.n_qubits
         self.batch = tables.batch
+        if mode not in ("sesolve", "mesolve", "mcsolve"):
+            raise ValueError(f"unknown mode {mode!r}")
         self.mode = RYD_MESOLVE if mode == "mesolve" else RYD_SESOLVE
+        self.monte_carlo = mode == "mcsolve"
         self.device_index = (
             self.torch.cuda.current_device() if device is None else int(device)
         )
@@ -100,6 +103,13 @@ class Engine:
         if self.mode == RYD_MESOLVE and t.dissipator is not None:
             s = np.ascontiguousarray(t.dissipator, dtype=np.complex128)
             _lib.check(self.lib.ryd_set_dissipator(self._h, s.ctypes.data))
+        if self.monte_carlo:
+            if t.collapse_local is None:
+                raise ValueError("mcsolve needs collapse operators (tables.collapse_local)")
+            c = np.ascontiguousarray(t.collapse_local, dtype=np.complex128)
+            if c.shape[1:] != (2, 2):
+                raise NotImplementedError("Monte-Carlo trajectories need 2-level collapse operators")
+            _lib.check(self.lib.ryd_set_collapse(self._h, c.shape[0], c.ctypes.data))
 
     @classmethod
     def from_problems(
@@ -228,6 +238,51 @@ class Engine:
             )
         )
         return out
+
+    def mc_solve(
+        self,
+        state: Any,
+        times: Sequence[float],
+        seeds: Sequence[int],
+        store: bool = True,
+        taylor_order: int = 0,
+        tol: float = 0.0,
+        max_step: float = 0.0,
+        max_order: int = 0,
+        magnus_tol: float = 0.0,
+    ) -> Any:
+        """One quantum-jump trajectory per batch entry (``qutip.mcsolve`` with
+        ``ntraj=1``, simulation.py:705-735): ``seeds`` holds one uint64 per batch
+        entry.  Returns the normalised kets at times[1:] like :meth:`solve`."""
+        if not self.monte_carlo:
+            raise RuntimeError("engine was not created with mode='mcsolve'")
+        self._check_state(state)
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        if t.ndim != 1 or len(t) < 2:
+            raise ValueError("times must hold at least two values")
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        if sd.shape != (self.batch,):
+            raise ValueError(f"need one seed per batch entry ({self.batch}), got {sd.shape}")
+        out = None
+        if store:
+            out = self.torch.empty((len(t) - 1,) + self.state_shape, dtype=self.torch.complex128,
+                                   device=self.device)
+        opts = RydOpts(taylor_order=int(taylor_order), max_order=int(max_order), tol=float(tol),
+                       max_step=float(max_step), magnus_tol=float(magnus_tol))
+        _lib.check(
+            self.lib.ryd_mc_solve(
+                self._h, state.data_ptr(), len(t), t.ctypes.data,
+                out.data_ptr() if out is not None else None, sd.ctypes.data, C.byref(opts),
+                self._stream(),
+            )
+        )
+        return out
+
+    def mc_jumps(self) -> np.ndarray:
+        """Number of collapses of every trajectory of the last :meth:`mc_solve`."""
+        counts = np.zeros(self.batch, dtype=np.int32)
+        _lib.check(self.lib.ryd_mc_get_jumps(self._h, counts.ctypes.data, self._stream()))
+        return counts
 
     def set_path(self, force_generic: bool, no_fast_apply: bool = False,
                  no_tile14: bool = False, force_tile14: bool = False) -> None:

@@ -560,7 +560,7 @@ class HamiltonianData:
         detuning offset (times the slot mask) and the bad-atom zeroing.
         """
         from .terms import (DESC_DTYPE, DeviceTables, _SeriesPool, adapt_to_sampling_rate,
-                            local_dissipator, lower, sampling_times)
+                            local_collapse_ops, local_dissipator, lower, sampling_times)
         from scipy.interpolate import CubicSpline
 
         if not self.factorable():
@@ -632,4 +632,5 @@ class HamiltonianData:
             desc=desc, interaction=np.ascontiguousarray(np.stack(mats[:1] if shared else mats)),
             dissipator=local_dissipator(ops, self.eigenbasis, paulis),
             series_knots=pool.arrays,
+            collapse_local=local_collapse_ops(ops, self.eigenbasis, paulis),
         )

@@ -436,6 +436,7 @@ class QutipEmulator:
                                                append=end_point))))
             return min(mins)
 
+        self._mc_rng = None  # a new run restarts the jump-seed generator (option ``seeds``)
         options.setdefault(
             "max_step", min(min_variation(ch) for ch in self.samples_obj.channels) / 1000
         )
@@ -455,13 +456,41 @@ class QutipEmulator:
             mode = "mcsolve" if has_stochastic_noise(self.noise_model) else "mesolve"
         else:
             mode = {Solver.MCSOLVER: "mcsolve", Solver.MESOLVER: "mesolve"}[self.solver]
-        if mode == "mcsolve":
-            raise NotImplementedError(
-                "The Monte-Carlo wavefunction solver (qutip.mcsolve) is not part of "
-                "the MI355X backend; pass solver=Solver.MESOLVER to integrate the "
-                "master equation for every noise trajectory instead."
-            )
         return mode
+
+    @staticmethod
+    def _mc_fast_ok(problem: dict[str, Any]) -> bool:
+        """Quantum-jump trajectories run on the tuned ket kernels for 2-level
+        Ising problems whose ``sum C^dag C`` is diagonal (every built-in noise
+        channel).  Everything else that would take ``qutip.mcsolve`` is
+        integrated with the master equation instead - the state ``mcsolve``
+        samples in expectation."""
+        from .terms import SUPPORTED_BASES, local_collapse_ops
+
+        if problem["basis_name"] not in SUPPORTED_BASES or len(problem["eigenbasis"]) != 2:
+            return False
+        if problem.get("interaction_type") == "XY":
+            return False
+        c = local_collapse_ops(problem.get("collapse_ops", []), problem["eigenbasis"],
+                               problem.get("depolarizing_pauli_2ds"))
+        if c is None:
+            return False
+        m = sum(x.conj().T @ x for x in c)
+        return bool(abs(m[0, 1]) <= 1e-13 * max(abs(m[0, 0]), abs(m[1, 1]), 1e-300)) and len(c) <= 16
+
+    def _mc_seeds(self, n: int, options: dict[str, Any]) -> np.ndarray:
+        """One 64-bit seed per quantum-jump trajectory.  Like ``qutip.mcsolve``
+        (option ``seeds``) the jump randomness does not touch the global
+        ``np.random`` stream that the noise trajectories and the sampling use."""
+        override = getattr(self, "_mc_seed_override", None)
+        if override is not None:  # multi-GPU ensembles: rank 0 drew the seeds of every trajectory
+            sd = np.asarray(override, dtype=np.uint64)
+            if sd.shape != (n,):
+                raise ValueError(f"need {n} trajectory seeds, got {sd.shape}")
+            return sd
+        if getattr(self, "_mc_rng", None) is None:
+            self._mc_rng = np.random.default_rng(options.get("seeds"))
+        return self._mc_rng.integers(0, 2**64, size=n, dtype=np.uint64)
 
     def _engine_kwargs(self, options: dict[str, Any]) -> dict[str, Any]:
         kw = {}
@@ -473,11 +502,14 @@ class QutipEmulator:
         return kw
 
     def _solve_batch(self, problems: list[dict[str, Any]], progress_bar: Any,
-                     options: dict[str, Any], tables: Any = None) -> list[CoherentResults]:
+                     options: dict[str, Any], tables: Any = None,
+                     mc_ntraj: int | None = None) -> list[CoherentResults]:
         """The solver call of ``_run_solver`` (simulation.py:689-766) for a batch
         of trajectories in ONE engine (one GPU launch sequence).  ``tables``:
         pre-lowered device tables for the batch (factored noise) instead of
-        ``problems``."""
+        ``problems``.  ``mc_ntraj``: the ``ntraj`` of ``qutip.mcsolve`` for the
+        deterministic run (simulation.py:843); ``None`` = one quantum-jump
+        trajectory per batch entry (the noisy runs, :726-727 with the default 1)."""
         if progress_bar not in (True, False, None):
             raise ValueError("`progress_bar` must be a bool.")
         from .engine import Engine
@@ -485,17 +517,34 @@ class QutipEmulator:
 
         if tables is None:
             mode = self._solver_mode(problems[0])
-            if not self._fast_path_ok(problems[0]):
+            if mode == "mcsolve" and not self._mc_fast_ok(problems[0]):
+                mode = "mesolve"
+            if mode == "mcsolve":
+                if mc_ntraj is not None:
+                    return [self._solve_mc_average(problems[0], mc_ntraj, options)]
+            elif not self._fast_path_ok(problems[0]):
                 return self._solve_general(problems, mode, options)
             tables = lower(problems)
         else:
             mode = self._solver_mode({"collapse_ops": [1] if tables.dissipator is not None else []})
+            if mode == "mcsolve" and tables.collapse_local is None:
+                mode = "mesolve"
         n_batch = tables.batch
         times = self._eval_times_array
         with Engine(tables, mode=mode) as eng:
-            state = eng.new_state(np.asarray(self._initial_state).reshape(1, -1))
+            init = np.asarray(self._initial_state)
+            if mode == "mcsolve" and init.ndim == 2 and init.shape[0] == init.shape[1] and init.shape[0] > 1:
+                raise NotImplementedError(
+                    "Quantum-jump trajectories need a ket as initial state; use "
+                    "solver=Solver.MESOLVER with a density matrix.")
+            state = eng.new_state(init.reshape(1, -1))
             first = state.cpu().numpy()
-            snaps = eng.solve(state, times, store=True, **self._engine_kwargs(options))
+            if mode == "mcsolve":
+                snaps = eng.mc_solve(state, times, self._mc_seeds(n_batch, options), store=True,
+                                     **self._engine_kwargs(options))
+                self.last_mc_jumps = eng.mc_jumps()
+            else:
+                snaps = eng.solve(state, times, store=True, **self._engine_kwargs(options))
             host = snaps.cpu().numpy()
             self.last_engine_stats = eng.stats()
         meas_errors = (
@@ -537,6 +586,61 @@ class QutipEmulator:
                     if c not in (r, 3 - r) and S[r, c] != 0:
                         return False
         return True
+
+    def _solve_mc_average(self, problem: dict[str, Any], ntraj: int,
+                          options: dict[str, Any]) -> CoherentResults:
+        """``qutip.mcsolve(..., ntraj=n_trajectories)`` of the deterministic run
+        (simulation.py:726-727, 843): ``result.states`` is the trajectory-averaged
+        density matrix at every evaluation time.  The trajectories run as GPU
+        batches of kets; ``|psi><psi|`` is accumulated on the device."""
+        from .engine import Engine
+        from .terms import lower
+
+        times = self._eval_times_array
+        n = self._hamiltonian_data.n_qudits
+        D = 2 ** n
+        if (len(times) * D * D * 16) > (16 << 30):
+            raise MemoryError(
+                f"Averaged density matrices at {len(times)} evaluation times of a {n}-atom "
+                "register do not fit; use fewer evaluation times.")
+        init = np.asarray(self._initial_state)
+        if init.ndim == 2 and init.shape[0] == init.shape[1] and init.shape[0] > 1:
+            raise NotImplementedError(
+                "Quantum-jump trajectories need a ket as initial state; use "
+                "solver=Solver.MESOLVER with a density matrix.")
+        chunk = int(max(1, min(ntraj, 1024, (2 << 30) // max(1, D * 16 * len(times)))))
+        acc = None
+        done = 0
+        jumps = []
+        while done < ntraj:
+            b = min(chunk, ntraj - done)
+            tables = lower([problem] * b)
+            with Engine(tables, mode="mcsolve") as eng:
+                torch = eng.torch
+                if acc is None:
+                    acc = torch.zeros((len(times), D, D), dtype=torch.complex128, device=eng.device)
+                state = eng.new_state(init.reshape(1, -1))
+                eng.outer_accumulate(state, acc[0])
+                snaps = eng.mc_solve(state, times, self._mc_seeds(b, options), store=True,
+                                     **self._engine_kwargs(options))
+                for i in range(1, len(times)):
+                    eng.outer_accumulate(snaps[i - 1], acc[i])
+                jumps.append(eng.mc_jumps())
+                self.last_engine_stats = eng.stats()
+            done += b
+        self.last_mc_jumps = np.concatenate(jumps)
+        host = (acc / ntraj).cpu().numpy()
+        meas_errors = (
+            {"epsilon": self.noise_model.p_false_pos, "epsilon_prime": self.noise_model.p_false_neg}
+            if "SPAM" in self.noise_model.noise_types else None
+        )
+        qids = tuple(self.samples_obj.qubit_ids)
+        results = [
+            StateResult(qids, self._meas_basis, QState(host[i]), self._meas_basis in self.basis_name,
+                        evaluation_time=float(t / (self._tot_duration * 1e-3)))
+            for i, t in enumerate(times)
+        ]
+        return CoherentResults(results, n, self.basis_name, times, self._meas_basis, meas_errors)
 
     def _solve_general(self, problems: list[dict[str, Any]], mode: str,
                        options: dict[str, Any]) -> list[CoherentResults]:
@@ -586,7 +690,8 @@ class QutipEmulator:
         if not has_stochastic_noise(self.noise_model):
             if print_progress:
                 print("Emulating Trajectory 1/1")
-            return self._solve_batch([self._current_problem], progress_bar, options)[0]
+            return self._solve_batch([self._current_problem], progress_bar, options,
+                                     mc_ntraj=self.n_trajectories or 1)[0]
 
         total_count = np.array([Counter() for _ in self._eval_times_array])
         for res, reps in self._noisy_runs(progress_bar, print_progress, **options):

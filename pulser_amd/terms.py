@@ -60,6 +60,7 @@ class DeviceTables:
     interaction: np.ndarray  # float64[n_mats][N][N]
     dissipator: np.ndarray | None  # complex128[4][4] or None
     series_knots: list[np.ndarray]  # the knot arrays (for tests / bounds)
+    collapse_local: np.ndarray | None = None  # complex128[n_ops][2][2] (Monte-Carlo solver)
 
 
 DESC_DTYPE = np.dtype(
@@ -92,6 +93,37 @@ class _SeriesPool:
             self._index[key] = len(self.arrays)
             self.arrays.append(arr)
         return self._index[key]
+
+
+def local_collapse_ops(
+    collapse_ops: Sequence[tuple[Any, Any]],
+    eigenbasis: Sequence[str],
+    paulis: Mapping[str, Sequence[tuple[complex, str]]] | None = None,
+) -> np.ndarray | None:
+    """The local d x d collapse operators ``coeff * op`` themselves,
+    complex128[n_ops][d][d], expanded as ``Hamiltonian._build_collapse_operators``
+    does (hamiltonian.py:97-124) - what ``qutip.mcsolve`` receives as ``c_ops``,
+    one copy per atom."""
+    if not collapse_ops:
+        return None
+    d = len(eigenbasis)
+    proj: dict[str, np.ndarray] = {}
+    for i, a in enumerate(eigenbasis):
+        for j, b in enumerate(eigenbasis):
+            m = np.zeros((d, d), dtype=complex)
+            m[i, j] = 1.0
+            proj["sigma_" + a + b] = m
+    out = []
+    for coeff, op in collapse_ops:
+        if isinstance(op, str):
+            if op in proj:
+                c = coeff * proj[op]
+            else:
+                c = sum(coeff * pc * proj[po] for pc, po in (paulis or {})[op])
+        else:
+            c = coeff * np.asarray(op, dtype=complex)
+        out.append(np.asarray(c, dtype=np.complex128))
+    return np.ascontiguousarray(np.stack(out))
 
 
 def local_dissipator(
@@ -226,4 +258,7 @@ def lower(problems: Sequence[Mapping[str, Any]]) -> DeviceTables:
         interaction=np.ascontiguousarray(interaction),
         dissipator=S,
         series_knots=pool.arrays,
+        collapse_local=local_collapse_ops(
+            p0.get("collapse_ops", []), p0["eigenbasis"], p0.get("depolarizing_pauli_2ds")
+        ),
     )

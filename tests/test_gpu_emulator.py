@@ -90,11 +90,6 @@ def test_spam_state_prep_trajectories_mesolve_counts():
     nm = NoiseModel(dephasing_rate=0.05, state_prep_error=0.1, p_false_pos=0.01,
                     p_false_neg=0.05, samples_per_run=5)
     np.random.seed(11)
-    with pytest.raises(NotImplementedError, match="Monte-Carlo"):
-        with pytest.warns(DeprecationWarning):
-            QutipEmulator(inputs, noise_model=nm, n_trajectories=12,
-                          evaluation_times="Minimal").run()
-    np.random.seed(11)
     emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=12, solver=Solver.MESOLVER,
                         evaluation_times="Minimal")
     reps = [p["reps"] for p in emu._problems]

@@ -1,0 +1,201 @@
+"""GPU quantum-jump trajectories (``qutip.mcsolve`` on the path,
+pulser-simulation/pulser_simulation/simulation.py:705-735).
+
+qutip seeds its own generators, so parity with the reference is statistical;
+what CAN be pinned is pinned here:
+
+* the no-jump evolution under H_eff against the tight CPU integration;
+* every trajectory (states, number/position of jumps) against the CPU
+  restatement of the same algorithm with the same Philox stream
+  (``oracle/mcwf.py``);
+* the trajectory average against the oracle's ``mesolve`` (itself pinned on the
+  reference's golden Counters) within the Monte-Carlo error;
+* the front-end: Solver.DEFAULT with stochastic noise and Solver.MCSOLVER.
+"""
+import numpy as np
+import pytest
+
+from helpers import DEPOL_PAULIS, load_fixture, local_problem, with_anneal_samples
+from test_host_logic import _inputs_from_problem
+
+from pulser_amd import NoiseModel, QutipEmulator, Solver
+from pulser_amd._lib import RydError
+from pulser_amd.engine import Engine
+from pulser_amd.terms import lower
+
+pytestmark = pytest.mark.gpu
+
+GRID = np.arange(401) / 1000.0
+EVAL = np.array([0.0, 0.1, 0.25, 0.4])
+OPS = [(np.sqrt(3.0), "sigma_gr"), (np.sqrt(2 * 0.9), "sigma_rr")] + \
+      [(np.sqrt(1.2 / 4), p) for p in "xyz"]
+
+
+def _problem(n, seed=3):
+    return local_problem(n, seed=seed, collapse_ops=OPS, paulis=DEPOL_PAULIS)
+
+
+def test_no_jump_evolution_under_h_eff():
+    from oracle import mcwf, qutip_path as qp
+
+    prob = _problem(3)
+    ham = qp.build_hamiltonian(prob)
+    psi0 = qp.all_ground_state(3, prob["eigenbasis"])
+    ref = qp._zvode(mcwf.effective_rhs(ham), psi0, EVAL, qp.TIGHT)
+    with Engine(lower([prob]), mode="mcsolve") as eng:
+        state = eng.new_state(psi0.reshape(1, -1))
+        got = eng.solve(state, EVAL).cpu().numpy()
+        assert eng.stats()["n_steps"] == 400  # one CF4 step per sample interval
+    for i in range(1, len(EVAL)):
+        assert np.max(np.abs(got[i - 1][0] - ref[i])) < 1e-8
+    assert np.vdot(ref[-1], ref[-1]).real < 0.7  # the norm really decays
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_trajectories_match_cpu_restatement(n):
+    from oracle import mcwf, qutip_path as qp
+
+    prob = _problem(n, seed=5)
+    ham = qp.build_hamiltonian(prob)
+    psi0 = qp.all_ground_state(n, prob["eigenbasis"])
+    seeds = np.array([1, 2**40 + 17, 123456789012345, 2**64 - 1, 99, 4242], dtype=np.uint64)
+    with Engine(lower([prob] * len(seeds)), mode="mcsolve") as eng:
+        state = eng.new_state(psi0.reshape(1, -1))
+        got = eng.mc_solve(state, EVAL, seeds).cpu().numpy()
+        counts = eng.mc_jumps()
+        final = state.cpu().numpy()
+        assert eng.stats()["n_steps"] == 400
+    total = 0
+    for b, seed in enumerate(seeds):
+        ref, jumps = mcwf.mcwf_trajectory(ham, psi0, GRID, EVAL, int(seed))
+        assert counts[b] == len(jumps)
+        total += len(jumps)
+        for i in range(1, len(EVAL)):
+            assert np.max(np.abs(got[i - 1][b] - ref[i])) < 1e-7, (b, i, jumps)
+        assert np.max(np.abs(final[b] - ref[-1])) < 1e-7
+        assert abs(np.linalg.norm(final[b]) - 1) < 1e-12
+    assert total >= len(seeds)  # the test exercises jumps, not only decay
+
+
+def test_trajectory_is_a_function_of_its_seed_only():
+    prob = _problem(4, seed=8)
+    seeds = np.arange(100, 116, dtype=np.uint64)
+    runs = []
+    for sel in (slice(0, 16), slice(5, 9)):
+        sd = seeds[sel]
+        with Engine(lower([prob] * len(sd)), mode="mcsolve") as eng:
+            state = eng.new_state()
+            eng.mc_solve(state, EVAL, sd, store=False)
+            runs.append((state.cpu().numpy(), eng.mc_jumps()))
+    assert np.array_equal(runs[0][0][5:9], runs[1][0])
+    assert np.array_equal(runs[0][1][5:9], runs[1][1])
+
+
+def test_trajectory_average_converges_to_master_equation():
+    from oracle import qutip_path as qp
+
+    prob = _problem(3, seed=11)
+    ham = qp.build_hamiltonian(prob)
+    psi0 = qp.all_ground_state(3, prob["eigenbasis"])
+    rho = qp.mesolve(ham, psi0, EVAL, **qp.TIGHT)
+    ntraj = 16384
+    seeds = np.random.default_rng(0).integers(0, 2**64, size=ntraj, dtype=np.uint64)
+    with Engine(lower([prob] * ntraj), mode="mcsolve") as eng:
+        state = eng.new_state(psi0.reshape(1, -1))
+        snaps = eng.mc_solve(state, EVAL, seeds)
+        jumps = eng.mc_jumps()
+        acc = eng.torch.zeros((len(EVAL) - 1, 8, 8), dtype=eng.torch.complex128, device=eng.device)
+        for i in range(len(EVAL) - 1):
+            eng.outer_accumulate(snaps[i], acc[i])
+        avg = (acc / ntraj).cpu().numpy()
+    assert jumps.mean() > 1.0
+    for i in range(1, len(EVAL)):
+        r = np.asarray(rho[i]).reshape(8, 8)
+        # element-wise Monte-Carlo error: <= 0.5 / sqrt(ntraj) = 0.004; allow 5 sigma
+        assert np.max(np.abs(avg[i - 1] - r)) < 0.02, i
+        assert abs(np.trace(avg[i - 1]).real - 1) < 1e-12
+    assert np.trace(avg[-1] @ avg[-1]).real < 0.9  # a mixed state, not a ket
+
+
+def test_non_diagonal_decay_is_rejected_by_the_kernels():
+    prob = local_problem(2, collapse_ops=[(0.3, np.array([[1.0, 1.0], [0.0, 0.0]]))])
+    with pytest.raises(RydError, match="not diagonal"):
+        Engine(lower([prob]), mode="mcsolve")
+
+
+def _tri4_inputs():
+    prob, extra = load_fixture("cfg3_tri4_dephasing.npz")
+    return _inputs_from_problem(with_anneal_samples(prob), "ground-rydberg")
+
+
+def _tv(c1, c2):
+    keys = set(c1) | set(c2)
+    n1, n2 = sum(c1.values()), sum(c2.values())
+    return 0.5 * sum(abs(c1.get(k, 0) / n1 - c2.get(k, 0) / n2) for k in keys)
+
+
+def test_default_solver_with_stochastic_noise_runs_quantum_jumps():
+    """simulation.py:705-712: collapse operators + stochastic noise -> mcsolve
+    with one jump trajectory per noise trajectory; same distribution as
+    integrating the master equation for every noise trajectory."""
+    inputs = _tri4_inputs()
+    nm = NoiseModel(dephasing_rate=0.3, relaxation_rate=0.2, state_prep_error=0.05,
+                    amp_sigma=0.05, samples_per_run=4)
+    counts = {}
+    for solver in (Solver.DEFAULT, Solver.MESOLVER):
+        np.random.seed(21)
+        emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=600, solver=solver,
+                            evaluation_times="Minimal")
+        assert emu._solver_mode(emu._current_problem) == ("mcsolve" if solver == Solver.DEFAULT
+                                                          else "mesolve")
+        with pytest.warns(DeprecationWarning):
+            res = emu.run(seeds=5)
+        assert res.n_measures == 2400
+        counts[solver] = res[-1].bitstring_counts
+        if solver == Solver.DEFAULT:
+            assert emu.last_mc_jumps.sum() > 0
+            first = dict(counts[solver])
+            np.random.seed(21)
+            emu2 = QutipEmulator(inputs, noise_model=nm, n_trajectories=600,
+                                 evaluation_times="Minimal")
+            with pytest.warns(DeprecationWarning):
+                assert dict(emu2.run(seeds=5)[-1].bitstring_counts) == first  # reproducible
+    # 16 outcomes, 2400 samples each: the total-variation distance of two draws
+    # of one distribution is ~ 0.03-0.05
+    assert _tv(counts[Solver.DEFAULT], counts[Solver.MESOLVER]) < 0.1
+
+
+def test_mcsolver_deterministic_run_returns_the_averaged_density_matrix():
+    """simulation.py:843: ntraj = n_trajectories; result.states are the
+    trajectory-averaged density matrices."""
+    inputs = _tri4_inputs()
+    nm = NoiseModel(dephasing_rate=0.3, relaxation_rate=0.2)
+    ref = QutipEmulator(inputs, noise_model=nm, evaluation_times="Minimal")
+    with pytest.warns(DeprecationWarning):
+        exact = ref.run()
+    rho = np.asarray(exact.states[-1])
+    emu = QutipEmulator(inputs, noise_model=nm, solver=Solver.MCSOLVER, n_trajectories=3000,
+                        evaluation_times="Minimal")
+    with pytest.warns(DeprecationWarning):
+        res = emu.run(seeds=1)
+    got = np.asarray(res.states[-1])
+    assert got.shape == (16, 16) and len(emu.last_mc_jumps) == 3000
+    assert abs(np.trace(got).real - 1) < 1e-12 and np.allclose(got, got.conj().T)
+    assert np.max(np.abs(got - rho)) < 5 * 0.5 / np.sqrt(3000)
+    assert np.allclose(np.asarray(res.states[0]), np.asarray(exact.states[0]))
+    assert sum(res.sample_final_state(500).values()) == 500
+
+
+def test_exotic_collapse_operators_fall_back_to_the_master_equation():
+    """sum C^dag C not diagonal: no quantum jumps on the ket kernels - the master
+    equation (the average mcsolve estimates) is integrated instead."""
+    inputs = _tri4_inputs()
+    op = np.array([[1.0, 1.0], [0.0, 0.0]], dtype=complex)
+    nm = NoiseModel(eff_noise_opers=[op], eff_noise_rates=[0.2])
+    a = QutipEmulator(inputs, noise_model=nm, evaluation_times="Minimal")
+    b = QutipEmulator(inputs, noise_model=nm, solver=Solver.MCSOLVER, n_trajectories=5,
+                      evaluation_times="Minimal")
+    assert not b._mc_fast_ok(b._current_problem)
+    with pytest.warns(DeprecationWarning):
+        ra, rb = a.run(), b.run()
+    assert np.allclose(np.asarray(ra.states[-1]), np.asarray(rb.states[-1]), atol=1e-12)
