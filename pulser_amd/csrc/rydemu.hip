@@ -1075,13 +1075,20 @@ struct TrajArgs {
   const StepDesc* steps;
   int n_int, n_steps, B;
   double a1, a2;
+  // Monte-Carlo wavefunction instantiations (MC = true)
+  McState mc;
+  double mc_a, mc_b;  // real diagonal of G_eff: mc_a + mc_b * popc(index)
+  int mc_jumps;       // 0: no-jump evolution under H_eff only
 };
 
 // MODEL 0: per-atom complex drive coefficients (local addressing, noise).
 // MODEL 1: one real drive coefficient shared by the driven atoms of the
 //          trajectory (global channel with constant zero phase; bad atoms are
 //          masked out) - the flip partners are summed first, 2 DADD each.
-template <int N, int NTT, int MODEL>
+// MC: the generator is G_eff (adds the real decay diagonal); with A.mc_jumps the
+//     norm threshold is tested after every step and collapses are applied in
+//     place (same arithmetic and random stream as the k_mc_* kernels).
+template <int N, int NTT, int MODEL, bool MC>
 __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
   constexpr int D = 1 << N;
   constexpr int R = D / NTT > 0 ? D / NTT : 1;
@@ -1092,6 +1099,8 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
   cplx* ws1 = ws0 + D;                            // ping-pongs, one barrier per stage
   double* cfA = reinterpret_cast<double*>(ws1 + D);  // [16][4]: cr, ci, delta, 0 for exp A
   double* cfB = cfA + 64;                            // same for exp B
+  double* mcred = cfB + 64;                          // [16][4] per-wave partial sums
+  double* mcrho = mcred + 64;                        // [16][4] reduced density matrices
 
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
@@ -1106,6 +1115,18 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
     const int l = tid + j * NTT;
     psi[j] = active ? st[l] : make_double2(0.0, 0.0);
     e0r[j] = active ? e0g[l] : 0.0;
+  }
+  // Monte-Carlo bookkeeping (block-uniform)
+  const bool jumps = MC && A.mc_jumps != 0;
+  double mc_target = 0.0, mc_ref = 1.0, mc_n2 = 1.0;
+  int mc_count = 0;
+  unsigned long long mc_seed = 0;
+  if (jumps) {
+    mc_target = A.mc.target[b];
+    mc_ref = A.mc.refnorm[b];
+    mc_n2 = A.mc.lastnorm[b];
+    mc_count = A.mc.count[b];
+    mc_seed = A.mc.seeds[b];
   }
 
   for (int s = 0; s < A.n_steps; ++s) {
@@ -1189,6 +1210,12 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
           if (!((l >> q) & 1)) sdet -= draw[q];
         eg[j] = sdet + (wmix * e0r[j] - shift);
       }
+      double er[MC ? R : 1];  // centred real part of the G_eff diagonal
+      if (MC) {
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+          er[j] = wmix * A.mc_b * ((double)__popc(tid + j * NTT) - 0.5 * N);
+      }
       cplx w[R];
 #pragma unroll
       for (int j = 0; j < R; ++j) {
@@ -1233,6 +1260,11 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
             acc[j] = make_double2(fma(cuni, sy, eg[j] * w[j].y), -fma(cuni, sx, eg[j] * w[j].x));
           }
         }
+        if (MC) {
+#pragma unroll
+          for (int j = 0; j < R; ++j)
+            acc[j] = make_double2(fma(er[j], w[j].x, acc[j].x), fma(er[j], w[j].y, acc[j].y));
+        }
 #pragma unroll
         for (int j = 0; j < R; ++j)
           w[j] = make_double2(fma(sc, acc[j].x, psi[j].x), fma(sc, acc[j].y, psi[j].y));
@@ -1246,20 +1278,125 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
           wr = const_cast<cplx*>(t);
         }
       }
-      const cplx post = make_double2(cos(sd.h * shift), -sin(sd.h * shift));
+      const double mag = MC ? exp(sd.h * wmix * (A.mc_a + 0.5 * N * A.mc_b)) : 1.0;
+      const cplx post = make_double2(mag * cos(sd.h * shift), -mag * sin(sd.h * shift));
 #pragma unroll
       for (int j = 0; j < R; ++j) psi[j] = cmul(post, w[j]);
       __syncthreads();  // last-stage reads done before ws0 / cf are rewritten
     }
+    if (jumps) {
+      constexpr int NW = NTT / 64;
+      const int lane = tid & 63, wave = tid >> 6;
+      double s2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < R; ++j) s2 = fma(psi[j].x, psi[j].x, fma(psi[j].y, psi[j].y, s2));
+      if (!active) s2 = 0.0;  // lanes beyond a small state hold garbage
+      for (int o = 32; o > 0; o >>= 1) s2 += __shfl_down(s2, o, 64);
+      if (lane == 0) mcred[wave] = s2;
+      __syncthreads();
+      double n2 = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) n2 += mcred[wv];
+      mc_n2 = n2;
+      __syncthreads();
+      if (n2 <= mc_target * mc_ref) {  // block-uniform: this trajectory jumps now
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+          if (active) ws0[tid + j * NTT] = psi[j];
+        __syncthreads();
+        for (int a = 0; a < N; ++a) {
+          const int bit = 1 << (N - 1 - a);
+          double rr = 0.0, gg = 0.0, cr = 0.0, ci = 0.0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const int l = tid + j * NTT;
+            const cplx v = psi[j];
+            const double m = v.x * v.x + v.y * v.y;
+            if (l & bit) {
+              gg += m;
+            } else {
+              const cplx wv = ws0[(l | bit) & (D - 1)];
+              rr += m;
+              cr += v.x * wv.x + v.y * wv.y;
+              ci += v.y * wv.x - v.x * wv.y;
+            }
+          }
+          if (!active) rr = gg = cr = ci = 0.0;
+          for (int o = 32; o > 0; o >>= 1) {
+            rr += __shfl_down(rr, o, 64);
+            gg += __shfl_down(gg, o, 64);
+            cr += __shfl_down(cr, o, 64);
+            ci += __shfl_down(ci, o, 64);
+          }
+          if (lane == 0) {
+            mcred[4 * wave + 0] = rr;
+            mcred[4 * wave + 1] = gg;
+            mcred[4 * wave + 2] = cr;
+            mcred[4 * wave + 3] = ci;
+          }
+          __syncthreads();
+          if (tid < 4) {
+            double t = 0.0;
+            for (int wv = 0; wv < NW; ++wv) t += mcred[4 * wv + tid];
+            mcrho[4 * a + tid] = t;
+          }
+          __syncthreads();
+        }
+        // selection: every thread repeats the (uniform) arithmetic of k_mc_select
+        double total = 0.0;
+        for (int a = 0; a < N; ++a)
+          for (int k = 0; k < A.mc.n_ops; ++k)
+            total += fmax(mc_weight(A.mc.ops + 4 * k, mcrho + 4 * a), 0.0);
+        if (total > 0.0) {
+          double ut, us;
+          mc_uniforms(mc_seed, (unsigned)mc_count, &ut, &us);
+          const double x = us * total;
+          double cum = 0.0, psel = 0.0, plast = 0.0;
+          int sel = -1, lastpos = -1;
+          for (int a = 0; a < N; ++a)
+            for (int k = 0; k < A.mc.n_ops; ++k) {
+              const double p = fmax(mc_weight(A.mc.ops + 4 * k, mcrho + 4 * a), 0.0);
+              cum += p;
+              if (p > 0.0) { lastpos = a * MC_MAX_OPS + k; plast = p; }
+              if (sel < 0 && p > 0.0 && cum > x) { sel = a * MC_MAX_OPS + k; psel = p; }
+            }
+          if (sel < 0) { sel = lastpos; psel = plast; }
+          const int pbit = N - 1 - sel / MC_MAX_OPS;
+          const cplx* C = A.mc.ops + 4 * (sel % MC_MAX_OPS);
+          const double sc2 = 1.0 / sqrt(psel);
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const int l = tid + j * NTT;
+            const int row = (l >> pbit) & 1;
+            const cplx v0 = ws0[(l & ~(1 << pbit)) & (D - 1)], v1 = ws0[(l | (1 << pbit)) & (D - 1)];
+            const cplx o = cfma(C[2 * row], v0, cmul(C[2 * row + 1], v1));
+            if (active) psi[j] = make_double2(sc2 * o.x, sc2 * o.y);
+          }
+          ++mc_count;
+          mc_uniforms(mc_seed, (unsigned)mc_count, &ut, &us);
+          mc_target = ut;
+          mc_ref = 1.0;
+          mc_n2 = 1.0;
+        }
+        __syncthreads();  // partner reads of ws0 done before the next step rewrites it
+      }
+    }
     if (sd.snap >= 0 && A.snaps && active) {
       cplx* o = A.snaps + ((size_t)sd.snap * A.B + b) * D;
+      const double ns = jumps ? rsqrt(mc_n2) : 1.0;  // stored kets are normalised
 #pragma unroll
-      for (int j = 0; j < R; ++j) o[tid + j * NTT] = psi[j];
+      for (int j = 0; j < R; ++j) o[tid + j * NTT] = make_double2(ns * psi[j].x, ns * psi[j].y);
     }
   }
   if (active) {
 #pragma unroll
     for (int j = 0; j < R; ++j) st[tid + j * NTT] = psi[j];
+  }
+  if (jumps && tid == 0) {
+    A.mc.target[b] = mc_target;
+    A.mc.refnorm[b] = mc_ref;
+    A.mc.lastnorm[b] = mc_n2;
+    A.mc.count[b] = mc_count;
   }
 }
 
@@ -2446,25 +2583,29 @@ static int run_generic(ryd_handle* h, cplx* state, const std::vector<StepDesc>& 
   return RYD_OK;
 }
 
-template <int N, int MODEL>
+template <int N, int MODEL, bool MC>
 static int launch_traj2(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
   constexpr int D = 1 << N;
   constexpr int NTT = D < 64 ? 64 : (N >= 11 ? 1024 : (D > 512 ? 512 : D));
-  const size_t lds = 2 * (size_t)D * sizeof(cplx) + 4 * 16 * sizeof(double) * 2;
+  const size_t lds = 2 * (size_t)D * sizeof(cplx) + 4 * 16 * sizeof(double) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_traj<N, NTT, MODEL>,
+    HIPCHK(hipFuncSetAttribute((const void*)k_traj<N, NTT, MODEL, MC>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_traj<N, NTT, MODEL>), dim3(h->B), dim3(NTT), lds, st, A);
+  hipLaunchKernelGGL((k_traj<N, NTT, MODEL, MC>), dim3(h->B), dim3(NTT), lds, st, A);
   HIPCHK(hipGetLastError());
   return RYD_OK;
 }
 
 template <int N>
 static int launch_traj(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
-  return h->uniform_real_drive ? launch_traj2<N, 1>(h, A, st) : launch_traj2<N, 0>(h, A, st);
+  if (h->mc)
+    return h->uniform_real_drive ? launch_traj2<N, 1, true>(h, A, st)
+                                 : launch_traj2<N, 0, true>(h, A, st);
+  return h->uniform_real_drive ? launch_traj2<N, 1, false>(h, A, st)
+                               : launch_traj2<N, 0, false>(h, A, st);
 }
 
 // Persistent path (sesolve, N <= 12): one workgroup per trajectory keeps its
@@ -2496,6 +2637,10 @@ static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc
   A.B = h->B;
   A.a1 = kA1;
   A.a2 = kA2;
+  A.mc = h->mcs;
+  A.mc_a = h->mc_a;
+  A.mc_b = h->mc_b;
+  A.mc_jumps = h->mc_active ? 1 : 0;
   int rc = RYD_ERR_INVALID;
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
@@ -2528,7 +2673,7 @@ static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc
 }
 
 static bool use_persistent(const ryd_handle* h) {
-  return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 12 && !h->force_generic && !h->mc;
+  return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 12 && !h->force_generic;
 }
 
 extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,

@@ -51,8 +51,9 @@ def test_no_jump_evolution_under_h_eff():
     assert np.vdot(ref[-1], ref[-1]).real < 0.7  # the norm really decays
 
 
-@pytest.mark.parametrize("n", [2, 3])
-def test_trajectories_match_cpu_restatement(n):
+@pytest.mark.parametrize("n,generic", [(2, False), (3, False), (3, True)])
+def test_trajectories_match_cpu_restatement(n, generic):
+    """Persistent LDS-resident kernel (one launch) and the multi-launch kernels."""
     from oracle import mcwf, qutip_path as qp
 
     prob = _problem(n, seed=5)
@@ -60,6 +61,7 @@ def test_trajectories_match_cpu_restatement(n):
     psi0 = qp.all_ground_state(n, prob["eigenbasis"])
     seeds = np.array([1, 2**40 + 17, 123456789012345, 2**64 - 1, 99, 4242], dtype=np.uint64)
     with Engine(lower([prob] * len(seeds)), mode="mcsolve") as eng:
+        eng.set_path(generic)
         state = eng.new_state(psi0.reshape(1, -1))
         got = eng.mc_solve(state, EVAL, seeds).cpu().numpy()
         counts = eng.mc_jumps()
@@ -75,6 +77,26 @@ def test_trajectories_match_cpu_restatement(n):
         assert np.max(np.abs(final[b] - ref[-1])) < 1e-7
         assert abs(np.linalg.norm(final[b]) - 1) < 1e-12
     assert total >= len(seeds)  # the test exercises jumps, not only decay
+
+
+@pytest.mark.parametrize("n", [5, 7, 10, 11, 12])
+def test_persistent_and_multi_launch_trajectories_agree(n):
+    """Every workgroup shape of the persistent kernel (64 .. 1024 threads, 1-4
+    amplitudes per thread) against the tiled multi-launch kernels: same seeds,
+    same jumps, same kets."""
+    prob = _problem(n, seed=20 + n)
+    seeds = np.arange(7, 7 + 12, dtype=np.uint64) * np.uint64(2654435761)
+    out = []
+    for generic in (False, True):
+        with Engine(lower([prob] * len(seeds)), mode="mcsolve") as eng:
+            eng.set_path(generic)
+            state = eng.new_state()
+            snaps = eng.mc_solve(state, np.array([0.0, 0.15, 0.3]), seeds).cpu().numpy()
+            out.append((snaps, eng.mc_jumps(), eng.stats()["n_launches"]))
+    assert out[0][2] == 1 and out[1][2] > 100
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][1].sum() > 0
+    assert np.max(np.abs(out[0][0] - out[1][0])) < 1e-10
+    assert np.allclose(np.linalg.norm(out[0][0], axis=-1), 1.0, atol=1e-12)
 
 
 def test_trajectory_is_a_function_of_its_seed_only():
