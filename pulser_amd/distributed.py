@@ -115,6 +115,7 @@ def run_ensemble(
     solve_fn: Callable[[list[dict[str, Any]]], np.ndarray] | None = None,
     dist: Any = None,
     batch: int = 128,
+    mc_seed: int | None = None,
 ) -> dict[str, Any]:
     """Sharded equivalent of the stochastic branch of ``QutipEmulator.run``
     (simulation.py:847-883).
@@ -142,10 +143,13 @@ def run_ensemble(
     if rank == 0:
         trajs = hd.noise_trajectories
         rnd = predraw_sampling([t.reps for t in trajs], n_eval, nm.samples_per_run, n, meas_err)
-        payload = [(trajs, rnd)]
+        # quantum-jump seeds (used only when the solver is the Monte-Carlo one):
+        # like qutip.mcsolve's, NOT from the global np.random stream
+        mc_seeds = np.random.default_rng(mc_seed).integers(0, 2**64, size=len(trajs), dtype=np.uint64)
+        payload = [(trajs, rnd, mc_seeds)]
     if dist is not None:
         dist.broadcast_object_list(payload, src=0)
-    trajs, rnd = payload[0]
+    trajs, rnd, mc_seeds = payload[0]
     lo, hi = partition([t.reps for t in trajs], world)[rank]
     hist = np.zeros((n_eval, 2**n), dtype=np.int64)
     occ_sum = np.zeros((n_eval, n + 1), dtype=np.float64)
@@ -153,6 +157,8 @@ def run_ensemble(
         def solve_fn(problems: list[dict[str, Any]]) -> np.ndarray:
             res = emulator._solve_batch(problems, False, {})
             return np.stack([[np.asarray(s) for s in r.states] for r in res])
+    else:
+        mc_seeds = None
     from .results import QState, StateResult
 
     qids = tuple(emulator.samples_obj.qubit_ids)
@@ -160,7 +166,12 @@ def run_ensemble(
     for start in range(lo, hi, batch):
         block = list(range(start, min(hi, start + batch)))
         problems = [hd.problem(trajs[i], emulator._sampling_rate) for i in block]
-        states = solve_fn(problems)
+        if mc_seeds is not None:  # a trajectory's jumps depend on its seed only, not on the sharding
+            emulator._mc_seed_override = mc_seeds[block]
+        try:
+            states = solve_fn(problems)
+        finally:
+            emulator._mc_seed_override = None
         for j, i in enumerate(block):
             for ti in range(n_eval):
                 st = QState(states[j][ti])
