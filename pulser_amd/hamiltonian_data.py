@@ -1,6 +1,6 @@
 """Backend-agnostic inputs of the hot path and their noise trajectories.
 
-Restates, for Ising (ground-rydberg / digital) sequences without a DMM, what
+Restates, for Ising (ground-rydberg / digital, incl. DMM channels) and XY sequences, what
 ``pulser._hamiltonian_data.HamiltonianData`` does between the sampler and the
 Hamiltonian (pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py):
 
@@ -19,7 +19,7 @@ from __future__ import annotations
 
 from collections import Counter
 from dataclasses import dataclass, field, replace
-from typing import Any, Iterator, Sequence
+from typing import Mapping, Any, Iterator, Sequence
 
 import numpy as np
 
@@ -59,6 +59,36 @@ class ChannelInput:
     phase: np.ndarray
     slots: list[Slot] = field(default_factory=list)
     propagation_dir: tuple[float, float, float] | None = None
+    # DMM channels (``DMMSamples``, sampler/samples.py:448-456): the detuning map
+    # (sorted trap coordinates + weights, register/weight_maps.py:78-90), the
+    # register positions it was sampled with (by qubit index; NaN = qubit unknown
+    # to the map) and the spot waist of the samples.
+    dmm_trap_coords: np.ndarray | None = None
+    dmm_weights: np.ndarray | None = None
+    dmm_qubit_coords: np.ndarray | None = None
+    dmm_spot_waist: float | None = None
+
+    @property
+    def is_dmm(self) -> bool:
+        return self.dmm_weights is not None
+
+    def dmm_weight_map(self, spot_waist: float | None) -> np.ndarray:
+        """``DetuningMap.get_qubit_weight_map`` (register/weight_maps.py:92-114):
+        weight of the detuning on every qubit - the trap it sits on (within
+        COORD_PRECISION), or with a spot waist the Gaussian-weighted sum over
+        all traps (crosstalk)."""
+        q = np.asarray(self.dmm_qubit_coords, float)
+        traps = np.asarray(self.dmm_trap_coords, float)
+        known = ~np.isnan(q).any(axis=1)
+        dim = min(q.shape[1], traps.shape[1])
+        diff = np.where(known[:, None, None], q[:, None, :dim] - traps[None, :, :dim], np.inf)
+        dists = np.sqrt((diff * diff).sum(axis=2))
+        if spot_waist:
+            shape = np.exp(-(dists**2) / (2 * spot_waist**2))
+        else:
+            shape = dists < np.sqrt(2) * (10 ** (-6))
+        w = shape @ np.asarray(self.dmm_weights, float)
+        return np.where(known, w, 0.0)  # defaultdict(int) for qubits outside the map
 
     @property
     def duration(self) -> int:
@@ -108,7 +138,12 @@ class SequenceInputs:
                  "amp": np.asarray(c.amp, float), "det": np.asarray(c.det, float),
                  "phase": np.asarray(c.phase, float),
                  "slots": [np.array([s.ti, s.tf] + list(s.targets), dtype=np.int64) for s in c.slots],
-                 "propagation_dir": np.zeros(0) if c.propagation_dir is None else np.asarray(c.propagation_dir, float)}
+                 "propagation_dir": np.zeros(0) if c.propagation_dir is None else np.asarray(c.propagation_dir, float),
+                 "dmm_trap_coords": np.zeros((0, 2)) if not c.is_dmm else np.asarray(c.dmm_trap_coords, float),
+                 "dmm_weights": np.zeros(0) if not c.is_dmm else np.asarray(c.dmm_weights, float),
+                 "dmm_qubit_coords": np.zeros((0, 2)) if not c.is_dmm else np.asarray(c.dmm_qubit_coords, float),
+                 "dmm_spot_waist": -1.0 if c.dmm_spot_waist is None else float(c.dmm_spot_waist),
+                 "is_dmm": bool(c.is_dmm)}
                 for c in self.channels
             ],
         }
@@ -119,8 +154,15 @@ class SequenceInputs:
         for c in d["channels"]:
             slots = [Slot(int(a[0]), int(a[1]), tuple(int(x) for x in a[2:])) for a in c["slots"]]
             pd = tuple(float(x) for x in c["propagation_dir"]) if len(c["propagation_dir"]) else None
-            chans.append(ChannelInput(c["name"], c["addressing"], c["basis"], np.asarray(c["amp"], float),
-                                      np.asarray(c["det"], float), np.asarray(c["phase"], float), slots, pd))
+            ch = ChannelInput(c["name"], c["addressing"], c["basis"], np.asarray(c["amp"], float),
+                              np.asarray(c["det"], float), np.asarray(c["phase"], float), slots, pd)
+            if c.get("is_dmm", False):
+                sw = float(c["dmm_spot_waist"])
+                ch = replace(ch, dmm_trap_coords=np.asarray(c["dmm_trap_coords"], float),
+                             dmm_weights=np.asarray(c["dmm_weights"], float),
+                             dmm_qubit_coords=np.asarray(c["dmm_qubit_coords"], float),
+                             dmm_spot_waist=None if sw < 0 else sw)
+            chans.append(ch)
         mf = tuple(float(x) for x in d["magnetic_field"]) if len(d["magnetic_field"]) else None
         xy = None if d["interaction_coeff_xy"] < 0 else float(d["interaction_coeff_xy"])
         return cls(np.asarray(d["coords"], float), tuple(d["qubit_ids"]), chans,
@@ -148,10 +190,15 @@ class SequenceInputs:
     def extend_duration(self, new_duration: int) -> "SequenceInputs":
         return replace(self, channels=[c.extend_duration(new_duration) for c in self.channels])
 
-    def to_nested_dict(self, all_local: bool = False) -> dict[str, Any]:
-        """sampler/samples.py:524-621 without DMM channels.  In XY mode a global
-        channel only reaches the SLM-masked atoms after ``slm_end``; before it the
-        unmasked atoms get the samples as local entries (:574-587, :594-596)."""
+    def to_nested_dict(self, all_local: bool = False,
+                       dmm: Mapping[str, tuple[float, float | None]] | None = None) -> dict[str, Any]:
+        """sampler/samples.py:524-621.  In XY mode a global channel only reaches
+        the SLM-masked atoms after ``slm_end``; before it the unmasked atoms get
+        the samples as local entries (:574-587, :594-596).  A DMM channel is
+        always distributed per qubit, its detuning times the qubit's map weight
+        (:560-571, :598-608); ``dmm[name] = (factor, spot_waist)`` replaces the
+        sampled detuning scale / spot waist the way
+        ``_sample_with_trajectory`` does (hamiltonian_data.py:414-421)."""
         T = self.max_duration
         in_xy = self.in_xy
         d: dict[str, Any] = {"Global": {}, "Local": {}}
@@ -166,7 +213,13 @@ class SequenceInputs:
         for ch in self.channels:
             cs = ch.extend_duration(T)
             xy = ch.basis == "XY"
-            if ch.addressing == "Global" and not all_local:
+            weights = None
+            det = cs.det
+            if ch.is_dmm:
+                factor, waist = (dmm or {}).get(ch.name, (1.0, ch.dmm_spot_waist))
+                det = cs.det * factor
+                weights = ch.dmm_weight_map(waist)
+            if ch.addressing == "Global" and not all_local and not ch.is_dmm:
                 g = d["Global"].setdefault(ch.basis, entry())
                 start = self.slm_end if xy else 0
                 g["amp"][start:] += cs.amp[start:]
@@ -190,7 +243,7 @@ class SequenceInputs:
                         e = loc.setdefault(t, entry())
                         sl = slice(ti, s.tf)
                         e["amp"][sl] += cs.amp[sl]
-                        e["det"][sl] += cs.det[sl]
+                        e["det"][sl] += det[sl] if weights is None else det[sl] * weights[t]
                         e["phase"][sl] += cs.phase[sl]
         return d
 
@@ -238,6 +291,7 @@ class NoiseTrajectory:
     coords: np.ndarray
     interaction_matrix: np.ndarray
     reps: int = 1
+    dmm_det_fluctuation: dict[str, float] = field(default_factory=dict)
 
 
 def generate_detuning_fluctuations(
@@ -433,10 +487,16 @@ class HamiltonianData:
                         {c: 1.0 for c in chans}, {c: 0.0 for c in chans},
                         {c: np.array(0.0) for c in chans},
                         self.samples.coords, self.interaction_matrix(self.samples.coords, bad),
-                        reps,
+                        reps, {c: 1.0 for c in chans},
                     )
                 )
             return out
+        # The reference creates this dict ONCE, outside the trajectory loop
+        # (hamiltonian_data.py:794), and hands the same object to every
+        # NoiseTrajectory: the draws advance the RNG per trajectory, but every
+        # trajectory ends up with the factors drawn last.  Kept as is.
+        dmm_f: dict[str, float] = {}
+        is_dmm = {c.name: c.is_dmm for c in self.samples.channels}
         for _ in range(ntrajs):
             amp_f: dict[str, float] = {}
             det_f: dict[str, float] = {}
@@ -457,6 +517,10 @@ class HamiltonianData:
                     det_ph[c] = np.random.uniform(0.0, 2 * np.pi, size=len(nm.detuning_hf_omegas) - 1)
                 else:
                     det_ph[c] = np.array(0.0)
+                if nm.dmm_sigma and is_dmm[c]:  # :880-888
+                    dmm_f[c] = max(0, np.random.normal(1.0, nm.dmm_sigma))
+                else:
+                    dmm_f[c] = 1.0
             if "register" in nm.noise_types:
                 sxy, sz = register_sigma_xy_z(nm.temperature, nm.trap_waist, float(nm.trap_depth))
                 pos = np.asarray(coords, float)
@@ -467,16 +531,18 @@ class HamiltonianData:
                 coords = pos + np.column_stack((narr_xy, narr_z))
             out.append(
                 NoiseTrajectory(bad, dop, amp_f, det_f, det_ph, coords,
-                                self.interaction_matrix(coords, bad), 1)
+                                self.interaction_matrix(coords, bad), 1, dmm_f)
             )
         return out
 
     # -- noisy samples (hamiltonian_data.py:408-534) ----------------------------
     def nested_samples(self, traj: NoiseTrajectory) -> dict[str, Any]:
         nm = self.noise_model
-        d = self.samples.to_nested_dict(all_local=self.local_noises)
-        if not self.local_noises:
-            return d
+        if not self.local_noises:  # the noiseless samples as they are (:532-533)
+            return self.samples.to_nested_dict(all_local=False)
+        dmm = {c.name: (traj.dmm_det_fluctuation.get(c.name, 1.0), nm.detuning_map_spot_waist)
+               for c in self.samples.channels if c.is_dmm}  # :414-421
+        d = self.samples.to_nested_dict(all_local=True, dmm=dmm)
         T = self.samples.max_duration
         for ch in self.samples.channels:
             loc = d["Local"][ch.basis]

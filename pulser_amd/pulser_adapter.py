@@ -117,8 +117,19 @@ def sequence_inputs_from_pulser(samples: Any, register: Any, device: Any) -> Any
     channels = []
     for name, cs in samples.channel_samples.items():
         ch_obj = samples._ch_objs[name]
-        if type(cs).__name__ == "DMMSamples":
-            raise NotImplementedError("DMM channels are not supported by the MI355X backend yet.")
+        dmm_kw: dict[str, Any] = {}
+        if type(cs).__name__ == "DMMSamples":  # sampler/samples.py:448-456
+            det_map = cs.detuning_map
+            pos = {q: _np(v).astype(float) for q, v in cs.qubits.items()}
+            dim = len(next(iter(pos.values()))) if pos else 2
+            qc = np.full((len(qids), dim), np.nan)
+            for q, v in pos.items():
+                if q in index:
+                    qc[index[q]] = v
+            dmm_kw = dict(dmm_trap_coords=np.asarray(det_map.sorted_coords, float),
+                          dmm_weights=np.asarray(det_map.sorted_weights, float),
+                          dmm_qubit_coords=qc,
+                          dmm_spot_waist=None if cs.spot_waist is None else float(cs.spot_waist))
         slots = []
         for s in cs.slots:
             if ch_obj.addressing == "Global":
@@ -135,7 +146,7 @@ def sequence_inputs_from_pulser(samples: Any, register: Any, device: Any) -> Any
             ChannelInput(
                 str(name), ch_obj.addressing, ch_obj.basis, _np(cs.amp).astype(float),
                 _np(cs.det).astype(float), _np(cs.phase).astype(float), slots,
-                getattr(ch_obj, "propagation_dir", None),
+                getattr(ch_obj, "propagation_dir", None), **dmm_kw,
             )
         )
     coords = np.array([_np(register.qubits[q]) for q in qids], dtype=float)

@@ -638,6 +638,66 @@ def gen_cfg4(n=12, ntraj=1024, keep=3):
     )
 
 
+def gen_dmm():
+    """Detuning-map-modulator channel next to a global Rydberg channel (4 atoms):
+    noiseless, and with dmm_sigma + crosstalk (spot waist) + doppler noise.  The
+    per-trajectory nested samples come from pulser-core's HamiltonianData."""
+    from pulser_amd.pulser_adapter import problem_from_trajectory, sequence_inputs_from_pulser
+
+    reg = Register.rectangle(2, 2, 6.0, prefix="q")
+    det_map = reg.define_detuning_map({"q0": 0.1, "q1": 0.4, "q2": 0.2, "q3": 0.3})
+    seq = Sequence(reg, MockDevice)
+    seq.config_detuning_map(det_map, "dmm_0")
+    seq.declare_channel("ising", "rydberg_global")
+    seq.add(Pulse.ConstantPulse(200, 2 * np.pi, -3.0, 0.2), "ising")
+    seq.add_dmm_detuning(RampWaveform(200, -20.0, -4.0), "dmm_0")
+    seq.add(Pulse.ConstantAmplitude(5.0, RampWaveform(152, -6.0, 8.0), 0.0), "ising", protocol="no-delay")
+    T = seq.get_duration()
+    samples = sampler.sample(seq, extended_duration=T)
+    inputs = sequence_inputs_from_pulser(samples, seq.register, seq.device)
+    ext = samples.extend_duration(T + 1)
+    sel_t = np.array([0.0, 0.2, T * 1e-3])
+    cases = {
+        "noiseless": (NoiseModel(), 1),
+        "noisy": (NoiseModel(dmm_sigma=0.2, detuning_map_spot_waist=4.0, temperature=40.0,
+                             state_prep_error=0.1, runs=5, samples_per_run=1), 5),
+    }
+    extra = {}
+    for name, (nm, ntraj) in cases.items():
+        np.random.seed(77)
+        hd = HamiltonianData(ext, seq.register, seq.device, nm, ntraj)
+        probe = np.random.get_state()[1][:4].copy()
+        opts = qp.default_options(channel_amp_det(ext), T)
+        opts.update(qp.TIGHT)
+        dets, amps, finals, dmmf, bad = [], [], [], [], []
+        for traj, noisy, reps in hd.noisy_samples:
+            prob = problem_from_trajectory(hd, traj, noisy, reps, 1.0)
+            nested = prob["samples"]
+            if nested["Local"].get("ground-rydberg"):
+                loc = nested["Local"]["ground-rydberg"]
+                dets.append(np.stack([loc[q]["det"] for q in range(4)]))
+                amps.append(np.stack([loc[q]["amp"] for q in range(4)]))
+            else:
+                g = nested["Global"]["ground-rydberg"]
+                dets.append(np.stack([g["det"]] * 4))
+                amps.append(np.stack([g["amp"]] * 4))
+            ham = qp.build_hamiltonian(prob)
+            psi0 = qp.all_ground_state(4, prob["eigenbasis"])
+            finals.append(np.stack(qp.sesolve(ham, psi0, sel_t, **opts)))
+            dmmf.append(traj.dmm_det_fluctuation["dmm_0"])
+            bad.append([traj.bad_atoms[q] for q in reg.qubits])
+        extra[name] = dict(det=np.stack(dets), amp=np.stack(amps), states=np.stack(finals),
+                           dmm_factor=np.array(dmmf), bad=np.array(bad), rng_probe=probe)
+        print(f"dmm[{name}]: {len(dets)} trajectories, dmm factors {dmmf}")
+    P.save_problem(
+        os.path.join(HERE, "dmm_square4.npz"), {"inputs": inputs.to_dict()},
+        seed=77, eval_times=sel_t,
+        noisy_model=dict(dmm_sigma=0.2, detuning_map_spot_waist=4.0, temperature=40.0,
+                         state_prep_error=0.1, runs=5, samples_per_run=1),
+        **{f"{k}_{q}": v for k, d in extra.items() for q, v in d.items()},
+    )
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rydberg", "digital", "three", "cfg1", "cfg2", "cfg3", "cfg4"]
     print("pulser", pulser.__version__)
@@ -661,3 +721,5 @@ if __name__ == "__main__":
         gen_cfg3_small(2, 3)
     if "cfg4" in which:
         gen_cfg4()
+    if "dmm" in which:
+        gen_dmm()

@@ -284,3 +284,27 @@ def test_get_hamiltonian_reference_goldens():
                   [0.09606404, -0.59902269, 0.0, 0.09606404],
                   [0.09606404, 0.0, -0.70099956, 0.09606404],
                   [0.0, 0.09606404, 0.09606404, 0.0]], dtype=complex), rtol=1e-7, atol=1e-9)
+
+
+def test_dmm_channel_trajectories_against_oracle():
+    """DMM + global Rydberg channel (4 atoms), noiseless and with dmm_sigma +
+    crosstalk + doppler + SPAM trajectories captured from pulser-core: the GPU
+    states equal the oracle's tight solutions of pulser-core's noisy samples."""
+    from pulser_amd.hamiltonian_data import SequenceInputs
+
+    prob, extra = load_fixture("dmm_square4.npz")
+    inputs = SequenceInputs.from_dict(prob["inputs"])
+    times = list(extra["eval_times"])
+    np.random.seed(77)
+    emu = QutipEmulator(inputs, evaluation_times=times)
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    for i in range(len(times)):
+        assert np.max(np.abs(np.asarray(res.states[i])[:, 0] - extra["noiseless_states"][0][i])) < 1e-7
+    np.random.seed(77)
+    emu = QutipEmulator(inputs, noise_model=NoiseModel(**extra["noisy_model"]), evaluation_times=times)
+    assert len(emu._problems) == 5
+    got = emu._solve_batch(emu._problems, False, {})
+    for b in range(5):
+        for i in range(len(times)):
+            assert np.max(np.abs(np.asarray(got[b].states[i])[:, 0] - extra["noisy_states"][b][i])) < 1e-7

@@ -567,3 +567,47 @@ def test_emulator_golden_counters_xy(k, monkeypatch):
     with pytest.raises(NotImplementedError, match="mode 'XY' does not support simulation of"):
         QutipEmulator(SequenceInputs.from_dict(load_fixture(f"noisy_xy_{k}.npz")[0]["inputs"]),
                       noise_model=NoiseModel(temperature=50), n_trajectories=1)
+
+
+# ------------------------------------------------------------------ DMM channels
+def test_dmm_channel_samples_and_noise_follow_pulser_core():
+    """Detuning-map-modulator channel (sampler/samples.py:448-456, 560-608) next to
+    a global Rydberg channel: per-qubit weights, dmm_sigma / crosstalk / doppler
+    trajectories exactly as pulser-core's HamiltonianData produced them -
+    including the reference's shared ``dmm_det_fluctuation`` dict (every
+    trajectory carries the factor drawn last, hamiltonian_data.py:794, 880-888)."""
+    prob, extra = load_fixture("dmm_square4.npz")
+    inputs = SequenceInputs.from_dict(prob["inputs"])
+    dmm = [c for c in inputs.channels if c.is_dmm]
+    assert len(dmm) == 1 and dmm[0].addressing == "Global" and not np.any(dmm[0].amp)
+    assert np.allclose(dmm[0].dmm_weight_map(None), [0.1, 0.4, 0.2, 0.3])
+    ext = inputs.extend_duration(inputs.max_duration + 1)
+    # noiseless: global channel stays global, the DMM is distributed per qubit
+    np.random.seed(77)
+    hd = HamiltonianData(ext, NoiseModel(), 1)
+    assert np.array_equal(np.random.get_state()[1][:4], extra["noiseless_rng_probe"])
+    nested = hd.problem(hd.noise_trajectories[0], 1.0)["samples"]
+    assert np.any(nested["Global"]["ground-rydberg"]["amp"])
+    loc = nested["Local"]["ground-rydberg"]
+    assert np.array_equal(np.stack([loc[q]["det"] for q in range(4)]), extra["noiseless_det"][0])
+    assert not np.any(np.stack([loc[q]["amp"] for q in range(4)]))
+    # noisy: everything local; detuning = rydberg det + doppler (twice: once per
+    # channel slot, as the reference adds it) + factor * crosstalk weight * dmm det
+    nm = NoiseModel(**extra["noisy_model"])
+    assert {"dmm_sigma", "dmm_crosstalk", "doppler", "SPAM"} <= set(nm.noise_types)
+    np.random.seed(77)
+    hd = HamiltonianData(ext, nm, 5)
+    assert np.array_equal(np.random.get_state()[1][:4], extra["noisy_rng_probe"])
+    trajs = hd.noise_trajectories
+    assert len(trajs) == 5 and not hd.factorable()
+    assert np.allclose([t.dmm_det_fluctuation["dmm_0"] for t in trajs], extra["noisy_dmm_factor"])
+    assert len(set(extra["noisy_dmm_factor"])) == 1  # the shared-dict quirk
+    assert np.array_equal(np.array([t.bad_atoms for t in trajs]), extra["noisy_bad"])
+    for i, t in enumerate(trajs):
+        loc = hd.problem(t, 1.0)["samples"]["Local"]["ground-rydberg"]
+        assert np.array_equal(np.stack([loc[q]["det"] for q in range(4)]), extra["noisy_det"][i]), i
+        assert np.array_equal(np.stack([loc[q]["amp"] for q in range(4)]), extra["noisy_amp"][i]), i
+    # round trip of the DMM fields
+    back = SequenceInputs.from_dict(inputs.to_dict())
+    assert np.array_equal(back.channels[0].dmm_weight_map(4.0) if back.channels[0].is_dmm
+                          else back.channels[1].dmm_weight_map(4.0), dmm[0].dmm_weight_map(4.0))
