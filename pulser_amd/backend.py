@@ -17,6 +17,7 @@ matrix-free generator kernel on the device (``ryd_apply_generator``).
 
 from __future__ import annotations
 
+import json
 import uuid
 import warnings
 from collections import Counter, defaultdict
@@ -46,6 +47,22 @@ class RydState:
         self._state = QState(state)
         d = len(self.eigenstates)
         self._n = int(round(np.log(self._state.shape[0]) / np.log(d)))
+        self._amplitudes: Mapping[str, complex] | None = None
+
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        """pulser/backend/state.py:234-254: only states built by
+        ``from_state_amplitudes`` (and not modified since) can be serialised."""
+        if self._amplitudes is None:
+            raise ValueError(
+                "Failed to serialize state of type 'RydState' because it was not created "
+                "via 'RydState.from_state_amplitudes()'.")
+        stashed = self.from_state_amplitudes(eigenstates=self.eigenstates,
+                                             amplitudes=self._amplitudes)
+        if abs(float(self.overlap(stashed)) - 1.0) > 1e-12:
+            raise ValueError(
+                "Failed to serialize state of type 'RydState' because it was modified in "
+                "place after its creation.")
+        return {"eigenstates": tuple(self.eigenstates), "amplitudes": dict(self._amplitudes)}
 
     @property
     def n_qudits(self) -> int:
@@ -133,7 +150,9 @@ class RydState:
             for ch in key:
                 idx = idx * d + list(eigenstates).index(ch)
             vec[idx] = amp
-        return cls(QState(vec).unit(), eigenstates=eigenstates)
+        out = cls(QState(vec).unit(), eigenstates=eigenstates)
+        out._amplitudes = dict(amplitudes)
+        return out
 
 
 class HamiltonianOperator:
@@ -343,8 +362,120 @@ class EnergyVariance(Observable):
 
 
 # ------------------------------------------------------------------- results
+# AggregationMethod (pulser/backend/observable.py:79-86) <-> the kinds used here
+_AGG_CODE = {"skip": 0, "skip_warn": 1, "density_matrix": 1, "mean": 2, "bag_union": 3, "meanstd": 4}
+_AGG_KIND = {0: "skip", 1: "skip_warn", 2: "mean", 3: "bag_union", 4: "meanstd"}
+
+
+class _AbstractReprEncoder(json.JSONEncoder):
+    """pulser/json/abstract_repr/serializer.py:39-60."""
+
+    def default(self, o: Any) -> Any:
+        if hasattr(o, "_to_abstract_repr"):
+            return o._to_abstract_repr()
+        if isinstance(o, np.ndarray):
+            return o.tolist()
+        if isinstance(o, np.integer):
+            return int(o)
+        if isinstance(o, np.floating):
+            return float(o)
+        if isinstance(o, set):
+            return list(o)
+        if isinstance(o, (complex, np.complexfloating)):
+            o = complex(o)
+            return o.real if o.imag == 0 else dict(real=o.real, imag=o.imag)
+        if type(o).__module__.startswith("torch") and hasattr(o, "tolist"):
+            return o.tolist()
+        return json.JSONEncoder.default(self, o)
+
+
+def _deserialize_complex(obj: Any) -> Any:
+    """pulser/json/abstract_repr/deserializer.py:427-437."""
+    if isinstance(obj, list):
+        return [_deserialize_complex(e) for e in obj]
+    if isinstance(obj, dict):
+        if obj.keys() == {"real", "imag"}:
+            return obj["real"] + 1j * obj["imag"]
+        return {k: _deserialize_complex(v) for k, v in obj.items()}
+    return obj
+
+
+def _mean_of(values: list[Any]) -> Any:
+    """pulser/backend/aggregators.py:119-156."""
+    elt = values[0]
+    if isinstance(elt, np.ndarray):
+        return np.stack(values).mean(axis=0)
+    if isinstance(elt, (float, int)) and not isinstance(elt, bool):
+        return float(np.mean(values))
+    if isinstance(elt, complex):
+        return complex(np.mean(values))
+    if not isinstance(elt, (list, tuple)):
+        raise ValueError(f"Mean aggregator cannot process data of type {type(elt)}.")
+    return list(np.mean(values, axis=0).tolist())
+
+
+def _std_of(values: list[Any]) -> Any:
+    """pulser/backend/aggregators.py:80-116 (sample standard deviation, ddof=1)."""
+    elt = values[0]
+    if isinstance(elt, np.ndarray):
+        return np.stack(values).std(axis=0, ddof=1)
+    if isinstance(elt, (float, int)) and not isinstance(elt, bool):
+        return float(np.std(values, ddof=1))
+    if isinstance(elt, complex):
+        return complex(np.std(values, ddof=1))
+    if not isinstance(elt, (list, tuple)):
+        raise ValueError(f"Std aggregator cannot process data of type {type(elt)}.")
+    return list(np.std(values, axis=0, ddof=1).tolist())
+
+
 class Results:
-    """pulser/backend/results.py:52-490 (storage, lookup, aggregation)."""
+    """pulser/backend/results.py:52-490 (storage, lookup, aggregation, JSON
+    abstract representation)."""
+
+    # -- abstract representation (results.py:267-330) --------------------------
+    @staticmethod
+    def _encoder() -> type:
+        return _AbstractReprEncoder
+
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        return {
+            "atom_order": [str(q) for q in self.atom_order],
+            "total_duration": self.total_duration,
+            "tagmap": {k: str(v) for k, v in self._tagmap.items()},
+            "results": {str(k): v for k, v in self._results.items()},
+            "times": {str(k): v for k, v in self._times.items()},
+            "aggregation_methods": {str(k): _AGG_CODE[v] for k, v in self._aggregation.items()},
+        }
+
+    def to_abstract_repr(self, skip_validation: bool = False) -> str:
+        """JSON string; numpy arrays become lists, complex numbers
+        ``{"real", "imag"}`` (real numbers when the imaginary part is 0).  The
+        reference validates against its JSON schema; here the document is checked
+        by deserialising it again unless ``skip_validation``."""
+        text = json.dumps(self._to_abstract_repr(), cls=_AbstractReprEncoder)
+        if not skip_validation:
+            type(self).from_abstract_repr(text)
+        return text
+
+    @classmethod
+    def _from_abstract_repr(cls, obj: Mapping[str, Any]) -> "Results":
+        for key in ("atom_order", "total_duration", "tagmap", "results", "times"):
+            if key not in obj:
+                raise ValueError(f"Invalid results representation: missing {key!r}.")
+        out = cls(tuple(obj["atom_order"]), obj["total_duration"])
+        for tag, uid in obj["tagmap"].items():
+            out._tagmap[tag] = uuid.UUID(uid)
+        for uid, value in obj["results"].items():
+            out._results[uuid.UUID(uid)] = _deserialize_complex(value)
+        for uid, value in obj["times"].items():
+            out._times[uuid.UUID(uid)] = value
+        for uid, code in obj.get("aggregation_methods", {}).items():
+            out._aggregation[uuid.UUID(uid)] = _AGG_KIND[int(code)]
+        return out
+
+    @classmethod
+    def from_abstract_repr(cls, repr: str) -> "Results":
+        return cls._from_abstract_repr(json.loads(repr))
 
     def __init__(self, atom_order: tuple, total_duration: int) -> None:
         self.atom_order = tuple(atom_order)
@@ -401,36 +532,60 @@ class Results:
 
     @classmethod
     def aggregate(cls, results: Sequence["Results"],
-                  **aggregators: Callable[[list[Any]], Any]) -> "Results":
-        """results.py:331-488 for the default aggregation kinds."""
+                  **aggregators: Any) -> "Results":
+        """results.py:331-488: combine the results of several runs tag by tag
+        with each observable's default aggregation (mean, Counter union, mean and
+        standard deviation, mean of density matrices) or the function / kind
+        name given for the tag; 'skip' / 'skip_warn' tags are dropped."""
         if not results:
             raise ValueError("no results to aggregate")
         first = results[0]
+        if not all(r.atom_order == first.atom_order for r in results):
+            raise ValueError("You're trying to aggregate incompatible results: "
+                             "they do not all have the same atom order.")
+        if not all(r.total_duration == first.total_duration for r in results):
+            raise ValueError("You're trying to aggregate incompatible results: "
+                             "they do not all have the same sequence duration.")
+        common = [t for t in first._tagmap if all(t in r._tagmap for r in results)]
+        if not all({t: r._aggregation.get(r._tagmap[t], "mean") for t in common}
+                   == {t: first._aggregation.get(first._tagmap[t], "mean") for t in common}
+                   for r in results):
+            raise ValueError("You're trying to aggregate incompatible results: "
+                             "they do not all contain the same aggregation functions.")
         out = cls(first.atom_order, first.total_duration)
-        for tag, uid in first._tagmap.items():
-            kind = first._aggregation[uid]
-            agg = aggregators.get(tag)
-            out._tagmap[tag] = uid
-            out._aggregation[uid] = kind
-            out._times[uid] = list(first._times[uid])
+        for tag in common:
+            uid = first._tagmap[tag]
+            kind = first._aggregation.get(uid, "mean")
+            agg = aggregators.get(tag, kind)
+            if agg in ("skip", "skip_warn"):
+                if agg == "skip_warn":
+                    warnings.warn(f"Skipping aggregation of `{tag}`.")
+                continue
+            times = first._times[uid]
+            if not all(r._times[r._tagmap[tag]] == times for r in results):
+                raise ValueError("The Results come from incompatible simulations: "
+                                 f"the times for `{tag}` are not all the same.")
+            uids = {r._tagmap[tag] for r in results}
+            new_uid = uid if len(uids) == 1 else uuid.uuid4()
             vals_t = []
-            for i in range(len(first._times[uid])):
+            for i in range(len(times)):
                 vals = [r._results[r._tagmap[tag]][i] for r in results]
-                if agg is not None:
+                if callable(agg):
                     vals_t.append(agg(vals))
-                elif kind == "bag_union":
-                    vals_t.append(sum(vals, Counter()))
-                elif kind == "density_matrix":
+                elif agg == "bag_union":
+                    vals_t.append(sum(map(Counter, vals), Counter()))
+                elif agg == "density_matrix":
                     vals_t.append(density_matrix_aggregator(vals))
-                elif isinstance(vals[0], (float, int)):
-                    vals_t.append(float(np.mean(vals)))
-                elif isinstance(vals[0], complex):
-                    vals_t.append(complex(np.mean(vals)))
-                elif isinstance(vals[0], np.ndarray):
-                    vals_t.append(np.stack(vals).mean(axis=0))
+                elif agg == "meanstd":
+                    vals_t.append((_mean_of(vals), _std_of(vals)))
+                elif agg == "mean":
+                    vals_t.append(_mean_of(vals))
                 else:
-                    vals_t.append(np.mean(vals, axis=0).tolist())
-            out._results[uid] = vals_t
+                    raise ValueError(f"Unknown aggregation {agg!r} for `{tag}`.")
+            out._tagmap[tag] = new_uid
+            out._aggregation[new_uid] = kind
+            out._times[new_uid] = list(times)
+            out._results[new_uid] = vals_t
         return out
 
 

@@ -698,6 +698,46 @@ def gen_dmm():
     )
 
 
+def gen_results_json():
+    """A ``pulser.backend.Results`` filled with raw values of every kind the
+    default observables store, serialised by pulser-core itself
+    (results.py:267-313), plus the aggregation of three such results."""
+    import json
+    import uuid as _uuid
+    from collections import Counter
+    from pulser.backend.observable import AggregationMethod
+    from pulser.backend.results import Results
+
+    def make(shift):
+        res = Results(atom_order=("q0", "q1", "q2"), total_duration=1000)
+        entries = [
+            ("bitstrings", AggregationMethod.BAG_UNION,
+             lambda t: Counter({"010": 3 + shift, "111": int(10 * t) + 1})),
+            ("occupation", AggregationMethod.MEAN, lambda t: [0.1 * t + shift, 0.5, 0.25 * (1 + t)]),
+            ("correlation_matrix", AggregationMethod.MEAN,
+             lambda t: [[t, 0.5 + shift], [0.5 + shift, 1 - t]]),
+            ("energy", AggregationMethod.MEAN, lambda t: -3.25 * t + shift),
+            ("expectation", AggregationMethod.MEAN, lambda t: complex(0.5 * t, 0.125 + shift)),
+            ("array", AggregationMethod.MEANSTD, lambda t: np.array([t, 2 * t + shift, 1.5])),
+            ("custom_skipped", AggregationMethod.SKIP, lambda t: {"note": "x", "z": complex(1, -t)}),
+        ]
+        for i, (tag, method, fn) in enumerate(entries):
+            uid = _uuid.UUID(int=1000 + i)
+            for t in (0.5, 1.0):
+                res._store_raw(uuid=uid, tag=tag, time=t, value=fn(t), aggregation_method=method)
+        return res
+
+    singles = [make(s) for s in (0, 1, 2)]
+    texts = [r.to_abstract_repr(skip_validation=True) for r in singles]
+    agg = Results.aggregate(singles)
+    agg_text = agg.to_abstract_repr(skip_validation=True)
+    P.save_problem(os.path.join(HERE, "results_abstract_repr.npz"), {},
+                   reference_cite="pulser-core/pulser/backend/results.py:267-488",
+                   json_texts=texts, aggregated_json=agg_text)
+    print("results json:", len(texts[0]), "chars; aggregated tags:", agg.get_result_tags())
+    print(json.dumps(json.loads(agg_text))[:400])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rydberg", "digital", "three", "cfg1", "cfg2", "cfg3", "cfg4"]
     print("pulser", pulser.__version__)
@@ -723,3 +763,5 @@ if __name__ == "__main__":
         gen_cfg4()
     if "dmm" in which:
         gen_dmm()
+    if "results" in which:
+        gen_results_json()

@@ -611,3 +611,47 @@ def test_dmm_channel_samples_and_noise_follow_pulser_core():
     back = SequenceInputs.from_dict(inputs.to_dict())
     assert np.array_equal(back.channels[0].dmm_weight_map(4.0) if back.channels[0].is_dmm
                           else back.channels[1].dmm_weight_map(4.0), dmm[0].dmm_weight_map(4.0))
+
+
+# ----------------------------------------------------- Results abstract repr
+def test_results_abstract_repr_and_aggregation_match_pulser_core():
+    """JSON written by pulser-core's own ``Results.to_abstract_repr`` and
+    ``Results.aggregate`` (pulser/backend/results.py:267-488; fixture): read it,
+    write it back identically, aggregate identically."""
+    import json
+
+    from pulser_amd.backend import Results, RydState
+
+    _, extra = load_fixture("results_abstract_repr.npz")
+    mine = []
+    for text in extra["json_texts"]:
+        res = Results.from_abstract_repr(text)
+        assert res.atom_order == ("q0", "q1", "q2") and res.total_duration == 1000
+        assert res.get_result("expectation", 1.0) == complex(0.5, json.loads(text)["results"][
+            str(res._tagmap["expectation"])][1]["imag"])
+        assert res.get_result_times("occupation") == [0.5, 1.0]
+        assert json.loads(res.to_abstract_repr()) == json.loads(text)
+        mine.append(res)
+    assert mine[1].bitstrings[1] == {"010": 4, "111": 11}
+    import warnings as _w
+    with _w.catch_warnings():  # 'custom_skipped' is SKIP: dropped silently
+        _w.simplefilter("error")
+        agg = Results.aggregate(mine)
+    ref = json.loads(extra["aggregated_json"])
+    got = json.loads(agg.to_abstract_repr())
+    assert set(got["tagmap"]) == set(ref["tagmap"]) and "custom_skipped" not in got["tagmap"]
+    assert got == ref
+    mean, std = agg.get_result("array", 1.0)
+    assert np.allclose(mean, [1.0, 3.0, 1.5]) and np.allclose(std, [0.0, 1.0, 0.0])
+    # user-supplied aggregators and incompatible inputs (results.py:356-430)
+    top = Results.aggregate(mine, energy=max, occupation="skip")
+    assert top.get_result("energy", 0.5) == 2 - 3.25 * 0.5 and "occupation" not in top.get_result_tags()
+    other = Results(("q0", "q1"), 1000)
+    with pytest.raises(ValueError, match="same atom order"):
+        Results.aggregate([mine[0], other])
+    # states serialise only when built from amplitudes (backend/state.py:234-254)
+    st = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rg": 1.0, "gr": 1j})
+    d = json.loads(json.dumps({"s": st}, cls=type(agg)._encoder()))
+    assert d["s"]["eigenstates"] == ["r", "g"] and d["s"]["amplitudes"]["gr"] == {"real": 0.0, "imag": 1.0}
+    with pytest.raises(ValueError, match="from_state_amplitudes"):
+        RydState(np.array([1.0, 0.0]), eigenstates=("r", "g"))._to_abstract_repr()
