@@ -83,16 +83,25 @@ def timed_run(eng, state_fn, t0, t1, steps, warmup, dist=None, torch=None):
     barrier()
     tic = time.perf_counter()
     occ = None
+    def all_reduce(t, op=None):
+        op = op if op is not None else dist.ReduceOp.SUM
+        if dist.get_backend() == "gloo":  # RYD_BENCH_BACKEND=gloo: 1-GPU check of the N > 1 path
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
+
     for st in states:
         eng.evolve(st, t0, t1)
         occ = eng.occupations(st).sum(dim=0)
         if dist is not None:
-            dist.all_reduce(occ)  # ensemble sum over ranks (RCCL over xGMI)
+            all_reduce(occ)  # ensemble sum over ranks (RCCL over xGMI)
     barrier()
     dt = time.perf_counter() - tic
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce(tmax, dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kms, kl = eng.kernel_timing()
     eng.set_kernel_timing(False)
@@ -190,8 +199,13 @@ def main() -> None:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RYD_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:  # test hook: every rank on the one GPU of the box, gloo for the reductions
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
     else:
         torch.cuda.set_device(0)
