@@ -139,11 +139,13 @@ __device__ __forceinline__ int tile_bit_pos(const Segs& s, int q) {
   return -1;
 }
 
-constexpr int NT = 512;  // threads per workgroup of the apply kernel
+// threads per workgroup of the apply kernel: 512 (two workgroups per CU when the
+// launch has many tiles) or 1024 (launches with at most ~2 tiles per CU: more
+// waves per CU to hide the load -> compute -> store latency of a lone tile)
 
 // out = post * (base + scale * (kin + G~_pass x))        (final pass)
 // kout = kin + G~_pass x                                  (other passes)
-template <int MODE>
+template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = A.T;
@@ -1660,8 +1662,18 @@ static void plan_passes(ryd_handle* h) {
           p = make_pass(nb, {{0, g}});
         }
       } else {
-        const int c = std::max(0, std::min(std::min(C, done), T - 1));
-        g = std::max(1, std::min(nb - done, T - c));
+        // the remaining bits are spread evenly over the passes they need, and
+        // the rest of each tile is filled with contiguous run bits (longer
+        // coalesced runs, full-size tiles) as long as >= 1024 workgroups remain
+        const int cmin = std::max(0, std::min(std::min(C, done), T - 1));
+        const int cap = std::max(1, T - cmin);
+        const int left = nb - done;
+        const int k = (left + cap - 1) / cap;
+        g = std::max(1, (left + k - 1) / k);
+        int c = cmin;
+        int logB = 0;
+        while ((1 << (logB + 1)) <= h->B) ++logB;
+        while (c + g < T && c < done && (nb - (c + 1 + g)) + logB >= 10) ++c;
         p = make_pass(nb, {{0, c}, {done, g}});
       }
       for (int j = 0; j < g; ++j) p.flip_q.push_back(local_of(p.tile, done + j));
@@ -1738,9 +1750,13 @@ extern "C" int ryd_create(const ryd_config* cfg, ryd_handle** out) {
   }
   for (int i = 0; i < 4; ++i) h->Sd[i] = h->J[i] = make_double2(0, 0);
   // the 2^12-amplitude tile needs 64 KiB + tables of dynamic LDS (CDNA4: 160 KiB/CU)
-  if ((e = hipFuncSetAttribute((const void*)k_apply<RYD_SESOLVE>,
+  if ((e = hipFuncSetAttribute((const void*)k_apply<RYD_SESOLVE, 512>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
-      (e = hipFuncSetAttribute((const void*)k_apply<RYD_MESOLVE>,
+      (e = hipFuncSetAttribute((const void*)k_apply<RYD_MESOLVE, 512>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply<RYD_SESOLVE, 1024>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply<RYD_MESOLVE, 1024>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
       (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, false, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
@@ -2149,10 +2165,16 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
         if (se) hipLaunchKernelGGL((k_apply12<RYD_SESOLVE, 4>), grid, dim3(512), lds12, st, A);
         else hipLaunchKernelGGL((k_apply12<RYD_MESOLVE, 4>), grid, dim3(512), lds12, st, A);
       }
-    } else if (h->cfg.mode == RYD_SESOLVE)
-      hipLaunchKernelGGL(k_apply<RYD_SESOLVE>, grid, dim3(NT), lds, st, A);
-    else
-      hipLaunchKernelGGL(k_apply<RYD_MESOLVE>, grid, dim3(NT), lds, st, A);
+    } else {
+      const bool wide = (size_t)grid.x * grid.y <= 512 && p.T >= 10;
+      if (h->cfg.mode == RYD_SESOLVE) {
+        if (wide) hipLaunchKernelGGL((k_apply<RYD_SESOLVE, 1024>), grid, dim3(1024), lds, st, A);
+        else hipLaunchKernelGGL((k_apply<RYD_SESOLVE, 512>), grid, dim3(512), lds, st, A);
+      } else {
+        if (wide) hipLaunchKernelGGL((k_apply<RYD_MESOLVE, 1024>), grid, dim3(1024), lds, st, A);
+        else hipLaunchKernelGGL((k_apply<RYD_MESOLVE, 512>), grid, dim3(512), lds, st, A);
+      }
+    }
     HIPCHK(hipGetLastError());
     if (h->timing) {
       HIPCHK(hipEventRecord(ev.second, st));
