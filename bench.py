@@ -283,6 +283,25 @@ def main() -> None:
                      "unit": "sim-us/s", "ms_per_sequence": sec * 1e3,
                      "roofline": roofline(12, 1, stats, kms, kl, "k_traj (1 workgroup)")})
         eng.close()
+        # quantum-jump trajectories (what Solver.DEFAULT runs for dissipation + stochastic noise)
+        mc_prob = chain_problem(12)
+        mc_prob["collapse_ops"] = [(float(np.sqrt(2 * 0.05)), "sigma_rr"), (float(np.sqrt(0.02)), "sigma_gr")]
+        eng = Engine.from_problems([mc_prob] * 256, mode="mcsolve")
+        seeds = np.arange(256, dtype=np.uint64) + np.uint64(12345)
+        st = eng.new_state()
+        eng.mc_solve(st, [0.0, 0.05], seeds, store=False)
+        torch.cuda.synchronize()
+        st = eng.new_state()
+        tic = time.perf_counter()
+        eng.mc_solve(st, [0.0, T_SEQ_US], seeds, store=False)
+        torch.cuda.synchronize()
+        sec = time.perf_counter() - tic
+        also.append({"workload": "256 quantum-jump (mcsolve) trajectories of the 12-atom anneal sequence, "
+                                 "dephasing 0.05/us + relaxation 0.02/us",
+                     "value": 256 * T_SEQ_US / sec, "unit": "sim-us/s", "ms_per_batch": sec * 1e3,
+                     "jumps_per_trajectory": float(eng.mc_jumps().mean()),
+                     "kernel": "k_traj<12,1024,1,MC> (persistent, jumps on the device, 1 launch)"})
+        eng.close()
         # north-star target size, Schroedinger leg: one 14-atom triangular-register sequence
         eng = Engine.from_problems([tri_problem(2, 7)], mode="sesolve")
         t0, t1 = 1.0, 1.1
