@@ -77,8 +77,11 @@ class RydState:
 
     def infer_one_state(self) -> str:
         """pulser/backend/state.py: the eigenstate measured as 1."""
+        eig = set(self.eigenstates) - {"x"}  # the leakage state never counts
+        if eig == {"0", "1"}:
+            return "1"
         for pair, one in _ONE_STATE.items():
-            if set(pair) == set(self.eigenstates):
+            if set(pair) == eig:
                 return one
         raise RuntimeError(f"Failed to infer the 'one state' from the eigenstates: {self.eigenstates}")
 
@@ -704,15 +707,12 @@ class QutipBackendV2:
 
     @staticmethod
     def _run_raw(sim: QutipEmulator, config: QutipConfig, options: dict[str, Any]) -> Results:
-        from .engine import Engine
+        from .engine import Engine, GeneralEngine
+        from .general import lower_general
 
         eigenstates = sim._hamiltonian_data.eigenbasis
         noiseless = dict(sim._noiseless_problem)
         noiseless["collapse_ops"] = []
-        if not sim._fast_path_ok(noiseless):
-            raise NotImplementedError(
-                "QutipBackendV2 observables need the matrix-free Hamiltonian; multi-level / XY "
-                "sequences are only available through QutipEmulator.run() for now.")
         qids = tuple(sim.samples_obj.qubit_ids)
         T = sim.total_duration_ns
 
@@ -726,7 +726,11 @@ class QutipBackendV2:
                 for obs in config.observables:
                     obs(config=config, t=float(t), state=state, hamiltonian=ham, result=res)
 
-        with Engine.from_problems([noiseless], mode="sesolve") as ham_engine:
+        # the noiseless H(t) the observables see (qutip_backend.py:259-264): matrix-free
+        # for 2-level Ising sequences, explicit sparse terms for multi-level / XY ones
+        ham_ctx = (Engine.from_problems([noiseless], mode="sesolve") if sim._fast_path_ok(noiseless)
+                   else GeneralEngine(lower_general(noiseless, mesolve=False)))
+        with ham_ctx as ham_engine:
             if not has_stochastic_noise(sim.noise_model):
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore", DeprecationWarning)
