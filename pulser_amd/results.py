@@ -103,6 +103,10 @@ class Result:
         nonzero = np.argwhere(weights != 0.0).flatten()
         return {np.binary_repr(i, self._size): float(weights[i]) for i in nonzero}
 
+    @property
+    def sampling_errors(self) -> dict[str, float]:  # pragma: no cover - abstract
+        raise NotImplementedError
+
     def get_samples(self, n_samples: int) -> Counter:
         """result.py:103-115 - insertion order = order of first occurrence."""
         return Counter(
@@ -122,6 +126,14 @@ class SampledResult(Result):
 
     def __post_init__(self) -> None:
         self.n_samples = sum(self.bitstring_counts.values())
+
+    @property
+    def sampling_errors(self) -> dict[str, float]:
+        """Standard error of the mean of every bitstring's rate (result.py:204-213)."""
+        return {
+            bitstr: float(np.sqrt(p * (1 - p) / self.n_samples))
+            for bitstr, p in self.sampling_dist.items()
+        }
 
     def _weights(self) -> np.ndarray:
         weights = np.zeros(2**self._size)
@@ -296,6 +308,14 @@ class SimulationResults(collections.abc.Sequence):
     def sample_final_state(self, N_samples: int = 1000) -> Counter:
         return self.sample_state(self._sim_times[-1], N_samples)
 
+    def plot(self, op: np.ndarray, fmt: str = "", label: str = "") -> None:
+        """Expectation value of ``op`` over the evaluation times (simresults.py:164-174)."""
+        import matplotlib.pyplot as plt
+
+        plt.plot(self._sim_times, self.expect([op])[0], fmt, label=label)
+        plt.xlabel("Time (µs)")
+        plt.ylabel("Expectation value")
+
     def _get_index_from_time(self, t_float: float, tol: float = 1.0e-3) -> int:
         """simresults.py:176-190 - the FIRST index within tol."""
         try:
@@ -352,6 +372,22 @@ class NoisyResults(SimulationResults):
 
     def get_final_state(self) -> QState:
         return self.get_state(self._sim_times[-1])
+
+    def plot(self, op: np.ndarray, fmt: str = ".", label: str = "",  # type: ignore[override]
+             error_bars: bool = True) -> None:
+        """simresults.py:325-360: a diagonal observable with the standard error
+        of the mean over ``n_measures`` shots as error bars."""
+        import matplotlib.pyplot as plt
+
+        if not error_bars:
+            super().plot(op, fmt, label)
+            return
+        moy = self.expect([op])[0]
+        sq = self.expect([np.asarray(op) @ np.asarray(op)])[0]
+        st = np.sqrt(np.maximum(np.real(sq) - np.real(moy) ** 2, 0.0) / self.n_measures)
+        plt.errorbar(self._sim_times, moy, st, fmt=fmt, lw=1, capsize=3, label=label)
+        plt.xlabel("Time (µs)")
+        plt.ylabel("Expectation value")
 
 
 class CoherentResults(SimulationResults):

@@ -100,8 +100,72 @@ class SimConfig:
         )
         noise = (self.noise,) if isinstance(self.noise, str) else tuple(self.noise)
         object.__setattr__(self, "noise", noise)
-        # temperature is given in uK and stored in K (simconfig.py)
-        object.__setattr__(self, "temperature", self.temperature * 1e-6)
+        if not isinstance(self.temperature, (int, float)):
+            raise TypeError(f"'temperature' must be a float, not {type(self.temperature)}.")
+        # temperature is given in uK and stored in K (simconfig.py:166)
+        object.__setattr__(self, "temperature", self.temperature / 1e6)
+        unknown = set(noise) - set(_NOISE_TYPE_PARAMS)
+        if unknown:
+            raise ValueError(f"'{sorted(unknown)[0]}' is not a valid noise type.")
+        for param, value in self.spam_dict.items():  # simconfig.py:242-248
+            if value > 1 or value < 0:
+                raise ValueError(f"SPAM parameter {param} = {value} must be"
+                                 + " greater than 0 and less than 1.")
+        if len(self.eff_noise_opers) != len(self.eff_noise_rates):
+            raise ValueError(
+                f"The operators list length({len(self.eff_noise_opers)}) and rates list length"
+                f"({len(self.eff_noise_rates)}) must be equal.")
+
+    @property
+    def with_leakage(self) -> bool:
+        return "leakage" in self.noise
+
+    @property
+    def spam_dict(self) -> dict[str, float]:
+        return {"eta": self.eta, "epsilon": self.epsilon, "epsilon_prime": self.epsilon_prime}
+
+    @property
+    def doppler_sigma(self) -> float:
+        from .noise_model import doppler_sigma
+
+        return doppler_sigma(self.temperature)
+
+    @property
+    def supported_noises(self) -> dict:
+        from .hamiltonian_data import SUPPORTED_NOISES
+
+        return SUPPORTED_NOISES
+
+    def __str__(self, solver_options: bool = False) -> str:
+        """simconfig.py:204-240."""
+        lines = [
+            "Options:",
+            "----------",
+            f"Number of runs:        {self.runs}",
+            f"Samples per run:       {self.samples_per_run}",
+        ]
+        if self.noise:
+            lines.append("Noise types:           " + ", ".join(self.noise))
+        if "SPAM" in self.noise:
+            lines.append(f"SPAM dictionary:       {self.spam_dict}")
+        if "eff_noise" in self.noise:
+            lines.append(f"Effective noise rates:       {self.eff_noise_rates}")
+            lines.append(f"Effective noise operators:       {self.eff_noise_opers}")
+        if "doppler" in self.noise:
+            lines.append(f"Temperature:           {self.temperature*1.e6}µK")
+        if "amplitude" in self.noise:
+            lines.append(f"Laser waist:           {self.laser_waist}μm")
+            lines.append(f"Amplitude standard dev.:  {self.amp_sigma}")
+        if "relaxation" in self.noise:
+            lines.append(f"Relaxation rate: {self.relaxation_rate}")
+        if "dephasing" in self.noise:
+            lines.append(f"Dephasing rate: {self.dephasing_rate} (Rydberg), "
+                         f"{self.hyperfine_dephasing_rate} (Hyperfine)")
+        if "depolarizing" in self.noise:
+            lines.append(f"Depolarizing rate: {self.depolarizing_rate}")
+        if solver_options:
+            lines.append("Solver Options: \n" + f"{str(self.solver_options)[10:-1]}")
+        return "\n".join(lines).rstrip()
 
     @classmethod
     def from_noise_model(cls, noise_model: Any) -> "SimConfig":
@@ -284,6 +348,116 @@ class QutipEmulator:
     def total_duration_ns(self) -> int:
         return self._tot_duration
 
+    # -- deprecated SimConfig surface (simulation.py:348-476) -------------------
+    def set_config(self, cfg: SimConfig) -> None:
+        """Replace the noise configuration (new noise-trajectory draws, initial
+        state re-validated or reset to all-ground when the dimension changes)."""
+        warnings.warn(
+            "Supplying a 'SimConfig' to QutipEmulator has been deprecated."
+            " Please instantiate with a 'NoiseModel' instead.",
+            DeprecationWarning,
+            stacklevel=2,
+        )
+        if not isinstance(cfg, SimConfig):
+            raise ValueError(f"Object {cfg} is not a valid `SimConfig`.")
+        v = self._hamiltonian_data.interaction_type
+        not_supported = set(cfg.noise) - cfg.supported_noises[v]
+        if not_supported:
+            raise NotImplementedError(
+                f"Interaction mode '{v}' "
+                "does not support simulation of noise types:"
+                f"{', '.join(not_supported)}."
+            )
+        former_dim = self.dim
+        former_ground = self._all_ground()
+        noise_model = cfg.to_noise_model()
+        self._noise_trajectories_used = False
+        self._hamiltonian_data = HamiltonianData(
+            self.samples_obj, noise_model,
+            self._get_n_trajectories(noise_model, check_value=True),
+        )
+        self._problems_cache = None
+        self._current_problem = self._hamiltonian_data.problem(
+            self._hamiltonian_data.noise_trajectories[0], self._sampling_rate)
+        if self.dim == former_dim:
+            self.set_initial_state(np.asarray(self._initial_state))
+            return
+        if not np.array_equal(np.asarray(self._initial_state), np.asarray(former_ground)):
+            warnings.warn(
+                "Current initial state's dimension does not match new"
+                " dimensions. Setting it to 'all-ground'."
+            )
+        self.set_initial_state("all-ground")
+
+    def add_config(self, config: SimConfig) -> None:
+        """Merge another configuration into the current one: noise types it adds
+        bring their parameters, noise types present in both keep the current ones."""
+        warnings.warn(
+            "Supplying a 'SimConfig' to QutipEmulator has been deprecated."
+            " Please instantiate with a 'NoiseModel' instead.",
+            DeprecationWarning,
+            stacklevel=2,
+        )
+        if not isinstance(config, SimConfig):
+            raise ValueError(f"Object {config} is not a valid `SimConfig`")
+        v = self._hamiltonian_data.interaction_type
+        not_supported = set(config.noise) - config.supported_noises[v]
+        if not_supported:
+            raise NotImplementedError(
+                f"Interaction mode '{v}' "
+                "does not support simulation of noise types: "
+                f"{', '.join(not_supported)}."
+            )
+        noise_model = config.to_noise_model()
+        current = self._hamiltonian_data.noise_model
+        old_noise_set = set(current.noise_types)
+        diff_noise_set = old_noise_set.union(noise_model.noise_types) - old_noise_set
+        from dataclasses import asdict
+
+        param_dict: dict[str, Any] = asdict(current)
+        for param in _find_relevant_params(diff_noise_set, noise_model.state_prep_error,
+                                           noise_model.amp_sigma, noise_model.laser_waist):
+            param_dict[param] = getattr(noise_model, param)
+        param_dict.pop("noise_types")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", DeprecationWarning)
+            self.set_config(SimConfig.from_noise_model(NoiseModel(**param_dict)))
+
+    def show_config(self, solver_options: bool = False) -> None:
+        """Prints the current configuration."""
+        print(self.config.__str__(solver_options))
+
+    def reset_config(self) -> None:
+        """Back to the default (noiseless) configuration."""
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", DeprecationWarning)
+            self.set_config(SimConfig())
+
+    def draw(self, draw_phase_area: bool = False, draw_phase_shifts: bool = False,
+             draw_phase_curve: bool = False, fig_name: str | None = None,
+             kwargs_savefig: dict = {}) -> None:
+        """Plots the samples the simulation uses, one panel per channel
+        (simulation.py:917-953; the reference delegates to pulser's sequence
+        drawer - this is the plain-matplotlib equivalent of its amplitude /
+        detuning curves)."""
+        import matplotlib.pyplot as plt
+
+        chans = self.samples_obj.channels
+        fig, axes = plt.subplots(len(chans), 1, sharex=True, squeeze=False,
+                                 figsize=(8, 2.2 * len(chans)))
+        t = np.arange(self.samples_obj.max_duration)
+        for ax, ch in zip(axes[:, 0], chans):
+            ax.plot(t, ch.amp, color="darkgreen", label="amplitude (rad/µs)")
+            ax.plot(t, ch.det, color="indigo", label="detuning (rad/µs)")
+            if draw_phase_curve and np.any(np.diff(ch.phase)):
+                ax.plot(t, ch.phase, color="gray", ls=":", label="phase (rad)")
+            ax.set_ylabel(ch.name)
+            ax.legend(loc="upper right", fontsize=7)
+        axes[-1, 0].set_xlabel("t (ns)")
+        if fig_name is not None:
+            plt.savefig(fig_name, **kwargs_savefig)
+        plt.show()
+
     @property
     def initial_state(self) -> QState:
         return self._initial_state
@@ -405,16 +579,19 @@ class QutipEmulator:
             raise ValueError(
                 f"Provided time (`time` = {time}) must be greater than or equal to 0."
             )
-        from .engine import Engine
+        from .engine import Engine, GeneralEngine
+        from .general import lower_general
 
         prob = dict(self._noiseless_problem if noiseless else self._current_problem)
         prob["collapse_ops"] = []
         n = prob["n_qudits"]
-        if n > 12:
-            raise ValueError("get_hamiltonian materialises a dense matrix; N <= 12 only.")
-        D = 2**n
+        D = len(prob["eigenbasis"]) ** n
+        if D > 4096:
+            raise ValueError("get_hamiltonian materialises a dense matrix; at most 4096 states.")
         cols = np.zeros((D, D), dtype=complex)
-        with Engine.from_problems([prob], mode="sesolve") as eng:
+        ctx = (Engine.from_problems([prob], mode="sesolve") if self._fast_path_ok(prob)
+               else GeneralEngine(lower_general(prob, mesolve=False)))
+        with ctx as eng:
             import torch
 
             for j in range(D):

@@ -308,3 +308,30 @@ def test_dmm_channel_trajectories_against_oracle():
     for b in range(5):
         for i in range(len(times)):
             assert np.max(np.abs(np.asarray(got[b].states[i])[:, 0] - extra["noisy_states"][b][i])) < 1e-7
+
+
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")
+def test_set_config_changes_the_hamiltonian():
+    """tests/pulser_simulation/test_simulation.py:828-866: doppler noise moves the
+    detuning entries, amplitude noise the drive entries; a 3-level (leakage)
+    configuration switches get_hamiltonian to the explicit-term engine."""
+    from pulser_amd import SimConfig
+    from test_host_logic import _two_atom_inputs
+
+    np.random.seed(123)
+    sim = QutipEmulator(_two_atom_inputs(), config=SimConfig(noise="SPAM"))
+    sim.reset_config()
+    clean = np.asarray(sim.get_hamiltonian(123))
+    sim.set_config(SimConfig(noise="doppler", temperature=10000))
+    noisy = np.asarray(sim.get_hamiltonian(123))
+    assert noisy[0, 0] != clean[0, 0] and noisy[3, 3] == clean[3, 3]
+    sim.set_config(SimConfig(noise="amplitude"))
+    noisy_amp = np.asarray(sim.get_hamiltonian(123))
+    assert noisy_amp[0, 0] == clean[0, 0] and noisy_amp[0, 1] != clean[0, 1]
+    z3 = np.diag([1.0, -1.0, 0.0]).astype(complex)
+    sim.set_config(SimConfig(noise=("leakage", "eff_noise"), eff_noise_opers=[z3], eff_noise_rates=[0.1]))
+    h3 = np.asarray(sim.get_hamiltonian(123))
+    assert h3.shape == (9, 9) and np.allclose(h3, h3.conj().T)
+    # (r, g, x) x (r, g, x): the 2-level block is the clean Hamiltonian
+    keep = [0, 1, 3, 4]
+    assert np.allclose(h3[np.ix_(keep, keep)], clean, atol=1e-12)

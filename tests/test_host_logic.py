@@ -655,3 +655,112 @@ def test_results_abstract_repr_and_aggregation_match_pulser_core():
     assert d["s"]["eigenstates"] == ["r", "g"] and d["s"]["amplitudes"]["gr"] == {"real": 0.0, "imag": 1.0}
     with pytest.raises(ValueError, match="from_state_amplitudes"):
         RydState(np.array([1.0, 0.0]), eigenstates=("r", "g"))._to_abstract_repr()
+
+
+# ------------------------------------------------------- SimConfig surface
+def _two_atom_inputs():
+    coords = np.array([[0.0, 0.0], [0.0, 5.0]])
+    n = 2500
+    return single_global_channel(coords, {"amp": np.full(n, np.pi), "det": np.zeros(n),
+                                          "phase": np.zeros(n)}, P.C6_LEVEL70, extended=False)
+
+
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")
+def test_simconfig_str_and_validation():
+    """tests/pulser_simulation/test_simconfig.py:40-100."""
+    config = SimConfig(noise=("SPAM", "doppler", "dephasing", "amplitude"), temperature=1000.0, runs=100)
+    assert config.temperature == 1000.0 * 1e-6  # stored in K
+    text = config.__str__(True)
+    assert "SPAM, doppler, dephasing, amplitude" in text
+    assert "1000.0µK" in text and "100" in text and "Solver Options" in text
+    assert config.to_noise_model().temperature == 1000.0
+    config = SimConfig(noise=("depolarizing", "relaxation", "doppler"))
+    assert config.temperature == pytest.approx(50.0e-6)
+    assert config.to_noise_model().temperature == 50.0
+    text = config.__str__(True)
+    assert f"Depolarizing rate: {config.depolarizing_rate}" in text
+    assert f"Relaxation rate: {config.relaxation_rate}" in text
+    assert config.spam_dict == {"eta": 0.005, "epsilon": 0.01, "epsilon_prime": 0.05}
+    # KEFF * sqrt(KB * T / MASS), hamiltonian_data.py:49-54, 122-129
+    assert config.doppler_sigma == pytest.approx(8.7 * np.sqrt(1.38e-23 * 50e-6 / 1.45e-25))
+    assert not config.with_leakage and "dmm_sigma" in config.supported_noises["ising"]
+    with pytest.raises(ValueError, match="is not a valid noise type."):
+        SimConfig(noise="bad_noise")
+    with pytest.raises(ValueError, match="SPAM parameter"):
+        SimConfig(eta=-1.0)
+    with pytest.raises(TypeError, match="'temperature' must be a float"):
+        SimConfig(temperature="0.0")
+    with pytest.raises(ValueError, match="must be equal"):
+        SimConfig(noise="eff_noise", eff_noise_opers=[np.eye(2)], eff_noise_rates=[])
+
+
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")
+def test_emulator_simconfig_surface(capsys):
+    """tests/pulser_simulation/test_simulation.py:828-891 and :1315-1395 (the parts
+    that do not need the solver): set / add / reset / show config."""
+    z3 = np.diag([1.0, -1.0, 0.0]).astype(complex)
+    np.random.seed(123)
+    with pytest.warns(DeprecationWarning, match="Supplying a 'SimConfig' to QutipEmulator"):
+        sim = QutipEmulator(_two_atom_inputs(), config=SimConfig(noise="SPAM"))
+    sim.reset_config()
+    assert sim.config == SimConfig()
+    sim.show_config()
+    assert "Number of runs:" in capsys.readouterr().out
+    with pytest.raises(ValueError, match="not a valid"):
+        sim.set_config("bad_config")
+    new_cfg = SimConfig(noise="doppler", temperature=10000)
+    with pytest.warns(DeprecationWarning, match="Supplying a 'SimConfig' to QutipEmulator"):
+        sim.set_config(new_cfg)
+    assert sim.config == new_cfg
+    ground2 = np.zeros(4); ground2[3] = 1
+    assert np.array_equal(np.asarray(sim.initial_state)[:, 0], ground2)
+    # in the ground state: the initial state follows the new dimension silently
+    sim.set_config(SimConfig(noise=("leakage", "eff_noise"), eff_noise_opers=[z3], eff_noise_rates=[0.1]))
+    assert sim.dim == 3
+    ground3 = np.zeros(9); ground3[4] = 1  # |g g> with (r, g, x) ordering
+    assert np.array_equal(np.asarray(sim.initial_state)[:, 0], ground3)
+    # otherwise it is reset to all-ground with a warning
+    other = np.zeros(9); other[0] = 1
+    sim.set_initial_state(other)
+    with pytest.warns(UserWarning, match="Current initial state's dimension does not match new dim"):
+        sim.set_config(SimConfig(noise="SPAM", eta=0.5))
+    assert np.array_equal(np.asarray(sim.initial_state)[:, 0], ground2)
+    # add_config (test_simulation.py:1315-1395)
+    with pytest.raises(ValueError, match="is not a valid"):
+        sim.add_config("bad_cfg")
+    sim.add_config(SimConfig(noise=("SPAM", "doppler", "eff_noise"),
+                             eff_noise_opers=[np.eye(2), np.array([[0, 1.0], [1.0, 0]])],
+                             eff_noise_rates=[0.4, 0.6], temperature=20000))
+    assert {"doppler", "SPAM", "eff_noise"} <= set(sim.config.noise)
+    assert sim.config.eta == 0.5 and sim.config.temperature == 20000.0e-6
+    sim.set_config(SimConfig(noise="doppler", laser_waist=175.0))
+    sim.add_config(SimConfig(noise=("SPAM", "amplitude", "dephasing"), laser_waist=172.0, amp_sigma=1e-2))
+    assert {"amplitude", "dephasing", "SPAM"} <= set(sim.config.noise)
+    assert sim.config.laser_waist == 172.0 and sim.config.amp_sigma == 1e-2
+    sim.set_config(SimConfig(noise="SPAM", eta=0.5))
+    sim.add_config(SimConfig(noise="depolarizing"))
+    assert "depolarizing" in sim.config.noise
+    with pytest.raises(NotImplementedError, match="does not support simulation of noise types"):
+        xy = SequenceInputs.from_dict(load_fixture("noisy_xy_0.npz")[0]["inputs"])
+        QutipEmulator(xy).set_config(SimConfig(noise="doppler"))
+
+
+def test_sampled_result_sampling_errors_and_plots(tmp_path):
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    from pulser_amd.results import NoisyResults, SampledResult
+
+    res = SampledResult(("q0", "q1"), "ground-rydberg", Counter({"00": 60, "11": 40}))
+    assert res.sampling_errors == {"00": pytest.approx(np.sqrt(0.6 * 0.4 / 100)),
+                                   "11": pytest.approx(np.sqrt(0.6 * 0.4 / 100))}
+    times = np.array([0.0, 1.0])
+    noisy = NoisyResults([res, res], 2, "ground-rydberg", times, 100)
+    op = np.diag([1.0, 0.0, 0.0, 0.0])
+    noisy.plot(op, label="x")
+    noisy.plot(op, error_bars=False)
+    plt.savefig(tmp_path / "p.png")
+    plt.close("all")
+    emu = QutipEmulator(_two_atom_inputs())
+    emu.draw(fig_name=str(tmp_path / "seq.png"))
+    assert (tmp_path / "seq.png").exists()
