@@ -330,6 +330,59 @@ def gen_noises_all():
 
 
 # ---------------------------------------------------------------------------
+# 2b'. test_simulation.py:889-918 (test_noise): CCZ sequence, SPAM with eta = 0.9,
+#      15 trajectories x 5 samples, all-basis sesolve, seed 3
+# ---------------------------------------------------------------------------
+def gen_noise_spam_all():
+    from collections import Counter
+    from pulser_amd.pulser_adapter import sequence_inputs_from_pulser, problem_from_trajectory
+
+    golden = {"000": 824, "100": 41, "101": 57, "001": 63, "010": 15}
+    np.random.seed(3)
+    seq = seq_all()
+    nm = NoiseModel(samples_per_run=5, p_false_pos=0.01, p_false_neg=0.05, state_prep_error=0.9)
+    samples = sampler.sample(seq, extended_duration=seq.get_duration())
+    inputs = sequence_inputs_from_pulser(samples, seq.register, seq.device)
+    T = samples.max_duration
+    ext = samples.extend_duration(T + 1)
+    hd = HamiltonianData(ext, seq.register, seq.device, nm, 15)
+    HamiltonianData(ext, seq.register, seq.device, NoiseModel(), 1)  # hidden noiseless draw
+    rate = 0.01
+    tlist = qp.sampling_times(T + 1, rate)
+    eval_times = np.union1d(tlist, [0.0, T * 1e-3])
+    opts = qp.default_options(channel_amp_det(ext), T)
+    total = [Counter() for _ in eval_times]
+    lookups, reps_list, bad_list = [], [], []
+    idx = osamp.index_from_time(eval_times, eval_times[-1])
+    for traj, noisy, reps in hd.noisy_samples:
+        prob = problem_from_trajectory(hd, traj, noisy, reps, rate)
+        ham = qp.build_hamiltonian(prob)
+        psi0 = qp.all_ground_state(3, prob["eigenbasis"])
+        states = qp.sesolve(ham, psi0, eval_times, **opts)
+        for i, t in enumerate(eval_times):
+            total[i] += osamp.sample_state(
+                states, eval_times, t, 5 * reps, 3, prob["eigenbasis"], "digital", False,
+                {"epsilon": 0.01, "epsilon_prime": 0.05})
+        lookups.append(states[idx]); reps_list.append(reps); bad_list.append(prob["bad_atoms"])
+    w = np.zeros(8)
+    n_meas = sum(total[idx].values())
+    for bs, c in total[idx].items():
+        w[int(bs, 2)] = c / n_meas
+    w = w / sum(w)
+    final = osamp.get_samples(w, 1000, 3)
+    ok = dict(final) == golden
+    print(f"noise_spam_all: {'OK' if ok else 'MISMATCH'} {dict(final)} reps={reps_list}")
+    P.save_problem(
+        os.path.join(HERE, "noise_spam_all.npz"), {"inputs": inputs.to_dict()},
+        seed=3, reference_golden_counter=golden,
+        reference_cite="tests/pulser_simulation/test_simulation.py:889-923 (test_noise)",
+        eval_times=eval_times, traj_reps=np.array(reps_list), traj_bad_atoms=np.array(bad_list),
+        oracle_traj_lookup_states=np.stack(lookups),
+        oracle_total_final_counter=dict(total[idx]),
+    )
+
+
+# ---------------------------------------------------------------------------
 # 2c. test_simulation.py:1536-1690 (XY mode, SLM mask, SPAM trajectories, mesolve)
 # ---------------------------------------------------------------------------
 
@@ -761,6 +814,8 @@ if __name__ == "__main__":
         gen_cfg3_small(2, 3)
     if "cfg4" in which:
         gen_cfg4()
+    if "spam_all" in which:
+        gen_noise_spam_all()
     if "dmm" in which:
         gen_dmm()
     if "results" in which:

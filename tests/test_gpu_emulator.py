@@ -335,3 +335,17 @@ def test_set_config_changes_the_hamiltonian():
     # (r, g, x) x (r, g, x): the 2-level block is the clean Hamiltonian
     keep = [0, 1, 3, 4]
     assert np.allclose(h3[np.ix_(keep, keep)], clean, atol=1e-12)
+
+
+def test_reference_golden_counter_test_noise_end_to_end(capsys):
+    """test_simulation.py:889-923 with the real solver on the GPU (3-level
+    "all" basis, 15 SPAM trajectories, seed 3)."""
+    from test_host_logic import _spam_all_emulator
+
+    emu, extra = _spam_all_emulator()
+    with pytest.warns(DeprecationWarning):
+        r = emu.run(print_progress=True)
+    assert capsys.readouterr().out.rstrip("\n").split("\n") == [
+        "Emulating Trajectories [1 - 13]/15", "Emulating Trajectory 14/15",
+        "Emulating Trajectory 15/15"]
+    assert r.sample_final_state() == Counter(extra["reference_golden_counter"])

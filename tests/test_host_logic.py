@@ -764,3 +764,98 @@ def test_sampled_result_sampling_errors_and_plots(tmp_path):
     emu = QutipEmulator(_two_atom_inputs())
     emu.draw(fig_name=str(tmp_path / "seq.png"))
     assert (tmp_path / "seq.png").exists()
+
+
+# ------------------------------------- reference goldens of the detuning noise
+def _three_channel_inputs(duration=10):
+    """The sequence of test_simulation.py:2269-2290: a global Rydberg channel with
+    two pulses and two local Raman channels (q0, q1), all amplitudes zero."""
+    z = np.zeros(2 * duration)
+    coords = np.array([[0.0, 0.0], [10.0, 10.0]])
+    chans = [
+        ChannelInput("ch0", "Global", "ground-rydberg", z, z, z,
+                     [Slot(0, duration, (0, 1)), Slot(duration, 2 * duration, (0, 1))]),
+        ChannelInput("ch1", "Local", "digital", z, z, z, [Slot(0, duration, (0,))]),
+        ChannelInput("ch2", "Local", "digital", z, z, z, [Slot(0, duration, (1,))]),
+    ]
+    return SequenceInputs(coords, ("q0", "q1"), chans, P.C6_LEVEL70)
+
+
+def test_detuning_sigma_noise_reference_golden():
+    """tests/pulser_simulation/test_simulation.py:2269-2310 (seed 1337)."""
+    duration = 10
+    np.random.seed(1337)
+    sim = QutipEmulator(_three_channel_inputs(duration), noise_model=NoiseModel(detuning_sigma=0.1),
+                        n_trajectories=1)
+    s = sim._current_problem["samples"]
+    assert s["Global"] == {}
+    ryd, dig = s["Local"]["ground-rydberg"], s["Local"]["digital"]
+    assert np.allclose(ryd[0]["det"], [-0.04902824] * (2 * duration) + [0.0])
+    assert np.allclose(ryd[1]["det"], [-0.04902824] * (2 * duration) + [0.0])
+    assert np.allclose(dig[0]["det"], [-0.17550787] * duration + [0.0] * (duration + 1))
+    assert np.allclose(dig[1]["det"], [-0.20112646] * duration + [0.0] * (duration + 1))
+
+
+def test_detuning_hf_noise_reference_golden():
+    """tests/pulser_simulation/test_simulation.py:2313-2413 (seed 1337)."""
+    np.random.seed(1337)
+    nm = NoiseModel(detuning_hf_psd=2.0 * np.pi * np.array([1, 2, 3]),
+                    detuning_hf_omegas=2.0 * np.pi * np.array([4, 5, 6]))
+    sim = QutipEmulator(_three_channel_inputs(10), noise_model=nm, n_trajectories=1)
+    s = sim._current_problem["samples"]
+    ryd, dig = s["Local"]["ground-rydberg"], s["Local"]["digital"]
+    rydberg_expected = [
+        -17.09974803, -17.62331808, -18.12297186, -18.59816646, -19.04839245, -19.47317443,
+        -19.87207157, -20.24467805, -20.59062348, -20.9095733, -21.20122904, -21.46532868,
+        -21.70164676, -21.90999467, -22.09022068, -22.24221006, -22.36588509, -22.46120504,
+        -22.52816608, -22.56680119, 0.0]
+    assert np.allclose(ryd[0]["det"], rydberg_expected)
+    assert np.allclose(ryd[1]["det"], rydberg_expected)
+    assert np.allclose(dig[0]["det"], [
+        -20.70981369, -20.9854774, -21.23382708, -21.4546608, -21.64781307, -21.81315499,
+        -21.95059426, -22.06007519, -22.1415786, -22.19512177] + [0.0] * 11)
+    assert np.allclose(dig[1]["det"], [
+        -20.13322478, -19.96053451, -19.76371088, -19.54313969, -19.29923617, -19.03244438,
+        -18.74323637, -18.43211151, -18.09959565, -17.74624031] + [0.0] * 11)
+
+
+def _spam_all_emulator():
+    """test_simulation.py:889-903 (test_noise): CCZ sequence, eta = 0.9, seed 3."""
+    prob, extra = load_fixture("noise_spam_all.npz")
+    inputs = SequenceInputs.from_dict(prob["inputs"])
+    nm = NoiseModel(samples_per_run=5, p_false_pos=0.01, p_false_neg=0.05, state_prep_error=0.9)
+    np.random.seed(int(extra["seed"]))
+    emu = QutipEmulator(inputs, sampling_rate=0.01, noise_model=nm, n_trajectories=15)
+    return emu, extra
+
+
+def test_emulator_golden_counter_spam_trajectories_all_basis(monkeypatch, capsys):
+    """The reference's ``test_noise`` golden (test_simulation.py:904-923): 15 SPAM
+    trajectories deduplicated to reps [13, 1, 1], 3-level "all" basis measured in
+    the digital basis, per-time sampling + flips, final resampling; solver stubbed."""
+    emu, extra = _spam_all_emulator()
+    trajs = emu._hamiltonian_data.noise_trajectories
+    assert [t.reps for t in trajs] == list(extra["traj_reps"]) == [13, 1, 1]
+    assert np.array_equal(np.array([t.bad_atoms for t in trajs]), extra["traj_bad_atoms"])
+    assert emu.basis_name == "all" and emu._meas_basis == "digital"
+    assert np.array_equal(emu.evaluation_times, extra["eval_times"])
+    assert emu._current_problem["samples"]["Global"] == {}  # SPAM -> everything local
+    bad = trajs[0].bad_atoms
+    assert any(bad)
+    for basis in ("ground-rydberg", "digital"):
+        for q in np.nonzero(bad)[0]:
+            for qty in ("amp", "det", "phase"):
+                assert np.all(emu._current_problem["samples"]["Local"][basis][int(q)][qty] == 0.0)
+    monkeypatch.setattr(emu, "_solve_batch",
+                        _FakeSolvePerTrajectory(emu, extra["oracle_traj_lookup_states"]))
+    with pytest.warns(DeprecationWarning):
+        r = emu.run(print_progress=True)
+    assert capsys.readouterr().out.rstrip("\n").split("\n") == [
+        "Emulating Trajectories [1 - 13]/15", "Emulating Trajectory 14/15",
+        "Emulating Trajectory 15/15"]
+    idx = r._get_index_from_time(emu._eval_times_array[-1])
+    assert dict(r[idx].bitstring_counts) == extra["oracle_total_final_counter"]
+    assert r.sample_final_state() == Counter(extra["reference_golden_counter"])
+    with pytest.raises(NotImplementedError, match="Cannot include"):
+        QutipEmulator(SequenceInputs.from_dict(load_fixture("noise_spam_all.npz")[0]["inputs"]),
+                      noise_model=NoiseModel(depolarizing_rate=0.05))
