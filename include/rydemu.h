@@ -211,8 +211,8 @@ int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr, con
                          const double* val /* complex128[nnz] */, int32_t series, int32_t conj,
                          double scale_re, double scale_im, double row_norm);
 
-/* Test/bench hook (bit mask): 1 = disable the persistent small-N kernel, 2 = use
- * the generic kernel instead of the opt-in k_apply12, 4 = disable the 2^14
+/* Test/bench hook (bit mask): 1 = disable the persistent small-N kernel, 2 =
+ * reserved (accepted, ignored), 4 = disable the 2^14
  * register-tile kernel and the Hermitian mesolve path, 8 = force them even when
  * the launch has too few tiles to fill the GPU.  Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);

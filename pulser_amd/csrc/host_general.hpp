@@ -1,0 +1,139 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+// ---------------------------------------------------------------------------
+// General path (explicit CSR terms) - host side
+// ---------------------------------------------------------------------------
+extern "C" int ryd_general_create(const ryd_general_config* cfg, ryd_handle** out) {
+  if (!cfg || !out) return fail(RYD_ERR_INVALID, "null argument");
+  if (cfg->abi_version != RYD_ABI_VERSION)
+    return fail(RYD_ERR_INVALID, "ABI version mismatch: caller %d, library %d", cfg->abi_version,
+                RYD_ABI_VERSION);
+  if (cfg->dim < 1 || cfg->dim > ((int64_t)1 << 26))
+    return fail(RYD_ERR_INVALID, "dim=%lld out of range", (long long)cfg->dim);
+  if (cfg->batch < 1 || cfg->batch > 65535) return fail(RYD_ERR_INVALID, "batch out of range");
+  HIPCHK(hipSetDevice(cfg->device));
+  ryd_handle* h = new ryd_handle();
+  h->general = true;
+  h->cfg.abi_version = cfg->abi_version;
+  h->cfg.device = cfg->device;
+  h->cfg.mode = RYD_SESOLVE;
+  h->cfg.batch = cfg->batch;
+  h->B = cfg->batch;
+  h->dim = (size_t)cfg->dim;
+  h->N = 0;
+  h->nb = 0;
+  const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  hipError_t e;
+  if ((e = hipMalloc((void**)&h->wA, bytes)) != hipSuccess ||
+      (e = hipMalloc((void**)&h->wB, bytes)) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_tcoef, MAX_GEN_TERMS * sizeof(cplx))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_terms_dev, MAX_GEN_TERMS * sizeof(GenTermDev))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_series_dev, MAX_GEN_TERMS * sizeof(int))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_conj_dev, MAX_GEN_TERMS * sizeof(int))) != hipSuccess ||
+      (e = hipMalloc((void**)&h->gen_scale_dev, MAX_GEN_TERMS * sizeof(cplx))) != hipSuccess) {
+    ryd_destroy(h);
+    return fail(RYD_ERR_HIP, "hipMalloc (general path) failed: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return RYD_OK;
+}
+
+extern "C" int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr,
+                                    const int32_t* col, const double* val, int32_t series,
+                                    int32_t conj, double scale_re, double scale_im,
+                                    double row_norm) {
+  if (!h || !h->general) return fail(RYD_ERR_INVALID, "not a general-path handle");
+  if (!row_ptr || (nnz > 0 && (!col || !val))) return fail(RYD_ERR_INVALID, "null argument");
+  if ((int)h->gen_host.size() >= MAX_GEN_TERMS)
+    return fail(RYD_ERR_INVALID, "too many terms (max %d)", MAX_GEN_TERMS);
+  if (series < -1 || series >= std::max(h->n_series, 1) || (series >= 0 && h->n_series == 0))
+    return fail(RYD_ERR_INVALID, "series index %d out of range (call ryd_set_series first)", series);
+  if (row_ptr[0] != 0 || row_ptr[h->dim] != nnz)
+    return fail(RYD_ERR_INVALID, "row_ptr does not describe %lld non-zeros", (long long)nnz);
+  for (int64_t e = 0; e < nnz; ++e)
+    if (col[e] < 0 || (size_t)col[e] >= h->dim)
+      return fail(RYD_ERR_INVALID, "column index out of range at entry %lld", (long long)e);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  GenTermHost t;
+  t.series = series;
+  t.conj = conj;
+  t.scale = std::complex<double>(scale_re, scale_im);
+  t.row_norm = row_norm;
+  HIPCHK(hipMalloc((void**)&t.dev.row_ptr, (h->dim + 1) * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t.dev.col, std::max<int64_t>(nnz, 1) * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t.dev.val, std::max<int64_t>(nnz, 1) * sizeof(cplx)));
+  HIPCHK(hipMemcpy((void*)t.dev.row_ptr, row_ptr, (h->dim + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    HIPCHK(hipMemcpy((void*)t.dev.col, col, nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy((void*)t.dev.val, val, nnz * sizeof(cplx), hipMemcpyHostToDevice));
+  }
+  h->gen_host.push_back(t);
+  const int n = (int)h->gen_host.size();
+  std::vector<GenTermDev> devs(n);
+  std::vector<int> ser(n), cj(n);
+  std::vector<cplx> sc(n);
+  for (int i = 0; i < n; ++i) {
+    devs[i] = h->gen_host[i].dev;
+    ser[i] = h->gen_host[i].series;
+    cj[i] = h->gen_host[i].conj;
+    sc[i] = make_double2(h->gen_host[i].scale.real(), h->gen_host[i].scale.imag());
+  }
+  HIPCHK(hipMemcpy(h->gen_terms_dev, devs.data(), n * sizeof(GenTermDev), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->gen_series_dev, ser.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->gen_conj_dev, cj.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->gen_scale_dev, sc.data(), n * sizeof(cplx), hipMemcpyHostToDevice));
+  h->bounds_valid = false;
+  return RYD_OK;
+}
+
+static void compute_bounds_general(ryd_handle* h) {
+  const int n_int = h->n_knots - 1;
+  h->bd_drive.assign(n_int, 0.0);
+  h->bd_pos.assign(n_int, 0.0);
+  h->bd_neg.assign(n_int, 0.0);
+  h->bd_curv.assign(n_int, 0.0);
+  for (const GenTermHost& t : h->gen_host) {
+    const double w = std::abs(t.scale) * t.row_norm;
+    for (int i = 0; i < n_int; ++i) {
+      if (t.series >= 0) {
+        h->bd_drive[i] += w * h->s_abs[(size_t)t.series * n_int + i];
+        h->bd_curv[i] += w * h->s_curv[(size_t)t.series * n_int + i];
+      } else {
+        h->bd_drive[i] += w;
+      }
+    }
+  }
+  h->e0_min = h->e0_max = 0.0;
+  h->uniform_real_drive = false;
+  h->bounds_valid = true;
+}
+
+static int apply_general(ryd_handle* h, const MixPoint& m, const cplx* in, const cplx* base,
+                         cplx* out, double scale, hipStream_t st) {
+  const int n = (int)h->gen_host.size();
+  if (n == 0) return fail(RYD_ERR_STATE, "no terms: call ryd_general_add_term first");
+  GenArgs A;
+  A.in = in;
+  A.base = base;
+  A.out = out;
+  A.tcoef = h->gen_tcoef;
+  A.terms = h->gen_terms_dev;
+  A.dim = (long long)h->dim;
+  A.n_terms = n;
+  A.scale = scale;
+  dim3 grid((unsigned)((h->dim + 255) / 256), h->B);
+  hipLaunchKernelGGL(k_gen_apply, grid, dim3(256), 0, st, A);
+  HIPCHK(hipGetLastError());
+  h->stats.n_launches++;
+  h->stats.n_applications++;
+  (void)m;
+  return RYD_OK;
+}
+
+static int launch_eval_general(ryd_handle* h, const MixPoint& m, hipStream_t st) {
+  const int n = (int)h->gen_host.size();
+  hipLaunchKernelGGL(k_gen_coefs, dim3((n + 63) / 64), dim3(64), 0, st, h->pp_dev, h->n_knots - 1,
+                     h->gen_series_dev, h->gen_conj_dev, h->gen_scale_dev, n, m.idx1, m.u1, m.w1,
+                     m.u2, m.w2, h->gen_tcoef);
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
+}

@@ -1,0 +1,535 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct Pass {
+  Segs tile, outer;
+  int T = 0;
+  int n_outer_bits = 0;
+  std::vector<int> flip_q;
+  std::vector<std::pair<int, int>> dbl;  // (qb, qa)
+  bool include_diag = false;
+  bool use14 = false;  // pass 0 on 2^14 register tiles (k_apply14)
+};
+
+struct GenTermHost {
+  GenTermDev dev{nullptr, nullptr, nullptr};
+  int series = -1, conj = 0;
+  std::complex<double> scale{1.0, 0.0};
+  double row_norm = 0.0;
+};
+
+struct ryd_handle {
+  ryd_config cfg{};
+  int N = 0, nb = 0, B = 1, T = 12;
+  size_t dim = 0;  // elements per state (2^nb)
+  // tables
+  int n_series = 0, n_knots = 0;
+  std::vector<double> tknots;
+  std::vector<std::complex<double>> pp_host;  // [series][int][4]
+  std::vector<double> s_abs, s_pos, s_neg;    // per series, per interval bounds
+  std::vector<double> s_curv;                 // |quadratic| dt^2 + |cubic| dt^3 per interval
+  cplx* pp_dev = nullptr;
+  std::vector<ryd_qdesc> desc_host;
+  ryd_qdesc* desc_dev = nullptr;
+  std::vector<double> bd_drive, bd_pos, bd_neg;  // per interval, max over batch
+  std::vector<double> bd_curv;                   // per interval: non-linearity of H(t)
+  bool bounds_valid = false;
+  double* e0_dev = nullptr;
+  int e0_mats = 0;
+  double e0_min = 0, e0_max = 0;
+  double* coefs_dev = nullptr;
+  cplx Sd[4]{}, J[4]{};
+  double diss_norm = 0.0;
+  bool has_dbl = false;
+  // work vectors
+  cplx *wA = nullptr, *wB = nullptr, *kbuf = nullptr;
+  std::vector<Pass> passes;
+  bool passes_valid = false;
+  StepDesc* sched_dev = nullptr;
+  size_t sched_cap = 0;
+  // general path (explicit CSR terms)
+  bool general = false;
+  std::vector<GenTermHost> gen_host;
+  cplx* gen_tcoef = nullptr;
+  GenTermDev* gen_terms_dev = nullptr;
+  int* gen_series_dev = nullptr;
+  int* gen_conj_dev = nullptr;
+  cplx* gen_scale_dev = nullptr;
+  bool auto_tile = true;       // tile_bits == 0: tile size chosen by the library
+  bool force_generic = false;
+  bool no_tile14 = false;      // test hook: disable k_apply14 / the Hermitian mesolve path
+  bool force_tile14 = false;   // test hook: use them even when too few tiles fill the GPU
+  bool drive_real = false;     // every drive series is real-valued
+  bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
+  // Monte-Carlo wavefunction mode (sesolve handles with ryd_set_collapse)
+  bool mc = false;         // collapse operators set: H_eff carries -(i/2) sum C^dag C
+  bool mc_active = false;  // inside ryd_mc_solve: jump bookkeeping after every step
+  int mc_n_ops = 0;
+  double mc_a = 0.0, mc_b = 0.0;  // real diagonal of G_eff: mc_a + mc_b * popc(index)
+  void* mc_pool = nullptr;        // one allocation behind McState
+  McState mcs{};
+  unsigned long long* mc_seeds_dev = nullptr;
+  cplx* mc_ops_dev = nullptr;
+  int mc_slot = 0;
+  ryd_stats stats{};
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+  double timing_ms = 0;
+  int64_t timing_launches = 0;
+};
+
+static bool hermitian_path(const ryd_handle* h);
+
+static Segs make_segs(std::vector<std::pair<int, int>> v) {
+  Segs s;
+  for (int i = 0; i < 3; ++i) {
+    s.lo[i] = i < (int)v.size() ? v[i].first : 0;
+    s.len[i] = i < (int)v.size() ? v[i].second : 0;
+  }
+  return s;
+}
+
+// Build a pass whose tile consists of the bit ranges in `tile` (ascending,
+// disjoint); the outer segments are the complement within [0, nb).
+static Pass make_pass(int nb, std::vector<std::pair<int, int>> tile) {
+  Pass p;
+  std::vector<std::pair<int, int>> t2, outer;
+  for (auto& s : tile)
+    if (s.second > 0) t2.push_back(s);
+  // merge adjacent ranges
+  std::vector<std::pair<int, int>> merged;
+  for (auto& s : t2) {
+    if (!merged.empty() && merged.back().first + merged.back().second == s.first)
+      merged.back().second += s.second;
+    else
+      merged.push_back(s);
+  }
+  int pos = 0;
+  for (auto& s : merged) {
+    if (s.first > pos) outer.push_back({pos, s.first - pos});
+    pos = s.first + s.second;
+    p.T += s.second;
+  }
+  if (pos < nb) outer.push_back({pos, nb - pos});
+  // at most 3 outer segments by construction (<= 3 tile segments, first at 0)
+  p.tile = make_segs(merged);
+  p.outer = make_segs(outer);
+  p.n_outer_bits = nb - p.T;
+  return p;
+}
+
+// tile-local index of global bit p (or -1)
+static int local_of(const Segs& s, int p) {
+  int off = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (p >= s.lo[i] && p < s.lo[i] + s.len[i]) return off + p - s.lo[i];
+    off += s.len[i];
+  }
+  return -1;
+}
+
+// A 2^14 register tile keeps one whole CU busy per 16384 amplitudes; it only
+// pays when the launch has enough tiles for the 256 CUs (measured: 64 tiles of a
+// 20-atom ket are 1.4x slower than 256 LDS tiles of 2^12).
+static bool tile14_pays(const ryd_handle* h) {
+  if (h->no_tile14 || h->nb < 14) return false;
+  if (h->force_tile14) return true;
+  const long long tiles = (long long)h->B << (h->nb - 14);
+  if (tiles >= 512) return true;
+  // fewer tiles: only when the bigger tile saves a whole pass (e.g. 14-atom kets)
+  const int p12 = 1 + (std::max(h->nb - 12, 0) + 7) / 8, p14 = 1 + (h->nb - 14 + 7) / 8;
+  // measured on 14-atom kets: 16 tiles lose to two tiled passes (44 vs 58 sim-us/s),
+  // 64 tiles win (136 vs 103), 256 tiles win 2.2x
+  return p14 < p12 && tiles >= 48;
+}
+
+static void plan_passes(ryd_handle* h) {
+  h->passes.clear();
+  const int nb = h->nb, N = h->N, T = std::min(h->T, nb);
+  const int C = 4;  // run bits (256 B contiguous) kept in every tile
+  if (h->cfg.mode == RYD_MESOLVE && h->has_dbl) {
+    // pair passes: both bits of each atom in the same tile
+    int done = 0;  // atoms (counted from the low bit end) handled so far
+    bool first = true;
+    while (done < N) {
+      int g;
+      Pass p;
+      if (first) {
+        g = std::min(N, std::max(1, T / 2));
+        p = make_pass(nb, {{0, g}, {N, g}});
+      } else {
+        const int c = std::max(0, std::min(std::min(C, done), T - 2));
+        g = std::min(N - done, std::max(1, (T - c) / 2));
+        p = make_pass(nb, {{0, c}, {done, g}, {N + done, g}});
+      }
+      for (int j = 0; j < g; ++j) {
+        const int pb = done + j, pa = N + done + j;
+        const int qb = local_of(p.tile, pb), qa = local_of(p.tile, pa);
+        p.flip_q.push_back(qb);
+        p.flip_q.push_back(qa);
+        p.dbl.push_back({qb, qa});
+      }
+      p.include_diag = first;
+      h->passes.push_back(p);
+      done += std::max(g, 1);
+      first = false;
+    }
+  } else {
+    int done = 0;
+    bool first = true;
+    while (done < nb) {
+      int g;
+      Pass p;
+      if (first) {
+        g = T;
+        if (h->auto_tile && nb >= 14 && tile14_pays(h)) {
+          g = 14;
+          p = make_pass(nb, {{0, g}});
+          p.use14 = true;
+        } else {
+          p = make_pass(nb, {{0, g}});
+        }
+      } else {
+        // the remaining bits are spread evenly over the passes they need, and
+        // the rest of each tile is filled with contiguous run bits (longer
+        // coalesced runs, full-size tiles) as long as >= 1024 workgroups remain
+        const int cmin = std::max(0, std::min(std::min(C, done), T - 1));
+        const int cap = std::max(1, T - cmin);
+        const int left = nb - done;
+        const int k = (left + cap - 1) / cap;
+        g = std::max(1, (left + k - 1) / k);
+        int c = cmin;
+        int logB = 0;
+        while ((1 << (logB + 1)) <= h->B) ++logB;
+        while (c + g < T && c < done && (nb - (c + 1 + g)) + logB >= 10) ++c;
+        p = make_pass(nb, {{0, c}, {done, g}});
+      }
+      for (int j = 0; j < g; ++j) p.flip_q.push_back(local_of(p.tile, done + j));
+      p.include_diag = first;
+      h->passes.push_back(p);
+      done += std::max(g, 1);
+      first = false;
+    }
+  }
+  h->stats.passes = (int)h->passes.size();
+  h->passes_valid = true;
+}
+
+extern "C" const char* ryd_last_error(void) { return g_err.c_str(); }
+extern "C" int ryd_abi_version(void) { return RYD_ABI_VERSION; }
+
+extern "C" int ryd_create(const ryd_config* cfg, ryd_handle** out) {
+  if (!cfg || !out) return fail(RYD_ERR_INVALID, "null argument");
+  if (cfg->abi_version != RYD_ABI_VERSION)
+    return fail(RYD_ERR_INVALID, "ABI version mismatch: caller %d, library %d",
+                cfg->abi_version, RYD_ABI_VERSION);
+  if (cfg->mode != RYD_SESOLVE && cfg->mode != RYD_MESOLVE)
+    return fail(RYD_ERR_INVALID, "unknown mode %d", cfg->mode);
+  const int nb = cfg->mode == RYD_MESOLVE ? 2 * cfg->n_qubits : cfg->n_qubits;
+  if (cfg->n_qubits < 1 || nb > RYD_MAX_QUBITS)
+    return fail(RYD_ERR_INVALID, "n_qubits=%d out of range for mode %d (index bits %d > %d)",
+                cfg->n_qubits, cfg->mode, nb, RYD_MAX_QUBITS);
+  if (cfg->batch < 1 || cfg->batch > 65535)
+    return fail(RYD_ERR_INVALID, "batch=%d out of range [1, 65535]", cfg->batch);
+  int T = cfg->tile_bits ? cfg->tile_bits : 12;
+  if (T < 2 || T > 13) return fail(RYD_ERR_INVALID, "tile_bits=%d out of range [2, 13]", T);
+  HIPCHK(hipSetDevice(cfg->device));
+  ryd_handle* h = new ryd_handle();
+  h->cfg = *cfg;
+  h->N = cfg->n_qubits;
+  h->nb = nb;
+  h->B = cfg->batch;
+  h->T = T;
+  h->auto_tile = cfg->tile_bits == 0;
+  if (h->auto_tile) {
+    // Small states: the fewest passes first, then enough tiles to occupy the
+    // 256 CUs (a 2^12 tile keeps one CU busy for ~8 us; a 14-atom ket would
+    // run on 4 CUs).  passes(T) = 1 + ceil((nb - T) / (T - 4)).
+    auto passes = [&](int t) { return nb <= t ? 1 : 1 + (nb - t + (t - 5)) / (t - 4); };
+    int best = 12;
+    for (int t = 12; t >= 8; --t) {
+      if (passes(t) > passes(12)) break;
+      best = t;
+      if (((long long)cfg->batch << std::max(nb - t, 0)) >= 256) break;
+    }
+    h->T = best;
+  }
+  h->dim = (size_t)1 << nb;
+  const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  hipError_t e;
+  if ((e = hipMalloc((void**)&h->wA, bytes)) != hipSuccess ||
+      (e = hipMalloc((void**)&h->wB, bytes)) != hipSuccess ||
+      (e = hipMalloc((void**)&h->kbuf, bytes)) != hipSuccess ||
+      (e = hipMalloc((void**)&h->coefs_dev, (size_t)h->B * h->N * 4 * sizeof(double))) != hipSuccess) {
+    ryd_destroy(h);
+    return fail(RYD_ERR_HIP, "hipMalloc of work vectors (%zu B each) failed: %s", bytes,
+                hipGetErrorString(e));
+  }
+  // default: no interaction, no dissipator
+  h->e0_mats = 1;
+  if ((e = hipMalloc((void**)&h->e0_dev, ((size_t)1 << h->N) * sizeof(double))) != hipSuccess ||
+      (e = hipMemset(h->e0_dev, 0, ((size_t)1 << h->N) * sizeof(double))) != hipSuccess) {
+    ryd_destroy(h);
+    return fail(RYD_ERR_HIP, "hipMalloc e0 failed: %s", hipGetErrorString(e));
+  }
+  for (int i = 0; i < 4; ++i) h->Sd[i] = h->J[i] = make_double2(0, 0);
+  // the 2^12-amplitude tile needs 64 KiB + tables of dynamic LDS (CDNA4: 160 KiB/CU)
+  if ((e = hipFuncSetAttribute((const void*)k_apply<RYD_SESOLVE, 512>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply<RYD_MESOLVE, 512>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply<RYD_SESOLVE, 1024>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply<RYD_MESOLVE, 1024>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, false, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, false, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, true, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_SESOLVE, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, false, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, false, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, true, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+      (e = hipFuncSetAttribute((const void*)k_apply14<RYD_MESOLVE, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) {
+    ryd_destroy(h);
+    return fail(RYD_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+  }
+  plan_passes(h);
+  *out = h;
+  return RYD_OK;
+}
+
+extern "C" void ryd_destroy(ryd_handle* h) {
+  if (!h) return;
+  hipFree(h->wA);
+  hipFree(h->wB);
+  hipFree(h->kbuf);
+  hipFree(h->coefs_dev);
+  hipFree(h->e0_dev);
+  hipFree(h->pp_dev);
+  hipFree(h->desc_dev);
+  hipFree(h->sched_dev);
+  hipFree(h->gen_tcoef);
+  hipFree(h->gen_terms_dev);
+  hipFree(h->gen_series_dev);
+  hipFree(h->gen_conj_dev);
+  hipFree(h->gen_scale_dev);
+  hipFree(h->mc_pool);
+  for (auto& t : h->gen_host) {
+    hipFree((void*)t.dev.row_ptr);
+    hipFree((void*)t.dev.col);
+    hipFree((void*)t.dev.val);
+  }
+  for (auto& p : h->ev_used) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  for (auto& p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  delete h;
+}
+
+extern "C" int ryd_set_series(ryd_handle* h, int32_t n_series, int32_t n_knots,
+                              const double* tknots, const double* pp) {
+  if (!h || !tknots || !pp) return fail(RYD_ERR_INVALID, "null argument");
+  if (n_series < 1 || n_knots < 2) return fail(RYD_ERR_INVALID, "need >= 1 series and >= 2 knots");
+  for (int i = 1; i < n_knots; ++i)
+    if (!(tknots[i] > tknots[i - 1]))
+      return fail(RYD_ERR_INVALID, "tknots must be strictly increasing (index %d)", i);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int n_int = n_knots - 1;
+  h->n_series = n_series;
+  h->n_knots = n_knots;
+  h->tknots.assign(tknots, tknots + n_knots);
+  const size_t cnt = (size_t)n_series * n_int * 4;
+  h->pp_host.resize(cnt);
+  for (size_t i = 0; i < cnt; ++i) h->pp_host[i] = {pp[2 * i], pp[2 * i + 1]};
+  // per-interval bounds of each series: |S|, max(Re S, 0), max(-Re S, 0)
+  h->s_abs.assign((size_t)n_series * n_int, 0.0);
+  h->s_pos.assign((size_t)n_series * n_int, 0.0);
+  h->s_neg.assign((size_t)n_series * n_int, 0.0);
+  h->s_curv.assign((size_t)n_series * n_int, 0.0);
+  for (int s = 0; s < n_series; ++s)
+    for (int i = 0; i < n_int; ++i) {
+      const std::complex<double>* p = &h->pp_host[((size_t)s * n_int + i) * 4];
+      const double dt = tknots[i + 1] - tknots[i];
+      // value at the left knot is p[3]; deviation bounded by the other terms
+      const double dev = std::abs(p[2]) * dt + std::abs(p[1]) * dt * dt + std::abs(p[0]) * dt * dt * dt;
+      h->s_abs[(size_t)s * n_int + i] = std::abs(p[3]) + dev;
+      h->s_pos[(size_t)s * n_int + i] = std::max(p[3].real() + dev, 0.0);
+      h->s_neg[(size_t)s * n_int + i] = std::max(-p[3].real() + dev, 0.0);
+      h->s_curv[(size_t)s * n_int + i] = std::abs(p[1]) * dt * dt + std::abs(p[0]) * dt * dt * dt;
+    }
+  if (h->pp_dev) hipFree(h->pp_dev);
+  h->pp_dev = nullptr;
+  HIPCHK(hipMalloc((void**)&h->pp_dev, cnt * sizeof(cplx)));
+  HIPCHK(hipMemcpy(h->pp_dev, h->pp_host.data(), cnt * sizeof(cplx), hipMemcpyHostToDevice));
+  h->bounds_valid = false;
+  return RYD_OK;
+}
+
+extern "C" int ryd_set_qubit_desc(ryd_handle* h, const ryd_qdesc* desc) {
+  if (!h || !desc) return fail(RYD_ERR_INVALID, "null argument");
+  if (h->n_series == 0) return fail(RYD_ERR_STATE, "ryd_set_series must be called first");
+  const size_t cnt = (size_t)h->B * h->N;
+  for (size_t i = 0; i < cnt; ++i) {
+    const int idx[3] = {desc[i].drive_series, desc[i].det_series, desc[i].off_series};
+    for (int j = 0; j < 3; ++j)
+      if (idx[j] < -1 || idx[j] >= h->n_series)
+        return fail(RYD_ERR_INVALID, "series index %d out of range at entry %zu", idx[j], i);
+  }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  h->desc_host.assign(desc, desc + cnt);
+  if (!h->desc_dev) HIPCHK(hipMalloc((void**)&h->desc_dev, cnt * sizeof(ryd_qdesc)));
+  HIPCHK(hipMemcpy(h->desc_dev, desc, cnt * sizeof(ryd_qdesc), hipMemcpyHostToDevice));
+  h->bounds_valid = false;
+  return RYD_OK;
+}
+
+static void compute_bounds(ryd_handle* h) {
+  const int n_int = h->n_knots - 1;
+  h->bd_drive.assign(n_int, 0.0);
+  h->bd_pos.assign(n_int, 0.0);
+  h->bd_neg.assign(n_int, 0.0);
+  h->bd_curv.assign(n_int, 0.0);
+  std::vector<double> dr(n_int), po(n_int), ne(n_int), cu(n_int);
+  for (int b = 0; b < h->B; ++b) {
+    std::fill(dr.begin(), dr.end(), 0.0);
+    std::fill(po.begin(), po.end(), 0.0);
+    std::fill(ne.begin(), ne.end(), 0.0);
+    std::fill(cu.begin(), cu.end(), 0.0);
+    for (int k = 0; k < h->N; ++k) {
+      const ryd_qdesc& d = h->desc_host[(size_t)b * h->N + k];
+      if (d.drive_series >= 0) {
+        const double* a = &h->s_abs[(size_t)d.drive_series * n_int];
+        const double sc = std::fabs(d.drive_scale);
+        for (int i = 0; i < n_int; ++i) dr[i] += sc * a[i];
+        const double* cv = &h->s_curv[(size_t)d.drive_series * n_int];
+        for (int i = 0; i < n_int; ++i) cu[i] += sc * cv[i];
+      }
+      auto add_det = [&](int s, double sc) {
+        if (s < 0 || sc == 0.0) return;
+        const double* P = &h->s_pos[(size_t)s * n_int];
+        const double* M = &h->s_neg[(size_t)s * n_int];
+        const double* cv = &h->s_curv[(size_t)s * n_int];
+        for (int i = 0; i < n_int; ++i) cu[i] += std::fabs(sc) * cv[i];
+        for (int i = 0; i < n_int; ++i) {
+          if (sc > 0) { po[i] += sc * P[i]; ne[i] += sc * M[i]; }
+          else { po[i] += -sc * M[i]; ne[i] += -sc * P[i]; }
+        }
+      };
+      add_det(d.det_series, d.det_scale);
+      add_det(d.off_series, d.off_scale);
+    }
+    for (int i = 0; i < n_int; ++i) {
+      h->bd_drive[i] = std::max(h->bd_drive[i], dr[i]);
+      h->bd_pos[i] = std::max(h->bd_pos[i], po[i]);
+      h->bd_neg[i] = std::max(h->bd_neg[i], ne[i]);
+      h->bd_curv[i] = std::max(h->bd_curv[i], cu[i]);
+    }
+  }
+  // MODEL 1 of the persistent kernel: inside every trajectory all driven atoms
+  // share (series, scale) and that series is real-valued
+  const int n_int2 = h->n_knots - 1;
+  std::vector<char> series_real(h->n_series, 1);
+  for (int sidx = 0; sidx < h->n_series; ++sidx)
+    for (size_t i = 0; i < (size_t)n_int2 * 4; ++i)
+      if (h->pp_host[(size_t)sidx * n_int2 * 4 + i].imag() != 0.0) { series_real[sidx] = 0; break; }
+  bool uni = true;
+  for (int b = 0; b < h->B && uni; ++b) {
+    int ser = -2;
+    double sc = 0.0;
+    for (int k = 0; k < h->N; ++k) {
+      const ryd_qdesc& d = h->desc_host[(size_t)b * h->N + k];
+      if (d.drive_series < 0) continue;
+      if (ser == -2) { ser = d.drive_series; sc = d.drive_scale; }
+      else if (ser != d.drive_series || sc != d.drive_scale) { uni = false; break; }
+      if (!series_real[d.drive_series]) { uni = false; break; }
+    }
+  }
+  h->uniform_real_drive = uni;
+  bool dreal = true;
+  for (const ryd_qdesc& d : h->desc_host)
+    if (d.drive_series >= 0 && !series_real[d.drive_series]) { dreal = false; break; }
+  h->drive_real = dreal;
+  h->bounds_valid = true;
+}
+
+extern "C" int ryd_set_interaction(ryd_handle* h, const double* U, int32_t n_mats) {
+  if (!h || !U) return fail(RYD_ERR_INVALID, "null argument");
+  if (n_mats != 1 && n_mats != h->B)
+    return fail(RYD_ERR_INVALID, "n_mats must be 1 or batch (%d), got %d", h->B, n_mats);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int N = h->N;
+  const size_t D = (size_t)1 << N;
+  double lo = 0, hi = 0;
+  for (int m = 0; m < n_mats; ++m) {
+    double l = 0, u = 0;
+    for (int i = 0; i < N; ++i)
+      for (int j = i + 1; j < N; ++j) {
+        const double v = U[((size_t)m * N + i) * N + j];
+        if (v != U[((size_t)m * N + j) * N + i])
+          return fail(RYD_ERR_INVALID, "interaction matrix %d not symmetric at (%d,%d)", m, i, j);
+        if (v > 0) u += v; else l += v;
+      }
+    lo = std::min(lo, l);
+    hi = std::max(hi, u);
+  }
+  h->e0_min = lo;
+  h->e0_max = hi;
+  double* Udev = nullptr;
+  HIPCHK(hipMalloc((void**)&Udev, (size_t)n_mats * N * N * sizeof(double)));
+  hipError_t e = hipMemcpy(Udev, U, (size_t)n_mats * N * N * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    if (h->e0_dev) hipFree(h->e0_dev);
+    h->e0_dev = nullptr;
+    e = hipMalloc((void**)&h->e0_dev, (size_t)n_mats * D * sizeof(double));
+  }
+  if (e == hipSuccess) {
+    dim3 grid((unsigned)((D + 255) / 256), n_mats);
+    hipLaunchKernelGGL(k_build_e0, grid, dim3(256), 0, 0, Udev, N, h->e0_dev);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  hipFree(Udev);
+  if (e != hipSuccess) return fail(RYD_ERR_HIP, "building E0 failed: %s", hipGetErrorString(e));
+  h->e0_mats = n_mats;
+  return RYD_OK;
+}
+
+extern "C" int ryd_set_dissipator(ryd_handle* h, const double* S) {
+  if (!h || !S) return fail(RYD_ERR_INVALID, "null argument");
+  if (h->cfg.mode != RYD_MESOLVE)
+    return fail(RYD_ERR_INVALID, "dissipator only valid for a mesolve handle");
+  bool dbl = false;
+  double norm = 0.0;
+  for (int r = 0; r < 4; ++r) {
+    double row = 0.0;
+    for (int c = 0; c < 4; ++c) {
+      const double re = S[2 * (4 * r + c)], im = S[2 * (4 * r + c) + 1];
+      const double a = std::hypot(re, im);
+      row += a;
+      if (a == 0.0) continue;
+      if (c == r) continue;
+      if (c == 3 - r) { dbl = true; continue; }
+      return fail(RYD_ERR_UNSUPPORTED,
+                  "dissipator entry S[%d][%d] (single flip with pair-dependent coefficient) "
+                  "is not supported by this ABI version", r, c);
+    }
+    norm = std::max(norm, row);
+  }
+  for (int r = 0; r < 4; ++r) {
+    h->Sd[r] = make_double2(S[2 * (4 * r + r)], S[2 * (4 * r + r) + 1]);
+    h->J[r] = make_double2(S[2 * (4 * r + (3 - r))], S[2 * (4 * r + (3 - r)) + 1]);
+  }
+  h->diss_norm = norm * h->N;
+  const bool replan = dbl != h->has_dbl;
+  h->has_dbl = dbl;
+  if (replan) plan_passes(h);
+  return RYD_OK;
+}

@@ -1,0 +1,101 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+// ---------------------------------------------------------------------------
+// observables / marshalling
+// ---------------------------------------------------------------------------
+extern "C" int ryd_probabilities(ryd_handle* h, const void* state_dev, double* w_dev,
+                                 int32_t reverse, void* stream) {
+  if (!h || !state_dev || !w_dev) return fail(RYD_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t D = (size_t)1 << h->N;
+  dim3 grid((unsigned)((D + 255) / 256), h->B);
+  hipLaunchKernelGGL(k_probabilities, grid, dim3(256), 0, (hipStream_t)stream,
+                     (const cplx*)state_dev, h->N, h->cfg.mode == RYD_MESOLVE, reverse, w_dev);
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
+}
+
+extern "C" int ryd_occupations(ryd_handle* h, const void* state_dev, double* out_dev,
+                               void* stream) {
+  if (!h || !state_dev || !out_dev) return fail(RYD_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(out_dev, 0, (size_t)h->B * (h->N + 1) * sizeof(double), st));
+  const size_t D = (size_t)1 << h->N;
+  const unsigned nblk = (unsigned)std::min<size_t>((D + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_occupations, dim3(nblk, h->B), dim3(256), 0, st, (const cplx*)state_dev,
+                     h->N, h->cfg.mode == RYD_MESOLVE, out_dev);
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
+}
+
+extern "C" int ryd_ket_to_dm(ryd_handle* h, const void* psi_dev, void* rho_dev, void* stream) {
+  if (!h || !psi_dev || !rho_dev) return fail(RYD_ERR_INVALID, "null argument");
+  if (2 * h->N > RYD_MAX_QUBITS) return fail(RYD_ERR_INVALID, "2N exceeds %d", RYD_MAX_QUBITS);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t DD = (size_t)1 << (2 * h->N);
+  dim3 grid((unsigned)((DD + 255) / 256), h->B);
+  hipLaunchKernelGGL(k_ket_to_dm, grid, dim3(256), 0, (hipStream_t)stream, (const cplx*)psi_dev,
+                     h->N, (cplx*)rho_dev);
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
+}
+
+extern "C" int ryd_outer_accumulate(ryd_handle* h, const void* psi_dev, const double* weights,
+                                    void* acc_dev, void* stream) {
+  if (!h || !psi_dev || !acc_dev) return fail(RYD_ERR_INVALID, "null argument");
+  if (2 * h->N > RYD_MAX_QUBITS) return fail(RYD_ERR_INVALID, "2N exceeds %d", RYD_MAX_QUBITS);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  hipStream_t st = (hipStream_t)stream;
+  double* wdev = nullptr;
+  if (weights) {
+    HIPCHK(hipMalloc((void**)&wdev, h->B * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(wdev, weights, h->B * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { hipFree(wdev); return fail(RYD_ERR_HIP, "weights upload: %s", hipGetErrorString(e)); }
+  }
+  const size_t DD = (size_t)1 << (2 * h->N);
+  hipLaunchKernelGGL(k_outer_acc, dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, st,
+                     (const cplx*)psi_dev, h->N, h->B, wdev, (cplx*)acc_dev);
+  hipError_t e = hipGetLastError();
+  if (wdev) { hipStreamSynchronize(st); hipFree(wdev); }
+  if (e != hipSuccess) return fail(RYD_ERR_HIP, "k_outer_acc: %s", hipGetErrorString(e));
+  return RYD_OK;
+}
+
+extern "C" int ryd_get_stats(const ryd_handle* h, ryd_stats* out) {
+  if (!h || !out) return fail(RYD_ERR_INVALID, "null argument");
+  *out = h->stats;
+  if (hermitian_path(h)) out->passes = 2;  // row pass + symmetrisation
+  return RYD_OK;
+}
+
+extern "C" int ryd_reset_stats(ryd_handle* h) {
+  if (!h) return fail(RYD_ERR_INVALID, "null handle");
+  const int passes = h->stats.passes;
+  std::memset(&h->stats, 0, sizeof h->stats);
+  h->stats.passes = passes;
+  return RYD_OK;
+}
+
+extern "C" int ryd_set_kernel_timing(ryd_handle* h, int32_t enable) {
+  if (!h) return fail(RYD_ERR_INVALID, "null handle");
+  h->timing = enable != 0;
+  if (enable) { h->timing_ms = 0; h->timing_launches = 0; }
+  return RYD_OK;
+}
+
+extern "C" int ryd_get_kernel_timing(ryd_handle* h, double* total_ms, int64_t* launches) {
+  if (!h || !total_ms || !launches) return fail(RYD_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  for (auto& ev : h->ev_used) {
+    HIPCHK(hipEventSynchronize(ev.second));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+    h->timing_ms += ms;
+    h->timing_launches++;
+    h->ev_free.push_back(ev);
+  }
+  h->ev_used.clear();
+  *total_ms = h->timing_ms;
+  *launches = h->timing_launches;
+  return RYD_OK;
+}

@@ -1,0 +1,490 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+// ---------------------------------------------------------------------------
+// stepping: schedule (host) -> generic multi-launch path or persistent kernel
+// ---------------------------------------------------------------------------
+static const double kS3 = 1.7320508075688772;
+static const double kC1 = 0.5 - kS3 / 6.0, kC2 = 0.5 + kS3 / 6.0;  // Gauss nodes
+static const double kA1 = 0.25 + kS3 / 6.0, kA2 = 0.25 - kS3 / 6.0;  // CF4 weights
+
+// Taylor order and spectral shift of one exponential exp(h (w1 G(t1) + w2 G(t2)))
+// with both Gauss points inside knot interval `idx`.
+static void plan_exp(ryd_handle* h, int idx, double hstep, double w1, double w2,
+                     const ryd_opts& o, int* order_out, double* shift_out) {
+  const double wmix = w1 + w2;
+  const double drive = wmix * h->bd_drive[idx];
+  const double dpos = wmix * h->bd_pos[idx], dneg = wmix * h->bd_neg[idx];
+  const double lo = wmix * h->e0_min - dpos, hi = wmix * h->e0_max + dneg;
+  double bound, shift = 0.0;
+  if (h->general) {
+    bound = drive;  // sum_t |coef_t| ||A_t||_inf; no spectral shift
+  } else if (h->cfg.mode == RYD_SESOLVE) {
+    shift = 0.5 * (lo + hi);  // H' = H - shift: halves the spectral radius
+    bound = 0.5 * (hi - lo) + drive;
+    if (h->mc) bound += wmix * std::fabs(h->mc_b) * 0.5 * h->N;  // centred decay diagonal
+  } else {
+    bound = 2.0 * (0.5 * (hi - lo) + drive) + wmix * h->diss_norm;
+  }
+  h->stats.norm_bound = bound / std::max(wmix, 1e-300);
+  const double rho = std::fabs(hstep) * bound;
+  int order = o.taylor_order;
+  if (order <= 0) {
+    const int cap = std::min(o.max_order > 0 ? o.max_order : 24, 32);
+    const double tol = o.tol > 0 ? o.tol : 1e-12;
+    double term = rho;  // rho^(m+1)/(m+1)! for m = 0
+    order = 1;
+    while (order < cap) {
+      term *= rho / (order + 1);  // now rho^(order+1)/(order+1)!
+      if (term <= tol) break;
+      ++order;
+    }
+  }
+  if (order < 2) order = 2;
+  if (order > 32) order = 32;
+  h->stats.last_order = order;
+  *order_out = order;
+  *shift_out = shift;
+}
+
+// CF4 steps covering [t0, t1]: never straddling a spline knot (inside a knot
+// interval every coefficient is a single cubic), optionally capped by max_step.
+static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& o,
+                           std::vector<StepDesc>& out) {
+  const double eps = 1e-12;
+  double t = t0;
+  while (t < t1 - eps) {
+    const int idx = find_interval(h, t + eps);
+    double tend = t1;  // the last interval extends to t1 (extrapolation, as scipy does)
+    if (idx < h->n_knots - 2) tend = std::min(t1, h->tknots[idx + 1]);
+    if (tend <= t + eps) tend = t1;
+    const double len = tend - t;
+    int nsub = 1;
+    if (o.max_step > 0) nsub = std::max(1, (int)std::ceil(len / o.max_step - 1e-9));
+    {
+      // The local error of the 4th-order Magnus step is dominated by the
+      // non-linear (quadratic + cubic) part of the spline inside the interval -
+      // large only where it rings next to a kink of the waveform.  Calibrated
+      // against converged references: err ~ 1e-5 * h * curvature,
+      // and it falls as n^-4 with n equal sub-steps.
+      const double dtk = h->tknots[idx + 1] - h->tknots[idx];
+      const double frac = dtk > 0 ? std::min(1.0, len / dtk) : 1.0;
+      const double est = 1e-5 * len * h->bd_curv[idx] * frac * frac;
+      const double mtol = o.magnus_tol > 0 ? o.magnus_tol : 1e-10;
+      if (est > mtol) {
+        const int nm = (int)std::ceil(std::pow(est / mtol, 0.25));
+        nsub = std::max(nsub, std::min(nm, 256));
+      }
+    }
+    {
+      // keep the Taylor argument rho = h * ||G~|| near 1: beyond that the
+      // polynomial degree grows faster than the step (and cancellation sets in)
+      int ord;
+      double sh;
+      plan_exp(h, idx, len / nsub, kA1, kA2, o, &ord, &sh);
+      const double rho = (len / nsub) * h->stats.norm_bound * (kA1 + kA2);
+      if (rho > 1.5) nsub *= (int)std::ceil(rho / 1.0);
+    }
+    const double hs = len / nsub;
+    for (int s = 0; s < nsub; ++s) {
+      const double ta = t + s * hs;
+      StepDesc d;
+      std::memset(&d, 0, sizeof d);
+      d.h = hs;
+      d.idx = idx;
+      d.u1 = ta + kC1 * hs - h->tknots[idx];
+      d.u2 = ta + kC2 * hs - h->tknots[idx];
+      plan_exp(h, idx, hs, kA1, kA2, o, &d.order_a, &d.shift_a);
+      plan_exp(h, idx, hs, kA2, kA1, o, &d.order_b, &d.shift_b);
+      d.snap = -1;
+      out.push_back(d);
+    }
+    t = tend;
+  }
+}
+
+static bool hermitian_path(const ryd_handle* h) {
+  return !h->general && h->cfg.mode == RYD_MESOLVE && !h->has_dbl && h->N >= 7 && h->N <= 14 &&
+         h->auto_tile && tile14_pays(h);
+}
+
+// One exponential  state <- exp(h * G~) state  on the generic multi-launch path.
+static int exp_step(ryd_handle* h, cplx* state, double hstep, const MixPoint& m, int order,
+                    double shift, hipStream_t st) {
+  int rc;
+  if (h->general) {
+    if ((rc = launch_eval_general(h, m, st))) return rc;
+    const cplx* gin = state;
+    cplx* gbufs[2] = {h->wA, h->wB};
+    int gw = 0;
+    for (int j = order; j >= 1; --j) {
+      cplx* out = j == 1 ? state : gbufs[gw];
+      if ((rc = apply_general(h, m, gin, state, out, hstep / j, st))) return rc;
+      gin = out;
+      gw ^= 1;
+    }
+    return RYD_OK;
+  }
+  if ((rc = launch_eval(h, m, st))) return rc;
+  const double wmix = m.w1 + m.w2;
+  if (hermitian_path(h)) {
+    // rho stays Hermitian, so G rho = P + P^dagger with P = (1/2) D.rho + the
+    // column-bit flips only: one register-tile pass over rows + one tile-pair
+    // symmetrisation instead of three tiled passes.
+    const cplx* hin = state;
+    cplx* hb[2] = {h->wA, h->wB};
+    int hw = 0;
+    for (int j = order; j >= 1; --j) {
+      cplx* out = j == 1 ? state : hb[hw];
+      Apply14Args B;
+      std::memset(&B, 0, sizeof B);
+      B.in = hin;
+      B.kout = h->kbuf;
+      B.coefs = h->coefs_dev;
+      B.e0 = h->e0_dev;
+      B.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << h->N);
+      B.wmix = wmix;
+      B.diag_scale = 0.5;
+      B.scale = 1.0;
+      B.post = make_double2(1.0, 0.0);
+      for (int i = 0; i < 4; ++i) B.Sd[i] = h->Sd[i];
+      B.N = h->N;
+      B.nb = h->nb;
+      B.n_flip = h->N;
+      std::pair<hipEvent_t, hipEvent_t> ev;
+      if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+      if ((rc = launch_apply14(h, B, st))) return rc;
+      if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
+      SymmArgs S;
+      S.P = h->kbuf;
+      S.base = state;
+      S.out = out;
+      S.scale = hstep / j;
+      S.N = h->N;
+      const unsigned nt = 1u << (h->N - 5);
+      if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+      hipLaunchKernelGGL(k_symm, dim3(nt, nt, h->B), dim3(256), 0, st, S);
+      HIPCHK(hipGetLastError());
+      if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
+      h->stats.n_launches += 2;
+      h->stats.n_applications++;
+      hin = out;
+      hw ^= 1;
+    }
+    return RYD_OK;
+  }
+  // Horner: w_m = psi; w_{j-1} = psi + (h/j) G' w_j; result w_0, times e^{-i h shift}
+  const cplx one = make_double2(1.0, 0.0);
+  const cplx* in = state;
+  cplx* bufs[2] = {h->wA, h->wB};
+  int which = 0;
+  for (int j = order; j >= 1; --j) {
+    cplx* out = j == 1 ? state : bufs[which];
+    cplx post = one;
+    if (j == 1) {
+      // e^{-i h shift}, and for H_eff the centre of the decay diagonal
+      const double mag = h->mc ? std::exp(hstep * wmix * (h->mc_a + 0.5 * h->N * h->mc_b)) : 1.0;
+      post = make_double2(mag * std::cos(hstep * shift), -mag * std::sin(hstep * shift));
+    }
+    if ((rc = apply_generator(h, in, state, out, wmix, hstep / j, shift, post, st, h->mc))) return rc;
+    in = out;
+    which ^= 1;
+  }
+  return RYD_OK;
+}
+
+static unsigned mc_blocks(const ryd_handle* h) {
+  return (unsigned)std::min<size_t>(std::max<size_t>(h->dim >> 10, 1), 128);
+}
+
+// Jump bookkeeping after one CF4 step of a Monte-Carlo solve (all on `st`).
+static int mc_after_step(ryd_handle* h, cplx* state, hipStream_t st) {
+  const unsigned nblk = mc_blocks(h);
+  hipLaunchKernelGGL(k_mc_norm, dim3(nblk, h->B), dim3(256), 0, st, state, h->nb, h->mcs.norm2);
+  hipLaunchKernelGGL(k_mc_reduced, dim3(nblk, h->B), dim3(256), 0, st, state, h->N, h->mcs, h->B, 0);
+  hipLaunchKernelGGL(k_mc_select, dim3((h->B + 127) / 128), dim3(128), 0, st, h->mcs, h->B, h->N, 0);
+  hipLaunchKernelGGL(k_mc_jump, dim3(nblk, h->B), dim3(256), 0, st, state, h->N, h->mcs);
+  HIPCHK(hipGetLastError());
+  h->stats.n_launches += 4;
+  return RYD_OK;
+}
+
+// Snapshot of the state: a plain copy, or the normalised ket in a Monte-Carlo solve.
+static int snapshot_copy(ryd_handle* h, const cplx* state, cplx* dst, hipStream_t st) {
+  if (h->mc_active) {
+    hipLaunchKernelGGL(k_mc_normalize, dim3(mc_blocks(h), h->B), dim3(256), 0, st, state, dst, h->nb,
+                       h->mcs.lastnorm);
+    HIPCHK(hipGetLastError());
+    return RYD_OK;
+  }
+  HIPCHK(hipMemcpyAsync(dst, state, h->dim * (size_t)h->B * sizeof(cplx), hipMemcpyDeviceToDevice, st));
+  return RYD_OK;
+}
+
+static int run_generic(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched,
+                       cplx* snaps, hipStream_t st) {
+  int rc;
+  const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  for (const StepDesc& d : sched) {
+    MixPoint m;
+    m.idx1 = m.idx2 = d.idx;
+    m.u1 = d.u1;
+    m.u2 = d.u2;
+    m.w1 = kA1; m.w2 = kA2;
+    if ((rc = exp_step(h, state, d.h, m, d.order_a, d.shift_a, st))) return rc;
+    m.w1 = kA2; m.w2 = kA1;
+    if ((rc = exp_step(h, state, d.h, m, d.order_b, d.shift_b, st))) return rc;
+    h->stats.n_steps++;
+    if (h->mc_active && (rc = mc_after_step(h, state, st))) return rc;
+    if (d.snap >= 0 && snaps && (rc = snapshot_copy(h, state, snaps + (size_t)d.snap * h->dim * h->B, st)))
+      return rc;
+  }
+  (void)bytes;
+  return RYD_OK;
+}
+
+template <int N, int MODEL, bool MC>
+static int launch_traj2(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
+  constexpr int D = 1 << N;
+  constexpr int NTT = D < 64 ? 64 : (N >= 11 ? 1024 : (D > 512 ? 512 : D));
+  const size_t lds = 2 * (size_t)D * sizeof(cplx) + 4 * 16 * sizeof(double) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_traj<N, NTT, MODEL, MC>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_traj<N, NTT, MODEL, MC>), dim3(h->B), dim3(NTT), lds, st, A);
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
+}
+
+template <int N>
+static int launch_traj(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
+  if (h->mc)
+    return h->uniform_real_drive ? launch_traj2<N, 1, true>(h, A, st)
+                                 : launch_traj2<N, 0, true>(h, A, st);
+  return h->uniform_real_drive ? launch_traj2<N, 1, false>(h, A, st)
+                               : launch_traj2<N, 0, false>(h, A, st);
+}
+
+// Persistent path (sesolve, N <= 12): one workgroup per trajectory keeps its
+// state vector in LDS/registers for the whole schedule; one launch.
+static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched,
+                          cplx* snaps, hipStream_t st) {
+  if (sched.empty()) return RYD_OK;
+  const size_t bytes = sched.size() * sizeof(StepDesc);
+  if (h->sched_cap < sched.size()) {
+    if (h->sched_dev) hipFree(h->sched_dev);
+    h->sched_dev = nullptr;
+    h->sched_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->sched_dev, bytes * 2));
+    h->sched_cap = sched.size() * 2;
+  }
+  // the schedule buffer may still be read by an earlier launch on `st`
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMemcpyAsync(h->sched_dev, sched.data(), bytes, hipMemcpyHostToDevice, st));
+  TrajArgs A;
+  A.state = state;
+  A.snaps = snaps;
+  A.pp = h->pp_dev;
+  A.n_int = h->n_knots - 1;
+  A.desc = h->desc_dev;
+  A.e0 = h->e0_dev;
+  A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << h->N);
+  A.steps = h->sched_dev;
+  A.n_steps = (int)sched.size();
+  A.B = h->B;
+  A.a1 = kA1;
+  A.a2 = kA2;
+  A.mc = h->mcs;
+  A.mc_a = h->mc_a;
+  A.mc_b = h->mc_b;
+  A.mc_jumps = h->mc_active ? 1 : 0;
+  int rc = RYD_ERR_INVALID;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+  switch (h->N) {
+    case 1: rc = launch_traj<1>(h, A, st); break;
+    case 2: rc = launch_traj<2>(h, A, st); break;
+    case 3: rc = launch_traj<3>(h, A, st); break;
+    case 4: rc = launch_traj<4>(h, A, st); break;
+    case 5: rc = launch_traj<5>(h, A, st); break;
+    case 6: rc = launch_traj<6>(h, A, st); break;
+    case 7: rc = launch_traj<7>(h, A, st); break;
+    case 8: rc = launch_traj<8>(h, A, st); break;
+    case 9: rc = launch_traj<9>(h, A, st); break;
+    case 10: rc = launch_traj<10>(h, A, st); break;
+    case 11: rc = launch_traj<11>(h, A, st); break;
+    case 12: rc = launch_traj<12>(h, A, st); break;
+    default: return fail(RYD_ERR_INVALID, "persistent path needs N <= 12");
+  }
+  if (rc) return rc;
+  if (h->timing) {
+    HIPCHK(hipEventRecord(ev.second, st));
+    h->ev_used.push_back(ev);
+  }
+  for (const StepDesc& d : sched) {
+    h->stats.n_applications += d.order_a + d.order_b;
+    h->stats.n_steps++;
+  }
+  h->stats.n_launches++;
+  return RYD_OK;
+}
+
+static bool use_persistent(const ryd_handle* h) {
+  return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 12 && !h->force_generic;
+}
+
+extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
+                         void* out_dev, const ryd_opts* opts, void* stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!state_dev || !times || n_times < 2) return fail(RYD_ERR_INVALID, "need a state and >= 2 times");
+  for (int i = 1; i < n_times; ++i)
+    if (!(times[i] >= times[i - 1])) return fail(RYD_ERR_INVALID, "times must be non-decreasing");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (!h->bounds_valid) { if (h->general) compute_bounds_general(h); else compute_bounds(h); }
+  ryd_opts o;
+  std::memset(&o, 0, sizeof o);
+  if (opts) o = *opts;
+  hipStream_t st = (hipStream_t)stream;
+  cplx* state = (cplx*)state_dev;
+  cplx* snaps = (cplx*)out_dev;
+  const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  std::vector<StepDesc> sched;
+  // snapshot slot i-1 receives the state at times[i]
+  for (int i = 1; i < n_times; ++i) {
+    const size_t before = sched.size();
+    build_schedule(h, times[i - 1], times[i], o, sched);
+    if (snaps) {
+      if (sched.size() > before) {
+        sched.back().snap = i - 1;
+      } else {  // zero-length interval: the state is unchanged
+        if (before == 0) {
+          if ((rc = snapshot_copy(h, state, snaps + (size_t)(i - 1) * h->dim * h->B, st))) return rc;
+        } else {
+          // duplicate time after at least one step: flush what we have, copy, continue
+          if ((rc = use_persistent(h) ? run_persistent(h, state, sched, snaps, st)
+                                      : run_generic(h, state, sched, snaps, st)))
+            return rc;
+          sched.clear();
+          if ((rc = snapshot_copy(h, state, snaps + (size_t)(i - 1) * h->dim * h->B, st))) return rc;
+        }
+      }
+    }
+  }
+  return use_persistent(h) ? run_persistent(h, state, sched, snaps, st)
+                           : run_generic(h, state, sched, snaps, st);
+}
+
+extern "C" int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
+                          const ryd_opts* opts, void* stream) {
+  if (!(t1 >= t0)) return fail(RYD_ERR_INVALID, "t1 < t0");
+  const double times[2] = {t0, t1};
+  return ryd_solve(h, state_dev, 2, times, nullptr, opts, stream);
+}
+
+extern "C" int ryd_set_collapse(ryd_handle* h, int32_t n_ops, const double* ops) {
+  if (!h) return fail(RYD_ERR_INVALID, "null handle");
+  if (h->general || h->cfg.mode != RYD_SESOLVE)
+    return fail(RYD_ERR_INVALID, "collapse operators need a ket (sesolve) handle of the tuned path");
+  if (n_ops < 0 || n_ops > MC_MAX_OPS || (n_ops > 0 && !ops))
+    return fail(RYD_ERR_INVALID, "n_ops=%d out of range [0, %d]", n_ops, MC_MAX_OPS);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (n_ops == 0) {
+    h->mc = false;
+    h->mc_n_ops = 0;
+    h->mc_a = h->mc_b = 0.0;
+    return RYD_OK;
+  }
+  // M = sum C^dag C must be diagonal: H_eff then only gains a real diagonal
+  double m00 = 0, m11 = 0, m01r = 0, m01i = 0;
+  for (int k = 0; k < n_ops; ++k) {
+    const std::complex<double> c00(ops[8 * k + 0], ops[8 * k + 1]), c01(ops[8 * k + 2], ops[8 * k + 3]),
+        c10(ops[8 * k + 4], ops[8 * k + 5]), c11(ops[8 * k + 6], ops[8 * k + 7]);
+    m00 += std::norm(c00) + std::norm(c10);
+    m11 += std::norm(c01) + std::norm(c11);
+    const std::complex<double> x = std::conj(c00) * c01 + std::conj(c10) * c11;
+    m01r += x.real();
+    m01i += x.imag();
+  }
+  if (std::hypot(m01r, m01i) > 1e-13 * std::max(std::max(m00, m11), 1e-300))
+    return fail(RYD_ERR_UNSUPPORTED,
+                "sum C^dag C of the local collapse operators is not diagonal; use the "
+                "master-equation solver for this noise model");
+  const size_t B = (size_t)h->B, N = (size_t)h->N;
+  const size_t n_dbl = 2 * B + 4 * N * B + 4 * B;
+  const size_t bytes = n_dbl * sizeof(double) + B * sizeof(unsigned long long) +
+                       MC_MAX_OPS * 4 * sizeof(cplx) + 3 * B * sizeof(int);
+  if (!h->mc_pool) {
+    HIPCHK(hipMalloc(&h->mc_pool, bytes));
+    HIPCHK(hipMemset(h->mc_pool, 0, bytes));
+    char* p = (char*)h->mc_pool;
+    h->mcs.norm2 = (double*)p;    p += 2 * B * sizeof(double);
+    h->mcs.red = (double*)p;      p += 4 * N * B * sizeof(double);
+    h->mcs.target = (double*)p;   p += B * sizeof(double);
+    h->mcs.refnorm = (double*)p;  p += B * sizeof(double);
+    h->mcs.lastnorm = (double*)p; p += B * sizeof(double);
+    h->mcs.scale = (double*)p;    p += B * sizeof(double);
+    h->mc_seeds_dev = (unsigned long long*)p; p += B * sizeof(unsigned long long);
+    h->mc_ops_dev = (cplx*)p;     p += MC_MAX_OPS * 4 * sizeof(cplx);
+    h->mcs.flag = (int*)p;        p += B * sizeof(int);
+    h->mcs.sel = (int*)p;         p += B * sizeof(int);
+    h->mcs.count = (int*)p;
+    h->mcs.seeds = h->mc_seeds_dev;
+    h->mcs.ops = h->mc_ops_dev;
+  }
+  HIPCHK(hipMemcpy(h->mc_ops_dev, ops, (size_t)n_ops * 4 * sizeof(cplx), hipMemcpyHostToDevice));
+  h->mcs.n_ops = n_ops;
+  h->mc_n_ops = n_ops;
+  h->mc_a = -0.5 * m00 * h->N;
+  h->mc_b = 0.5 * (m00 - m11);
+  h->mc = true;
+  return RYD_OK;
+}
+
+extern "C" int ryd_mc_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
+                            void* out_dev, const uint64_t* seeds, const ryd_opts* opts,
+                            void* stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!h->mc) return fail(RYD_ERR_STATE, "ryd_set_collapse has not been called");
+  if (!state_dev || !seeds) return fail(RYD_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(h->mc_seeds_dev, seeds, (size_t)h->B * sizeof(unsigned long long),
+                        hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(h->mcs.norm2, 0, 2 * (size_t)h->B * sizeof(double), st));
+  hipLaunchKernelGGL(k_mc_norm, dim3(mc_blocks(h), h->B), dim3(256), 0, st, (const cplx*)state_dev,
+                     h->nb, h->mcs.norm2);
+  hipLaunchKernelGGL(k_mc_init, dim3((h->B + 127) / 128), dim3(128), 0, st, h->mcs, h->B, h->N);
+  HIPCHK(hipGetLastError());
+  h->mc_active = true;
+  rc = ryd_solve(h, state_dev, n_times, times, out_dev, opts, stream);
+  if (rc == RYD_OK) rc = snapshot_copy(h, (const cplx*)state_dev, (cplx*)state_dev, st);
+  h->mc_active = false;
+  return rc;
+}
+
+extern "C" int ryd_mc_get_jumps(ryd_handle* h, int32_t* counts, void* stream) {
+  if (!h || !counts) return fail(RYD_ERR_INVALID, "null argument");
+  if (!h->mc) return fail(RYD_ERR_STATE, "ryd_set_collapse has not been called");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipMemcpy(counts, h->mcs.count, (size_t)h->B * sizeof(int), hipMemcpyDeviceToHost));
+  return RYD_OK;
+}
+
+extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
+  if (!h) return fail(RYD_ERR_INVALID, "null handle");
+  h->force_generic = (force_generic & 1) != 0;
+  // bit 2 (a retired tile-kernel hook) is accepted and ignored
+  {
+    const bool nt = (force_generic & 4) != 0, ft = (force_generic & 8) != 0;
+    if (nt != h->no_tile14 || ft != h->force_tile14) {
+      h->no_tile14 = nt;
+      h->force_tile14 = ft;
+      plan_passes(h);
+    }
+  }
+  return RYD_OK;
+}

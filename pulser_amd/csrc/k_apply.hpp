@@ -1,0 +1,190 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+#define MAXF 16  // flips per pass (<= tile bits)
+#define MAXD 8   // double flips per pass
+
+struct PassArgs {
+  const cplx* in;    // x: the vector G is applied to
+  const cplx* kin;   // partial sums of earlier passes (or null)
+  cplx* kout;        // partial sums out (non-final pass)
+  const cplx* base;  // Horner base (or null)
+  cplx* out;         // final output: post * (base + scale * (kin + partial))
+  const double* coefs;  // [B][N][4] = Re c~, Im c~, delta~, 0 (time-mixed)
+  const double* e0;     // [n_mats][2^N] static interaction diagonal
+  long long e0_stride;  // 0 when shared by the batch
+  double wmix;          // weight of the static parts (w1 + w2)
+  double scale;         // h / j
+  double shift;         // spectral shift of H (sesolve)
+  double dec_a, dec_b;  // Monte-Carlo wavefunction: real diagonal dec_a + dec_b * popc(i) (sesolve)
+  cplx post;            // final multiplier
+  cplx Sd[4];           // mesolve: dissipator diagonal, index 2*a_k + b_k
+  cplx J[4];            // mesolve: double-flip coefficient, by output pair
+  Segs tile, outer;
+  int N, nb, T;
+  int n_flip, n_dbl;
+  int include_diag, final_pass;
+  signed char flip_q[MAXF];  // tile-local bit of each single flip
+  signed char dbl_qb[MAXD], dbl_qa[MAXD];
+};
+
+// Global bit position of tile-local bit q.
+__device__ __forceinline__ int tile_bit_pos(const Segs& s, int q) {
+  int off = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (q < off + s.len[i]) return s.lo[i] + (q - off);
+    off += s.len[i];
+  }
+  return -1;
+}
+
+// threads per workgroup of the apply kernel: 512 (two workgroups per CU when the
+// launch has many tiles) or 1024 (launches with at most ~2 tiles per CU: more
+// waves per CU to hide the load -> compute -> store latency of a lone tile)
+
+// out = post * (base + scale * (kin + G~_pass x))        (final pass)
+// kout = kin + G~_pass x                                  (other passes)
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = A.T;
+  const int tileSize = 1 << T;
+  const int TL = T >> 1, TH = T - TL;
+  cplx* xs = reinterpret_cast<cplx*>(smem);
+  double* tabLo = reinterpret_cast<double*>(xs + tileSize);
+  double* tabHi = tabLo + (1 << TL);
+  cplx* c0 = reinterpret_cast<cplx*>(tabHi + (1 << TH));
+  cplx* c1 = c0 + MAXF;
+
+  const int tid = threadIdx.x;
+  const int N = A.N;
+  const int b = blockIdx.y;
+  const unsigned long long base_idx = deposit((unsigned long long)blockIdx.x, A.outer);
+  const size_t boff = (size_t)b << A.nb;
+  const double* __restrict__ cf = A.coefs + (size_t)b * N * 4;
+  const cplx* __restrict__ xin = A.in + boff;
+
+  // ---- stage the tile (coalesced 16 B / lane) ----
+  for (int l = tid; l < tileSize; l += NT)
+    xs[l] = xin[base_idx | deposit((unsigned long long)l, A.tile)];
+
+  // ---- per-pass coefficient tables ----
+  if (tid < A.n_flip) {
+    const int p = tile_bit_pos(A.tile, A.flip_q[tid]);
+    cplx lo, hi;  // coefficient when the OUTPUT index has bit p = 0 / 1
+    if (MODE == RYD_SESOLVE) {
+      const int k = N - 1 - p;
+      const double cr = cf[4 * k], ci = cf[4 * k + 1];
+      // (H psi)(s_k = 1) += c psi(s_k = 0); (s_k = 0) += conj(c) psi(s_k = 1); G = -iH
+      hi = make_double2(ci, -cr);    // -i * c
+      lo = make_double2(-ci, -cr);   // -i * conj(c)
+    } else if (p >= N) {             // row bit: -i (H rho)
+      const int k = 2 * N - 1 - p;
+      const double cr = cf[4 * k], ci = cf[4 * k + 1];
+      hi = make_double2(ci, -cr);
+      lo = make_double2(-ci, -cr);
+    } else {                         // column bit: +i (rho H)
+      const int k = N - 1 - p;
+      const double cr = cf[4 * k], ci = cf[4 * k + 1];
+      lo = make_double2(-ci, cr);    // +i * c
+      hi = make_double2(ci, cr);     // +i * conj(c)
+    }
+    c0[tid] = lo;
+    c1[tid] = hi;
+  }
+  double eOuter = 0.0;
+  if (A.include_diag) {
+    // detuning part of the diagonal, split over (outer bits) + (low/high half
+    // of the tile bits): e_det(i) = sum_bits sgn * delta~_k * n_k, n_k = !bit.
+    for (int e = tid; e < (1 << TL) + (1 << TH); e += NT) {
+      const bool hiHalf = e >= (1 << TL);
+      const int v = hiHalf ? e - (1 << TL) : e;
+      const int q0 = hiHalf ? TL : 0, nq = hiHalf ? TH : TL;
+      double s = 0.0;
+      for (int q = 0; q < nq; ++q) {
+        const int p = tile_bit_pos(A.tile, q0 + q);
+        double sg;
+        int k;
+        if (MODE == RYD_SESOLVE) { k = N - 1 - p; sg = -1.0; }
+        else if (p >= N) { k = 2 * N - 1 - p; sg = -1.0; }
+        else { k = N - 1 - p; sg = 1.0; }
+        if (!((v >> q) & 1)) s += sg * cf[4 * k + 2];
+      }
+      (hiHalf ? tabHi : tabLo)[v] = s;
+    }
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < A.outer.len[i]; ++j) {
+        const int p = A.outer.lo[i] + j;
+        double sg;
+        int k;
+        if (MODE == RYD_SESOLVE) { k = N - 1 - p; sg = -1.0; }
+        else if (p >= N) { k = 2 * N - 1 - p; sg = -1.0; }
+        else { k = N - 1 - p; sg = 1.0; }
+        if (!((base_idx >> p) & 1ull)) eOuter += sg * cf[4 * k + 2];
+      }
+  }
+  __syncthreads();
+
+  const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride;
+  const unsigned Dm1 = (MODE == RYD_MESOLVE) ? ((1u << N) - 1u) : 0u;
+  const int maskLo = (1 << TL) - 1;
+
+  for (int l = tid; l < tileSize; l += NT) {
+    const unsigned long long gi = base_idx | deposit((unsigned long long)l, A.tile);
+    cplx acc = make_double2(0.0, 0.0);
+    if (A.include_diag) {
+      const cplx x = xs[l];
+      double e = tabLo[l & maskLo] + tabHi[l >> TL] + eOuter;
+      if (MODE == RYD_SESOLVE) {
+        e += A.wmix * e0[gi] - A.shift;
+        acc = make_double2(e * x.y, -e * x.x);  // -i e x
+        if (A.dec_a != 0.0 || A.dec_b != 0.0) {  // -(1/2) sum C^dag C of H_eff (diagonal)
+          const double dr = fma(A.dec_b, (double)__popcll(gi), A.dec_a);
+          acc.x = fma(dr, x.x, acc.x);
+          acc.y = fma(dr, x.y, acc.y);
+        }
+      } else {
+        const unsigned a = (unsigned)(gi >> N), bb = (unsigned)gi & Dm1;
+        e += A.wmix * (e0[a] - e0[bb]);
+        const int n11 = __popc(a & bb), n10 = __popc(a & ~bb & Dm1),
+                  n01 = __popc(~a & bb & Dm1), n00 = N - n11 - n10 - n01;
+        const double dr = A.wmix * (A.Sd[0].x * n00 + A.Sd[1].x * n01 +
+                                    A.Sd[2].x * n10 + A.Sd[3].x * n11);
+        const double di = A.wmix * (A.Sd[0].y * n00 + A.Sd[1].y * n01 +
+                                    A.Sd[2].y * n10 + A.Sd[3].y * n11) - e;
+        acc = make_double2(dr * x.x - di * x.y, dr * x.y + di * x.x);
+      }
+    }
+    for (int f = 0; f < A.n_flip; ++f) {
+      const int q = A.flip_q[f];
+      const cplx xv = xs[l ^ (1 << q)];
+      const cplx cc = ((l >> q) & 1) ? c1[f] : c0[f];
+      acc = cfma(cc, xv, acc);
+    }
+    if (MODE == RYD_MESOLVE) {
+      for (int d = 0; d < A.n_dbl; ++d) {
+        const int qb = A.dbl_qb[d], qa = A.dbl_qa[d];
+        const int r = (((l >> qa) & 1) << 1) | ((l >> qb) & 1);
+        const cplx jc = A.J[r];
+        const cplx xv = xs[l ^ (1 << qb) ^ (1 << qa)];
+        acc = cfma(make_double2(jc.x * A.wmix, jc.y * A.wmix), xv, acc);
+      }
+    }
+    const size_t go = boff + gi;
+    if (A.kin) {
+      const cplx kv = A.kin[go];
+      acc.x += kv.x;
+      acc.y += kv.y;
+    }
+    if (A.final_pass) {
+      cplx r = make_double2(A.scale * acc.x, A.scale * acc.y);
+      if (A.base) {
+        const cplx bv = A.base[go];
+        r.x += bv.x;
+        r.y += bv.y;
+      }
+      A.out[go] = cmul(A.post, r);
+    } else {
+      A.kout[go] = acc;
+    }
+  }
+}

@@ -284,13 +284,13 @@ class Engine:
         _lib.check(self.lib.ryd_mc_get_jumps(self._h, counts.ctypes.data, self._stream()))
         return counts
 
-    def set_path(self, force_generic: bool, no_fast_apply: bool = False,
-                 no_tile14: bool = False, force_tile14: bool = False) -> None:
-        """Test/bench hook: disable the persistent small-N kernel, the
-        specialised T = 12 tile kernel, and/or the 2^14 register-tile kernel with
-        the Hermitian mesolve path (the generic kernels are used instead)."""
+    def set_path(self, force_generic: bool, no_tile14: bool = False,
+                 force_tile14: bool = False) -> None:
+        """Test/bench hook: disable the persistent small-N kernel and/or the 2^14
+        register-tile kernel with the Hermitian mesolve path (the tiled
+        multi-pass kernels are used instead), or force the register tiles."""
         _lib.check(self.lib.ryd_set_path(
-            self._h, int(bool(force_generic)) | (2 if no_fast_apply else 0) | (4 if no_tile14 else 0)
+            self._h, int(bool(force_generic)) | (4 if no_tile14 else 0)
             | (8 if force_tile14 else 0)))
 
     def apply_generator(self, x: Any, t: float) -> Any:

@@ -228,28 +228,32 @@ def test_persistent_kernel_cfg2_chain12_snapshots():
         assert np.max(np.abs(snaps[i - 1][0] - ref[i])) < AMP_TOL
 
 
-@pytest.mark.parametrize("mode,n", [("sesolve", 12), ("sesolve", 17), ("mesolve", 6), ("mesolve", 9)])
-def test_specialised_tile_kernel_matches_generic(mode, n):
-    """k_apply12 (registers + batched loads) against the generic k_apply, for the
-    diagonal pass and the accumulation passes, and against the oracle at N = 12."""
+@pytest.mark.parametrize("mode,n,batch", [("sesolve", 13, 1), ("sesolve", 17, 1), ("sesolve", 13, 300),
+                                          ("mesolve", 6, 1), ("mesolve", 9, 1)])
+def test_tiled_kernel_workgroup_widths_and_pass_plans(mode, n, batch):
+    """The tiled kernel in both workgroup widths (1024 threads when a launch has
+    at most 512 tiles, 512 otherwise) and with balanced multi-pass plans, against
+    the oracle's sparse matvec / Lindblad right-hand side."""
+    from oracle import qutip_path as qp
+
     ops = [(np.sqrt(0.1), "sigma_rr")] if mode == "mesolve" else None
-    probs = [local_problem(n, seed=s, duration=21, collapse_ops=ops) for s in range(2)]
-    eng = _engine(probs, mode=mode)
+    prob = local_problem(n, seed=1, duration=21, collapse_ops=ops)
+    eng = _engine([prob] * batch, mode=mode)
+    eng.set_path(True, no_tile14=True)
     shape = eng.state_shape
     rng = np.random.default_rng(0)
-    x = rng.normal(size=shape) + 1j * rng.normal(size=shape)
-    dev = _to_dev(eng, x)
-    fast = eng.apply_generator(dev, 0.0123).cpu().numpy()
-    eng.set_path(True, no_fast_apply=True)
-    slow = eng.apply_generator(dev, 0.0123).cpu().numpy()
-    assert eng.stats()["passes"] == {12: 1, 17: 2, 6: 1, 9: 2}[n]
-    assert np.max(np.abs(fast - slow)) <= 1e-12 * np.max(np.abs(slow))
-    st_a = eng.new_state()
-    eng.evolve(st_a, 0.0, 0.004)
-    eng.set_path(True, no_fast_apply=False)
-    st_b = eng.new_state()
-    eng.evolve(st_b, 0.0, 0.004)
-    assert np.max(np.abs(st_a.cpu().numpy() - st_b.cpu().numpy())) < 1e-13
+    x = rng.normal(size=shape[1:]) + 1j * rng.normal(size=shape[1:])
+    dev = _to_dev(eng, np.broadcast_to(x, shape).copy())
+    got = eng.apply_generator(dev, 0.0123).cpu().numpy()
+    assert eng.stats()["passes"] == {13: 2, 17: 2, 6: 1, 9: 2}[n]
+    ham = qp.build_hamiltonian(prob)
+    if mode == "sesolve":
+        ref = -1j * ham.apply(0.0123, x)
+    else:
+        ref = qp.lindblad_rhs(ham)(0.0123, x.ravel()).reshape(x.shape)
+    scale = np.max(np.abs(ref))
+    for b in (0, batch - 1):
+        assert np.max(np.abs(got[b] - ref)) <= 1e-11 * scale
 
 
 @pytest.mark.parametrize("n", [7, 8, 9])
