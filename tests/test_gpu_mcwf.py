@@ -221,3 +221,23 @@ def test_exotic_collapse_operators_fall_back_to_the_master_equation():
     with pytest.warns(DeprecationWarning):
         ra, rb = a.run(), b.run()
     assert np.allclose(np.asarray(ra.states[-1]), np.asarray(rb.states[-1]), atol=1e-12)
+
+
+def test_quantum_jumps_on_register_tile_and_tiled_kernels_agree():
+    """14 atoms (beyond the persistent kernel): the 2^14 register-tile kernel and
+    the tiled two-pass kernels, both with the H_eff decay diagonal, give the same
+    trajectories; norms stay 1 and jumps happen."""
+    prob = _problem(14, seed=31)
+    seeds = np.arange(64, dtype=np.uint64) + np.uint64(5)
+    tables = lower([prob] * 64)
+    out = []
+    for no14 in (False, True):
+        with Engine(tables, mode="mcsolve") as eng:
+            eng.set_path(False, no_tile14=no14)
+            state = eng.new_state()
+            eng.mc_solve(state, np.array([0.0, 0.03]), seeds, store=False)
+            out.append((state.cpu().numpy(), eng.mc_jumps(), eng.stats()["passes"]))
+    assert out[0][2] == 1 and out[1][2] == 2
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][1].sum() > 10
+    assert np.max(np.abs(out[0][0] - out[1][0])) < 1e-10
+    assert np.allclose(np.linalg.norm(out[0][0], axis=-1), 1.0, atol=1e-12)
