@@ -246,11 +246,13 @@ static int launch_traj2(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
   constexpr int D = 1 << N;
   constexpr int NTT = D < 64 ? 64 : (N >= 11 ? 1024 : (D > 512 ? 512 : D));
   const size_t lds = 2 * (size_t)D * sizeof(cplx) + 4 * 16 * sizeof(double) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the dynamic-LDS limit is a per-device function attribute
+  static bool attr_set[64] = {};
+  const int dev = h->cfg.device;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     HIPCHK(hipFuncSetAttribute((const void*)k_traj<N, NTT, MODEL, MC>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL((k_traj<N, NTT, MODEL, MC>), dim3(h->B), dim3(NTT), lds, st, A);
   HIPCHK(hipGetLastError());
