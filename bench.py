@@ -302,6 +302,26 @@ def main() -> None:
                      "jumps_per_trajectory": float(eng.mc_jumps().mean()),
                      "kernel": "k_traj<12,1024,1,MC> (persistent, jumps on the device, 1 launch)"})
         eng.close()
+        # ensemble density matrix of 1024 trajectories (density_matrix_aggregator): fp64 MFMA
+        eng = Engine.from_problems([chain_problem(12)] * 1024, mode="sesolve")
+        psi = torch.randn(1024, 4096, dtype=torch.complex128, device=eng.device)
+        rho = torch.zeros(4096, 4096, dtype=torch.complex128, device=eng.device)
+        eng.outer_accumulate(psi, rho)
+        torch.cuda.synchronize()
+        tic = time.perf_counter()
+        for _ in range(5):
+            eng.outer_accumulate(psi, rho)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - tic) / 5
+        flops = 8.0 * 4096 * 4097 / 2 * 1024  # Hermitian: tiles on or above the diagonal only
+        also.append({"workload": "trajectory-averaged density matrix, 1024 x 12-atom kets (rho = sum |psi><psi|)",
+                     "value": 1.0 / sec, "unit": "aggregations/s", "ms": sec * 1e3,
+                     "roofline": {"bound": "mfma", "kernel": "k_outer_mfma (v_mfma_f64_16x16x4_f64, upper-triangle 64x64 tiles)",
+                                  "achieved": flops / sec / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                  "frac": flops / sec / 1e12 / 78.6, "traffic": None,
+                                  "note": "measured issue ceiling of the f64 MFMA on this part: 48 TFLOP/s "
+                                          "(tools/ubench/mfma_f64.hip); a full ZGEMM would need 2x the flops"}})
+        eng.close()
         # north-star target size, Schroedinger leg: one 14-atom triangular-register sequence
         eng = Engine.from_problems([tri_problem(2, 7)], mode="sesolve")
         t0, t1 = 1.0, 1.1

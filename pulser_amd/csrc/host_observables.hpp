@@ -53,8 +53,16 @@ extern "C" int ryd_outer_accumulate(ryd_handle* h, const void* psi_dev, const do
     if (e != hipSuccess) { hipFree(wdev); return fail(RYD_ERR_HIP, "weights upload: %s", hipGetErrorString(e)); }
   }
   const size_t DD = (size_t)1 << (2 * h->N);
-  hipLaunchKernelGGL(k_outer_acc, dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, st,
-                     (const cplx*)psi_dev, h->N, h->B, wdev, (cplx*)acc_dev);
+  if (h->N >= 6) {
+    // fp64 matrix cores, upper-triangle 64 x 64 tiles (k_outer_mfma)
+    constexpr int KT = 16;
+    const unsigned nt = 1u << (h->N - 6);
+    hipLaunchKernelGGL(k_outer_mfma<KT>, dim3(nt, nt), dim3(256), 2 * KT * 128 * sizeof(double), st,
+                       (const cplx*)psi_dev, h->N, h->B, wdev, (cplx*)acc_dev);
+  } else {
+    hipLaunchKernelGGL(k_outer_acc, dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, st,
+                       (const cplx*)psi_dev, h->N, h->B, wdev, (cplx*)acc_dev);
+  }
   hipError_t e = hipGetLastError();
   if (wdev) { hipStreamSynchronize(st); hipFree(wdev); }
   if (e != hipSuccess) return fail(RYD_ERR_HIP, "k_outer_acc: %s", hipGetErrorString(e));

@@ -132,3 +132,134 @@ __global__ void k_outer_acc(const cplx* __restrict__ psi, int N, int B,
   acc[i].x += sr;
   acc[i].y += si;
 }
+
+// ---------------------------------------------------------------------------
+// k_outer_mfma: acc[a][b] += sum_t w_t psi_t[a] conj(psi_t[b]) on the fp64 matrix
+// cores - the one GEMM-shaped operation of the path: the trajectory-averaged
+// density matrix of density_matrix_aggregator (pulser_simulation/
+// aggregators.py:20-37) and of qutip.mcsolve's averaged states.
+//
+// With X = Re psi, Y = Im psi (B x D):  Re = X^T X + Y^T Y,  Im = Y^T X - X^T Y,
+// so two trajectories fill the K = 4 of one v_mfma_f64_16x16x4_f64:
+//   A_re = (x, y, x', y'),  A_im = (y, -x, y', -x'),  B = (x, y, x', y').
+// One workgroup (4 waves, 2 x 2) owns a 64 x 64 tile of the Hermitian result and
+// only tiles on or above the diagonal are computed (the mirror is written from
+// registers): half the flops of a ZGEMM.  KT trajectories of the two 64-wide
+// column strips are staged per step in LDS (weights folded into the A strip);
+// fragment reads are ds_read_b64, conflict-free (lanes 0-15 take the even
+// doubles of a 256-B run, lanes 16-31 the odd ones).
+// Operand / result lane maps of the f64 MFMA (MI355X guide): A[i = l & 15][k = l >> 4],
+// B[k = l >> 4][j = l & 15], C: col = l & 15, row = (l >> 4) + 4 * reg.
+// ---------------------------------------------------------------------------
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+// Measured on MI355X (tools/ubench/mfma_f64.hip): one wave issues an f64 MFMA every
+// ~59 ns whatever the number of independent accumulators, two waves per SIMD reach
+// 47 TFLOP/s - the f64 matrix pipe needs >= 4 waves per SIMD to approach its
+// 78.6 TFLOP/s, so the kernel is held to 128 registers (64 of them accumulators).
+template <int KT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_outer_mfma(const cplx* __restrict__ psi, int N, int B,
+                                                    const double* __restrict__ wts,
+                                                    cplx* __restrict__ acc) {
+  const int ta = blockIdx.y, tb = blockIdx.x;  // row / column tile
+  if (tb < ta) return;                          // lower triangle: mirrored below
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* sA = reinterpret_cast<double*>(smem);  // [KT][64][2] = w_t * psi_t[a0 + .]
+  double* sB = sA + KT * 128;                    // [KT][64][2] =       psi_t[b0 + .]
+  const size_t D = (size_t)1 << N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;       // 32 x 32 sub-tile of this wave
+  const int li = lane & 15, lk = lane >> 4;      // operand row/col, k slot
+  const size_t a0 = (size_t)ta * 64, b0 = (size_t)tb * 64;
+
+  mfma_d4 cre[2][2], cim[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      cre[r][c] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+      cim[r][c] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    }
+
+  // software pipeline: the global loads of chunk c + 1 are in flight while chunk c
+  // is multiplied; every thread stages PER = KT * 64 / 256 amplitudes of each strip
+  constexpr int PER = KT * 64 / 256;
+  cplx pa[PER], pb[PER];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int e = tid + it * 256, tt = e >> 6, col = e & 63, t = t0 + tt;
+      pa[it] = make_double2(0.0, 0.0);
+      pb[it] = pa[it];
+      if (t < B) {
+        const double w = wts ? wts[t] : 1.0;
+        const cplx va = psi[((size_t)t << N) + a0 + col];
+        pb[it] = psi[((size_t)t << N) + b0 + col];
+        pa[it] = make_double2(w * va.x, w * va.y);
+      }
+    }
+  };
+  fetch(0);
+  for (int t0 = 0; t0 < B; t0 += KT) {
+    __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int e = tid + it * 256;
+      *reinterpret_cast<cplx*>(sA + 2 * e) = pa[it];
+      *reinterpret_cast<cplx*>(sB + 2 * e) = pb[it];
+    }
+    __syncthreads();
+    if (t0 + KT < B) fetch(t0 + KT);
+#pragma unroll 4
+    for (int tt = 0; tt < KT; tt += 2) {
+      // k slot lk: trajectory tt + (lk >> 1), component lk & 1
+      const int trow = (tt + (lk >> 1)) * 128, comp = lk & 1;
+      double are[2], aim[2], bb[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int idx = trow + 2 * (wr * 32 + r * 16 + li);
+        are[r] = sA[idx + comp];
+        const double o = sA[idx + (comp ^ 1)];
+        aim[r] = comp ? -o : o;  // (y, -x)
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bb[c] = sB[trow + 2 * (wc * 32 + c * 16 + li) + comp];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          cre[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[r], bb[c], cre[r][c], 0, 0, 0);
+          cim[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[r], bb[c], cim[r][c], 0, 0, 0);
+        }
+    }
+  }
+  // accumulate into the result: this tile and, off the diagonal, its mirror
+  // (conjugate transpose).  Eight old values are loaded before the eight stores of
+  // a phase (tile and mirror never overlap), so the round trips overlap without
+  // holding the whole tile twice in registers.
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int mirror = 0; mirror < 2; ++mirror) {
+      if (mirror && ta == tb) continue;
+      cplx old[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const size_t row = a0 + wr * 32 + r * 16 + (size_t)(lane >> 4) + 4 * g;
+          const size_t col = b0 + wc * 32 + c * 16 + (size_t)(lane & 15);
+          old[c][g] = mirror ? acc[col * D + row] : acc[row * D + col];
+        }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const size_t row = a0 + wr * 32 + r * 16 + (size_t)(lane >> 4) + 4 * g;
+          const size_t col = b0 + wc * 32 + c * 16 + (size_t)(lane & 15);
+          const double vr = cre[r][c][g], vi = cim[r][c][g];
+          if (mirror) acc[col * D + row] = make_double2(old[c][g].x + vr, old[c][g].y - vi);
+          else acc[row * D + col] = make_double2(old[c][g].x + vr, old[c][g].y + vi);
+        }
+    }
+}

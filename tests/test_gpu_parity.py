@@ -298,3 +298,27 @@ def test_register_tile_kernel_sesolve_14_and_16_atoms():
             res[no14] = st.cpu().numpy()
             assert eng.stats()["passes"] == ({14: 1, 16: 2}[n] if not no14 else 2)
         assert np.max(np.abs(res[False] - res[True])) < 1e-13
+
+
+@pytest.mark.parametrize("n,batch", [(3, 7), (6, 5), (7, 33), (9, 130)])
+def test_trajectory_averaged_density_matrix_kernels(n, batch):
+    """rho += sum_t w_t |psi_t><psi_t| (density_matrix_aggregator,
+    pulser_simulation/aggregators.py:20-37): the plain kernel (N < 6) and the
+    fp64 matrix-core kernel (upper-triangle tiles + mirror, ragged trajectory
+    counts, weights, accumulation into a non-zero matrix) against NumPy."""
+    prob = local_problem(n, seed=1, duration=21)
+    eng = _engine([prob] * batch, mode="sesolve")
+    rng = np.random.default_rng(n)
+    D = 2**n
+    psi = rng.normal(size=(batch, D)) + 1j * rng.normal(size=(batch, D))
+    w = rng.uniform(0.2, 2.0, batch)
+    start = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    acc = _to_dev(eng, start.copy())
+    dev = _to_dev(eng, psi)
+    eng.outer_accumulate(dev, acc, w)
+    eng.outer_accumulate(dev, acc)
+    ref = start + np.einsum("t,ta,tb->ab", w + 1.0, psi, psi.conj())
+    got = acc.cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref))
+    pure = got - start
+    assert np.max(np.abs(pure - pure.conj().T)) <= 1e-12 * np.max(np.abs(ref))
