@@ -751,6 +751,47 @@ def gen_dmm():
     )
 
 
+def gen_waist():
+    """Amplitude noise with a finite laser waist (hamiltonian_data.py:758-780,
+    450-463), detuning noise with a high-frequency PSD and register noise on a
+    3D-capable device: pulser-core's per-trajectory samples and interaction
+    matrices for a 5-atom triangular register (seed 5)."""
+    from pulser_amd.pulser_adapter import problem_from_trajectory, sequence_inputs_from_pulser
+
+    reg = Register.triangular_lattice(2, 3, spacing=6.5, prefix="q").with_automatic_layout(MockDevice) \
+        if False else Register.triangular_lattice(2, 3, spacing=6.5, prefix="q")
+    seq = Sequence(reg, MockDevice)
+    seq.declare_channel("ising", "rydberg_global")
+    seq.add(Pulse.ConstantDetuning(BlackmanWaveform(240, 2.5), -2.0, 0.3), "ising")
+    seq.add(Pulse.ConstantAmplitude(4.0, RampWaveform(160, -5.0, 6.0), 0.0), "ising")
+    T = seq.get_duration()
+    samples = sampler.sample(seq, extended_duration=T)
+    inputs = sequence_inputs_from_pulser(samples, seq.register, seq.device)
+    ext = samples.extend_duration(T + 1)
+    params = dict(amp_sigma=0.08, laser_waist=20.0, temperature=30.0, trap_depth=150.0, trap_waist=1.0,
+                  detuning_sigma=0.3, detuning_hf_psd=(3.0, 2.0, 1.0), detuning_hf_omegas=(10.0, 30.0, 70.0))
+    nm = NoiseModel(**params)
+    np.random.seed(5)
+    hd = HamiltonianData(ext, seq.register, seq.device, nm, 4)
+    probe = np.random.get_state()[1][:4].copy()
+    qids = list(reg.qubits)
+    dets, amps, inter, coords = [], [], [], []
+    for traj, noisy, reps in hd.noisy_samples:
+        prob = problem_from_trajectory(hd, traj, noisy, reps, 1.0)
+        loc = prob["samples"]["Local"]["ground-rydberg"]
+        dets.append(np.stack([loc[q]["det"] for q in range(len(qids))]))
+        amps.append(np.stack([loc[q]["amp"] for q in range(len(qids))]))
+        inter.append(np.asarray(prob["interaction_matrix"]))
+        coords.append(np.stack([np.asarray(traj.register.qubits[q].as_array()) for q in qids]))
+    print(f"waist: {len(dets)} trajectories; noise types {nm.noise_types}; amp ratio atom0 "
+          f"{amps[0][0][100] / float(np.asarray(ext.samples_list[0].amp.as_array())[100]):.4f}")
+    P.save_problem(os.path.join(HERE, "waist_tri6.npz"), {"inputs": inputs.to_dict()}, seed=5,
+                   noise_model={k: (list(v) if isinstance(v, tuple) else v) for k, v in params.items()},
+                   det=np.stack(dets), amp=np.stack(amps), interaction=np.stack(inter),
+                   coords=np.stack(coords), rng_probe=probe,
+                   reference_cite="pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py:408-534, 758-780")
+
+
 def gen_results_json():
     """A ``pulser.backend.Results`` filled with raw values of every kind the
     default observables store, serialised by pulser-core itself
@@ -820,3 +861,5 @@ if __name__ == "__main__":
         gen_dmm()
     if "results" in which:
         gen_results_json()
+    if "waist" in which:
+        gen_waist()

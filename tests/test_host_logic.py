@@ -859,3 +859,29 @@ def test_emulator_golden_counter_spam_trajectories_all_basis(monkeypatch, capsys
     with pytest.raises(NotImplementedError, match="Cannot include"):
         QutipEmulator(SequenceInputs.from_dict(load_fixture("noise_spam_all.npz")[0]["inputs"]),
                       noise_model=NoiseModel(depolarizing_rate=0.05))
+
+
+def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
+    """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
+    + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
+    in one noise model: the per-trajectory samples, noisy coordinates and
+    interaction matrices equal what pulser-core produced (fixture, seed 5)."""
+    prob, extra = load_fixture("waist_tri6.npz")
+    inputs = SequenceInputs.from_dict(prob["inputs"])
+    kw = dict(extra["noise_model"])
+    for k in ("detuning_hf_psd", "detuning_hf_omegas"):
+        kw[k] = tuple(kw[k])
+    nm = NoiseModel(**kw)
+    assert set(nm.noise_types) == {"amplitude", "detuning", "doppler", "register"}
+    np.random.seed(int(extra["seed"]))
+    hd = HamiltonianData(inputs.extend_duration(inputs.max_duration + 1), nm, 4)
+    assert np.array_equal(np.random.get_state()[1][:4], extra["rng_probe"])
+    assert not hd.factorable()  # the hf detuning noise is not a scaled copy of the samples
+    n = inputs.n_qudits
+    for i, t in enumerate(hd.noise_trajectories):
+        assert np.allclose(t.coords, extra["coords"][i], rtol=0, atol=1e-15)
+        p = hd.problem(t, 1.0)
+        loc = p["samples"]["Local"]["ground-rydberg"]
+        assert np.allclose(np.stack([loc[q]["amp"] for q in range(n)]), extra["amp"][i], rtol=1e-15, atol=0)
+        assert np.allclose(np.stack([loc[q]["det"] for q in range(n)]), extra["det"][i], rtol=1e-14, atol=1e-14)
+        assert np.allclose(p["interaction_matrix"], extra["interaction"][i], rtol=1e-13, atol=0)
