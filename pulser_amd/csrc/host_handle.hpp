@@ -255,6 +255,12 @@ extern "C" int ryd_create(const ryd_config* cfg, ryd_handle** out) {
       if (((long long)cfg->batch << std::max(nb - t, 0)) >= 256) break;
     }
     h->T = best;
+    // A 2^13 tile (128 KiB of LDS, one workgroup per CU) when it saves a whole
+    // pass and the launch still has >= 128 tiles (13-atom kets, batch 256: 465 vs
+    // 273 sim-us/s; batch 16: 43 vs 81 - measured, tools/t13_bench.py).
+    if (cfg->mode == RYD_SESOLVE && passes(13) < passes(12) &&
+        ((long long)cfg->batch << std::max(nb - 13, 0)) >= 128)
+      h->T = 13;
   }
   h->dim = (size_t)1 << nb;
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);

@@ -245,7 +245,8 @@ def test_tiled_kernel_workgroup_widths_and_pass_plans(mode, n, batch):
     x = rng.normal(size=shape[1:]) + 1j * rng.normal(size=shape[1:])
     dev = _to_dev(eng, np.broadcast_to(x, shape).copy())
     got = eng.apply_generator(dev, 0.0123).cpu().numpy()
-    assert eng.stats()["passes"] == {13: 2, 17: 2, 6: 1, 9: 2}[n]
+    # 13-atom kets: two 2^12-tile passes, or one pass of 2^13 tiles when >= 128 tiles remain
+    assert eng.stats()["passes"] == ({13: 2, 17: 2, 6: 1, 9: 2}[n] if batch < 128 else 1)
     ham = qp.build_hamiltonian(prob)
     if mode == "sesolve":
         ref = -1j * ham.apply(0.0123, x)
