@@ -349,3 +349,35 @@ def test_reference_golden_counter_test_noise_end_to_end(capsys):
         "Emulating Trajectories [1 - 13]/15", "Emulating Trajectory 14/15",
         "Emulating Trajectory 15/15"]
     assert r.sample_final_state() == Counter(extra["reference_golden_counter"])
+
+
+def test_sharded_ensemble_on_the_gpu_equals_the_serial_run():
+    """pulser_amd.distributed.run_ensemble with the real HIP solver (world size 1):
+    same Counters as QutipEmulator.run() for the same seed (all random numbers are
+    drawn in the reference's order), independent of the batch size; with
+    dissipation the quantum-jump seeds are per trajectory, so the split does not
+    matter either."""
+    from pulser_amd.distributed import run_ensemble
+
+    prob0, extra = load_fixture("cfg4_chain12_noise.npz")
+    nm = NoiseModel(**extra["noise_model"])
+
+    def make(noise=nm, n=24):
+        np.random.seed(7)
+        return QutipEmulator(_chain12_inputs(extra), noise_model=noise, n_trajectories=n,
+                             evaluation_times="Minimal")
+
+    with pytest.warns(DeprecationWarning):
+        serial = make().run()
+    for batch in (5, 64):
+        out = run_ensemble(make(), dist=None, batch=batch)
+        assert out["counters"][-1] == Counter(serial[-1].bitstring_counts)
+        assert out["n_measures"] == serial.n_measures
+    # dissipative + stochastic noise -> Monte-Carlo wavefunction trajectories
+    nm_mc = NoiseModel(temperature=50.0, amp_sigma=0.05, dephasing_rate=0.2, relaxation_rate=0.1)
+    a = run_ensemble(make(nm_mc, 12), dist=None, batch=4, mc_seed=11)
+    b = run_ensemble(make(nm_mc, 12), dist=None, batch=12, mc_seed=11)
+    assert a["counters"] == b["counters"]
+    assert np.array_equal(a["histograms"], b["histograms"])
+    c = run_ensemble(make(nm_mc, 12), dist=None, batch=12, mc_seed=12)
+    assert sum(c["counters"][-1].values()) == sum(a["counters"][-1].values())
