@@ -73,16 +73,29 @@ typedef struct ryd_config {
  * (pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py:408-534):
  *   c_k(t)     = drive_scale * S[drive_series](t)          (complex, = Omega/2 e^{-i phi})
  *   delta_k(t) = det_scale * Re S[det_series](t) + off_scale * Re S[off_series](t)
- * series index -1 = absent (coefficient 0).  */
+ *                + sum over the extra detuning terms of  scale * Re S[series](t)
+ * series index -1 = absent (coefficient 0).  `extra` = 1-based index of the
+ * first extra detuning term of this (trajectory, atom) in the table given to
+ * ryd_set_detuning_terms (0 = none); its terms are contiguous and the last one
+ * has `last` != 0.  The extra terms carry the high-frequency detuning noise
+ * sum_f A_f cos(w_f t + phi_f) of _generate_detuning_fluctuations
+ * (hamiltonian_data.py:132-169) as  A_f cos(phi_f) * [m cos(w_f t)] -
+ * A_f sin(phi_f) * [m sin(w_f t)]  on shared series (m = the slot mask). */
 typedef struct ryd_qdesc {
   int32_t drive_series;
   int32_t det_series;
   int32_t off_series;
-  int32_t pad;
+  int32_t extra;
   double drive_scale;
   double det_scale;
   double off_scale;
 } ryd_qdesc;
+
+typedef struct ryd_dterm {
+  int32_t series;
+  int32_t last; /* non-zero on the last term of a (trajectory, atom) */
+  double scale;
+} ryd_dterm;
 
 typedef struct ryd_opts {
   int32_t taylor_order; /* 0 = choose from norm bound and `tol` */

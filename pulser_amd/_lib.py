@@ -52,11 +52,15 @@ class RydQDesc(C.Structure):
         ("drive_series", C.c_int32),
         ("det_series", C.c_int32),
         ("off_series", C.c_int32),
-        ("pad", C.c_int32),
+        ("extra", C.c_int32),
         ("drive_scale", C.c_double),
         ("det_scale", C.c_double),
         ("off_scale", C.c_double),
     ]
+
+
+class RydDTerm(C.Structure):
+    _fields_ = [("series", C.c_int32), ("last", C.c_int32), ("scale", C.c_double)]
 
 
 class RydOpts(C.Structure):
@@ -88,6 +92,7 @@ SYMBOLS = {
     "ryd_destroy": (None, [C.c_void_p]),
     "ryd_set_series": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ryd_set_qubit_desc": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ryd_set_detuning_terms": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ryd_set_interaction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "ryd_set_dissipator": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ryd_evolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.POINTER(RydOpts), C.c_void_p]),

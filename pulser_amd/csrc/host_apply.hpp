@@ -16,7 +16,7 @@ static int find_interval(const ryd_handle* h, double t) {
 static int launch_eval(ryd_handle* h, const MixPoint& m, hipStream_t st) {
   const int total = h->B * h->N;
   hipLaunchKernelGGL(k_eval_coefs, dim3((total + 127) / 128), dim3(128), 0, st, h->pp_dev,
-                     h->n_knots - 1, h->desc_dev, total, m.idx1, m.u1, m.w1, m.idx2, m.u2, m.w2,
+                     h->n_knots - 1, h->desc_dev, h->dterms_dev, total, m.idx1, m.u1, m.w1, m.idx2, m.u2, m.w2,
                      h->coefs_dev);
   HIPCHK(hipGetLastError());
   return RYD_OK;
@@ -162,7 +162,7 @@ static int check_ready(const ryd_handle* h) {
     return RYD_OK;
   }
   if (!h->desc_dev) return fail(RYD_ERR_STATE, "ryd_set_qubit_desc has not been called");
-  return RYD_OK;
+  return validate_extras(h);
 }
 
 struct MixPoint;

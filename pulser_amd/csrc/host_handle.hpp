@@ -32,6 +32,8 @@ struct ryd_handle {
   cplx* pp_dev = nullptr;
   std::vector<ryd_qdesc> desc_host;
   ryd_qdesc* desc_dev = nullptr;
+  std::vector<ryd_dterm> dterms_host;  // extra detuning terms (ryd_qdesc.extra)
+  ryd_dterm* dterms_dev = nullptr;
   std::vector<double> bd_drive, bd_pos, bd_neg;  // per interval, max over batch
   std::vector<double> bd_curv;                   // per interval: non-linearity of H(t)
   bool bounds_valid = false;
@@ -323,6 +325,7 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->e0_dev);
   hipFree(h->pp_dev);
   hipFree(h->desc_dev);
+  hipFree(h->dterms_dev);
   hipFree(h->sched_dev);
   hipFree(h->gen_tcoef);
   hipFree(h->gen_terms_dev);
@@ -397,6 +400,40 @@ extern "C" int ryd_set_qubit_desc(ryd_handle* h, const ryd_qdesc* desc) {
   return RYD_OK;
 }
 
+extern "C" int ryd_set_detuning_terms(ryd_handle* h, int32_t n_terms, const ryd_dterm* terms) {
+  if (!h || (n_terms > 0 && !terms)) return fail(RYD_ERR_INVALID, "null argument");
+  if (h->general) return fail(RYD_ERR_INVALID, "not available on a general-path handle");
+  if (n_terms < 0) return fail(RYD_ERR_INVALID, "n_terms < 0");
+  if (n_terms > 0 && h->n_series == 0) return fail(RYD_ERR_STATE, "ryd_set_series must be called first");
+  for (int i = 0; i < n_terms; ++i)
+    if (terms[i].series < 0 || terms[i].series >= h->n_series)
+      return fail(RYD_ERR_INVALID, "series index %d out of range at term %d", terms[i].series, i);
+  if (n_terms > 0 && !terms[n_terms - 1].last)
+    return fail(RYD_ERR_INVALID, "the last detuning term must close its list (last != 0)");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->dterms_dev) hipFree(h->dterms_dev);
+  h->dterms_dev = nullptr;
+  h->dterms_host.assign(terms, terms + n_terms);
+  if (n_terms > 0) {
+    HIPCHK(hipMalloc((void**)&h->dterms_dev, (size_t)n_terms * sizeof(ryd_dterm)));
+    HIPCHK(hipMemcpy(h->dterms_dev, terms, (size_t)n_terms * sizeof(ryd_dterm), hipMemcpyHostToDevice));
+  }
+  h->bounds_valid = false;
+  return RYD_OK;
+}
+
+// every ryd_qdesc.extra must point into the table of extra detuning terms
+static int validate_extras(const ryd_handle* h) {
+  const int n = (int)h->dterms_host.size();
+  for (size_t i = 0; i < h->desc_host.size(); ++i) {
+    const int e = h->desc_host[i].extra;
+    if (e < 0 || e > n)
+      return fail(RYD_ERR_INVALID, "descriptor %zu: extra = %d outside the %d detuning terms "
+                  "(ryd_set_detuning_terms)", i, e, n);
+  }
+  return RYD_OK;
+}
+
 static void compute_bounds(ryd_handle* h) {
   const int n_int = h->n_knots - 1;
   h->bd_drive.assign(n_int, 0.0);
@@ -431,6 +468,12 @@ static void compute_bounds(ryd_handle* h) {
       };
       add_det(d.det_series, d.det_scale);
       add_det(d.off_series, d.off_scale);
+      if (d.extra > 0 && d.extra <= (int)h->dterms_host.size()) {
+        for (size_t e = (size_t)d.extra - 1; e < h->dterms_host.size(); ++e) {
+          add_det(h->dterms_host[e].series, h->dterms_host[e].scale);
+          if (h->dterms_host[e].last) break;
+        }
+      }
     }
     for (int i = 0; i < n_int; ++i) {
       h->bd_drive[i] = std::max(h->bd_drive[i], dr[i]);

@@ -290,6 +290,7 @@ static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc
   A.pp = h->pp_dev;
   A.n_int = h->n_knots - 1;
   A.desc = h->desc_dev;
+  A.dterms = h->dterms_dev;
   A.e0 = h->e0_dev;
   A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << h->N);
   A.steps = h->sched_dev;

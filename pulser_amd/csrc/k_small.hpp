@@ -2,7 +2,8 @@
 // coefs[b][k] = w1 * val(t1) + w2 * val(t2) for the drive (complex) and the
 // detuning (real) of atom k of trajectory b.  pp: [n_series][n_int][4] complex.
 __global__ void k_eval_coefs(const cplx* __restrict__ pp, int n_int,
-                             const ryd_qdesc* __restrict__ desc, int total,
+                             const ryd_qdesc* __restrict__ desc,
+                             const ryd_dterm* __restrict__ dterms, int total,
                              int idx1, double u1, double w1, int idx2, double u2,
                              double w2, double* __restrict__ coefs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -26,6 +27,13 @@ __global__ void k_eval_coefs(const cplx* __restrict__ pp, int n_int,
     dl += d.det_scale * (w1 * val(d.det_series, idx1, u1).x + w2 * val(d.det_series, idx2, u2).x);
   if (d.off_series >= 0)
     dl += d.off_scale * (w1 * val(d.off_series, idx1, u1).x + w2 * val(d.off_series, idx2, u2).x);
+  if (d.extra > 0 && dterms) {  // high-frequency detuning noise on shared series
+    for (int e = d.extra - 1;; ++e) {
+      const ryd_dterm t = dterms[e];
+      dl += t.scale * (w1 * val(t.series, idx1, u1).x + w2 * val(t.series, idx2, u2).x);
+      if (t.last) break;
+    }
+  }
   coefs[4 * (size_t)i + 0] = cr;
   coefs[4 * (size_t)i + 1] = ci;
   coefs[4 * (size_t)i + 2] = dl;

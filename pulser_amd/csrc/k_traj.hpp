@@ -28,6 +28,7 @@ struct TrajArgs {
   cplx* snaps;         // [n_slots][B][2^N] or null
   const cplx* pp;      // [n_series][n_int][4]
   const ryd_qdesc* desc;
+  const ryd_dterm* dterms;  // extra detuning terms (or null)
   const double* e0;
   long long e0_stride;
   const StepDesc* steps;
@@ -114,6 +115,15 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
         const double o1 = val(d.off_series, sd.u1).x, o2 = val(d.off_series, sd.u2).x;
         dlA += d.off_scale * (A.a1 * o1 + A.a2 * o2);
         dlB += d.off_scale * (A.a2 * o1 + A.a1 * o2);
+      }
+      if (d.extra > 0 && A.dterms) {
+        for (int e = d.extra - 1;; ++e) {
+          const ryd_dterm t = A.dterms[e];
+          const double o1 = val(t.series, sd.u1).x, o2 = val(t.series, sd.u2).x;
+          dlA += t.scale * (A.a1 * o1 + A.a2 * o2);
+          dlB += t.scale * (A.a2 * o1 + A.a1 * o2);
+          if (t.last) break;
+        }
       }
       cfA[4 * tid + 0] = d.drive_scale * (A.a1 * c1r + A.a2 * c2r);
       cfA[4 * tid + 1] = d.drive_scale * (A.a1 * c1i + A.a2 * c2i);

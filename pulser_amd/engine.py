@@ -98,6 +98,10 @@ class Engine:
         desc = np.ascontiguousarray(t.desc)
         assert desc.dtype.itemsize == C.sizeof(RydQDesc)
         _lib.check(self.lib.ryd_set_qubit_desc(self._h, desc.ctypes.data))
+        if t.dterms is not None and len(t.dterms):
+            dt = np.ascontiguousarray(t.dterms)
+            assert dt.dtype.itemsize == C.sizeof(_lib.RydDTerm)
+            _lib.check(self.lib.ryd_set_detuning_terms(self._h, len(dt), dt.ctypes.data))
         u = np.ascontiguousarray(t.interaction, dtype=np.float64)
         _lib.check(self.lib.ryd_set_interaction(self._h, u.ctypes.data, u.shape[0]))
         if self.mode == RYD_MESOLVE and t.dissipator is not None:

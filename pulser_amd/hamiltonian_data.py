@@ -601,10 +601,9 @@ class HamiltonianData:
     def factorable(self) -> bool:
         """True when every trajectory's noisy samples are the shared channel
         samples scaled / offset per (trajectory, atom): each atom driven by one
-        channel only, no high-frequency detuning noise, 2-level basis."""
+        channel only, 2-level basis (the high-frequency detuning noise factors
+        too: cos / sin series shared by the batch, per-trajectory amplitudes)."""
         if len(self.eigenbasis) != 2 or self.interaction_type != "ising":
-            return False
-        if self.noise_model.detuning_hf_psd:
             return False
         seen: set[tuple[str, int]] = set()
         for ch in self.samples.channels:
@@ -625,8 +624,9 @@ class HamiltonianData:
         (trajectory, atom) descriptor carries the amplitude factor, the doppler /
         detuning offset (times the slot mask) and the bad-atom zeroing.
         """
-        from .terms import (DESC_DTYPE, DeviceTables, _SeriesPool, adapt_to_sampling_rate,
-                            local_collapse_ops, local_dissipator, lower, sampling_times)
+        from .terms import (DESC_DTYPE, DTERM_DTYPE, DeviceTables, _SeriesPool,
+                            adapt_to_sampling_rate, local_collapse_ops, local_dissipator, lower,
+                            sampling_times)
         from scipy.interpolate import CubicSpline
 
         if not self.factorable():
@@ -636,6 +636,15 @@ class HamiltonianData:
         basis_name = self.basis_name
         tknots = sampling_times(T, sampling_rate)
         pool = _SeriesPool()
+        # high-frequency detuning noise (:132-169): sum_f A_f cos(w_f t + phi_f) inside the
+        # slots = A_f cos(phi_f) [m cos(w_f t)] - A_f sin(phi_f) [m sin(w_f t)]
+        hf = bool(nm.detuning_hf_psd) and "detuning" in nm.noise_types
+        if hf:
+            om = np.asarray(nm.detuning_hf_omegas, float)
+            hf_freqs = om[1:]
+            hf_amp = np.sqrt(2.0 * np.diff(om) * np.asarray(nm.detuning_hf_psd, float)[1:])
+            t_us = np.arange(0, T, 1) * 1e-3
+        hf_series: dict[int, list[tuple[int, int]]] = {}
         # per atom: (channel, drive series, det series, mask series)
         per_atom: dict[int, tuple[Any, int, int, int]] = {}
         for ch in self.samples.channels:
@@ -650,8 +659,15 @@ class HamiltonianData:
                 ti = pool.add(adapt_to_sampling_rate(m * cs.det, sampling_rate, T))
                 mi = pool.add(adapt_to_sampling_rate(m, sampling_rate, T))
                 per_atom[t] = (ch, di, ti, mi)
+                if hf:
+                    hf_series[t] = [
+                        (pool.add(adapt_to_sampling_rate(m * np.cos(w * t_us), sampling_rate, T)),
+                         pool.add(adapt_to_sampling_rate(m * np.sin(w * t_us), sampling_rate, T)))
+                        for w in hf_freqs
+                    ]
         desc = np.zeros((len(trajs), n), dtype=DESC_DTYPE)
         desc["drive_series"] = desc["det_series"] = desc["off_series"] = -1
+        dterms: list[tuple[int, int, float]] = []
         mats = []
         local = self.local_noises
         for b, tr in enumerate(trajs):
@@ -677,6 +693,18 @@ class HamiltonianData:
                     d["det_series"], d["det_scale"] = ti, 1.0
                 if off != 0.0 and mi >= 0:
                     d["off_series"], d["off_scale"] = mi, off
+                if hf and local:
+                    phases = np.atleast_1d(np.asarray(tr.det_phases[ch.name], float))
+                    first = len(dterms)
+                    for f, (cs_id, sn_id) in enumerate(hf_series[k]):
+                        if cs_id >= 0:
+                            dterms.append((cs_id, 0, float(hf_amp[f] * np.cos(phases[f]))))
+                        if sn_id >= 0:
+                            dterms.append((sn_id, 0, float(-hf_amp[f] * np.sin(phases[f]))))
+                    if len(dterms) > first:
+                        s_, _, sc_ = dterms[-1]
+                        dterms[-1] = (s_, 1, sc_)
+                        d["extra"] = first + 1
             bad = np.asarray(tr.bad_atoms, bool)
             u = np.array(tr.interaction_matrix, dtype=float)[-1].copy()
             np.fill_diagonal(u, 0.0)
@@ -699,4 +727,5 @@ class HamiltonianData:
             dissipator=local_dissipator(ops, self.eigenbasis, paulis),
             series_knots=pool.arrays,
             collapse_local=local_collapse_ops(ops, self.eigenbasis, paulis),
+            dterms=np.array(dterms, dtype=DTERM_DTYPE) if dterms else None,
         )

@@ -61,6 +61,7 @@ class DeviceTables:
     dissipator: np.ndarray | None  # complex128[4][4] or None
     series_knots: list[np.ndarray]  # the knot arrays (for tests / bounds)
     collapse_local: np.ndarray | None = None  # complex128[n_ops][2][2] (Monte-Carlo solver)
+    dterms: np.ndarray | None = None  # DTERM_DTYPE[n]: extra detuning terms (hf detuning noise)
 
 
 DESC_DTYPE = np.dtype(
@@ -68,13 +69,17 @@ DESC_DTYPE = np.dtype(
         ("drive_series", "<i4"),
         ("det_series", "<i4"),
         ("off_series", "<i4"),
-        ("pad", "<i4"),
+        ("extra", "<i4"),  # 1-based index of the first extra detuning term (0 = none)
         ("drive_scale", "<f8"),
         ("det_scale", "<f8"),
         ("off_scale", "<f8"),
     ],
     align=True,
 )
+
+
+# extra detuning terms (include/rydemu.h: ryd_dterm)
+DTERM_DTYPE = np.dtype([("series", "<i4"), ("last", "<i4"), ("scale", "<f8")], align=True)
 
 
 class _SeriesPool:

@@ -381,3 +381,34 @@ def test_sharded_ensemble_on_the_gpu_equals_the_serial_run():
     assert np.array_equal(a["histograms"], b["histograms"])
     c = run_ensemble(make(nm_mc, 12), dist=None, batch=12, mc_seed=12)
     assert sum(c["counters"][-1].values()) == sum(a["counters"][-1].values())
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_hf_detuning_noise_factored_on_device_equals_per_trajectory_solve(generic):
+    """High-frequency detuning noise + laser-waist amplitude noise + doppler +
+    register noise (pulser-core's trajectories, fixture): the factored lowering
+    with the on-device ``ryd_dterm`` synthesis gives the states of the
+    per-trajectory lowering, on the persistent and on the multi-launch kernels."""
+    from pulser_amd.engine import Engine
+    from pulser_amd.hamiltonian_data import HamiltonianData, SequenceInputs
+    from pulser_amd.terms import lower
+
+    prob, extra = load_fixture("waist_tri6.npz")
+    inputs = SequenceInputs.from_dict(prob["inputs"])
+    kw = dict(extra["noise_model"])
+    for key in ("detuning_hf_psd", "detuning_hf_omegas"):
+        kw[key] = tuple(kw[key])
+    np.random.seed(5)
+    hd = HamiltonianData(inputs.extend_duration(inputs.max_duration + 1), NoiseModel(**kw), 4)
+    trajs = hd.noise_trajectories
+    times = [0.0, 0.2, inputs.max_duration * 1e-3]
+    out = []
+    for tables in (hd.device_tables(trajs, 1.0), lower([hd.problem(t, 1.0) for t in trajs])):
+        with Engine(tables, mode="sesolve") as eng:
+            eng.set_path(generic)
+            state = eng.new_state()
+            out.append(eng.solve(state, times).cpu().numpy())
+            launches = eng.stats()["n_launches"]
+    assert (launches == 1) == (not generic)
+    assert np.max(np.abs(out[0] - out[1])) < 1e-9
+    assert np.max(np.abs(out[0][-1][0] - out[0][-1][1])) > 1e-3  # trajectories really differ

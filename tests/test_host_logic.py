@@ -876,7 +876,7 @@ def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     np.random.seed(int(extra["seed"]))
     hd = HamiltonianData(inputs.extend_duration(inputs.max_duration + 1), nm, 4)
     assert np.array_equal(np.random.get_state()[1][:4], extra["rng_probe"])
-    assert not hd.factorable()  # the hf detuning noise is not a scaled copy of the samples
+    assert hd.factorable()
     n = inputs.n_qudits
     for i, t in enumerate(hd.noise_trajectories):
         assert np.allclose(t.coords, extra["coords"][i], rtol=0, atol=1e-15)
@@ -885,3 +885,58 @@ def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
         assert np.allclose(np.stack([loc[q]["amp"] for q in range(n)]), extra["amp"][i], rtol=1e-15, atol=0)
         assert np.allclose(np.stack([loc[q]["det"] for q in range(n)]), extra["det"][i], rtol=1e-14, atol=1e-14)
         assert np.allclose(p["interaction_matrix"], extra["interaction"][i], rtol=1e-13, atol=0)
+
+
+def _eval_tables_detuning(tables, b, k, t):
+    """delta_k(t) of trajectory b from DeviceTables (host evaluation of the spline
+    pieces, the arithmetic of k_eval_coefs)."""
+    idx = np.clip(np.searchsorted(tables.tknots, t, side="right") - 1, 0, len(tables.tknots) - 2)
+    u = t - tables.tknots[idx]
+
+    def val(series):
+        c = tables.pp[series, idx]
+        return (((c[:, 0] * u + c[:, 1]) * u + c[:, 2]) * u + c[:, 3]).real
+
+    d = tables.desc[b, k]
+    out = np.zeros_like(t)
+    if d["det_series"] >= 0:
+        out += d["det_scale"] * val(d["det_series"])
+    if d["off_series"] >= 0:
+        out += d["off_scale"] * val(d["off_series"])
+    e = d["extra"] - 1
+    while e >= 0:
+        term = tables.dterms[e]
+        out += term["scale"] * val(term["series"])
+        if term["last"]:
+            break
+        e += 1
+    return out
+
+
+def test_factored_lowering_with_hf_detuning_noise_equals_per_trajectory_lowering():
+    """the high-frequency detuning noise is synthesised from
+    shared cos / sin series and per-trajectory amplitudes (ryd_dterm table) instead
+    of one spline per (trajectory, atom): same detuning, drive and interaction as
+    lowering every trajectory's noisy samples."""
+    from pulser_amd.terms import lower
+
+    prob, extra = load_fixture("waist_tri6.npz")
+    inputs = SequenceInputs.from_dict(prob["inputs"])
+    kw = dict(extra["noise_model"])
+    for key in ("detuning_hf_psd", "detuning_hf_omegas"):
+        kw[key] = tuple(kw[key])
+    np.random.seed(5)
+    hd = HamiltonianData(inputs.extend_duration(inputs.max_duration + 1), NoiseModel(**kw), 4)
+    trajs = hd.noise_trajectories
+    fact = hd.device_tables(trajs, 1.0)
+    assert fact.dterms is not None and np.all(fact.desc["extra"] > 0)
+    assert fact.dterms["last"].sum() == 4 * inputs.n_qudits
+    full = lower([hd.problem(t, 1.0) for t in trajs])
+    assert full.dterms is None and len(fact.pp) < len(full.pp)
+    t = np.random.default_rng(0).uniform(0.0, inputs.max_duration * 1e-3, 400)
+    for b in range(4):
+        for k in range(inputs.n_qudits):
+            a = _eval_tables_detuning(fact, b, k, t)
+            c = _eval_tables_detuning(full, b, k, t)
+            assert np.max(np.abs(a - c)) < 1e-11 * max(1.0, np.max(np.abs(c)))
+    assert np.allclose(fact.interaction, full.interaction, rtol=1e-14, atol=0)
