@@ -76,8 +76,9 @@ typedef struct ryd_config {
  *                + sum over the extra detuning terms of  scale * Re S[series](t)
  * series index -1 = absent (coefficient 0).  `extra` = 1-based index of the
  * first extra detuning term of this (trajectory, atom) in the table given to
- * ryd_set_detuning_terms (0 = none); its terms are contiguous and the last one
- * has `last` != 0.  The extra terms carry the high-frequency detuning noise
+ * ryd_set_detuning_terms (0 = none); its terms are contiguous and each carries
+ * the number of terms that still follow it (`remaining`, 0 on the last), so the
+ * first one gives the length of the list and a wave can evaluate it in parallel.  The extra terms carry the high-frequency detuning noise
  * sum_f A_f cos(w_f t + phi_f) of _generate_detuning_fluctuations
  * (hamiltonian_data.py:132-169) as  A_f cos(phi_f) * [m cos(w_f t)] -
  * A_f sin(phi_f) * [m sin(w_f t)]  on shared series (m = the slot mask). */
@@ -93,7 +94,7 @@ typedef struct ryd_qdesc {
 
 typedef struct ryd_dterm {
   int32_t series;
-  int32_t last; /* non-zero on the last term of a (trajectory, atom) */
+  int32_t remaining; /* terms of this (trajectory, atom) after this one */
   double scale;
 } ryd_dterm;
 

@@ -60,7 +60,7 @@ class RydQDesc(C.Structure):
 
 
 class RydDTerm(C.Structure):
-    _fields_ = [("series", C.c_int32), ("last", C.c_int32), ("scale", C.c_double)]
+    _fields_ = [("series", C.c_int32), ("remaining", C.c_int32), ("scale", C.c_double)]
 
 
 class RydOpts(C.Structure):

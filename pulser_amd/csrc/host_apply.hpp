@@ -15,7 +15,7 @@ static int find_interval(const ryd_handle* h, double t) {
 
 static int launch_eval(ryd_handle* h, const MixPoint& m, hipStream_t st) {
   const int total = h->B * h->N;
-  hipLaunchKernelGGL(k_eval_coefs, dim3((total + 127) / 128), dim3(128), 0, st, h->pp_dev,
+  hipLaunchKernelGGL(k_eval_coefs, dim3((total + 3) / 4), dim3(256), 0, st, h->pp_dev,
                      h->n_knots - 1, h->desc_dev, h->dterms_dev, total, m.idx1, m.u1, m.w1, m.idx2, m.u2, m.w2,
                      h->coefs_dev);
   HIPCHK(hipGetLastError());

@@ -408,8 +408,10 @@ extern "C" int ryd_set_detuning_terms(ryd_handle* h, int32_t n_terms, const ryd_
   for (int i = 0; i < n_terms; ++i)
     if (terms[i].series < 0 || terms[i].series >= h->n_series)
       return fail(RYD_ERR_INVALID, "series index %d out of range at term %d", terms[i].series, i);
-  if (n_terms > 0 && !terms[n_terms - 1].last)
-    return fail(RYD_ERR_INVALID, "the last detuning term must close its list (last != 0)");
+  for (int i = 0; i < n_terms; ++i)
+    if (terms[i].remaining < 0 || i + terms[i].remaining >= n_terms ||
+        (terms[i].remaining > 0 && terms[i + 1].remaining != terms[i].remaining - 1))
+      return fail(RYD_ERR_INVALID, "detuning term %d: inconsistent `remaining` count", i);
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->dterms_dev) hipFree(h->dterms_dev);
   h->dterms_dev = nullptr;
@@ -440,7 +442,8 @@ static void compute_bounds(ryd_handle* h) {
   h->bd_pos.assign(n_int, 0.0);
   h->bd_neg.assign(n_int, 0.0);
   h->bd_curv.assign(n_int, 0.0);
-  std::vector<double> dr(n_int), po(n_int), ne(n_int), cu(n_int);
+  std::vector<double> dr(n_int), po(n_int), ne(n_int), cu(n_int), q((size_t)n_int * 4);
+  std::unordered_map<int, std::vector<double>> extra_cache;  // combined cubic of an extra-term list
   for (int b = 0; b < h->B; ++b) {
     std::fill(dr.begin(), dr.end(), 0.0);
     std::fill(po.begin(), po.end(), 0.0);
@@ -455,24 +458,40 @@ static void compute_bounds(ryd_handle* h) {
         const double* cv = &h->s_curv[(size_t)d.drive_series * n_int];
         for (int i = 0; i < n_int; ++i) cu[i] += sc * cv[i];
       }
-      auto add_det = [&](int s, double sc) {
-        if (s < 0 || sc == 0.0) return;
-        const double* P = &h->s_pos[(size_t)s * n_int];
-        const double* M = &h->s_neg[(size_t)s * n_int];
-        const double* cv = &h->s_curv[(size_t)s * n_int];
-        for (int i = 0; i < n_int; ++i) cu[i] += std::fabs(sc) * cv[i];
-        for (int i = 0; i < n_int; ++i) {
-          if (sc > 0) { po[i] += sc * P[i]; ne[i] += sc * M[i]; }
-          else { po[i] += -sc * M[i]; ne[i] += -sc * P[i]; }
-        }
+      // The detuning of the atom is ONE real cubic per interval: combine every
+      // contribution (samples, doppler / constant offsets, the extra hf-noise
+      // terms whose phases largely cancel) before bounding it - bounding the
+      // terms one by one would over-estimate norm and curvature several times
+      // and cost as many extra steps.
+      std::fill(q.begin(), q.end(), 0.0);
+      auto add_series = [&](std::vector<double>& dst, int sidx, double sc) {
+        if (sidx < 0 || sc == 0.0) return;
+        const std::complex<double>* p = &h->pp_host[(size_t)sidx * n_int * 4];
+        for (size_t e = 0; e < (size_t)n_int * 4; ++e) dst[e] += sc * p[e].real();
       };
-      add_det(d.det_series, d.det_scale);
-      add_det(d.off_series, d.off_scale);
+      add_series(q, d.det_series, d.det_scale);
+      add_series(q, d.off_series, d.off_scale);
       if (d.extra > 0 && d.extra <= (int)h->dterms_host.size()) {
-        for (size_t e = (size_t)d.extra - 1; e < h->dterms_host.size(); ++e) {
-          add_det(h->dterms_host[e].series, h->dterms_host[e].scale);
-          if (h->dterms_host[e].last) break;
+        auto it = extra_cache.find(d.extra);
+        if (it == extra_cache.end()) {
+          std::vector<double> acc((size_t)n_int * 4, 0.0);
+          for (size_t e = (size_t)d.extra - 1; e < h->dterms_host.size(); ++e) {
+            add_series(acc, h->dterms_host[e].series, h->dterms_host[e].scale);
+            if (h->dterms_host[e].remaining == 0) break;
+          }
+          it = extra_cache.emplace(d.extra, std::move(acc)).first;
         }
+        const std::vector<double>& acc = it->second;
+        for (size_t e = 0; e < (size_t)n_int * 4; ++e) q[e] += acc[e];
+      }
+      for (int i = 0; i < n_int; ++i) {
+        const double dt = h->tknots[i + 1] - h->tknots[i];
+        const double* c = &q[(size_t)i * 4];  // c[0] u^3 + c[1] u^2 + c[2] u + c[3]
+        const double curv = std::fabs(c[1]) * dt * dt + std::fabs(c[0]) * dt * dt * dt;
+        const double dev = std::fabs(c[2]) * dt + curv;
+        po[i] += std::max(c[3] + dev, 0.0);
+        ne[i] += std::max(-c[3] + dev, 0.0);
+        cu[i] += curv;
       }
     }
     for (int i = 0; i < n_int; ++i) {

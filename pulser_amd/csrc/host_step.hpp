@@ -245,7 +245,7 @@ template <int N, int MODEL, bool MC>
 static int launch_traj2(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
   constexpr int D = 1 << N;
   constexpr int NTT = D < 64 ? 64 : (N >= 11 ? 1024 : (D > 512 ? 512 : D));
-  const size_t lds = 2 * (size_t)D * sizeof(cplx) + 4 * 16 * sizeof(double) * 4;
+  const size_t lds = 2 * (size_t)D * sizeof(cplx) + 4 * 16 * sizeof(double) * 4 + 2 * 16 * sizeof(double);
   // the dynamic-LDS limit is a per-device function attribute
   static bool attr_set[64] = {};
   const int dev = h->cfg.device;

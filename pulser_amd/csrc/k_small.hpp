@@ -1,12 +1,16 @@
 // Part of librydemu (included by rydemu.hip, one translation unit).
 // coefs[b][k] = w1 * val(t1) + w2 * val(t2) for the drive (complex) and the
 // detuning (real) of atom k of trajectory b.  pp: [n_series][n_int][4] complex.
-__global__ void k_eval_coefs(const cplx* __restrict__ pp, int n_int,
-                             const ryd_qdesc* __restrict__ desc,
-                             const ryd_dterm* __restrict__ dterms, int total,
-                             int idx1, double u1, double w1, int idx2, double u2,
-                             double w2, double* __restrict__ coefs) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per (b, k): lane 0 evaluates the three base series, all lanes share
+// the list of extra detuning terms (hf noise), summed by a wave reduction.
+__global__ __launch_bounds__(256) void k_eval_coefs(const cplx* __restrict__ pp, int n_int,
+                                                    const ryd_qdesc* __restrict__ desc,
+                                                    const ryd_dterm* __restrict__ dterms, int total,
+                                                    int idx1, double u1, double w1, int idx2,
+                                                    double u2, double w2,
+                                                    double* __restrict__ coefs) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= total) return;
   const ryd_qdesc d = desc[i];
   auto val = [&](int s, int idx, double u) -> cplx {
@@ -18,26 +22,33 @@ __global__ void k_eval_coefs(const cplx* __restrict__ pp, int n_int,
     return r;
   };
   double cr = 0, ci = 0, dl = 0;
-  if (d.drive_series >= 0) {
-    const cplx a = val(d.drive_series, idx1, u1), b2 = val(d.drive_series, idx2, u2);
-    cr = d.drive_scale * (w1 * a.x + w2 * b2.x);
-    ci = d.drive_scale * (w1 * a.y + w2 * b2.y);
-  }
-  if (d.det_series >= 0)
-    dl += d.det_scale * (w1 * val(d.det_series, idx1, u1).x + w2 * val(d.det_series, idx2, u2).x);
-  if (d.off_series >= 0)
-    dl += d.off_scale * (w1 * val(d.off_series, idx1, u1).x + w2 * val(d.off_series, idx2, u2).x);
-  if (d.extra > 0 && dterms) {  // high-frequency detuning noise on shared series
-    for (int e = d.extra - 1;; ++e) {
-      const ryd_dterm t = dterms[e];
-      dl += t.scale * (w1 * val(t.series, idx1, u1).x + w2 * val(t.series, idx2, u2).x);
-      if (t.last) break;
+  if (lane == 0) {
+    if (d.drive_series >= 0) {
+      const cplx a = val(d.drive_series, idx1, u1), b2 = val(d.drive_series, idx2, u2);
+      cr = d.drive_scale * (w1 * a.x + w2 * b2.x);
+      ci = d.drive_scale * (w1 * a.y + w2 * b2.y);
     }
+    if (d.det_series >= 0)
+      dl += d.det_scale * (w1 * val(d.det_series, idx1, u1).x + w2 * val(d.det_series, idx2, u2).x);
+    if (d.off_series >= 0)
+      dl += d.off_scale * (w1 * val(d.off_series, idx1, u1).x + w2 * val(d.off_series, idx2, u2).x);
   }
-  coefs[4 * (size_t)i + 0] = cr;
-  coefs[4 * (size_t)i + 1] = ci;
-  coefs[4 * (size_t)i + 2] = dl;
-  coefs[4 * (size_t)i + 3] = 0.0;
+  if (d.extra > 0 && dterms) {  // high-frequency detuning noise on shared series
+    const int count = dterms[d.extra - 1].remaining + 1;
+    double x = 0.0;
+    for (int e = lane; e < count; e += 64) {
+      const ryd_dterm t = dterms[d.extra - 1 + e];
+      x += t.scale * (w1 * val(t.series, idx1, u1).x + w2 * val(t.series, idx2, u2).x);
+    }
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    dl += x;
+  }
+  if (lane == 0) {
+    coefs[4 * (size_t)i + 0] = cr;
+    coefs[4 * (size_t)i + 1] = ci;
+    coefs[4 * (size_t)i + 2] = dl;
+    coefs[4 * (size_t)i + 3] = 0.0;
+  }
 }
 
 // E0[m][s] = sum_{i<j} U[m][i][j] n_i(s) n_j(s), n_k(s) = 1 - bit_{N-1-k}(s)

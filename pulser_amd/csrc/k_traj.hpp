@@ -60,6 +60,7 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
   double* cfB = cfA + 64;                            // same for exp B
   double* mcred = cfB + 64;                          // [16][4] per-wave partial sums
   double* mcrho = mcred + 64;                        // [16][4] reduced density matrices
+  double* hfx = mcrho + 64;                          // [16][2] extra detuning terms (exp A, exp B)
 
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
@@ -90,6 +91,32 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
 
   for (int s = 0; s < A.n_steps; ++s) {
     const StepDesc sd = A.steps[s];
+    if (A.dterms) {
+      // extra detuning terms (hf noise): wave w sums the list of atoms w, w + NW, ...
+      constexpr int NW = NTT / 64;
+      const int lane = tid & 63;
+      for (int k = tid >> 6; k < N; k += NW) {
+        const int ex = A.desc[(size_t)b * N + k].extra;
+        double xa = 0.0, xb = 0.0;
+        if (ex > 0) {
+          const int count = A.dterms[ex - 1].remaining + 1;
+          for (int e = lane; e < count; e += 64) {
+            const ryd_dterm t = A.dterms[ex - 1 + e];
+            const cplx* p = A.pp + ((size_t)t.series * A.n_int + sd.idx) * 4;
+            const double o1 = ((p[0].x * sd.u1 + p[1].x) * sd.u1 + p[2].x) * sd.u1 + p[3].x;
+            const double o2 = ((p[0].x * sd.u2 + p[1].x) * sd.u2 + p[2].x) * sd.u2 + p[3].x;
+            xa += t.scale * (A.a1 * o1 + A.a2 * o2);
+            xb += t.scale * (A.a2 * o1 + A.a1 * o2);
+          }
+          for (int o = 32; o > 0; o >>= 1) {
+            xa += __shfl_down(xa, o, 64);
+            xb += __shfl_down(xb, o, 64);
+          }
+        }
+        if (lane == 0) { hfx[2 * k] = xa; hfx[2 * k + 1] = xb; }
+      }
+      __syncthreads();
+    }
     if (tid < N) {
       const ryd_qdesc d = A.desc[(size_t)b * N + tid];
       auto val = [&](int ser, double u) -> cplx {
@@ -116,14 +143,9 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
         dlA += d.off_scale * (A.a1 * o1 + A.a2 * o2);
         dlB += d.off_scale * (A.a2 * o1 + A.a1 * o2);
       }
-      if (d.extra > 0 && A.dterms) {
-        for (int e = d.extra - 1;; ++e) {
-          const ryd_dterm t = A.dterms[e];
-          const double o1 = val(t.series, sd.u1).x, o2 = val(t.series, sd.u2).x;
-          dlA += t.scale * (A.a1 * o1 + A.a2 * o2);
-          dlB += t.scale * (A.a2 * o1 + A.a1 * o2);
-          if (t.last) break;
-        }
+      if (d.extra > 0 && A.dterms) {  // summed by one wave per atom above
+        dlA += hfx[2 * tid];
+        dlB += hfx[2 * tid + 1];
       }
       cfA[4 * tid + 0] = d.drive_scale * (A.a1 * c1r + A.a2 * c2r);
       cfA[4 * tid + 1] = d.drive_scale * (A.a1 * c1i + A.a2 * c2i);

@@ -667,7 +667,12 @@ class HamiltonianData:
                     ]
         desc = np.zeros((len(trajs), n), dtype=DESC_DTYPE)
         desc["drive_series"] = desc["det_series"] = desc["off_series"] = -1
-        dterms: list[tuple[int, int, float]] = []
+        dterms: list[np.ndarray] = []
+        n_dterms = 0
+        hf_index: dict[tuple, int] = {}
+        # per atom: the (cos, sin) series ids interleaved, and which of them exist
+        hf_ids = {k: (np.array(v, dtype=np.int32).reshape(-1),
+                      np.array(v, dtype=np.int32).reshape(-1) >= 0) for k, v in hf_series.items()}
         mats = []
         local = self.local_noises
         for b, tr in enumerate(trajs):
@@ -695,16 +700,20 @@ class HamiltonianData:
                     d["off_series"], d["off_scale"] = mi, off
                 if hf and local:
                     phases = np.atleast_1d(np.asarray(tr.det_phases[ch.name], float))
-                    first = len(dterms)
-                    for f, (cs_id, sn_id) in enumerate(hf_series[k]):
-                        if cs_id >= 0:
-                            dterms.append((cs_id, 0, float(hf_amp[f] * np.cos(phases[f]))))
-                        if sn_id >= 0:
-                            dterms.append((sn_id, 0, float(-hf_amp[f] * np.sin(phases[f]))))
-                    if len(dterms) > first:
-                        s_, _, sc_ = dterms[-1]
-                        dterms[-1] = (s_, 1, sc_)
-                        d["extra"] = first + 1
+                    ids, keep = hf_ids[k]
+                    key = (b, ch.name, ids.tobytes())
+                    if key in hf_index:  # atoms sharing channel and slot mask share the list
+                        d["extra"] = hf_index[key]
+                    elif keep.any():
+                        sc = np.empty(2 * len(hf_amp))
+                        sc[0::2] = hf_amp * np.cos(phases)
+                        sc[1::2] = -hf_amp * np.sin(phases)
+                        block = np.zeros(int(keep.sum()), dtype=DTERM_DTYPE)
+                        block["series"], block["scale"] = ids[keep], sc[keep]
+                        block["remaining"] = np.arange(len(block) - 1, -1, -1)
+                        dterms.append(block)
+                        d["extra"] = hf_index[key] = n_dterms + 1
+                        n_dterms += len(block)
             bad = np.asarray(tr.bad_atoms, bool)
             u = np.array(tr.interaction_matrix, dtype=float)[-1].copy()
             np.fill_diagonal(u, 0.0)
@@ -727,5 +736,5 @@ class HamiltonianData:
             dissipator=local_dissipator(ops, self.eigenbasis, paulis),
             series_knots=pool.arrays,
             collapse_local=local_collapse_ops(ops, self.eigenbasis, paulis),
-            dterms=np.array(dterms, dtype=DTERM_DTYPE) if dterms else None,
+            dterms=np.concatenate(dterms) if dterms else None,
         )

@@ -79,7 +79,7 @@ DESC_DTYPE = np.dtype(
 
 
 # extra detuning terms (include/rydemu.h: ryd_dterm)
-DTERM_DTYPE = np.dtype([("series", "<i4"), ("last", "<i4"), ("scale", "<f8")], align=True)
+DTERM_DTYPE = np.dtype([("series", "<i4"), ("remaining", "<i4"), ("scale", "<f8")], align=True)
 
 
 class _SeriesPool:

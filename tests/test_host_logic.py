@@ -907,7 +907,7 @@ def _eval_tables_detuning(tables, b, k, t):
     while e >= 0:
         term = tables.dterms[e]
         out += term["scale"] * val(term["series"])
-        if term["last"]:
+        if term["remaining"] == 0:
             break
         e += 1
     return out
@@ -930,7 +930,7 @@ def test_factored_lowering_with_hf_detuning_noise_equals_per_trajectory_lowering
     trajs = hd.noise_trajectories
     fact = hd.device_tables(trajs, 1.0)
     assert fact.dterms is not None and np.all(fact.desc["extra"] > 0)
-    assert fact.dterms["last"].sum() == 4 * inputs.n_qudits
+    assert (fact.dterms["remaining"] == 0).sum() == 4  # one shared list per trajectory (global channel)
     full = lower([hd.problem(t, 1.0) for t in trajs])
     assert full.dterms is None and len(fact.pp) < len(full.pp)
     t = np.random.default_rng(0).uniform(0.0, inputs.max_duration * 1e-3, 400)
