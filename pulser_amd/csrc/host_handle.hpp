@@ -442,9 +442,18 @@ static void compute_bounds(ryd_handle* h) {
   h->bd_pos.assign(n_int, 0.0);
   h->bd_neg.assign(n_int, 0.0);
   h->bd_curv.assign(n_int, 0.0);
+  // batch entries are independent: a few host threads, each with its own
+  // accumulators, merged by a maximum at the end
+  const int n_thr = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, h->B / 8}));
+  std::vector<std::vector<double>> part(n_thr, std::vector<double>((size_t)n_int * 4, 0.0));
+  auto work = [&](int tix) {
   std::vector<double> dr(n_int), po(n_int), ne(n_int), cu(n_int), q((size_t)n_int * 4);
   std::unordered_map<int, std::vector<double>> extra_cache;  // combined cubic of an extra-term list
-  for (int b = 0; b < h->B; ++b) {
+  double* bd_drive = &part[tix][0];
+  double* bd_pos = bd_drive + n_int;
+  double* bd_neg = bd_pos + n_int;
+  double* bd_curv = bd_neg + n_int;
+  for (int b = tix; b < h->B; b += n_thr) {
     std::fill(dr.begin(), dr.end(), 0.0);
     std::fill(po.begin(), po.end(), 0.0);
     std::fill(ne.begin(), ne.end(), 0.0);
@@ -495,12 +504,27 @@ static void compute_bounds(ryd_handle* h) {
       }
     }
     for (int i = 0; i < n_int; ++i) {
-      h->bd_drive[i] = std::max(h->bd_drive[i], dr[i]);
-      h->bd_pos[i] = std::max(h->bd_pos[i], po[i]);
-      h->bd_neg[i] = std::max(h->bd_neg[i], ne[i]);
-      h->bd_curv[i] = std::max(h->bd_curv[i], cu[i]);
+      bd_drive[i] = std::max(bd_drive[i], dr[i]);
+      bd_pos[i] = std::max(bd_pos[i], po[i]);
+      bd_neg[i] = std::max(bd_neg[i], ne[i]);
+      bd_curv[i] = std::max(bd_curv[i], cu[i]);
     }
   }
+  };
+  if (n_thr == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int tix = 0; tix < n_thr; ++tix) pool.emplace_back(work, tix);
+    for (auto& th : pool) th.join();
+  }
+  for (int tix = 0; tix < n_thr; ++tix)
+    for (int i = 0; i < n_int; ++i) {
+      h->bd_drive[i] = std::max(h->bd_drive[i], part[tix][i]);
+      h->bd_pos[i] = std::max(h->bd_pos[i], part[tix][(size_t)n_int + i]);
+      h->bd_neg[i] = std::max(h->bd_neg[i], part[tix][(size_t)2 * n_int + i]);
+      h->bd_curv[i] = std::max(h->bd_curv[i], part[tix][(size_t)3 * n_int + i]);
+    }
   // MODEL 1 of the persistent kernel: inside every trajectory all driven atoms
   // share (series, scale) and that series is real-valued
   const int n_int2 = h->n_knots - 1;
