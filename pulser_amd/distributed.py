@@ -153,7 +153,9 @@ def run_ensemble(
     lo, hi = partition([t.reps for t in trajs], world)[rank]
     hist = np.zeros((n_eval, 2**n), dtype=np.int64)
     occ_sum = np.zeros((n_eval, n + 1), dtype=np.float64)
-    if solve_fn is None:
+    default_solver = solve_fn is None
+    fast = default_solver and emulator._fast_path_ok(emulator._current_problem)
+    if default_solver:
         def solve_fn(problems: list[dict[str, Any]]) -> np.ndarray:
             res = emulator._solve_batch(problems, False, {})
             return np.stack([[np.asarray(s) for s in r.states] for r in res])
@@ -165,11 +167,15 @@ def run_ensemble(
     idx_bits = 1 - ((np.arange(2**n)[:, None] >> (n - 1 - np.arange(n))[None, :]) & 1)
     for start in range(lo, hi, batch):
         block = list(range(start, min(hi, start + batch)))
-        problems = [hd.problem(trajs[i], emulator._sampling_rate) for i in block]
         if mc_seeds is not None:  # a trajectory's jumps depend on its seed only, not on the sharding
             emulator._mc_seed_override = mc_seeds[block]
         try:
-            states = solve_fn(problems)
+            if fast:  # factored lowering: shared spline tables + per-(trajectory, atom) scales
+                tables = hd.device_tables([trajs[i] for i in block], emulator._sampling_rate)
+                res = emulator._solve_batch([], False, {}, tables=tables)
+                states = np.stack([[np.asarray(s) for s in r.states] for r in res])
+            else:
+                states = solve_fn([hd.problem(trajs[i], emulator._sampling_rate) for i in block])
         finally:
             emulator._mc_seed_override = None
         for j, i in enumerate(block):
