@@ -249,6 +249,55 @@ def main() -> None:
             "application never reaches HBM; frac > 1 is on-chip reuse, not an HBM measurement"
         )
         eng.close()
+    elif args.workload == "cfg4":
+        # BASELINE configs[3]: 1024 noise trajectories of the 12-atom sequence, END TO END through
+        # the emulator front-end (noise draws on rank 0, factored lowering, solve, reference-order
+        # sampling), sharded over the ranks with one all-reduce of the histograms (strong scaling)
+        from pulser_amd import NoiseModel, QutipEmulator, problem as P
+        from pulser_amd.distributed import run_ensemble
+        from pulser_amd.hamiltonian_data import single_global_channel
+
+        coords = P.register_coords(P.square_rect(1, 12), blockade_radius())
+        smp = {k: v[:-1] for k, v in P.anneal_samples().items()}
+        inputs = single_global_channel(coords, smp, P.C6_LEVEL70, extended=False)
+        nm = NoiseModel(temperature=50.0, amp_sigma=0.05, state_prep_error=0.005,
+                        p_false_pos=0.01, p_false_neg=0.05)
+        n_traj = 1024
+
+        def one_pass(seed):
+            np.random.seed(seed)
+            emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=n_traj, evaluation_times="Minimal")
+            return run_ensemble(emu, dist=dist, batch=256)
+
+        for w in range(args.warmup):
+            one_pass(100 + w)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        tic = time.perf_counter()
+        for k in range(args.steps):
+            res = one_pass(k)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        sec = (time.perf_counter() - tic) / args.steps
+        if dist is not None:
+            tmax = torch.tensor([sec], dtype=torch.float64)
+            if dist.get_backend() != "gloo":
+                tmax = tmax.cuda()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            sec = float(tmax.item())
+        out = {"metric": "noise trajectories/s, 12-atom anneal sequence, end to end (draws, lowering, sesolve, sampling)",
+               "value": n_traj / sec, **common, "unit": "trajectories/s", "scaling": "strong",
+               "ms_per_step": sec * 1e3,
+               "config": {"workload": "BASELINE configs[3]: 12-atom register, 1024 noise trajectories "
+                                      "(doppler + amplitude + SPAM), sharded over the ranks, one all-reduce "
+                                      "of the bitstring histograms", "n_atoms": 12, "n_trajectories": n_traj,
+                          "sim_us_per_s": n_traj * T_SEQ_US / sec, "n_measures": int(res["n_measures"]),
+                          "parallelism": f"dp{n_gpus} over trajectories"},
+               "roofline": None}
+        args.no_extras = True
+        args.no_cpu = True
     elif args.workload in ("cfg3", "cfg5"):
         # HBM-streaming workloads as the primary line (used for the rocprofv3 passes)
         if args.workload == "cfg3":
