@@ -20,3 +20,9 @@ for rep in range(2):
     torch.cuda.synchronize()
     t2 = time.time()
     print(f"run {rep}: ctor {t1-t0:.3f}s run {t2-t1:.3f}s -> {n*3.1/(t2-t1):.1f} sim-us/s end-to-end; top counts {res[-1].bitstring_counts.most_common(3) if hasattr(res[-1].bitstring_counts,'most_common') else ''}", flush=True)
+if os.environ.get("RYD_PROFILE"):
+    import cProfile, pstats
+    np.random.seed(0)
+    emu = QutipEmulator(_chain12_inputs(extra), noise_model=nm, n_trajectories=n, evaluation_times="Minimal")
+    pr = cProfile.Profile(); pr.enable(); emu.run(); pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
