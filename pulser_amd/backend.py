@@ -212,6 +212,16 @@ class Observable:
 
     _base_tag = "observable"
 
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        """pulser/backend/observable.py:132-139."""
+        return {
+            "observable": self._base_tag,
+            "evaluation_times": None if self.evaluation_times is None else self.evaluation_times.tolist(),
+            "tag_suffix": self._tag_suffix,
+            "default_aggregation_method": _AGG_CODE[self.default_aggregation],
+            "uuid": str(self._uuid),
+        }
+
     @property
     def tag(self) -> str:
         return self._base_tag if self._tag_suffix is None else f"{self._base_tag}_{self._tag_suffix}"
@@ -234,6 +244,12 @@ class StateResult(Observable):
     _base_tag = "state"
     default_aggregation = "density_matrix"
 
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        raise ValueError(  # default_observables.py:66-73
+            "`StateResult` observable is not supported in any remote backend. If you are "
+            "interested in the full quantum state at arbitrary times during the emulation, "
+            "please, consider using the local version of the same backend.")
+
     def apply(self, *, state: RydState, **kw: Any) -> RydState:
         return RydState(np.array(state.to_qobj()), eigenstates=state.eigenstates)
 
@@ -250,6 +266,12 @@ class BitStrings(Observable):
             raise ValueError(f"'num_shots' must be greater than or equal to 1, not {num_shots}.")
         self._num_shots = None if num_shots is None else int(num_shots)
         self.one_state = one_state
+
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        d = super()._to_abstract_repr()
+        d["num_shots"] = self._num_shots
+        d["one_state"] = self.one_state
+        return d
 
     def apply(self, *, config: "QutipConfig", state: RydState, **kw: Any) -> Counter:
         return state.sample(
@@ -270,6 +292,11 @@ class Fidelity(Observable):
             raise TypeError(f"'state' must be a RydState, not {type(state)}.")
         self.state = state
 
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        d = super()._to_abstract_repr()
+        d["state"] = self.state
+        return d
+
     def apply(self, *, state: RydState, **kw: Any) -> float:
         return self.state.overlap(state)
 
@@ -283,6 +310,10 @@ class Expectation(Observable):
                  tag_suffix: str | None = None) -> None:
         super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
         self.operator = np.asarray(operator, dtype=complex)
+
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        raise ValueError("An 'Expectation' of a dense matrix has no abstract representation "
+                         "(the reference serialises operators given as sums of tensor products).")
 
     def apply(self, *, state: RydState, **kw: Any) -> Any:
         s = np.asarray(state.to_qobj())
@@ -315,6 +346,11 @@ class Occupation(Observable):
         super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
         self.one_state = one_state
 
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        d = super()._to_abstract_repr()
+        d["one_state"] = self.one_state
+        return d
+
     def apply(self, *, state: RydState, **kw: Any) -> list:
         p = _probabilities(state)
         return [float(v) for v in p @ _one_mask(state, self.one_state)]
@@ -329,6 +365,11 @@ class CorrelationMatrix(Observable):
                  one_state: str | None = None, tag_suffix: str | None = None) -> None:
         super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
         self.one_state = one_state
+
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        d = super()._to_abstract_repr()
+        d["one_state"] = self.one_state
+        return d
 
     def apply(self, *, state: RydState, **kw: Any) -> list[list]:
         p = _probabilities(state)
@@ -358,6 +399,7 @@ class EnergySecondMoment(Observable):
 
 class EnergyVariance(Observable):
     _base_tag = "energy_variance"
+    default_aggregation = "skip_warn"  # a variance is not averaged over trajectories (:503-504)
 
     def apply(self, *, state: RydState, hamiltonian: HamiltonianOperator, **kw: Any) -> float:
         second = EnergySecondMoment.apply(self, state=state, hamiltonian=hamiltonian)  # type: ignore[arg-type]
@@ -642,7 +684,95 @@ class QutipConfig:
         self.default_num_shots = int(default_num_shots)
         self.progress_bar = progress_bar
         self.print_progress = print_progress
+        if backend_options.get("interaction_matrix") is not None:
+            raise NotImplementedError("'QutipBackendV2' does not handle custom interaction matrices.")
         self._extra = dict(backend_options)
+
+    # -- read-only views / JSON abstract representation (config.py:116-118, 438-470)
+    @property
+    def _backend_options(self) -> dict[str, Any]:
+        ev = self.default_evaluation_times
+        return {
+            "sampling_rate": self.sampling_rate, "solver": self.solver,
+            "print_progress": self.print_progress, "progress_bar": self.progress_bar,
+            "callbacks": list(self.callbacks), "observables": list(self.observables),
+            "default_evaluation_times": ev if isinstance(ev, str) else ev.tolist(),
+            "initial_state": self.initial_state, "with_modulation": self.with_modulation,
+            "interaction_matrix": None, "prefer_device_noise_model": self.prefer_device_noise_model,
+            "noise_model": self.noise_model, "n_trajectories": self.n_trajectories,
+            "default_num_shots": self.default_num_shots,
+        }
+
+    def with_changes(self, **changes: Any) -> "QutipConfig":
+        """A copy of the configuration with the given changes."""
+        opts = self._backend_options | changes
+        opts.pop("interaction_matrix", None)
+        return type(self)(**opts)
+
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        d = self._backend_options
+        if d["callbacks"]:
+            raise ValueError("Callbacks cannot be serialized.")
+        d["solver"] = self.solver.value
+        return d
+
+    def to_abstract_repr(self, skip_validation: bool = False) -> str:
+        """JSON document of the configuration; ``from_abstract_repr`` reads it
+        back (and reads the documents pulser-core's ``EmulationConfig`` writes)."""
+        text = json.dumps(self, cls=_AbstractReprEncoder)
+        if not skip_validation:
+            type(self).from_abstract_repr(text)
+        return text
+
+    @classmethod
+    def from_abstract_repr(cls, obj_str: str) -> "QutipConfig":
+        """json/abstract_repr/deserializer.py (``_deserialize_emulation_config``)."""
+        if not isinstance(obj_str, str):
+            raise TypeError("The serialized EmulationConfig must be given as a string. "
+                            f"Instead, got object of type {type(obj_str)}.")
+        obj = json.loads(obj_str)
+        kinds = {c._base_tag: c for c in (BitStrings, Occupation, CorrelationMatrix, Energy,
+                                          EnergyVariance, EnergySecondMoment, Fidelity)}
+        observables = []
+        for o in obj.get("observables", []):
+            if o["observable"] not in kinds:
+                raise ValueError(f"Observable {o['observable']!r} cannot be deserialized.")
+            kw: dict[str, Any] = {"evaluation_times": o.get("evaluation_times"),
+                                  "tag_suffix": o.get("tag_suffix")}
+            if "num_shots" in o:
+                kw["num_shots"] = o["num_shots"]
+            if "one_state" in o:
+                kw["one_state"] = o["one_state"]
+            if "state" in o:
+                st = o["state"]
+                amps = {k: (v["real"] + 1j * v["imag"] if isinstance(v, dict) else v)
+                        for k, v in st["amplitudes"].items()}
+                observables.append(Fidelity(RydState.from_state_amplitudes(
+                    eigenstates=tuple(st["eigenstates"]), amplitudes=amps), **kw))
+            else:
+                observables.append(kinds[o["observable"]](**kw))
+            observables[-1]._uuid = uuid.UUID(o["uuid"])
+            if "default_aggregation_method" in o:
+                observables[-1].default_aggregation = _AGG_KIND[int(o["default_aggregation_method"])]
+        init = obj.get("initial_state")
+        if init is not None:
+            amps = {k: (v["real"] + 1j * v["imag"] if isinstance(v, dict) else v)
+                    for k, v in init["amplitudes"].items()}
+            init = RydState.from_state_amplitudes(eigenstates=tuple(init["eigenstates"]), amplitudes=amps)
+        nm = obj.get("noise_model")
+        kwargs = dict(
+            observables=observables, default_evaluation_times=obj.get("default_evaluation_times", (1.0,)),
+            initial_state=init, with_modulation=obj.get("with_modulation", False),
+            noise_model=NoiseModel._from_abstract_repr(nm) if nm is not None else None,
+            prefer_device_noise_model=obj.get("prefer_device_noise_model", False),
+            n_trajectories=obj.get("n_trajectories"), interaction_matrix=obj.get("interaction_matrix"),
+        )
+        for key in ("sampling_rate", "solver", "print_progress", "progress_bar"):
+            if key in obj:
+                kwargs[key] = obj[key]
+        if obj.get("default_num_shots") is not None:
+            kwargs["default_num_shots"] = obj["default_num_shots"]
+        return cls(**kwargs)
 
     def is_evaluation_time(self, t: float, tol: float = 1e-6) -> bool:
         """config.py:419-427."""

@@ -152,6 +152,72 @@ class NoiseModel:
             types.discard("doppler")
         object.__setattr__(self, "noise_types", tuple(sorted(types)))
 
+    # -- JSON abstract representation (pulser/noise_model.py:676-699) ----------
+    _OPTIONAL_IN_ABSTR_REPR = ("detuning_sigma", "trap_waist", "trap_depth", "detuning_hf_psd",
+                               "detuning_hf_omegas", "dmm_sigma", "detuning_map_spot_waist")
+
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        defaults = {f.name: f.default for f in fields(self) if f.init}
+        out: dict[str, Any] = {}
+        for f in fields(self):
+            value = getattr(self, f.name)
+            if f.name in self._OPTIONAL_IN_ABSTR_REPR and defaults[f.name] == value:
+                continue
+            out[f.name] = value
+        out.pop("disable_doppler")
+        out.pop("with_leakage")
+        rates, opers = out.pop("eff_noise_rates"), out.pop("eff_noise_opers")
+        out["eff_noise"] = [[r, np.asarray(o).tolist()] for r, o in zip(rates, opers)]
+        if "detuning_hf_psd" in out:
+            psd, om = out.pop("detuning_hf_psd"), out.pop("detuning_hf_omegas")
+            out["detuning_hf"] = [list(p) for p in zip(psd, om)]
+        out["noise_types"] = list(out["noise_types"])
+        return out
+
+    @classmethod
+    def _from_abstract_repr(cls, obj: dict[str, Any]) -> "NoiseModel":
+        """pulser/json/abstract_repr/deserializer.py:440-505."""
+        def cplx(v: Any) -> Any:
+            if isinstance(v, list):
+                return [cplx(e) for e in v]
+            if isinstance(v, dict) and v.keys() == {"real", "imag"}:
+                return v["real"] + 1j * v["imag"]
+            return v
+
+        obj = dict(obj)
+        rates, opers = [], []
+        for rate, oper in obj.pop("eff_noise"):
+            rates.append(rate)
+            opers.append(np.array(cplx(oper)))
+        noise_types = list(obj.pop("noise_types"))
+        disable_doppler = obj["temperature"] > 0 and "doppler" not in noise_types
+        relevant: set[str] = set()
+        for nt in noise_types + (["doppler"] if disable_doppler else []):
+            relevant.update(_NOISE_TYPE_PARAMS[nt])
+            if nt == "register":
+                relevant.add("temperature")
+            if (nt in ("doppler", "detuning", "register", "dmm_sigma")
+                    or (nt == "amplitude" and obj["amp_sigma"] != 0.0)
+                    or (nt == "SPAM" and obj["state_prep_error"] != 0.0)):
+                relevant.update(("runs", "samples_per_run"))
+        if obj.get("laser_waist") is None:
+            relevant.discard("laser_waist")
+        relevant -= {"eff_noise_rates", "eff_noise_opers", "with_leakage", "detuning_sigma",
+                     "detuning_hf_psd", "detuning_hf_omegas", "dmm_sigma", "detuning_map_spot_waist"}
+        psd, om = [], []
+        for p_, f_ in obj.pop("detuning_hf", []):
+            psd.append(p_)
+            om.append(f_)
+        nm = cls(**{p: obj[p] for p in relevant if p in obj},
+                 eff_noise_rates=tuple(rates), eff_noise_opers=tuple(opers),
+                 with_leakage="leakage" in noise_types, disable_doppler=disable_doppler,
+                 detuning_hf_psd=tuple(psd), detuning_hf_omegas=tuple(om),
+                 detuning_sigma=obj.get("detuning_sigma", 0), dmm_sigma=obj.get("dmm_sigma", 0),
+                 detuning_map_spot_waist=obj.get("detuning_map_spot_waist"))
+        if set(nm.noise_types) != set(noise_types):
+            raise ValueError(f"Inconsistent noise model: {sorted(nm.noise_types)} != {sorted(noise_types)}")
+        return nm
+
     def __repr__(self) -> str:
         shown = {f.name: getattr(self, f.name) for f in fields(self)
                  if f.init and getattr(self, f.name) not in (None, 0, 0.0, (), False)

@@ -792,6 +792,40 @@ def gen_waist():
                    reference_cite="pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py:408-534, 758-780")
 
 
+def gen_config_json():
+    """``EmulationConfig.to_abstract_repr`` documents written by pulser-core
+    (pulser/backend/config.py:438-447, noise_model.py:676-699, observable.py:132-139)."""
+    import json
+    from pulser.backend import (BitStrings, CorrelationMatrix, EmulationConfig, Energy,
+                                EnergySecondMoment, EnergyVariance, Fidelity, Occupation)
+    from pulser.backend.state import StateRepr
+
+    target = StateRepr.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rgr": 0.6, "ggg": 0.8j})
+    cfgs = {
+        "plain": EmulationConfig(observables=[BitStrings(num_shots=50, evaluation_times=[0.5, 1.0]),
+                                              Occupation(one_state="r"), CorrelationMatrix(),
+                                              Energy(tag_suffix="x"), EnergyVariance(),
+                                              EnergySecondMoment(), Fidelity(target)],
+                                 default_evaluation_times=[0.25, 1.0], with_modulation=True),
+        "noisy": EmulationConfig(
+            observables=[BitStrings()], default_evaluation_times="Full", n_trajectories=7,
+            noise_model=NoiseModel(dephasing_rate=0.1, temperature=20.0, state_prep_error=0.02,
+                                   p_false_pos=0.01, amp_sigma=0.05, laser_waist=150.0,
+                                   eff_noise_opers=[np.array([[0, 1], [0, 0]]), np.array([[1, 0], [0, -1j]])],
+                                   eff_noise_rates=[0.3, 0.1], detuning_sigma=0.2,
+                                   detuning_hf_psd=(1.0, 2.0), detuning_hf_omegas=(3.0, 4.0))),
+        "register": EmulationConfig(
+            observables=[Occupation()], n_trajectories=3, prefer_device_noise_model=True,
+            noise_model=NoiseModel(temperature=30.0, disable_doppler=True, trap_depth=150.0, trap_waist=1.0,
+                                   relaxation_rate=0.2, dmm_sigma=0.1, detuning_map_spot_waist=4.0)),
+    }
+    docs = {k: c.to_abstract_repr(skip_validation=True) for k, c in cfgs.items()}
+    P.save_problem(os.path.join(HERE, "config_abstract_repr.npz"), {},
+                   reference_cite="pulser-core/pulser/backend/config.py:438-470", **docs)
+    for k, v in docs.items():
+        print(k, json.dumps(json.loads(v))[:300])
+
+
 def gen_results_json():
     """A ``pulser.backend.Results`` filled with raw values of every kind the
     default observables store, serialised by pulser-core itself
@@ -863,3 +897,5 @@ if __name__ == "__main__":
         gen_results_json()
     if "waist" in which:
         gen_waist()
+    if "config" in which:
+        gen_config_json()

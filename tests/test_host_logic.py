@@ -940,3 +940,42 @@ def test_factored_lowering_with_hf_detuning_noise_equals_per_trajectory_lowering
             c = _eval_tables_detuning(full, b, k, t)
             assert np.max(np.abs(a - c)) < 1e-11 * max(1.0, np.max(np.abs(c)))
     assert np.allclose(fact.interaction, full.interaction, rtol=1e-14, atol=0)
+
+
+def test_config_abstract_repr_reads_and_rewrites_pulser_core_documents():
+    """EmulationConfig JSON written by pulser-core (backend/config.py:438-447,
+    noise_model.py:676-699, observable.py:132-139; fixture): read into a
+    QutipConfig and written back - identical except for the four QuTiP-backend
+    options this config adds (qutip_config.py:144-150)."""
+    import json
+
+    from pulser_amd.backend import BitStrings, Fidelity, QutipConfig, StateResult
+
+    _, extra = load_fixture("config_abstract_repr.npz")
+    for name in ("plain", "noisy", "register"):
+        ref = json.loads(extra[name])
+        cfg = QutipConfig.from_abstract_repr(extra[name])
+        got = json.loads(cfg.to_abstract_repr())
+        for key in ("sampling_rate", "solver", "print_progress", "progress_bar"):
+            assert key in got
+            got.pop(key)
+        assert got == ref, name
+    cfg = QutipConfig.from_abstract_repr(extra["noisy"])
+    nm = cfg.noise_model
+    assert set(nm.noise_types) == {"SPAM", "amplitude", "dephasing", "detuning", "doppler", "eff_noise"}
+    assert nm.laser_waist == 150.0 and nm.detuning_hf_omegas == (3.0, 4.0) and cfg.n_trajectories == 7
+    assert np.array_equal(np.asarray(nm.eff_noise_opers[1]), np.array([[1, 0], [0, -1j]]))
+    reg = QutipConfig.from_abstract_repr(extra["register"]).noise_model
+    assert reg.disable_doppler and "doppler" not in reg.noise_types and reg.trap_depth == 150.0
+    plain = QutipConfig.from_abstract_repr(extra["plain"])
+    assert [o.tag for o in plain.observables] == ["bitstrings", "occupation", "correlation_matrix",
+                                                  "energy_x", "energy_variance", "energy_second_moment",
+                                                  "fidelity"]
+    assert isinstance(plain.observables[-1], Fidelity) and plain.observables[4].default_aggregation == "skip_warn"
+    assert str(plain.observables[0]._uuid) == json.loads(extra["plain"])["observables"][0]["uuid"]
+    changed = plain.with_changes(sampling_rate=0.5, n_trajectories=9)
+    assert changed.sampling_rate == 0.5 and changed.n_trajectories == 9 and len(changed.observables) == 7
+    with pytest.raises(ValueError, match="not supported in any remote backend"):
+        QutipConfig(observables=[StateResult()]).to_abstract_repr()
+    with pytest.raises(NotImplementedError, match="custom interaction matrices"):
+        QutipConfig(observables=[BitStrings()], interaction_matrix=np.eye(2))
