@@ -30,7 +30,7 @@ from .results import QState, multinomial
 from .simulation import QutipEmulator, Solver
 
 __all__ = [
-    "QutipBackendV2", "QutipConfig", "RydState", "Results", "Observable", "StateResult",
+    "QutipBackendV2", "QutipConfig", "RydState", "RydOperator", "Results", "Observable", "StateResult",
     "BitStrings", "Fidelity", "Expectation", "CorrelationMatrix", "Occupation", "Energy",
     "EnergyVariance", "EnergySecondMoment",
 ]
@@ -156,6 +156,128 @@ class RydState:
         out = cls(QState(vec).unit(), eigenstates=eigenstates)
         out._amplitudes = dict(amplitudes)
         return out
+
+
+class RydOperator:
+    """``QutipOperator`` (pulser_simulation/qutip_op.py:30-260) on a SciPy sparse
+    matrix: the operator type of ``Expectation`` and of custom callbacks."""
+
+    def __init__(self, operator: Any, *, eigenstates: Sequence[str]) -> None:
+        import scipy.sparse as sp
+
+        self.eigenstates = tuple(eigenstates)
+        self._operator = sp.csr_matrix(operator, dtype=complex)
+        if self._operator.shape[0] != self._operator.shape[1]:
+            raise ValueError("An operator must be a square matrix.")
+        self._n_qudits: int | None = None
+        self._operations: Any = None
+
+    def to_qobj(self) -> Any:
+        return self._operator
+
+    def _validate_other(self, other: Any, expected: type, op_name: str) -> None:
+        """qutip_op.py:240-260."""
+        if not isinstance(other, expected):
+            raise TypeError(f"'{op_name}' expects a '{expected.__name__}' instance, not {type(other)}.")
+        if self.eigenstates != other.eigenstates:
+            msg = (f"Can't apply {op_name} between a {self.__class__.__name__} with eigenstates "
+                   f"{self.eigenstates} and a {other.__class__.__name__} with {other.eigenstates}.")
+            if set(self.eigenstates) != set(other.eigenstates):
+                raise ValueError(msg)
+            raise NotImplementedError(msg)
+
+    def apply_to(self, state: RydState) -> RydState:
+        """O|psi> or O rho O^dag (qutip_op.py:75-88)."""
+        self._validate_other(state, RydState, "RydOperator.apply_to()")
+        a = np.asarray(state.to_qobj())
+        out = self._operator @ a
+        if not state.to_qobj().isket:
+            out = (self._operator @ out.conj().T).conj().T
+        return RydState(out, eigenstates=state.eigenstates)
+
+    def expect(self, state: RydState) -> complex:
+        """<psi|O|psi> or Tr(O rho) (qutip_op.py:90-100)."""
+        self._validate_other(state, RydState, "RydOperator.expect()")
+        a = np.asarray(state.to_qobj())
+        if state.to_qobj().isket:
+            return complex(np.vdot(a, self._operator @ a))
+        return complex((self._operator @ a).trace())
+
+    def __add__(self, other: "RydOperator") -> "RydOperator":
+        self._validate_other(other, RydOperator, "__add__")
+        return RydOperator(self._operator + other._operator, eigenstates=self.eigenstates)
+
+    def __rmul__(self, scalar: complex) -> "RydOperator":
+        return RydOperator(complex(scalar) * self._operator, eigenstates=self.eigenstates)
+
+    def __matmul__(self, other: "RydOperator") -> "RydOperator":
+        self._validate_other(other, RydOperator, "__matmul__")
+        return RydOperator(self._operator @ other._operator, eigenstates=self.eigenstates)
+
+    def __eq__(self, other: Any) -> bool:
+        return (isinstance(other, RydOperator) and self.eigenstates == other.eigenstates
+                and (self._operator != other._operator).nnz == 0)
+
+    __hash__ = None  # type: ignore[assignment]
+
+    @classmethod
+    def from_operator_repr(cls, *, eigenstates: Sequence[str], n_qudits: int,
+                           operations: Sequence[tuple[complex, Sequence[tuple[Mapping[str, complex], Any]]]]
+                           ) -> "RydOperator":
+        """pulser/backend/operator.py:115-186 + qutip_op.py:149-220:
+        ``operations = [(coeff, [({"rr": 1.0, ...}, {qudit indices}), ...]), ...]`` - a
+        weighted sum of tensor products of single-qudit operators ``|i><j|``."""
+        import scipy.sparse as sp
+
+        eigenstates = tuple(eigenstates)
+        d = len(eigenstates)
+        for num, (_, tensor_op) in enumerate(operations):  # operator.py:205-235
+            free = set(range(n_qudits))
+            for qudit_op, inds in tensor_op:
+                if bad := (set(inds) - free):
+                    raise ValueError(
+                        f"Got invalid indices for a system with {n_qudits} qudits: {bad}. For "
+                        f"TensorOp #{num}, only indices {free} were still available.")
+                free.difference_update(inds)
+                for proj in qudit_op:
+                    if len(proj) != 2 or any(c not in eigenstates for c in proj):
+                        raise ValueError(
+                            "Every QuditOp key must be made up of two eigenstates among "
+                            f"{eigenstates}; instead, got '{proj}'.")
+        full = sp.csr_matrix((d**n_qudits, d**n_qudits), dtype=complex)
+        eye = sp.identity(d, dtype=complex, format="csr")
+        rebuilt = []
+        for coeff, tensor_op in operations:
+            factors = [eye] * n_qudits
+            re_tensor = []
+            for qudit_op, inds in tensor_op:
+                local = np.zeros((d, d), dtype=complex)
+                for proj, c in qudit_op.items():
+                    local[eigenstates.index(proj[0]), eigenstates.index(proj[1])] += complex(c)
+                for i in inds:
+                    factors[i] = sp.csr_matrix(local)
+                re_tensor.append(({k: complex(v) for k, v in qudit_op.items()}, set(inds)))
+            term = sp.identity(1, dtype=complex, format="csr")
+            for f in factors:
+                term = sp.kron(term, f, format="csr")
+            full = full + complex(coeff) * term
+            rebuilt.append((complex(coeff), re_tensor))
+        out = cls(full, eigenstates=eigenstates)
+        out._n_qudits, out._operations = int(n_qudits), rebuilt
+        return out
+
+    def _to_abstract_repr(self) -> dict[str, Any]:
+        """operator.py:188-203."""
+        if self._operations is None:
+            raise ValueError(
+                "Failed to serialize state of type 'RydOperator' because it was not created "
+                "via 'RydOperator.from_operator_repr()'.")
+        return {"eigenstates": tuple(self.eigenstates), "n_qudits": self._n_qudits,
+                "operations": self._operations}
+
+    def __repr__(self) -> str:
+        return "\n".join(["RydOperator", "-----------", f"Eigenstates: {self.eigenstates}",
+                          repr(self._operator)])
 
 
 class HamiltonianOperator:
@@ -302,24 +424,34 @@ class Fidelity(Observable):
 
 
 class Expectation(Observable):
-    """<O> of a dense operator (d^N x d^N array)."""
+    """<O> of an operator (default_observables.py:239-288): a :class:`RydOperator`
+    (e.g. from ``from_operator_repr``) or, as a convenience, a dense d^N x d^N array."""
 
     _base_tag = "expectation"
 
-    def __init__(self, operator: np.ndarray, *, evaluation_times: Sequence[float] | None = None,
+    def __init__(self, operator: Any, *, evaluation_times: Sequence[float] | None = None,
                  tag_suffix: str | None = None) -> None:
         super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
-        self.operator = np.asarray(operator, dtype=complex)
+        if not isinstance(operator, (RydOperator, np.ndarray)):
+            raise TypeError(f"'operator' must be an Operator instance; got {type(operator)} instead.")
+        self.operator = operator
 
     def _to_abstract_repr(self) -> dict[str, Any]:
-        raise ValueError("An 'Expectation' of a dense matrix has no abstract representation "
-                         "(the reference serialises operators given as sums of tensor products).")
+        if not isinstance(self.operator, RydOperator):
+            raise ValueError("An 'Expectation' of a dense matrix has no abstract representation; "
+                             "build the operator with 'RydOperator.from_operator_repr()'.")
+        d = super()._to_abstract_repr()
+        d["operator"] = self.operator
+        return d
 
     def apply(self, *, state: RydState, **kw: Any) -> Any:
+        if isinstance(self.operator, RydOperator):
+            return self.operator.expect(state)
         s = np.asarray(state.to_qobj())
+        op = np.asarray(self.operator, dtype=complex)
         if s.shape[1] == 1:
-            return complex(np.vdot(s, self.operator @ s))
-        return complex(np.trace(self.operator @ s))
+            return complex(np.vdot(s, op @ s))
+        return complex(np.trace(op @ s))
 
 
 def _probabilities(state: RydState) -> np.ndarray:
@@ -732,7 +864,7 @@ class QutipConfig:
                             f"Instead, got object of type {type(obj_str)}.")
         obj = json.loads(obj_str)
         kinds = {c._base_tag: c for c in (BitStrings, Occupation, CorrelationMatrix, Energy,
-                                          EnergyVariance, EnergySecondMoment, Fidelity)}
+                                          EnergyVariance, EnergySecondMoment, Fidelity, Expectation)}
         observables = []
         for o in obj.get("observables", []):
             if o["observable"] not in kinds:
@@ -743,7 +875,13 @@ class QutipConfig:
                 kw["num_shots"] = o["num_shots"]
             if "one_state" in o:
                 kw["one_state"] = o["one_state"]
-            if "state" in o:
+            if o["observable"] == "expectation":
+                op = o["operator"]
+                ops = [(_deserialize_complex(c), [(_deserialize_complex(q), set(inds)) for q, inds in t])
+                       for c, t in op["operations"]]
+                observables.append(Expectation(RydOperator.from_operator_repr(
+                    eigenstates=tuple(op["eigenstates"]), n_qudits=op["n_qudits"], operations=ops), **kw))
+            elif "state" in o:
                 st = o["state"]
                 amps = {k: (v["real"] + 1j * v["imag"] if isinstance(v, dict) else v)
                         for k, v in st["amplitudes"].items()}

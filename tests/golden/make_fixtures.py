@@ -819,6 +819,15 @@ def gen_config_json():
             noise_model=NoiseModel(temperature=30.0, disable_doppler=True, trap_depth=150.0, trap_waist=1.0,
                                    relaxation_rate=0.2, dmm_sigma=0.1, detuning_map_spot_waist=4.0)),
     }
+    from pulser.backend import Expectation
+    from pulser.backend.operator import OperatorRepr
+
+    X = {"gr": 1.0, "rg": 1.0}
+    Y = {"gr": 1.0j, "rg": -1.0j}
+    Z = {"rr": 1.0, "gg": -1.0}
+    op = OperatorRepr.from_operator_repr(eigenstates=("r", "g"), n_qudits=3,
+                                         operations=[(0.5, [(X, {0}), (Z, {1, 2})]), (2.0 - 1.0j, [(Y, {1})])])
+    cfgs["operator"] = EmulationConfig(observables=[Expectation(op, evaluation_times=[1.0])])
     docs = {k: c.to_abstract_repr(skip_validation=True) for k, c in cfgs.items()}
     P.save_problem(os.path.join(HERE, "config_abstract_repr.npz"), {},
                    reference_cite="pulser-core/pulser/backend/config.py:438-470", **docs)

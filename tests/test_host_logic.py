@@ -952,7 +952,7 @@ def test_config_abstract_repr_reads_and_rewrites_pulser_core_documents():
     from pulser_amd.backend import BitStrings, Fidelity, QutipConfig, StateResult
 
     _, extra = load_fixture("config_abstract_repr.npz")
-    for name in ("plain", "noisy", "register"):
+    for name in ("plain", "noisy", "register", "operator"):
         ref = json.loads(extra[name])
         cfg = QutipConfig.from_abstract_repr(extra[name])
         got = json.loads(cfg.to_abstract_repr())
@@ -975,6 +975,25 @@ def test_config_abstract_repr_reads_and_rewrites_pulser_core_documents():
     assert str(plain.observables[0]._uuid) == json.loads(extra["plain"])["observables"][0]["uuid"]
     changed = plain.with_changes(sampling_rate=0.5, n_trajectories=9)
     assert changed.sampling_rate == 0.5 and changed.n_trajectories == 9 and len(changed.observables) == 7
+    # Expectation of an operator given as a sum of tensor products (operator.py:115-235)
+    from pulser_amd.backend import Expectation, RydOperator, RydState
+    op = QutipConfig.from_abstract_repr(extra["operator"]).observables[0].operator
+    sx, sy, sz = np.array([[0, 1], [1, 0]]), np.array([[0, -1j], [1j, 0]]), np.diag([1.0, -1.0])
+    dense = 0.5 * np.kron(np.kron(sx, sz), sz) + (2.0 - 1.0j) * np.kron(np.kron(np.eye(2), sy), np.eye(2))
+    assert np.allclose(op.to_qobj().toarray(), dense)
+    psi = np.random.default_rng(3).normal(size=8) + 1j * np.random.default_rng(4).normal(size=8)
+    st = RydState(psi / np.linalg.norm(psi), eigenstates=("r", "g"))
+    assert np.isclose(Expectation(op).apply(state=st), np.vdot(np.asarray(st.to_qobj()), dense @ np.asarray(st.to_qobj())))
+    rho = RydState(np.outer(psi, psi.conj()) / np.vdot(psi, psi), eigenstates=("r", "g"))
+    assert np.isclose(op.expect(rho), op.expect(st))
+    assert np.allclose(np.asarray(op.apply_to(st).to_qobj())[:, 0], dense @ np.asarray(st.to_qobj())[:, 0])
+    assert (2 * op + op) == 3 * op and (op @ op).to_qobj().shape == (8, 8)
+    with pytest.raises(ValueError, match="Got invalid indices"):
+        RydOperator.from_operator_repr(eigenstates=("r", "g"), n_qudits=2, operations=[(1.0, [({"rr": 1}, {2})])])
+    with pytest.raises(ValueError, match="Every QuditOp key must be made up"):
+        RydOperator.from_operator_repr(eigenstates=("r", "g"), n_qudits=2, operations=[(1.0, [({"rx": 1}, {0})])])
+    with pytest.raises(ValueError, match="Can't apply"):
+        op.expect(RydState(psi, eigenstates=("g", "h")))
     with pytest.raises(ValueError, match="not supported in any remote backend"):
         QutipConfig(observables=[StateResult()]).to_abstract_repr()
     with pytest.raises(NotImplementedError, match="custom interaction matrices"):
