@@ -13,7 +13,7 @@ from .results import (CoherentResults, NoisyResults, QState, SampledResult,
                       SimulationResults, StateResult)
 from .simulation import QutipEmulator, SimConfig, Solver
 from . import backend
-from .backend import QutipBackendV2, QutipConfig, RydState, Results
+from .backend import QutipBackendV2, QutipConfig, Results, RydOperator, RydState
 
 __version__ = "0.1.0"
 
@@ -21,5 +21,5 @@ __all__ = [
     "QutipEmulator", "Solver", "SimConfig", "NoiseModel", "CoherentResults",
     "NoisyResults", "SimulationResults", "StateResult", "SampledResult", "QState",
     "SequenceInputs", "ChannelInput", "Slot", "HamiltonianData", "single_global_channel",
-    "QutipBackendV2", "QutipConfig", "RydState", "Results", "backend",
+    "QutipBackendV2", "QutipConfig", "RydState", "RydOperator", "Results", "backend",
 ]
