@@ -23,6 +23,16 @@ struct Apply14Args {
   int N, nb, n_flip;
 };
 
+// value of `v` held by the lane selected by the DPP control (full row / bank masks)
+template <int CTRL>
+__device__ __forceinline__ cplx dpp_cplx(cplx v) {
+  const int a = __builtin_amdgcn_mov_dpp(__double2loint(v.x), CTRL, 0xF, 0xF, true);
+  const int b = __builtin_amdgcn_mov_dpp(__double2hiint(v.x), CTRL, 0xF, 0xF, true);
+  const int c = __builtin_amdgcn_mov_dpp(__double2loint(v.y), CTRL, 0xF, 0xF, true);
+  const int d = __builtin_amdgcn_mov_dpp(__double2hiint(v.y), CTRL, 0xF, 0xF, true);
+  return make_double2(__hiloint2double(b, a), __hiloint2double(d, c));
+}
+
 template <int MODE, bool REAL, bool FULL>
 __global__ __launch_bounds__(1024) void k_apply14(const Apply14Args A) {
   // FULL: all 14 tile bits are flipped (n_flip == 14) - no per-flip predicates.
@@ -133,7 +143,13 @@ __global__ __launch_bounds__(1024) void k_apply14(const Apply14Args A) {
 #pragma unroll
       for (int jj = 0; jj < GS; ++jj) {
         const int j = g0 + jj;
-        if (f < LOGNT) pv[jj] = xs[jj * NTT + (tid ^ (1 << f))];
+        // partners inside a 16-lane row come over the DPP crossbar (xor 1, 2: quad
+        // permutes; xor 8: row rotate by 8) and never touch LDS, the other lane
+        // bits are ds_read_b128, tile bits 10-13 are register moves
+        if (f == 0) pv[jj] = dpp_cplx<0xB1>(x[j]);
+        else if (f == 1) pv[jj] = dpp_cplx<0x4E>(x[j]);
+        else if (f == 3) pv[jj] = dpp_cplx<0x128>(x[j]);
+        else if (f < LOGNT) pv[jj] = xs[jj * NTT + (tid ^ (1 << f))];
         else pv[jj] = x[(j ^ (1 << (f >= LOGNT ? f - LOGNT : 0))) & (R - 1)];
       }
 #pragma unroll
