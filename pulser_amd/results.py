@@ -21,7 +21,7 @@ import collections.abc
 from collections import Counter
 from dataclasses import dataclass
 from functools import lru_cache
-from typing import Any, Mapping, Optional, Sequence, Union
+from typing import Any, Mapping, Optional, Sequence
 
 import numpy as np
 

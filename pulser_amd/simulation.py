@@ -603,7 +603,6 @@ class QutipEmulator:
     # --------------------------------------------------------------------- run
     def _validate_options(self, options: dict[str, Any]) -> None:
         """simulation.py:768-797."""
-        from .hamiltonian_data import ChannelInput  # noqa: F401
 
         def min_variation(ch: Any) -> int:  # simulation.py:663-687
             end_point = ch.duration - 1
