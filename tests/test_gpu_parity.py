@@ -323,3 +323,29 @@ def test_trajectory_averaged_density_matrix_kernels(n, batch):
     assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref))
     pure = got - start
     assert np.max(np.abs(pure - pure.conj().T)) <= 1e-12 * np.max(np.abs(ref))
+
+
+def test_large_ket_against_the_product_state_solution():
+    """25 atoms (0.5 GiB ket, three tiled passes per application, 64-bit index
+    arithmetic): with the atoms far apart every atom evolves on its own, so any
+    amplitude is a product of single-atom amplitudes.  (tools/big_ket.py runs the
+    same check at 28 and 30 atoms = 4 and 16 GiB kets.)"""
+    from pulser_amd import problem as P
+
+    n, T = 25, 8
+    coords = P.register_coords(P.square_rect(1, n), 40.0)
+    samples = {"amp": np.full(T + 1, 6.0), "det": np.full(T + 1, -2.0), "phase": np.zeros(T + 1)}
+    eng = _engine([P.make_ising_problem(coords, samples)], mode="sesolve")
+    st = eng.new_state()
+    eng.evolve(st, 0.0, 0.004)
+    assert eng.stats()["passes"] == 3
+    h1 = np.array([[2.0, 3.0], [3.0, 0.0]])  # (r, g): -delta n_r + (Omega / 2) sigma_x
+    w, v = np.linalg.eigh(h1)
+    a1 = (v @ np.diag(np.exp(-1j * w * 0.004)) @ v.conj().T) @ np.array([0.0, 1.0])
+    idx = [0, 1, (1 << n) - 1, (1 << (n - 1)) + 5, 0x155AAAA]
+    got = st[0, idx].cpu().numpy()
+    ref = np.array([np.prod([a1[(i >> (n - 1 - k)) & 1] for k in range(n)]) for i in idx])
+    assert np.max(np.abs(got - ref)) < 1e-12
+    import torch
+    assert abs(float(torch.linalg.vector_norm(st).item()) - 1.0) < 1e-13
+    eng.close()
