@@ -421,7 +421,8 @@ extern "C" int ryd_set_collapse(ryd_handle* h, int32_t n_ops, const double* ops)
   if (!h->mc_pool) {
     HIPCHK(hipMalloc(&h->mc_pool, bytes));
     HIPCHK(hipMemset(h->mc_pool, 0, bytes));
-    char* p = (char*)h->mc_pool;
+    char* p = (char*)h->mc_pool;  // 16-byte objects first, then 8-byte, then 4-byte ones
+    h->mc_ops_dev = (cplx*)p;     p += MC_MAX_OPS * 4 * sizeof(cplx);
     h->mcs.norm2 = (double*)p;    p += 2 * B * sizeof(double);
     h->mcs.red = (double*)p;      p += 4 * N * B * sizeof(double);
     h->mcs.target = (double*)p;   p += B * sizeof(double);
@@ -429,7 +430,6 @@ extern "C" int ryd_set_collapse(ryd_handle* h, int32_t n_ops, const double* ops)
     h->mcs.lastnorm = (double*)p; p += B * sizeof(double);
     h->mcs.scale = (double*)p;    p += B * sizeof(double);
     h->mc_seeds_dev = (unsigned long long*)p; p += B * sizeof(unsigned long long);
-    h->mc_ops_dev = (cplx*)p;     p += MC_MAX_OPS * 4 * sizeof(cplx);
     h->mcs.flag = (int*)p;        p += B * sizeof(int);
     h->mcs.sel = (int*)p;         p += B * sizeof(int);
     h->mcs.count = (int*)p;
