@@ -161,7 +161,7 @@ int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
  * (simulation.py:729-735, result.states at every evaluation time).  Advances
  * `state_dev` in place through times[0..n_times-1] (us, non-decreasing) and, if
  * `out_dev` is not NULL, stores the state reached at times[i] (i >= 1) in slot
- * i-1 of out_dev, complex128[n_times-1][batch][dim].  For sesolve with N <= 12
+ * i-1 of out_dev, complex128[n_times-1][batch][dim].  For sesolve with N <= 13
  * the whole call is ONE launch of the persistent LDS-resident trajectory kernel
  * (one workgroup per batch entry); otherwise the tiled multi-pass kernels run
  * once per Taylor stage. */

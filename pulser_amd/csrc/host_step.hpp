@@ -245,7 +245,8 @@ template <int N, int MODEL, bool MC>
 static int launch_traj2(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
   constexpr int D = 1 << N;
   constexpr int NTT = D < 64 ? 64 : (N >= 11 ? 1024 : (D > 512 ? 512 : D));
-  const size_t lds = 2 * (size_t)D * sizeof(cplx) + 4 * 16 * sizeof(double) * 4 + 2 * 16 * sizeof(double);
+  const size_t copies = (size_t)2 * D * sizeof(cplx) > 144 * 1024 ? 1 : 2;  // see k_traj: SINGLE
+  const size_t lds = copies * (size_t)D * sizeof(cplx) + 4 * 16 * sizeof(double) * 4 + 2 * 16 * sizeof(double);
   // the dynamic-LDS limit is a per-device function attribute
   static bool attr_set[64] = {};
   const int dev = h->cfg.device;
@@ -268,7 +269,7 @@ static int launch_traj(ryd_handle* h, const TrajArgs& A, hipStream_t st) {
                                : launch_traj2<N, 0, false>(h, A, st);
 }
 
-// Persistent path (sesolve, N <= 12): one workgroup per trajectory keeps its
+// Persistent path (sesolve, N <= 13): one workgroup per trajectory keeps its
 // state vector in LDS/registers for the whole schedule; one launch.
 static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched,
                           cplx* snaps, hipStream_t st) {
@@ -318,7 +319,8 @@ static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc
     case 10: rc = launch_traj<10>(h, A, st); break;
     case 11: rc = launch_traj<11>(h, A, st); break;
     case 12: rc = launch_traj<12>(h, A, st); break;
-    default: return fail(RYD_ERR_INVALID, "persistent path needs N <= 12");
+    case 13: rc = launch_traj<13>(h, A, st); break;
+    default: return fail(RYD_ERR_INVALID, "persistent path needs N <= 13");
   }
   if (rc) return rc;
   if (h->timing) {
@@ -334,7 +336,7 @@ static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc
 }
 
 static bool use_persistent(const ryd_handle* h) {
-  return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 12 && !h->force_generic;
+  return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 13 && !h->force_generic;
 }
 
 extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,

@@ -1,6 +1,6 @@
 // Part of librydemu (included by rydemu.hip, one translation unit).
 // ---------------------------------------------------------------------------
-// Persistent trajectory kernel (sesolve, N <= 12)
+// Persistent trajectory kernel (sesolve, N <= 13)
 // ---------------------------------------------------------------------------
 // One workgroup evolves one state vector through a whole schedule of CF4 steps
 // in a single launch: psi lives in registers (thread t owns amplitudes
@@ -52,11 +52,17 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
   constexpr int D = 1 << N;
   constexpr int R = D / NTT > 0 ? D / NTT : 1;
   constexpr int LOGNT = NTT == 1024 ? 10 : (NTT == 512 ? 9 : (NTT == 256 ? 8 : (NTT == 128 ? 7 : 6)));
-  constexpr int NLDS = N < LOGNT ? N : LOGNT;  // bits whose partner is read from LDS
+  // two LDS buffers: the Horner iterate ping-pongs, one barrier per stage.  13 atoms
+  // (128 KiB per copy) only fit once: one buffer, two barriers per stage; there every
+  // partner (also of the register-index bits) is read from LDS, so a new amplitude
+  // can replace the old one in its register at once (8 amplitudes per thread leave
+  // no room for an old and a new copy).
+  constexpr bool SINGLE = (size_t)2 * D * sizeof(cplx) > 144 * 1024;
+  constexpr int NLDS = SINGLE ? N : (N < LOGNT ? N : LOGNT);  // bits whose partner is read from LDS
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cplx* ws0 = reinterpret_cast<cplx*>(smem);      // two buffers: the Horner iterate
-  cplx* ws1 = ws0 + D;                            // ping-pongs, one barrier per stage
-  double* cfA = reinterpret_cast<double*>(ws1 + D);  // [16][4]: cr, ci, delta, 0 for exp A
+  cplx* ws0 = reinterpret_cast<cplx*>(smem);
+  cplx* ws1 = SINGLE ? ws0 : ws0 + D;
+  double* cfA = reinterpret_cast<double*>(ws0 + (SINGLE ? D : 2 * D));  // [16][4]: cr, ci, delta, 0 for exp A
   double* cfB = cfA + 64;                            // same for exp B
   double* mcred = cfB + 64;                          // [16][4] per-wave partial sums
   double* mcrho = mcred + 64;                        // [16][4] reduced density matrices
@@ -223,6 +229,29 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
           const int l = tid + j * NTT;
           // issue every LDS partner read of this element before using any
           cplx xv[NLDS > 0 ? NLDS : 1];
+          if (SINGLE && MODEL == 1) {
+            // 13 atoms: two half-batches of partner reads (7 + 6) keep psi and w in
+            // registers; all partners share one real coefficient, so they are summed
+            double s0x = 0.0, s0y = 0.0, s1x = 0.0, s1y = 0.0;
+#pragma unroll
+            for (int q0 = 0; q0 < N; q0 += 7) {
+#pragma unroll
+              for (int q = q0; q < q0 + 7 && q < N; ++q) xv[q - q0] = rd[(l ^ (1 << q)) & (D - 1)];
+#pragma unroll
+              for (int q = q0; q < q0 + 7 && q < N; ++q) {
+                const cplx x = xv[q - q0];
+                if (q & 1) { s1x = fma(mq[q], x.x, s1x); s1y = fma(mq[q], x.y, s1y); }
+                else { s0x = fma(mq[q], x.x, s0x); s0y = fma(mq[q], x.y, s0y); }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            const double sx = s0x + s1x, sy = s0y + s1y;
+            acc[j] = make_double2(fma(cuni, sy, eg[j] * w[j].y), -fma(cuni, sx, eg[j] * w[j].x));
+            if (MC) acc[j] = make_double2(fma(er[j], w[j].x, acc[j].x), fma(er[j], w[j].y, acc[j].y));
+            w[j] = make_double2(fma(sc, acc[j].x, psi[j].x), fma(sc, acc[j].y, psi[j].y));
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+          }
 #pragma unroll
           for (int q = 0; q < NLDS; ++q) xv[q] = rd[(l ^ (1 << q)) & (D - 1)];
           if (MODEL == 0) {
@@ -249,16 +278,24 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
             // -i (e w + c sum)
             acc[j] = make_double2(fma(cuni, sy, eg[j] * w[j].y), -fma(cuni, sx, eg[j] * w[j].x));
           }
+          if (SINGLE) {  // in place: nothing else reads w[j] from the register
+            if (MC) acc[j] = make_double2(fma(er[j], w[j].x, acc[j].x), fma(er[j], w[j].y, acc[j].y));
+            w[j] = make_double2(fma(sc, acc[j].x, psi[j].x), fma(sc, acc[j].y, psi[j].y));
+            __builtin_amdgcn_sched_barrier(0);  // keep the 13 partner reads of the next amplitude behind this one
+          }
         }
-        if (MC) {
+        if (MC && !SINGLE) {
 #pragma unroll
           for (int j = 0; j < R; ++j)
             acc[j] = make_double2(fma(er[j], w[j].x, acc[j].x), fma(er[j], w[j].y, acc[j].y));
         }
+        if (!SINGLE) {
 #pragma unroll
-        for (int j = 0; j < R; ++j)
-          w[j] = make_double2(fma(sc, acc[j].x, psi[j].x), fma(sc, acc[j].y, psi[j].y));
+          for (int j = 0; j < R; ++j)
+            w[j] = make_double2(fma(sc, acc[j].x, psi[j].x), fma(sc, acc[j].y, psi[j].y));
+        }
         if (jj > 1) {
+          if (SINGLE) __syncthreads();  // every partner read of the old iterate is done
 #pragma unroll
           for (int j = 0; j < R; ++j)
             if (active) wr[tid + j * NTT] = w[j];

@@ -79,7 +79,7 @@ def test_trajectories_match_cpu_restatement(n, generic):
     assert total >= len(seeds)  # the test exercises jumps, not only decay
 
 
-@pytest.mark.parametrize("n", [5, 7, 10, 11, 12])
+@pytest.mark.parametrize("n", [5, 7, 10, 11, 12, 13])
 def test_persistent_and_multi_launch_trajectories_agree(n):
     """Every workgroup shape of the persistent kernel (64 .. 1024 threads, 1-4
     amplitudes per thread) against the tiled multi-launch kernels: same seeds,

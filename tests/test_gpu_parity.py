@@ -190,7 +190,7 @@ def test_ket_to_dm_and_outer_accumulate():
     assert np.max(np.abs(acc.cpu().numpy() - ref)) < 1e-15
 
 
-@pytest.mark.parametrize("n", [1, 3, 6, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("n", [1, 3, 6, 8, 9, 10, 11, 12, 13])
 def test_persistent_kernel_matches_generic_and_oracle(n):
     """The LDS-resident trajectory kernel (one launch) against the tiled path
     (one launch per Taylor stage) and the oracle, with per-qubit coefficients."""
