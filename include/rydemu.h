@@ -162,7 +162,8 @@ int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
  * `state_dev` in place through times[0..n_times-1] (us, non-decreasing) and, if
  * `out_dev` is not NULL, stores the state reached at times[i] (i >= 1) in slot
  * i-1 of out_dev, complex128[n_times-1][batch][dim].  For sesolve with N <= 13
- * the whole call is ONE launch of the persistent LDS-resident trajectory kernel
+ * (and for mesolve with N <= 6: a density matrix of at most 4096 entries) the
+ * whole call is ONE launch of the persistent LDS-resident trajectory kernel
  * (one workgroup per batch entry); otherwise the tiled multi-pass kernels run
  * once per Taylor stage. */
 int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,

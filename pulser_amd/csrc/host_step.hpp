@@ -335,8 +335,91 @@ static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc
   return RYD_OK;
 }
 
+template <int N, bool DBL>
+static int launch_traj_dm(ryd_handle* h, const TrajDmArgs& A, hipStream_t st) {
+  constexpr int D = 1 << (2 * N);
+  constexpr int NTT = D < 64 ? 64 : (2 * N >= 11 ? 1024 : (D > 512 ? 512 : D));
+  const size_t lds = 2 * (size_t)D * sizeof(cplx) + 2 * 32 * sizeof(double);
+  static bool attr_set[64] = {};
+  const int dev = h->cfg.device;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_traj_dm<N, NTT, DBL>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((k_traj_dm<N, NTT, DBL>), dim3(h->B), dim3(NTT), lds, st, A);
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
+}
+
+// Persistent path for small density matrices (mesolve, N <= 6): one launch.
+static int run_persistent_dm(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched,
+                             cplx* snaps, hipStream_t st) {
+  if (sched.empty()) return RYD_OK;
+  const size_t bytes = sched.size() * sizeof(StepDesc);
+  if (h->sched_cap < sched.size()) {
+    if (h->sched_dev) hipFree(h->sched_dev);
+    h->sched_dev = nullptr;
+    h->sched_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->sched_dev, bytes * 2));
+    h->sched_cap = sched.size() * 2;
+  }
+  HIPCHK(hipStreamSynchronize(st));  // the buffer may still be read by an earlier launch
+  HIPCHK(hipMemcpyAsync(h->sched_dev, sched.data(), bytes, hipMemcpyHostToDevice, st));
+  TrajDmArgs A;
+  A.state = state;
+  A.snaps = snaps;
+  A.pp = h->pp_dev;
+  A.desc = h->desc_dev;
+  A.dterms = h->dterms_dev;
+  A.e0 = h->e0_dev;
+  A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << h->N);
+  A.steps = h->sched_dev;
+  A.n_int = h->n_knots - 1;
+  A.n_steps = (int)sched.size();
+  A.B = h->B;
+  A.a1 = kA1;
+  A.a2 = kA2;
+  for (int i = 0; i < 4; ++i) { A.Sd[i] = h->Sd[i]; A.J[i] = h->J[i]; }
+  int rc = RYD_ERR_INVALID;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+#define RYD_DM_CASE(NN) \
+  case NN: rc = h->has_dbl ? launch_traj_dm<NN, true>(h, A, st) : launch_traj_dm<NN, false>(h, A, st); break;
+  switch (h->N) {
+    RYD_DM_CASE(1) RYD_DM_CASE(2) RYD_DM_CASE(3) RYD_DM_CASE(4) RYD_DM_CASE(5) RYD_DM_CASE(6)
+    default: return fail(RYD_ERR_INVALID, "persistent density-matrix path needs N <= 6");
+  }
+#undef RYD_DM_CASE
+  if (rc) return rc;
+  if (h->timing) {
+    HIPCHK(hipEventRecord(ev.second, st));
+    h->ev_used.push_back(ev);
+  }
+  for (const StepDesc& d : sched) {
+    h->stats.n_applications += d.order_a + d.order_b;
+    h->stats.n_steps++;
+  }
+  h->stats.n_launches++;
+  return RYD_OK;
+}
+
+static bool use_persistent_dm(const ryd_handle* h) {
+  return !h->general && h->cfg.mode == RYD_MESOLVE && h->N <= 6 && !h->force_generic;
+}
+
+static int run_steps(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
+                     hipStream_t st);
+
 static bool use_persistent(const ryd_handle* h) {
   return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 13 && !h->force_generic;
+}
+
+static int run_steps(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
+                     hipStream_t st) {
+  if (use_persistent(h)) return run_persistent(h, state, sched, snaps, st);
+  if (use_persistent_dm(h)) return run_persistent_dm(h, state, sched, snaps, st);
+  return run_generic(h, state, sched, snaps, st);
 }
 
 extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
@@ -368,17 +451,14 @@ extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const 
           if ((rc = snapshot_copy(h, state, snaps + (size_t)(i - 1) * h->dim * h->B, st))) return rc;
         } else {
           // duplicate time after at least one step: flush what we have, copy, continue
-          if ((rc = use_persistent(h) ? run_persistent(h, state, sched, snaps, st)
-                                      : run_generic(h, state, sched, snaps, st)))
-            return rc;
+          if ((rc = run_steps(h, state, sched, snaps, st))) return rc;
           sched.clear();
           if ((rc = snapshot_copy(h, state, snaps + (size_t)(i - 1) * h->dim * h->B, st))) return rc;
         }
       }
     }
   }
-  return use_persistent(h) ? run_persistent(h, state, sched, snaps, st)
-                           : run_generic(h, state, sched, snaps, st);
+  return run_steps(h, state, sched, snaps, st);
 }
 
 extern "C" int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,

@@ -52,6 +52,7 @@ typedef double2 cplx;
 #include "k_small.hpp"
 #include "k_mc.hpp"
 #include "k_traj.hpp"
+#include "k_traj_dm.hpp"
 #include "k_general.hpp"
 #include "host_handle.hpp"
 #include "host_apply.hpp"

@@ -349,3 +349,38 @@ def test_large_ket_against_the_product_state_solution():
     import torch
     assert abs(float(torch.linalg.vector_norm(st).item()) - 1.0) < 1e-13
     eng.close()
+
+
+@pytest.mark.parametrize("case", list(ME_CASES))
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6])
+def test_persistent_density_matrix_kernel_matches_tiled_kernels_and_oracle(case, n):
+    """mesolve of small registers (rho = 4 ... 4096 entries): the persistent
+    one-launch kernel against the tiled kernels (one launch per Taylor stage) and,
+    up to 4 atoms, the tight oracle - dephasing, relaxation and depolarizing
+    (double-flip) dissipators, per-qubit drives, snapshots at evaluation times."""
+    from oracle import qutip_path as qp
+
+    ops, paulis = ME_CASES[case]
+    probs = [local_problem(n, seed=s, duration=41, collapse_ops=ops, paulis=paulis) for s in range(3)]
+    times = np.array([0.0, 0.0105, 0.0105, 0.04])
+    outs = {}
+    for force in (False, True):
+        eng = _engine(probs, mode="mesolve")
+        eng.set_path(force)
+        st = eng.new_state()
+        snaps = eng.solve(st, times).cpu().numpy()
+        assert np.array_equal(snaps[-1], st.cpu().numpy())
+        outs[force] = snaps
+        launches = eng.stats()["n_launches"]
+        assert (launches == 2) if not force else (launches > 50)  # split at the duplicated time
+    assert np.max(np.abs(outs[False] - outs[True])) < 1e-13
+    assert np.array_equal(outs[False][0], outs[False][1])
+    tr = np.trace(outs[False][-1], axis1=1, axis2=2)
+    assert np.max(np.abs(tr - 1.0)) < 1e-12
+    if n <= 4:
+        for b, p in enumerate(probs):
+            ham = qp.build_hamiltonian(p)
+            ref = qp.mesolve(ham, qp.all_ground_state(n, p["eigenbasis"]), times[[0, 1, 3]],
+                             max_step=1e-3, **qp.TIGHT)
+            assert np.max(np.abs(outs[False][0][b] - ref[1])) < AMP_TOL
+            assert np.max(np.abs(outs[False][2][b] - ref[2])) < AMP_TOL
