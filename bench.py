@@ -351,6 +351,15 @@ def main() -> None:
                      "jumps_per_trajectory": float(eng.mc_jumps().mean()),
                      "kernel": "k_traj<12,1024,1,MC> (persistent, jumps on the device, 1 launch)"})
         eng.close()
+        # small noisy registers (the reference's typical mesolve workloads): persistent dm kernel
+        ops4 = [(float(np.sqrt(2 * 0.05)), "sigma_rr"), (float(np.sqrt(0.02)), "sigma_gr")]
+        eng = Engine.from_problems([chain_problem(4, ops4)] * 256, mode="mesolve")
+        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, 2, 1, None, torch)
+        also.append({"workload": "256 master-equation trajectories of a 4-atom anneal sequence "
+                                 "(dephasing + relaxation), one launch",
+                     "value": 256 * T_SEQ_US / sec, "unit": "sim-us/s", "ms_per_batch": sec * 1e3,
+                     "kernel": "k_traj_dm<4,256,true> (persistent, LDS-resident density matrix)"})
+        eng.close()
         # ensemble density matrix of 1024 trajectories (density_matrix_aggregator): fp64 MFMA
         eng = Engine.from_problems([chain_problem(12)] * 1024, mode="sesolve")
         psi = torch.randn(1024, 4096, dtype=torch.complex128, device=eng.device)
