@@ -335,7 +335,7 @@ static int run_persistent(ryd_handle* h, cplx* state, const std::vector<StepDesc
   return RYD_OK;
 }
 
-template <int N, bool DBL>
+template <int N, bool DBL, bool REALU>
 static int launch_traj_dm(ryd_handle* h, const TrajDmArgs& A, hipStream_t st) {
   constexpr int D = 1 << (2 * N);
   constexpr int NTT = D < 64 ? 64 : (2 * N >= 11 ? 1024 : (D > 512 ? 512 : D));
@@ -343,11 +343,11 @@ static int launch_traj_dm(ryd_handle* h, const TrajDmArgs& A, hipStream_t st) {
   static bool attr_set[64] = {};
   const int dev = h->cfg.device;
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_traj_dm<N, NTT, DBL>,
+    HIPCHK(hipFuncSetAttribute((const void*)k_traj_dm<N, NTT, DBL, REALU>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((k_traj_dm<N, NTT, DBL>), dim3(h->B), dim3(NTT), lds, st, A);
+  hipLaunchKernelGGL((k_traj_dm<N, NTT, DBL, REALU>), dim3(h->B), dim3(NTT), lds, st, A);
   HIPCHK(hipGetLastError());
   return RYD_OK;
 }
@@ -384,8 +384,13 @@ static int run_persistent_dm(ryd_handle* h, cplx* state, const std::vector<StepD
   int rc = RYD_ERR_INVALID;
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
-#define RYD_DM_CASE(NN) \
-  case NN: rc = h->has_dbl ? launch_traj_dm<NN, true>(h, A, st) : launch_traj_dm<NN, false>(h, A, st); break;
+#define RYD_DM_CASE(NN)                                                                        \
+  case NN:                                                                                     \
+    rc = h->has_dbl ? (h->uniform_real_drive ? launch_traj_dm<NN, true, true>(h, A, st)         \
+                                             : launch_traj_dm<NN, true, false>(h, A, st))       \
+                    : (h->uniform_real_drive ? launch_traj_dm<NN, false, true>(h, A, st)        \
+                                             : launch_traj_dm<NN, false, false>(h, A, st));     \
+    break;
   switch (h->N) {
     RYD_DM_CASE(1) RYD_DM_CASE(2) RYD_DM_CASE(3) RYD_DM_CASE(4) RYD_DM_CASE(5) RYD_DM_CASE(6)
     default: return fail(RYD_ERR_INVALID, "persistent density-matrix path needs N <= 6");

@@ -29,7 +29,10 @@ struct TrajDmArgs {
   cplx Sd[4], J[4];
 };
 
-template <int N, int NTT, bool DBL>
+// REALU: every driven atom of the trajectory shares one real drive coefficient (global
+// channel, phase 0; bad atoms masked out): the flip partners are summed first, row
+// partners with +1 and column partners with -1, and multiplied once (-i c (S_row - S_col)).
+template <int N, int NTT, bool DBL, bool REALU>
 __global__ __launch_bounds__(NTT) void k_traj_dm(const TrajDmArgs A) {
   constexpr int NB = 2 * N;
   constexpr int D = 1 << NB;
@@ -99,11 +102,11 @@ __global__ __launch_bounds__(NTT) void k_traj_dm(const TrajDmArgs A) {
       cfA[4 * tid + 0] = d.drive_scale * (A.a1 * c1r + A.a2 * c2r);
       cfA[4 * tid + 1] = d.drive_scale * (A.a1 * c1i + A.a2 * c2i);
       cfA[4 * tid + 2] = dlA;
-      cfA[4 * tid + 3] = 0.0;
+      cfA[4 * tid + 3] = d.drive_series >= 0 ? 1.0 : 0.0;
       cfB[4 * tid + 0] = d.drive_scale * (A.a2 * c1r + A.a1 * c2r);
       cfB[4 * tid + 1] = d.drive_scale * (A.a2 * c1i + A.a1 * c2i);
       cfB[4 * tid + 2] = dlB;
-      cfB[4 * tid + 3] = 0.0;
+      cfB[4 * tid + 3] = d.drive_series >= 0 ? 1.0 : 0.0;
     }
     __syncthreads();
 
@@ -123,6 +126,17 @@ __global__ __launch_bounds__(NTT) void k_traj_dm(const TrajDmArgs A) {
         cr[q] = uniform_d(-s2 * cf[4 * k + 0]);
         ci[q] = uniform_d(cf[4 * k + 1]);
         dq[q] = uniform_d(s2 * cf[4 * k + 2]);
+      }
+      double mq[REALU ? NB : 1];  // +1 row bit / -1 column bit of a driven atom, 0 otherwise
+      double cuni = 0.0;
+      if (REALU) {
+        double cv = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) cv = cf[4 * k + 3] != 0.0 ? cf[4 * k + 0] : cv;
+        cuni = uniform_d(cv);
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+          mq[q] = uniform_d(cf[4 * (N - 1 - (q % N)) + 3] * (q < N ? -1.0 : 1.0));
       }
       double dgi[R];
 #pragma unroll
@@ -159,13 +173,26 @@ __global__ __launch_bounds__(NTT) void k_traj_dm(const TrajDmArgs A) {
           }
           // diagonal: (dr + i di) x
           cplx a = make_double2(ddr[j] * w[j].x - dgi[j] * w[j].y, ddr[j] * w[j].y + dgi[j] * w[j].x);
+          if (REALU) {
+            double s0x = 0.0, s0y = 0.0, s1x = 0.0, s1y = 0.0;  // two chains
 #pragma unroll
-          for (int q = 0; q < NB; ++q) {
-            const int rb = q >= LOGNT ? q - LOGNT : 0;
-            const cplx x = q < NLDS ? xv[q < NLDS ? q : 0] : w[(j ^ (1 << rb)) & (R - 1)];
-            // row bit: (sgi, -c_r); column bit: (sgi, +c_r); sgi = +-c_i by the output bit
-            const double sgi = ((l >> q) & 1) ? ci[q] : -ci[q];
-            a = cfma(make_double2(sgi, -cr[q]), x, a);
+            for (int q = 0; q < NB; ++q) {
+              const int rb = q >= LOGNT ? q - LOGNT : 0;
+              const cplx x = q < NLDS ? xv[q < NLDS ? q : 0] : w[(j ^ (1 << rb)) & (R - 1)];
+              if (q & 1) { s1x = fma(mq[q], x.x, s1x); s1y = fma(mq[q], x.y, s1y); }
+              else { s0x = fma(mq[q], x.x, s0x); s0y = fma(mq[q], x.y, s0y); }
+            }
+            // -i c (S_row - S_col)
+            a = make_double2(fma(cuni, s0y + s1y, a.x), fma(-cuni, s0x + s1x, a.y));
+          } else {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+              const int rb = q >= LOGNT ? q - LOGNT : 0;
+              const cplx x = q < NLDS ? xv[q < NLDS ? q : 0] : w[(j ^ (1 << rb)) & (R - 1)];
+              // row bit: (sgi, -c_r); column bit: (sgi, +c_r); sgi = +-c_i by the output bit
+              const double sgi = ((l >> q) & 1) ? ci[q] : -ci[q];
+              a = cfma(make_double2(sgi, -cr[q]), x, a);
+            }
           }
           if (DBL) {
 #pragma unroll

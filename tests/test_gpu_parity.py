@@ -384,3 +384,33 @@ def test_persistent_density_matrix_kernel_matches_tiled_kernels_and_oracle(case,
                              max_step=1e-3, **qp.TIGHT)
             assert np.max(np.abs(outs[False][0][b] - ref[1])) < AMP_TOL
             assert np.max(np.abs(outs[False][2][b] - ref[2])) < AMP_TOL
+
+
+@pytest.mark.parametrize("case", ["dephasing", "all"])
+@pytest.mark.parametrize("n", [2, 4, 6])
+def test_persistent_density_matrix_kernel_global_real_drive(case, n):
+    """The uniform-real-drive variant (global channel, phase 0; one trajectory of the
+    batch has a badly prepared atom, which is masked out of the partner sums)."""
+    from oracle import qutip_path as qp
+
+    ops, paulis = ME_CASES[case]
+    base = chain_problem(n, collapse_ops=ops)
+    base["depolarizing_pauli_2ds"] = dict(paulis)
+    bad = dict(base)
+    bad["bad_atoms"] = np.array([i == 1 for i in range(n)])
+    probs = [base, bad]
+    times = np.array([0.0, 0.9, 2.0])
+    outs = {}
+    for force in (False, True):
+        eng = _engine(probs, mode="mesolve")
+        eng.set_path(force)
+        st = eng.new_state()
+        outs[force] = eng.solve(st, times).cpu().numpy()
+        assert (eng.stats()["n_launches"] == 1) == (not force)
+    assert np.max(np.abs(outs[False] - outs[True])) < 1e-12
+    assert np.max(np.abs(outs[False][-1][0] - outs[False][-1][1])) > 1e-3
+    if n <= 4:
+        for b, p in enumerate(probs):
+            ham = qp.build_hamiltonian(p)
+            ref = qp.mesolve(ham, qp.all_ground_state(n, p["eigenbasis"]), times, max_step=1e-3, **qp.TIGHT)
+            assert np.max(np.abs(outs[False][-1][b] - ref[-1])) < AMP_TOL
