@@ -409,6 +409,64 @@ static int run_persistent_dm(ryd_handle* h, cplx* state, const std::vector<StepD
   return RYD_OK;
 }
 
+// Persistent path of the general (explicit CSR terms) engine for small vectors.
+static int run_persistent_general(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched,
+                                  cplx* snaps, hipStream_t st) {
+  if (sched.empty()) return RYD_OK;
+  const size_t bytes = sched.size() * sizeof(StepDesc);
+  if (h->sched_cap < sched.size()) {
+    if (h->sched_dev) hipFree(h->sched_dev);
+    h->sched_dev = nullptr;
+    h->sched_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->sched_dev, bytes * 2));
+    h->sched_cap = sched.size() * 2;
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMemcpyAsync(h->sched_dev, sched.data(), bytes, hipMemcpyHostToDevice, st));
+  GenTrajArgs A;
+  A.state = state;
+  A.snaps = snaps;
+  A.pp = h->pp_dev;
+  A.series = h->gen_series_dev;
+  A.conjf = h->gen_conj_dev;
+  A.scale = h->gen_scale_dev;
+  A.terms = h->gen_terms_dev;
+  A.steps = h->sched_dev;
+  A.n_int = h->n_knots - 1;
+  A.n_steps = (int)sched.size();
+  A.n_terms = (int)h->gen_host.size();
+  A.dim = (int)h->dim;
+  A.a1 = kA1;
+  A.a2 = kA2;
+  const size_t lds = 2 * 4096 * sizeof(cplx) + 2 * MAX_GEN_TERMS * sizeof(cplx);
+  static bool attr_set[64] = {};
+  const int dev = h->cfg.device;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_gen_traj, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  int rc;
+  if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+  hipLaunchKernelGGL(k_gen_traj, dim3(1), dim3(1024), lds, st, A);
+  HIPCHK(hipGetLastError());
+  if (h->timing) {
+    HIPCHK(hipEventRecord(ev.second, st));
+    h->ev_used.push_back(ev);
+  }
+  for (const StepDesc& d : sched) {
+    h->stats.n_applications += d.order_a + d.order_b;
+    h->stats.n_steps++;
+  }
+  h->stats.n_launches++;
+  return RYD_OK;
+}
+
+static bool use_persistent_general(const ryd_handle* h) {
+  return h->general && h->B == 1 && h->dim <= 4096 && !h->force_generic && !h->gen_host.empty();
+}
+
 static bool use_persistent_dm(const ryd_handle* h) {
   return !h->general && h->cfg.mode == RYD_MESOLVE && h->N <= 6 && !h->force_generic;
 }
@@ -424,6 +482,7 @@ static int run_steps(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
                      hipStream_t st) {
   if (use_persistent(h)) return run_persistent(h, state, sched, snaps, st);
   if (use_persistent_dm(h)) return run_persistent_dm(h, state, sched, snaps, st);
+  if (use_persistent_general(h)) return run_persistent_general(h, state, sched, snaps, st);
   return run_generic(h, state, sched, snaps, st);
 }
 

@@ -446,6 +446,11 @@ class GeneralEngine:
                                                 self._stream()))
         return out
 
+    def set_path(self, force_multi_launch: bool) -> None:
+        """Test hook: one launch per Taylor stage instead of the persistent
+        one-launch kernel used for vectors of at most 4096 entries."""
+        _lib.check(self.lib.ryd_set_path(self._h, int(bool(force_multi_launch))))
+
     def stats(self) -> dict[str, Any]:
         s = RydStats()
         _lib.check(self.lib.ryd_get_stats(self._h, C.byref(s)))

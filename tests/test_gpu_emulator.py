@@ -412,3 +412,37 @@ def test_hf_detuning_noise_factored_on_device_equals_per_trajectory_solve(generi
     assert (launches == 1) == (not generic)
     assert np.max(np.abs(out[0] - out[1])) < 1e-9
     assert np.max(np.abs(out[0][-1][0] - out[0][-1][1])) > 1e-3  # trajectories really differ
+
+
+@pytest.mark.parametrize("fixture,mesolve", [("noises_all_0.npz", True), ("noises_all_0.npz", False),
+                                             ("noisy_xy_0.npz", True), ("noises_digital_6.npz", True)])
+def test_general_path_persistent_kernel_matches_multi_launch(fixture, mesolve):
+    """Explicit-term engine (3- / 4-level bases, XY): the one-launch kernel for
+    vectors of at most 4096 entries against one launch per Taylor stage."""
+    from pulser_amd.engine import GeneralEngine
+    from pulser_amd.general import lower_general
+    from pulser_amd.hamiltonian_data import SequenceInputs
+
+    prob, extra = load_fixture(fixture)
+    if "inputs" in prob:  # XY fixtures store the sequence inputs
+        emu = QutipEmulator(SequenceInputs.from_dict(prob["inputs"]), sampling_rate=0.1,
+                            noise_model=NoiseModel(dephasing_rate=0.05))
+        prob = emu._current_problem
+        init = np.asarray(emu.initial_state).reshape(-1)
+    else:
+        d, n = len(prob["eigenbasis"]), prob["n_qudits"]
+        init = np.zeros(d**n, dtype=complex)
+        init[-1 if d == 2 else sum((list(prob["eigenbasis"]).index("g")) * d**k for k in range(n))] = 1.0
+    tables = lower_general(prob, mesolve=mesolve)
+    T = int(prob["duration"]) - 1
+    times = np.array([0.0, 0.3 * T * 1e-3, 0.3 * T * 1e-3, T * 1e-3])
+    outs, launches = [], []
+    for multi in (False, True):
+        with GeneralEngine(tables) as eng:
+            eng.set_path(multi)
+            st = eng.new_state(init)
+            outs.append(eng.solve(st, times).cpu().numpy())
+            launches.append(eng.stats()["n_launches"])
+    assert launches[0] == 2 and launches[1] > 20
+    assert np.max(np.abs(outs[0] - outs[1])) < 1e-12
+    assert np.max(np.abs(outs[0][-1] - outs[0][0])) > 1e-3
