@@ -383,6 +383,116 @@ def gen_noise_spam_all():
 
 
 # ---------------------------------------------------------------------------
+# 2b''. tests/pulser_simulation/test_simresults.py:63-90, 383-389, 446-456 (results_noisy):
+#       2 atoms, global Blackman pi pulse, doppler + laser-waist amplitude + SPAM noise,
+#       15 trajectories x 5 samples at all 1001 evaluation times, seed 123
+# ---------------------------------------------------------------------------
+def gen_results_noisy():
+    from collections import Counter
+    from pulser_amd.pulser_adapter import sequence_inputs_from_pulser, problem_from_trajectory
+
+    golden = {"11": 676, "10": 295, "01": 137, "00": 126}
+    reg = Register({"A": np.array([0.0, 0.0]), "B": np.array([0.0, 10.0])})
+    seq = Sequence(reg, DigitalAnalogDevice)
+    seq.declare_channel("ryd", "rydberg_global")
+    seq.add(Pulse.ConstantDetuning(BlackmanWaveform(1000, np.pi), 0.0, 0), "ryd")
+    params = dict(samples_per_run=5, temperature=50.0, state_prep_error=0.005, p_false_pos=0.01,
+                  p_false_neg=0.05, amp_sigma=1e-3, laser_waist=175.0)
+    nm = NoiseModel(**params)
+    np.random.seed(123)
+    samples = sampler.sample(seq, extended_duration=seq.get_duration())
+    inputs = sequence_inputs_from_pulser(samples, seq.register, seq.device)
+    T = samples.max_duration
+    ext = samples.extend_duration(T + 1)
+    hd = HamiltonianData(ext, seq.register, seq.device, nm, 15)
+    HamiltonianData(ext, seq.register, seq.device, NoiseModel(), 1)  # hidden noiseless draw
+    tlist = qp.sampling_times(T + 1, 1.0)
+    eval_times = np.union1d(tlist, [0.0, T * 1e-3])
+    opts = qp.default_options(channel_amp_det(ext), T)
+    total = [Counter() for _ in eval_times]
+    all_states = []
+    for traj, noisy, reps in hd.noisy_samples:
+        prob = problem_from_trajectory(hd, traj, noisy, reps, 1.0)
+        ham = qp.build_hamiltonian(prob)
+        psi0 = qp.all_ground_state(2, prob["eigenbasis"])
+        states = qp.sesolve(ham, psi0, eval_times, **opts)
+        for i, t in enumerate(eval_times):
+            total[i] += osamp.sample_state(
+                states, eval_times, t, 5 * reps, 2, prob["eigenbasis"], "ground-rydberg", True,
+                {"epsilon": 0.01, "epsilon_prime": 0.05})
+        all_states.append(np.stack(states))
+    idx = osamp.index_from_time(eval_times, eval_times[-1])
+    n_meas = sum(total[idx].values())
+    w = np.zeros(4)
+    for bs, c in total[idx].items():
+        w[int(bs, 2)] = c / n_meas
+    expect_last = w[1] + w[3]  # <I x |r><r|>: atom B measured in 1 (test_simresults.py:388-389)
+    w = w / sum(w)
+    np.random.seed(123)
+    final = osamp.get_samples(w, 1234, 2)
+    ok = dict(final) == golden
+    print(f"results_noisy: {'OK' if ok else 'MISMATCH'} {dict(final)}; expect[-1] = {expect_last:.4f} (reference: ~0.68)")
+    P.save_problem(
+        os.path.join(HERE, "results_noisy.npz"), {"inputs": inputs.to_dict()}, seed=123,
+        noise_model=params, reference_golden_counter=golden, reference_expect_last=0.68,
+        reference_cite="tests/pulser_simulation/test_simresults.py:63-90, 383-389, 446-456",
+        eval_times=eval_times, oracle_traj_lookup_states=np.stack(all_states)[:, idx],
+        oracle_total_final_counter=dict(total[idx]),
+    )
+
+
+# ---------------------------------------------------------------------------
+# 2b-3. tests/pulser_simulation/test_simresults.py:244-275 (test_get_final_state_noisy):
+#       raman_local pi pulse on atom A (digital basis), doppler + trap position
+#       fluctuations + SPAM, 15 trajectories x 5 samples, seed 123
+# ---------------------------------------------------------------------------
+def gen_final_state_noisy():
+    from collections import Counter
+    from pulser_amd.pulser_adapter import sequence_inputs_from_pulser, problem_from_trajectory
+
+    reg = Register({"A": np.array([0.0, 0.0]), "B": np.array([0.0, 10.0])})
+    seq = Sequence(reg, DigitalAnalogDevice)
+    seq.declare_channel("ram", "raman_local", initial_target="A")
+    seq.add(Pulse.ConstantDetuning(BlackmanWaveform(1000, np.pi), 0.0, 0), "ram")
+    params = dict(samples_per_run=5, temperature=50.0, trap_depth=0.01, trap_waist=0.02,
+                  state_prep_error=0.005, p_false_pos=0.01, p_false_neg=0.05)
+    nm = NoiseModel(**params)
+    np.random.seed(123)
+    samples = sampler.sample(seq, extended_duration=seq.get_duration())
+    inputs = sequence_inputs_from_pulser(samples, seq.register, seq.device)
+    T = samples.max_duration
+    ext = samples.extend_duration(T + 1)
+    hd = HamiltonianData(ext, seq.register, seq.device, nm, 15)
+    HamiltonianData(ext, seq.register, seq.device, NoiseModel(), 1)  # hidden noiseless draw
+    tlist = qp.sampling_times(T + 1, 1.0)
+    eval_times = np.union1d(tlist, [0.0, T * 1e-3])
+    opts = qp.default_options(channel_amp_det(ext), T)
+    total = [Counter() for _ in eval_times]
+    lookup = []
+    idx = osamp.index_from_time(eval_times, eval_times[-1])
+    for traj, noisy, reps in hd.noisy_samples:
+        prob = problem_from_trajectory(hd, traj, noisy, reps, 1.0)
+        ham = qp.build_hamiltonian(prob)
+        psi0 = qp.all_ground_state(2, prob["eigenbasis"])
+        states = qp.sesolve(ham, psi0, eval_times, **opts)
+        for i, t in enumerate(eval_times):
+            total[i] += osamp.sample_state(
+                states, eval_times, t, 5 * reps, 2, prob["eigenbasis"], "digital", True,
+                {"epsilon": 0.01, "epsilon_prime": 0.05})
+        lookup.append(states[idx])
+    final = {k: v / 75 for k, v in total[-1].items()}
+    golden = {"10": 0.96, "00": 0.04}
+    print(f"final_state_noisy: {'OK' if final == golden else 'MISMATCH'} {final}")
+    P.save_problem(
+        os.path.join(HERE, "final_state_noisy.npz"), {"inputs": inputs.to_dict()}, seed=123,
+        noise_model=params, reference_golden_results_last=golden,
+        reference_cite="tests/pulser_simulation/test_simresults.py:244-275",
+        eval_times=eval_times, oracle_traj_lookup_states=np.stack(lookup),
+        traj_reps=np.array([r for _, _, r in hd.noisy_samples]),
+    )
+
+
+# ---------------------------------------------------------------------------
 # 2c. test_simulation.py:1536-1690 (XY mode, SLM mask, SPAM trajectories, mesolve)
 # ---------------------------------------------------------------------------
 
@@ -900,6 +1010,10 @@ if __name__ == "__main__":
         gen_cfg4()
     if "spam_all" in which:
         gen_noise_spam_all()
+    if "results_noisy" in which:
+        gen_results_noisy()
+    if "final_state_noisy" in which:
+        gen_final_state_noisy()
     if "dmm" in which:
         gen_dmm()
     if "results" in which:

@@ -351,6 +351,37 @@ def test_reference_golden_counter_test_noise_end_to_end(capsys):
     assert r.sample_final_state() == Counter(extra["reference_golden_counter"])
 
 
+def test_reference_results_noisy_goldens_end_to_end():
+    """test_simresults.py:63-90, 383-389, 446-456 with the real solver on the GPU:
+    15 doppler/amplitude/SPAM trajectories x 1001 evaluation times, seed 123."""
+    from test_host_logic import _check_results_noisy, _results_noisy_emulator
+
+    emu, extra = _results_noisy_emulator()
+    with pytest.warns(DeprecationWarning):
+        r = emu.run()
+    assert dict(r[-1].bitstring_counts) == extra["oracle_total_final_counter"]
+    _check_results_noisy(r, extra)
+    # test_simresults.py:400-409 (the same sequence without noise)
+    from pulser_amd.hamiltonian_data import SequenceInputs
+
+    clean = QutipEmulator(SequenceInputs.from_dict(load_fixture("results_noisy.npz")[0]["inputs"]))
+    with pytest.warns(DeprecationWarning):
+        res = clean.run()
+    np.random.seed(123)
+    assert res.sample_final_state(1) == Counter({"11": 1})
+
+
+def test_reference_get_final_state_noisy_golden_end_to_end():
+    """test_simresults.py:244-275 with the real solver on the GPU (digital basis,
+    doppler + trap position fluctuations + SPAM, seed 123)."""
+    from test_host_logic import _check_final_state_noisy, _final_state_noisy_emulator
+
+    emu, extra = _final_state_noisy_emulator()
+    with pytest.warns(DeprecationWarning):
+        r = emu.run()
+    _check_final_state_noisy(r, extra)
+
+
 def test_sharded_ensemble_on_the_gpu_equals_the_serial_run():
     """pulser_amd.distributed.run_ensemble with the real HIP solver (world size 1):
     same Counters as QutipEmulator.run() for the same seed (all random numbers are

@@ -534,7 +534,7 @@ class _FakeSolvePerTrajectory:
 
     def __call__(self, problems, progress_bar, options, tables=None, mc_ntraj=None):
         out = []
-        for _ in problems:
+        for _ in range(len(problems) if tables is None else tables.batch):
             out += _FakeSolve(self.emu, self.states[self.k])([None], progress_bar, options)
             self.k += 1
         return out
@@ -859,6 +859,80 @@ def test_emulator_golden_counter_spam_trajectories_all_basis(monkeypatch, capsys
     with pytest.raises(NotImplementedError, match="Cannot include"):
         QutipEmulator(SequenceInputs.from_dict(load_fixture("noise_spam_all.npz")[0]["inputs"]),
                       noise_model=NoiseModel(depolarizing_rate=0.05))
+
+
+def _results_noisy_emulator():
+    """tests/pulser_simulation/test_simresults.py:63-90 (``results_noisy``), seed 123."""
+    prob, extra = load_fixture("results_noisy.npz")
+    nm = NoiseModel(**{k: (int(v) if k == "samples_per_run" else float(v))
+                       for k, v in extra["noise_model"].items()})
+    np.random.seed(int(extra["seed"]))
+    emu = QutipEmulator(SequenceInputs.from_dict(prob["inputs"]), noise_model=nm, n_trajectories=15)
+    return emu, extra
+
+
+def _check_results_noisy(r, extra):
+    """test_simresults.py:383-389 (expect ~ 0.68), :446-456 (seeded final Counter)."""
+    op = np.kron(np.eye(2), np.diag([1.0, 0.0])).astype(complex)
+    assert np.isclose(r.expect([op])[0][-1], float(extra["reference_expect_last"]))
+    bad = op.copy()
+    bad[0, 1] = 1.0
+    with pytest.raises(ValueError, match="non-diagonal"):
+        r.expect([bad])
+    np.random.seed(123)
+    assert r.sample_final_state(N_samples=1234) == Counter(extra["reference_golden_counter"])
+
+
+def test_results_noisy_reference_goldens(monkeypatch):
+    """Doppler + laser-waist amplitude + SPAM trajectories sampled at all 1001
+    evaluation times: the reference's seeded ``results_noisy`` goldens with the
+    solver stubbed (RNG order of 15 x 1001 sample_state calls)."""
+    emu, extra = _results_noisy_emulator()
+    assert set(emu.noise_model.noise_types) == {"SPAM", "doppler", "amplitude"}
+    assert np.array_equal(emu.evaluation_times, extra["eval_times"]) and len(emu.evaluation_times) == 1001
+    assert [t.reps for t in emu._hamiltonian_data.noise_trajectories] == [1] * 15
+    monkeypatch.setattr(emu, "_solve_batch",
+                        _FakeSolvePerTrajectory(emu, extra["oracle_traj_lookup_states"]))
+    with pytest.warns(DeprecationWarning):
+        r = emu.run()
+    assert len(r) == 1001 and r._use_pseudo_dens
+    assert dict(r[-1].bitstring_counts) == extra["oracle_total_final_counter"]
+    _check_results_noisy(r, extra)
+
+
+def _final_state_noisy_emulator():
+    """tests/pulser_simulation/test_simresults.py:244-261, seed 123."""
+    prob, extra = load_fixture("final_state_noisy.npz")
+    nm = NoiseModel(**{k: (int(v) if k == "samples_per_run" else float(v))
+                       for k, v in extra["noise_model"].items()})
+    np.random.seed(int(extra["seed"]))
+    emu = QutipEmulator(SequenceInputs.from_dict(prob["inputs"]), noise_model=nm, n_trajectories=15)
+    return emu, extra
+
+
+def _check_final_state_noisy(r, extra):
+    """test_simresults.py:267-275."""
+    r._meas_basis = "digital"
+    final = np.asarray(r.get_final_state())
+    assert np.count_nonzero(final - np.diag(np.diagonal(final))) == 0
+    r._meas_basis = "ground-rydberg"
+    assert final[0, 0] == 0.04 + 0j and final[2, 2] == 0.96 + 0j
+    assert np.array_equal(np.asarray(r.states[-1]), final)
+    assert r.results[-1] == Counter(extra["reference_golden_results_last"])
+
+
+def test_get_final_state_noisy_reference_golden(monkeypatch):
+    """Digital basis, local Raman pulse, doppler + trap position fluctuations +
+    SPAM: the reference's seeded pseudo-density golden with the solver stubbed."""
+    emu, extra = _final_state_noisy_emulator()
+    assert set(emu.noise_model.noise_types) == {"SPAM", "doppler", "register"}
+    assert emu.basis_name == "digital" and emu._meas_basis == "digital"
+    assert [t.reps for t in emu._hamiltonian_data.noise_trajectories] == list(extra["traj_reps"])
+    monkeypatch.setattr(emu, "_solve_batch",
+                        _FakeSolvePerTrajectory(emu, extra["oracle_traj_lookup_states"]))
+    with pytest.warns(DeprecationWarning):
+        r = emu.run()
+    _check_final_state_noisy(r, extra)
 
 
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
