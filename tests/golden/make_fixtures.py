@@ -493,6 +493,165 @@ def gen_final_state_noisy():
 
 
 # ---------------------------------------------------------------------------
+# 2b-4. tests/pulser_simulation/test_simulation.py:1928-2042 (effective size with
+#       an SLM mask and SPAM bad atoms; mw / rydberg / raman global channels)
+# ---------------------------------------------------------------------------
+def gen_slm_effective_size():
+    from pulser_amd.pulser_adapter import problem_from_trajectory, sequence_inputs_from_pulser
+
+    reg = Register.square(2, prefix="atom")
+    rise = Pulse.ConstantPulse(1500, 1, 0, 0)
+    for ch in ("mw_global", "rydberg_global", "raman_global"):
+        np.random.seed(15092021)
+        seq = Sequence(reg, MockDevice)
+        seq.declare_channel("ch0", ch)
+        seq.add(rise, "ch0")
+        seq.config_slm_mask(["atom1"])
+        samples = sampler.sample(seq, extended_duration=seq.get_duration())
+        inputs = sequence_inputs_from_pulser(samples, seq.register, seq.device)
+        T = samples.max_duration
+        ext = samples.extend_duration(T + 1)
+        params = dict(samples_per_run=5, state_prep_error=0.4, p_false_pos=0.01, p_false_neg=0.05)
+        hd = HamiltonianData(ext, seq.register, seq.device, NoiseModel(**params), 15)
+        traj, noisy, reps = next(iter(hd.noisy_samples))
+        prob = problem_from_trajectory(hd, traj, noisy, reps, 0.01)
+        bad = np.array([traj.bad_atoms[q] for q in reg.qubit_ids])
+        assert list(bad) == [True, False, True, False]  # the reference's own assertion
+        ham = qp.build_hamiltonian(prob)
+        h0 = ham.matrix(0.0).toarray()
+        extra = dict(seed=15092021, channel=ch, noise_model=params, traj0_bad_atoms=bad,
+                     traj0_reps=reps, oracle_h0=h0, slm_end=int(samples._slm_mask.end),
+                     reference_cite="tests/pulser_simulation/test_simulation.py:1928-2042")
+        loc = prob["samples"]["Local"]
+        for basis, per_atom in loc.items():
+            for q, s in per_atom.items():
+                for qty in ("amp", "det", "phase"):
+                    extra[f"local__{basis}__{q}__{qty}"] = np.asarray(s[qty])
+        print(f"slm_effective_size[{ch}]: bases {list(loc)}, |H(0)| = {np.abs(h0).sum():.4f}, dim {h0.shape}")
+        P.save_problem(os.path.join(HERE, f"slm_effective_size_{ch}.npz"),
+                       {"inputs": inputs.to_dict()}, **extra)
+
+
+# ---------------------------------------------------------------------------
+# 2b-5. tests/pulser_simulation/test_simulation.py:1748-1926 (SLM mask: XY masking
+#       equals removing the qubit; masked first pulse; mask next to a local channel)
+# ---------------------------------------------------------------------------
+def gen_slm_masks():
+    from pulser_amd.pulser_adapter import sequence_inputs_from_pulser
+
+    def capture(seq):
+        samples = sampler.sample(seq, extended_duration=seq.get_duration())
+        return sequence_inputs_from_pulser(samples, seq.register, seq.device).to_dict()
+
+    reg3 = Register({"q0": (0, 0), "q1": (10, 10), "q2": (-10, -10)})
+    reg2 = Register({"q0": (0, 0), "q1": (10, 10)})
+    pulse = Pulse.ConstantPulse(100, 10, 0, 0)
+    no_pulse = Pulse.ConstantPulse(100, 0, 0, 0)
+    out = {}
+    # :1748-1789
+    s = Sequence(reg3, MockDevice)
+    s.set_magnetic_field(0, 1.0, 0.0)
+    s.declare_channel("ch_masked", "mw_global")
+    s.config_slm_mask(["q2"])
+    s.add(pulse, "ch_masked")
+    out["eq_masked"] = capture(s)
+    s = Sequence(reg2, MockDevice)
+    s.set_magnetic_field(0, 1.0, 0.0)
+    s.declare_channel("ch_two", "mw_global")
+    s.add(pulse, "ch_two")
+    out["eq_two"] = capture(s)
+    # :1792-1838
+    s = Sequence(reg3, MockDevice)
+    s.declare_channel("ch_masked", "mw_global")
+    s.config_slm_mask(["q2"])
+    for _ in range(3):
+        s.add(pulse, "ch_masked")
+    out["tp_masked"] = capture(s)
+    mask_time = list(s._slm_mask_time)
+    s = Sequence(reg3, MockDevice)
+    s.declare_channel("ch_three", "mw_global")
+    for p in (no_pulse, pulse, pulse):
+        s.add(p, "ch_three")
+    out["tp_three"] = capture(s)
+    s = Sequence(reg2, MockDevice)
+    s.declare_channel("ch_two", "mw_global")
+    for p in (pulse, no_pulse, no_pulse):
+        s.add(p, "ch_two")
+    out["tp_two"] = capture(s)
+    # :1841-1926
+    s = Sequence(Register.square(2, prefix="q"), MockDevice)
+    s.declare_channel("rydberg_global", "rydberg_global")
+    s.config_slm_mask(["q0", "q3"])
+    s.add(Pulse.ConstantPulse(1000, 10, 0, 0), "rydberg_global")
+    s.declare_channel("raman_local", "raman_local", initial_target="q0")
+    s.add(Pulse.ConstantPulse(1000, 10, -5, np.pi), "raman_local", protocol="no-delay")
+    assert s._slm_mask_time == [0, 1000] and s._slm_mask_targets == {"q0", "q3"}
+    out["local"] = capture(s)
+    P.save_problem(os.path.join(HERE, "slm_masks.npz"), out, tp_mask_time=np.array(mask_time),
+                   reference_cite="tests/pulser_simulation/test_simulation.py:1748-1926")
+    print("slm_masks:", list(out), "mask time", mask_time)
+
+
+# ---------------------------------------------------------------------------
+# 2b-6. tests/pulser_simulation/test_simulation.py:2045-2153 (output modulation,
+#       doppler + laser-waist amplitude noise, beam propagation direction)
+# ---------------------------------------------------------------------------
+def gen_modulation():
+    import dataclasses
+
+    from pulser.channels import Raman, Rydberg
+    from pulser.devices import Device
+    from pulser_amd.pulser_adapter import problem_from_trajectory, sequence_inputs_from_pulser
+
+    reg = Register({"control1": np.array([-4.0, 0.0]), "target": np.array([0.0, 4.0]),
+                    "control2": np.array([4.0, 0.0])})
+    pulse1 = Pulse.ConstantPulse(120, 1, 0, 2.0)
+    params = dict(samples_per_run=1, temperature=50.0, laser_waist=175.0)
+    for tag, pdir in (("none", None), ("x", (1, 0, 0)), ("y", (0, 1, 0)), ("z", (0, 0, 1))):
+        dev = Device(
+            name="ModulatedDevice", dimensions=3, rydberg_level=70, max_atom_num=100,
+            max_radial_distance=100, min_atom_distance=1,
+            channel_objects=(
+                Rydberg.Global(1000, 200, clock_period=1, min_duration=1, mod_bandwidth=4.0,
+                               propagation_dir=pdir),
+                Raman.Local(2 * np.pi * 20, 2 * np.pi * 10, max_targets=2, fixed_retarget_t=0,
+                            min_retarget_interval=220, clock_period=4, mod_bandwidth=4.0),
+            ),
+        )
+        seq = Sequence(reg, dev)
+        seq.declare_channel("ch0", "rydberg_global")
+        seq.declare_channel("ch1", "raman_local", initial_target="target")
+        seq.add(pulse1, "ch1")
+        seq.target("control1", "ch1")
+        seq.add(pulse1, "ch1")
+        seq.add(pulse1, "ch0")
+        ch1 = seq.declared_channels["ch1"]
+        mod = ch1.modulate(pulse1.amplitude.samples).as_array()
+        mod_dt = pulse1.duration + pulse1.fall_time(ch1)
+        np.random.seed(20260927)
+        samples = sampler.sample(seq, modulation=True,
+                                 extended_duration=seq.get_duration(include_fall_time=True))
+        inputs = sequence_inputs_from_pulser(samples, seq.register, seq.device)
+        T = samples.max_duration
+        ext = samples.extend_duration(T + 1)
+        hd = HamiltonianData(ext, seq.register, seq.device, NoiseModel(**params), 15)
+        traj, noisy, reps = next(iter(hd.noisy_samples))
+        prob = problem_from_trajectory(hd, traj, noisy, reps, 1.0)
+        extra = dict(seed=20260927, noise_model=params, mod_dt=int(mod_dt), modulated_pulse=mod,
+                     propagation_dir=np.zeros(0) if pdir is None else np.array(pdir, float),
+                     doppler=np.array([traj.doppler_detune[q] for q in reg.qubit_ids]),
+                     reference_cite="tests/pulser_simulation/test_simulation.py:2045-2153")
+        assert prob["samples"]["Global"] == {}
+        for basis, per_atom in prob["samples"]["Local"].items():
+            for q, s in per_atom.items():
+                for qty in ("amp", "det", "phase"):
+                    extra[f"local__{basis}__{q}__{qty}"] = np.asarray(s[qty])
+        P.save_problem(os.path.join(HERE, f"modulation_dir_{tag}.npz"),
+                       {"inputs": inputs.to_dict()}, **extra)
+        print(f"modulation[{tag}]: duration {T}, mod_dt {mod_dt}")
+
+
+# ---------------------------------------------------------------------------
 # 2c. test_simulation.py:1536-1690 (XY mode, SLM mask, SPAM trajectories, mesolve)
 # ---------------------------------------------------------------------------
 
@@ -868,8 +1027,7 @@ def gen_waist():
     matrices for a 5-atom triangular register (seed 5)."""
     from pulser_amd.pulser_adapter import problem_from_trajectory, sequence_inputs_from_pulser
 
-    reg = Register.triangular_lattice(2, 3, spacing=6.5, prefix="q").with_automatic_layout(MockDevice) \
-        if False else Register.triangular_lattice(2, 3, spacing=6.5, prefix="q")
+    reg = Register.triangular_lattice(2, 3, spacing=6.5, prefix="q")
     seq = Sequence(reg, MockDevice)
     seq.declare_channel("ising", "rydberg_global")
     seq.add(Pulse.ConstantDetuning(BlackmanWaveform(240, 2.5), -2.0, 0.3), "ising")
@@ -1014,6 +1172,12 @@ if __name__ == "__main__":
         gen_results_noisy()
     if "final_state_noisy" in which:
         gen_final_state_noisy()
+    if "slm_effective_size" in which:
+        gen_slm_effective_size()
+    if "slm_masks" in which:
+        gen_slm_masks()
+    if "modulation" in which:
+        gen_modulation()
     if "dmm" in which:
         gen_dmm()
     if "results" in which:

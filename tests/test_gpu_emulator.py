@@ -382,6 +382,39 @@ def test_reference_get_final_state_noisy_golden_end_to_end():
     _check_final_state_noisy(r, extra)
 
 
+@pytest.mark.parametrize("ch", ["mw_global", "rydberg_global", "raman_global"])
+def test_slm_effective_size_hamiltonians(ch):
+    """test_simulation.py:1928-2000: H(0) of the first SPAM trajectory with an SLM
+    mask (XY: only the unmasked, well-prepared atom3 is driven: amp/2 sigma_x)."""
+    from test_host_logic import _slm_effective_size_emulator
+
+    emu, extra = _slm_effective_size_emulator(ch)
+    h0 = np.asarray(emu.get_hamiltonian(0))
+    np.testing.assert_allclose(h0, extra["oracle_h0"], atol=1e-9 * np.abs(extra["oracle_h0"]).max())
+    if ch == "mw_global":
+        sx = np.array([[0.0, 1.0], [1.0, 0.0]])
+        np.testing.assert_allclose(h0, 0.5 * np.kron(np.eye(8), sx), atol=1e-12)
+
+
+def test_slm_mask_xy_equals_removing_the_qubit():
+    """test_simulation.py:1748-1838 through ``get_hamiltonian`` on the GPU: while the
+    mask is on, H_masked = H_two x 1; afterwards H_masked = H_three."""
+    from test_host_logic import _slm_mask_emulators
+
+    (masked, three, two, eq_m, eq_2), extra = _slm_mask_emulators(
+        "tp_masked", "tp_three", "tp_two", "eq_masked", "eq_two")
+    ti, tf = (int(x) for x in extra["tp_mask_time"])
+    for t in (0, 37, 100, 101, 150, 299):
+        m = np.asarray(masked.get_hamiltonian(t))
+        if ti <= t <= tf:
+            np.testing.assert_allclose(m, np.kron(np.asarray(two.get_hamiltonian(t)), np.eye(2)), atol=1e-10)
+        else:
+            np.testing.assert_allclose(m, np.asarray(three.get_hamiltonian(t)), atol=1e-10)
+    for t in (0, 50, 99):
+        np.testing.assert_allclose(np.asarray(eq_m.get_hamiltonian(t)),
+                                   np.kron(np.asarray(eq_2.get_hamiltonian(t)), np.eye(2)), atol=1e-10)
+
+
 def test_sharded_ensemble_on_the_gpu_equals_the_serial_run():
     """pulser_amd.distributed.run_ensemble with the real HIP solver (world size 1):
     same Counters as QutipEmulator.run() for the same seed (all random numbers are

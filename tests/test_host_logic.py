@@ -935,6 +935,127 @@ def test_get_final_state_noisy_reference_golden(monkeypatch):
     _check_final_state_noisy(r, extra)
 
 
+def _slm_effective_size_emulator(ch):
+    """test_simulation.py:1928-1988: square(2) register, 1.5 us constant pulse,
+    SLM mask on atom1, state_prep_error 0.4, seed 15092021."""
+    prob, extra = load_fixture(f"slm_effective_size_{ch}.npz")
+    nm = NoiseModel(**{k: (int(v) if k == "samples_per_run" else float(v))
+                       for k, v in extra["noise_model"].items()})
+    np.random.seed(int(extra["seed"]))
+    emu = QutipEmulator(SequenceInputs.from_dict(prob["inputs"]), sampling_rate=0.01,
+                        noise_model=nm, n_trajectories=15)
+    return emu, extra
+
+
+@pytest.mark.parametrize("ch", ["mw_global", "rydberg_global", "raman_global"])
+def test_slm_mask_and_bad_atoms_effective_size(ch):
+    """test_simulation.py:1960-2042 (``test_effective_size_disjoint``): the first
+    trajectory's bad atoms and per-atom samples - the SLM detuning map on the
+    masked atom (-10 x amp), zeroed pulses on the badly prepared atoms - equal what
+    pulser-core's HamiltonianData produced."""
+    emu, extra = _slm_effective_size_emulator(ch)
+    assert list(emu._hamiltonian_data.noise_trajectories[0].bad_atoms) == [True, False, True, False]
+    assert list(extra["traj0_bad_atoms"]) == [True, False, True, False]
+    assert emu.samples_obj.slm_end == int(extra["slm_end"]) == 1500
+    loc = emu._current_problem["samples"]["Local"]
+    keys = [k for k in extra if k.startswith("local__")]
+    assert {k.split("__")[1] for k in keys} == set(loc)
+    for k in keys:
+        _, basis, q, qty = k.split("__")
+        assert np.array_equal(loc[basis][int(q)][qty], extra[k]), k
+    if ch != "mw_global":
+        basis = "ground-rydberg" if ch == "rydberg_global" else "digital"
+        amp = np.concatenate((np.ones(1500), [0.0]))
+        assert np.array_equal(loc[basis][1]["amp"], amp) and np.array_equal(loc[basis][3]["amp"], amp)
+        assert np.all(loc["ground-rydberg"][1]["det"] == -10 * amp)
+        assert not np.any(loc[basis][3]["det"]) and not np.any(loc[basis][0]["amp"])
+
+
+def _slm_mask_emulators(*names):
+    prob, extra = load_fixture("slm_masks.npz")
+    return [QutipEmulator(SequenceInputs.from_dict(prob[n])) for n in names], extra
+
+
+def test_slm_mask_next_to_a_local_channel():
+    """test_simulation.py:1841-1926: the global Rydberg pulse stays global, the SLM
+    mask appears as a -10 x amp detuning map on the masked atoms, the local Raman
+    pulse (phase pi) stays on its target."""
+    (emu,), _ = _slm_mask_emulators("local")
+    assert emu.samples_obj.slm_end == 1000 and set(emu.samples_obj.slm_targets) == {0, 3}
+    nested = emu._current_problem["samples"]
+    g = nested["Global"]["ground-rydberg"]
+    ten = np.concatenate((10.0 * np.ones(1000), [0.0]))
+    assert np.array_equal(g["amp"], ten) and not np.any(g["det"]) and not np.any(g["phase"])
+    loc = nested["Local"]["ground-rydberg"]
+    for q in range(4):
+        assert np.array_equal(loc[q]["det"], -10 * ten if q in (0, 3) else 0 * ten)
+        assert not np.any(loc[q]["amp"]) and not np.any(loc[q]["phase"])
+    dig = nested["Local"]["digital"]
+    assert list(dig) == [0]
+    assert np.array_equal(dig[0]["amp"], ten)
+    assert np.array_equal(dig[0]["det"], np.concatenate((-5.0 * np.ones(1000), [0.0])))
+    assert np.allclose(dig[0]["phase"], np.concatenate((np.pi * np.ones(1000), [0.0])))
+
+
+def test_slm_mask_xy_equals_removing_the_qubit_host_assembly():
+    """test_simulation.py:1748-1838 on the host: the problems the emulator hands to
+    the solver, assembled by the oracle - masked XY Hamiltonian = two-qubit
+    Hamiltonian x identity while the mask is on, = unmasked Hamiltonian afterwards."""
+    from oracle import qutip_path as qp
+
+    (masked, three, two, eq_m, eq_2), extra = _slm_mask_emulators(
+        "tp_masked", "tp_three", "tp_two", "eq_masked", "eq_two")
+    ti, tf = (int(x) for x in extra["tp_mask_time"])
+    hm, h3, h2 = (qp.build_hamiltonian(e._current_problem) for e in (masked, three, two))
+    for t in masked.sampling_times[::7]:
+        m = hm.matrix(t).toarray()
+        if ti <= t * 1e3 <= tf:
+            assert np.allclose(m, np.kron(h2.matrix(t).toarray(), np.eye(2)), atol=1e-12), t
+        else:
+            assert np.allclose(m, h3.matrix(t).toarray(), atol=1e-12), t
+    hm, h2 = (qp.build_hamiltonian(e._current_problem) for e in (eq_m, eq_2))
+    for t in eq_2.sampling_times[::5]:
+        assert np.allclose(hm.matrix(t).toarray(), np.kron(h2.matrix(t).toarray(), np.eye(2)), atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["none", "x", "y", "z"])
+def test_modulated_samples_with_laser_waist_and_propagation_direction(tag):
+    """test_simulation.py:2045-2153: output-modulated samples, doppler + laser-waist
+    amplitude noise for the four beam propagation directions; the first trajectory's
+    per-atom samples equal what pulser-core's HamiltonianData produced."""
+    prob, extra = load_fixture(f"modulation_dir_{tag}.npz")
+    nm = NoiseModel(**{k: (int(v) if k == "samples_per_run" else float(v))
+                       for k, v in extra["noise_model"].items()})
+    np.random.seed(int(extra["seed"]))
+    emu = QutipEmulator(SequenceInputs.from_dict(prob["inputs"]), noise_model=nm, n_trajectories=15)
+    nested = emu._current_problem["samples"]
+    assert nested["Global"] == {}  # all samples stored in local (:2095-2097)
+    keys = [k for k in extra if k.startswith("local__")]
+    assert {k.split("__")[1] for k in keys} == set(nested["Local"])
+    for k in keys:
+        _, basis, q, qty = k.split("__")
+        np.testing.assert_allclose(nested["Local"][basis][int(q)][qty], extra[k], rtol=1e-13, atol=1e-14,
+                                   err_msg=k)
+    # the reference's own checks (:2098-2150)
+    mod, dt = extra["modulated_pulse"], int(extra["mod_dt"])
+    dop = emu._hamiltonian_data.noise_trajectories[0].doppler_detune
+    assert np.array_equal(dop, extra["doppler"])
+    raman = nested["Local"]["digital"]
+    for q, sl in ((1, slice(0, dt)), (0, slice(dt, 2 * dt))):  # target, control1
+        np.testing.assert_allclose(raman[q]["amp"][sl], mod, atol=1e-2)
+        assert np.all(raman[q]["det"][sl] == dop[q])
+        np.testing.assert_allclose(raman[q]["phase"][sl], 2.0)
+    coords = np.array([[-4.0, 0.0], [0.0, 4.0], [4.0, 0.0]])
+    r = {"none": coords[:, 0], "y": coords[:, 0], "x": coords[:, 1],
+         "z": np.linalg.norm(coords, axis=1)}[tag]
+    pos = np.exp(-((r / 175.0) ** 2))
+    ryd, sl = nested["Local"]["ground-rydberg"], slice(2 * dt, 3 * dt)
+    base = ryd[1]["amp"][sl] / (mod * pos[1])
+    for q in range(3):
+        np.testing.assert_allclose(ryd[q]["amp"][sl], mod * base * pos[q])
+        assert np.all(ryd[q]["det"][sl] == dop[q])
+
+
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
     + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
