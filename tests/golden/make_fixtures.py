@@ -652,6 +652,75 @@ def gen_modulation():
 
 
 # ---------------------------------------------------------------------------
+# 2b-7. tests/pulser_simulation/test_simulation.py:2593-2660 (EOM mode at the
+#       detuning limits, phase-drift correction; seeded final Counters)
+# ---------------------------------------------------------------------------
+def gen_eom_limit_det():
+    from pulser.channels import Rydberg
+    from pulser.channels.eom import RydbergBeam, RydbergEOM
+    from pulser.devices import Device
+    from pulser_amd.pulser_adapter import problem_from_trajectory, sequence_inputs_from_pulser
+
+    goldens = {
+        True: {"000": 850, "100": 53, "001": 46, "010": 42, "101": 9},
+        False: {"000": 879, "010": 49, "100": 40, "001": 32},
+    }
+    reg = Register({"control1": np.array([-4.0, 0.0]), "target": np.array([0.0, 4.0]),
+                    "control2": np.array([4.0, 0.0])})
+    for min_det_on in (False, True):
+        eom = RydbergEOM(mod_bandwidth=30.0, limiting_beam=RydbergBeam.RED,
+                         max_limiting_amp=50 * 2 * np.pi, intermediate_detuning=800 * 2 * np.pi,
+                         controlled_beams=(RydbergBeam.BLUE,) if min_det_on else (RydbergBeam.RED,))
+        dev = Device(
+            name="EomDevice", dimensions=3, rydberg_level=70, max_atom_num=2000,
+            max_radial_distance=1000, min_atom_distance=1,
+            channel_objects=(Rydberg.Global(1000, 200, clock_period=1, min_duration=1,
+                                            mod_bandwidth=4.0, eom_config=eom),),
+        )
+        seq = Sequence(reg, dev)
+        seq.declare_channel("ryd_glob", "rydberg_global")
+        seq.add(Pulse.ConstantPulse(1000, np.pi / 2, 0, 0), "ryd_glob")
+        max_abs_det = seq.declared_channels["ryd_glob"].max_abs_detuning
+        det_on = -max_abs_det if min_det_on else max_abs_det
+        seq.enable_eom_mode("ryd_glob", np.pi, det_on, correct_phase_drift=True)
+        det_off = float(seq._schedule["ryd_glob"].eom_blocks[-1].detuning_off)
+        det_on = float(det_on)
+        assert det_off < det_on if min_det_on else det_off > det_on
+        seq.add_eom_pulse("ryd_glob", 1000, 0)
+        seq.delay(500, "ryd_glob")
+        seq.modify_eom_setpoint("ryd_glob", np.pi / 2, 0, 0, correct_phase_drift=True)
+        seq.add_eom_pulse("ryd_glob", 1000, 0)
+        samples = sampler.sample(seq, extended_duration=seq.get_duration())
+        inputs = sequence_inputs_from_pulser(samples, seq.register, seq.device)
+        T = samples.max_duration
+        ext = samples.extend_duration(T + 1)
+        np.random.seed(123)
+        hd = HamiltonianData(ext, seq.register, seq.device, NoiseModel(), 1)
+        traj, noisy, reps = next(iter(hd.noisy_samples))
+        prob = problem_from_trajectory(hd, traj, noisy, reps, 1.0)
+        ham = qp.build_hamiltonian(prob)
+        tlist = qp.sampling_times(T + 1, 1.0)
+        eval_times = np.union1d(tlist, [0.0, T * 1e-3])
+        opts = qp.default_options(channel_amp_det(ext), T)
+        psi0 = qp.all_ground_state(3, prob["eigenbasis"])
+        states = qp.sesolve(ham, psi0, eval_times, **opts)
+        tight = qp.sesolve(ham, psi0, np.array([0.0, eval_times[-1]]), **{**opts, **qp.TIGHT})[-1]
+        idx = osamp.index_from_time(eval_times, eval_times[-1])
+        final = osamp.sample_state(states, eval_times, eval_times[-1], 1000, 3, prob["eigenbasis"],
+                                   "ground-rydberg", True, None)
+        ok = dict(final) == goldens[min_det_on]
+        print(f"eom_limit_det[min_detuning_on={min_det_on}]: {'OK' if ok else 'MISMATCH'} {dict(final)};"
+              f" T = {T}, det_on {det_on:.2f}, det_off {det_off:.2f}")
+        P.save_problem(
+            os.path.join(HERE, f"eom_limit_det_{int(min_det_on)}.npz"), {"inputs": inputs.to_dict()},
+            seed=123, reference_golden_counter=goldens[min_det_on], eval_times=eval_times,
+            oracle_lookup_state=states[idx], oracle_final_state_tight=tight,
+            detuning_on=det_on, detuning_off=det_off,
+            reference_cite="tests/pulser_simulation/test_simulation.py:2593-2660",
+        )
+
+
+# ---------------------------------------------------------------------------
 # 2c. test_simulation.py:1536-1690 (XY mode, SLM mask, SPAM trajectories, mesolve)
 # ---------------------------------------------------------------------------
 
@@ -1178,6 +1247,8 @@ if __name__ == "__main__":
         gen_slm_masks()
     if "modulation" in which:
         gen_modulation()
+    if "eom_limit_det" in which:
+        gen_eom_limit_det()
     if "dmm" in which:
         gen_dmm()
     if "results" in which:

@@ -415,6 +415,50 @@ def test_slm_mask_xy_equals_removing_the_qubit():
                                    np.kron(np.asarray(eq_2.get_hamiltonian(t)), np.eye(2)), atol=1e-10)
 
 
+@pytest.mark.parametrize("k", [0, 1])
+def test_reference_golden_counters_eom_detuning_limits_end_to_end(k):
+    """test_simulation.py:2593-2660 with the real solver: |detuning| = 1000 rad/us
+    for 4.5 us (the stiffest golden), then the detuning_sigma variant must run."""
+    from test_host_logic import _eom_emulator
+    from pulser_amd.hamiltonian_data import SequenceInputs
+
+    emu, extra = _eom_emulator(k)
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
+    final = np.asarray(res.states[-1]).ravel()
+    assert np.max(np.abs(final - extra["oracle_final_state_tight"])) < 1e-7
+    noisy = QutipEmulator(SequenceInputs.from_dict(load_fixture(f"eom_limit_det_{k}.npz")[0]["inputs"]),
+                          noise_model=NoiseModel(detuning_sigma=0.1), n_trajectories=1)
+    with pytest.warns(DeprecationWarning):
+        r = noisy.run()
+    assert sum(sum(x.bitstring_counts.values()) for x in r) == len(r) == 4521
+
+
+def test_relaxation_noise_population_decays(capsys):
+    """test_simulation.py:1049-1076: one atom, Blackman pi pulse then 10 us of free
+    relaxation (rate 0.1): the sampled Rydberg population decays monotonically."""
+    w = np.clip(np.blackman(1000), 0, np.inf)
+    amp = np.concatenate((w * np.pi / (w.sum() * 1e-3), np.zeros(10000), [0.0]))
+    inputs = single_global_channel(np.zeros((1, 2)), dict(amp=amp, det=0 * amp, phase=0 * amp),
+                                   P.C6_LEVEL70)
+    emu = QutipEmulator(inputs, noise_model=NoiseModel(relaxation_rate=0.1))
+    assert len(emu._current_problem["collapse_ops"]) == 1
+    with pytest.warns(DeprecationWarning):
+        res = emu.run(print_progress=True)
+    assert capsys.readouterr().out.rstrip("\n").split("\n") == ["Emulating Trajectory 1/1"]
+    np.random.seed(7)
+    start = res.sample_state(1)
+    pop = start["1"]
+    assert pop > start.get("0", 0)
+    for t in range(2, 10):
+        new = res.sample_state(t)["1"]
+        assert new < pop
+        pop = new
+    rho = np.asarray(res.get_state(6.0))
+    assert abs(rho[0, 0].real - np.asarray(res.get_state(1.0))[0, 0].real * np.exp(-0.5)) < 1e-6
+
+
 def test_sharded_ensemble_on_the_gpu_equals_the_serial_run():
     """pulser_amd.distributed.run_ensemble with the real HIP solver (world size 1):
     same Counters as QutipEmulator.run() for the same seed (all random numbers are

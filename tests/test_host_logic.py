@@ -1056,6 +1056,28 @@ def test_modulated_samples_with_laser_waist_and_propagation_direction(tag):
         assert np.all(ryd[q]["det"][sl] == dop[q])
 
 
+def _eom_emulator(k):
+    """test_simulation.py:2593-2641: EOM mode at the detuning limits, seed 123."""
+    prob, extra = load_fixture(f"eom_limit_det_{k}.npz")
+    np.random.seed(int(extra["seed"]))
+    return QutipEmulator(SequenceInputs.from_dict(prob["inputs"])), extra
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_emulator_golden_counters_eom_detuning_limits(k, monkeypatch):
+    """The reference's seeded Counters of ``test_eom_limit_det`` (detuning_on =
+    +/- max_abs_detuning, phase-drift correction) with the solver stubbed."""
+    emu, extra = _eom_emulator(k)
+    assert emu._tot_duration == 4520 and np.array_equal(emu.evaluation_times, extra["eval_times"])
+    det = emu._current_problem["samples"]["Global"]["ground-rydberg"]["det"]
+    assert abs(det).max() == pytest.approx(max(abs(float(extra["detuning_on"])),
+                                               abs(float(extra["detuning_off"]))))
+    monkeypatch.setattr(emu, "_solve_batch", _FakeSolve(emu, extra["oracle_lookup_state"]))
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
+
+
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
     + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
