@@ -67,6 +67,9 @@ class ChannelInput:
     dmm_weights: np.ndarray | None = None
     dmm_qubit_coords: np.ndarray | None = None
     dmm_spot_waist: float | None = None
+    # Sequence left in EOM mode (``eom_blocks[-1].tf is None``): extensions keep the
+    # detuning at the block's detuning_off instead of zero (samples.py:170-180).
+    final_detuning: float = 0.0
 
     @property
     def is_dmm(self) -> bool:
@@ -95,8 +98,9 @@ class ChannelInput:
         return len(self.amp)
 
     def extend_duration(self, new_duration: int) -> "ChannelInput":
-        """``ChannelSamples.extend_duration`` (samples.py:152-200): pad amp and
-        det with zeros, phase with its last value ('edge')."""
+        """``ChannelSamples.extend_duration`` (samples.py:152-200): pad amp with
+        zeros, det with zeros (or detuning_off while in EOM mode), phase with its
+        last value ('edge')."""
         extra = new_duration - self.duration
         if extra < 0:
             raise ValueError("Can't extend samples to a lower duration.")
@@ -106,7 +110,9 @@ class ChannelInput:
         phase = (
             pad(self.phase, "edge") if self.duration > 0 else np.zeros(new_duration)
         )
-        return replace(self, amp=pad(self.amp, "constant"), det=pad(self.det, "constant"), phase=phase)
+        det = np.pad(np.asarray(self.det, float), (0, extra), mode="constant",
+                     constant_values=float(self.final_detuning))
+        return replace(self, amp=pad(self.amp, "constant"), det=det, phase=phase)
 
 
 @dataclass
@@ -143,7 +149,7 @@ class SequenceInputs:
                  "dmm_weights": np.zeros(0) if not c.is_dmm else np.asarray(c.dmm_weights, float),
                  "dmm_qubit_coords": np.zeros((0, 2)) if not c.is_dmm else np.asarray(c.dmm_qubit_coords, float),
                  "dmm_spot_waist": -1.0 if c.dmm_spot_waist is None else float(c.dmm_spot_waist),
-                 "is_dmm": bool(c.is_dmm)}
+                 "is_dmm": bool(c.is_dmm), "final_detuning": float(c.final_detuning)}
                 for c in self.channels
             ],
         }
@@ -162,6 +168,8 @@ class SequenceInputs:
                              dmm_weights=np.asarray(c["dmm_weights"], float),
                              dmm_qubit_coords=np.asarray(c["dmm_qubit_coords"], float),
                              dmm_spot_waist=None if sw < 0 else sw)
+            if float(c.get("final_detuning", 0.0)) != 0.0:
+                ch = replace(ch, final_detuning=float(c["final_detuning"]))
             chans.append(ch)
         mf = tuple(float(x) for x in d["magnetic_field"]) if len(d["magnetic_field"]) else None
         xy = None if d["interaction_coeff_xy"] < 0 else float(d["interaction_coeff_xy"])

@@ -147,6 +147,8 @@ def sequence_inputs_from_pulser(samples: Any, register: Any, device: Any) -> Any
                 str(name), ch_obj.addressing, ch_obj.basis, _np(cs.amp).astype(float),
                 _np(cs.det).astype(float), _np(cs.phase).astype(float), slots,
                 getattr(ch_obj, "propagation_dir", None), **dmm_kw,
+                final_detuning=(float(cs.eom_blocks[-1].detuning_off)
+                                if cs.eom_blocks and cs.eom_blocks[-1].tf is None else 0.0),
             )
         )
     coords = np.array([_np(register.qubits[q]) for q in qids], dtype=float)

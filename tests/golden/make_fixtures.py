@@ -716,6 +716,7 @@ def gen_eom_limit_det():
             seed=123, reference_golden_counter=goldens[min_det_on], eval_times=eval_times,
             oracle_lookup_state=states[idx], oracle_final_state_tight=tight,
             detuning_on=det_on, detuning_off=det_off,
+            reference_det=np.asarray(prob["samples"]["Global"]["ground-rydberg"]["det"]),
             reference_cite="tests/pulser_simulation/test_simulation.py:2593-2660",
         )
 

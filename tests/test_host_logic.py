@@ -1072,6 +1072,10 @@ def test_emulator_golden_counters_eom_detuning_limits(k, monkeypatch):
     det = emu._current_problem["samples"]["Global"]["ground-rydberg"]["det"]
     assert abs(det).max() == pytest.approx(max(abs(float(extra["detuning_on"])),
                                                abs(float(extra["detuning_off"]))))
+    # the sequence ends in EOM mode: the extra trailing sample keeps the block's
+    # detuning_off instead of zero (sampler/samples.py:170-180)
+    assert np.array_equal(det, extra["reference_det"]) and det[-1] != 0.0
+    assert emu.samples_obj.channels[0].final_detuning == det[-1]
     monkeypatch.setattr(emu, "_solve_batch", _FakeSolve(emu, extra["oracle_lookup_state"]))
     with pytest.warns(DeprecationWarning):
         res = emu.run()
