@@ -432,7 +432,7 @@ def test_reference_golden_counters_eom_detuning_limits_end_to_end(k):
                           noise_model=NoiseModel(detuning_sigma=0.1), n_trajectories=1)
     with pytest.warns(DeprecationWarning):
         r = noisy.run()
-    assert sum(sum(x.bitstring_counts.values()) for x in r) == len(r) == 4521
+    assert sum(sum(x.bitstring_counts.values()) for x in r) == len(r) == len(extra["eval_times"])
 
 
 def test_relaxation_noise_population_decays(capsys):
