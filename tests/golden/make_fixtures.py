@@ -722,6 +722,81 @@ def gen_eom_limit_det():
 
 
 # ---------------------------------------------------------------------------
+# 2b-8. Per-trajectory noisy samples of multi-channel sequences: test_simulation.py
+#       :2193-2266 (amp_sigma per channel, two local channels sharing a basis),
+#       :2422-2470 (the five test_noisy_runs noise models) and :1401-1427
+#       (concurrent local + global pulses with doppler noise)
+# ---------------------------------------------------------------------------
+def gen_multichannel_noise():
+    from pulser_amd.pulser_adapter import problem_from_trajectory, sequence_inputs_from_pulser
+
+    def three_channel_seq(pulse, retarget):
+        reg = Register({"q0": (0, 0), "q1": (10, 10)})
+        seq = Sequence(reg, MockDevice)
+        seq.declare_channel("ch0", "rydberg_global")
+        seq.declare_channel("ch1", "raman_local", initial_target="q0")
+        seq.declare_channel("ch2", "raman_local", initial_target="q1")
+        seq.add(pulse, "ch0")
+        seq.add(pulse, "ch0")
+        seq.add(pulse, "ch1", protocol="no-delay")
+        if retarget:
+            seq.target("q1", "ch1")
+            seq.add(pulse, "ch1", protocol="no-delay")
+        seq.add(pulse, "ch2", protocol="no-delay")
+        return seq
+
+    def concurrent_seq():
+        seq = Sequence(Register({"q0": (0, 0)}), DigitalAnalogDevice)
+        seq.declare_channel("ch_local", "rydberg_local", initial_target="q0")
+        seq.declare_channel("ch_global", "rydberg_global")
+        pulse = Pulse.ConstantPulse(20, 10, 0, 0)
+        seq.add(pulse, "ch_local")
+        seq.add(pulse, "ch_global", protocol="no-delay")
+        return seq
+
+    zero = Pulse.ConstantPulse(10, 0, 0, 0)
+    cases = {
+        "amp_sigma": (three_channel_seq(Pulse.ConstantPulse(120, 1, 0, 2.0), True),
+                      dict(amp_sigma=0.1), 3, 11),
+        "runs_detuning_sigma": (three_channel_seq(zero, False), dict(detuning_sigma=1.0), 2, 1337),
+        "runs_amp_sigma": (three_channel_seq(zero, False), dict(amp_sigma=1.0), 2, 1337),
+        "runs_temperature": (three_channel_seq(zero, False), dict(temperature=10.0), 2, 1337),
+        "runs_trap": (three_channel_seq(zero, False),
+                      dict(temperature=10.0, disable_doppler=True, trap_depth=1000.0, trap_waist=0.1), 2, 1337),
+        "runs_hf": (three_channel_seq(zero, False),
+                    dict(detuning_hf_psd=(1.0, 2.0), detuning_hf_omegas=(3.0, 4.0)), 2, 1337),
+        "concurrent": (concurrent_seq(), dict(samples_per_run=5, temperature=50.0), 15, 99),
+    }
+    out, extra = {}, {}
+    for name, (seq, params, ntraj, seed) in cases.items():
+        samples = sampler.sample(seq, extended_duration=seq.get_duration())
+        out[name] = sequence_inputs_from_pulser(samples, seq.register, seq.device).to_dict()
+        ext = samples.extend_duration(samples.max_duration + 1)
+        np.random.seed(seed)
+        hd = HamiltonianData(ext, seq.register, seq.device, NoiseModel(**params), ntraj)
+        extra[f"{name}__rng_probe"] = np.random.get_state()[1][:4].copy()
+        extra[f"{name}__noise_model"] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in params.items()}
+        extra[f"{name}__seed"], extra[f"{name}__n_trajectories"] = seed, ntraj
+        n_seen = 0
+        for i, (traj, noisy, reps) in enumerate(hd.noisy_samples):
+            prob = problem_from_trajectory(hd, traj, noisy, reps, 1.0)
+            assert prob["samples"]["Global"] == {}
+            for basis, per_atom in prob["samples"]["Local"].items():
+                for q, s in per_atom.items():
+                    for qty in ("amp", "det", "phase"):
+                        extra[f"{name}__traj{i}__{basis}__{q}__{qty}"] = np.asarray(s[qty])
+            extra[f"{name}__traj{i}__interaction"] = np.asarray(prob["interaction_matrix"])
+            extra[f"{name}__traj{i}__reps"] = reps
+            n_seen += 1
+        extra[f"{name}__n_distinct"] = n_seen
+        print(f"multichannel_noise[{name}]: {n_seen} distinct trajectories, "
+              f"bases {list(prob['samples']['Local'])}")
+    P.save_problem(os.path.join(HERE, "multichannel_noise.npz"), out,
+                   reference_cite="tests/pulser_simulation/test_simulation.py:1401-1427, 2193-2266, 2422-2470",
+                   **extra)
+
+
+# ---------------------------------------------------------------------------
 # 2c. test_simulation.py:1536-1690 (XY mode, SLM mask, SPAM trajectories, mesolve)
 # ---------------------------------------------------------------------------
 
@@ -1250,6 +1325,8 @@ if __name__ == "__main__":
         gen_modulation()
     if "eom_limit_det" in which:
         gen_eom_limit_det()
+    if "multichannel_noise" in which:
+        gen_multichannel_noise()
     if "dmm" in which:
         gen_dmm()
     if "results" in which:

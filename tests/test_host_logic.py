@@ -1082,6 +1082,50 @@ def test_emulator_golden_counters_eom_detuning_limits(k, monkeypatch):
     assert res.sample_final_state() == Counter(extra["reference_golden_counter"])
 
 
+MULTICHANNEL_CASES = ["amp_sigma", "runs_detuning_sigma", "runs_amp_sigma", "runs_temperature",
+                      "runs_trap", "runs_hf", "concurrent"]
+
+
+@pytest.mark.parametrize("name", MULTICHANNEL_CASES)
+def test_multichannel_noisy_samples_follow_pulser_core(name):
+    """Per-trajectory samples of multi-channel sequences - one amplitude factor per
+    channel with two local channels sharing a basis (test_simulation.py:2193-2266),
+    the five ``test_noisy_runs`` noise models (:2422-2470) and concurrent local +
+    global pulses under doppler noise (:1401-1427) - equal pulser-core's."""
+    prob, extra = load_fixture("multichannel_noise.npz")
+    inputs = SequenceInputs.from_dict(prob[name])
+    kw = dict(extra[f"{name}__noise_model"])
+    for k in ("detuning_hf_psd", "detuning_hf_omegas"):
+        if k in kw:
+            kw[k] = tuple(kw[k])
+    if "samples_per_run" in kw:
+        kw["samples_per_run"] = int(kw["samples_per_run"])
+    np.random.seed(int(extra[f"{name}__seed"]))
+    hd = HamiltonianData(inputs.extend_duration(inputs.max_duration + 1), NoiseModel(**kw),
+                         int(extra[f"{name}__n_trajectories"]))
+    assert np.array_equal(np.random.get_state()[1][:4], extra[f"{name}__rng_probe"])
+    trajs = hd.noise_trajectories
+    assert len(trajs) == int(extra[f"{name}__n_distinct"])
+    for i, t in enumerate(trajs):
+        p = hd.problem(t, 1.0)
+        assert p["samples"]["Global"] == {} and t.reps == int(extra[f"{name}__traj{i}__reps"])
+        keys = [k for k in extra if k.startswith(f"{name}__traj{i}__") and k.count("__") == 4]
+        assert {k.split("__")[2] for k in keys} == set(p["samples"]["Local"])
+        for k in keys:
+            _, _, basis, q, qty = k.split("__")
+            np.testing.assert_allclose(p["samples"]["Local"][basis][int(q)][qty], extra[k],
+                                       rtol=1e-14, atol=1e-14, err_msg=k)
+        np.testing.assert_allclose(p["interaction_matrix"], extra[f"{name}__traj{i}__interaction"],
+                                   rtol=1e-13, atol=0)
+    if name == "amp_sigma":  # the reference's own assertions (:2226-2266)
+        loc = hd.problem(trajs[0], 1.0)["samples"]["Local"]
+        f0 = loc["ground-rydberg"][0]["amp"][0]
+        f1, f2 = loc["digital"][0]["amp"][0], loc["digital"][1]["amp"][0]
+        assert len({f0, f1, f2}) == 3 and all(f > 0 and f != 1 for f in (f0, f1, f2))
+        q1 = loc["digital"][1]["amp"]
+        assert np.all(q1[:120] == f2) and np.all(q1[-121:-1] == f1)
+
+
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
     + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
