@@ -955,23 +955,55 @@ class QutipBackendV2:
         self._config = config or QutipConfig(observables=[BitStrings(evaluation_times=[1.0]),
                                                           StateResult()])
         cfg = self._config
-        nm = cfg.noise_model
-        if cfg.prefer_device_noise_model and getattr(getattr(sequence, "device", None), "noise_model", None):
-            nm = sequence.device.noise_model
+        nm = self._get_noise_model(cfg, getattr(sequence, "device", None))
+        has_dmm = (any(c.is_dmm for c in sequence.channels) if hasattr(sequence, "channels")
+                   else any(type(ch).__name__ == "DMM"
+                            for ch in getattr(sequence, "declared_channels", {}).values()))
+        if (nm is not None and has_dmm and "register" in nm.noise_types
+                and nm.detuning_map_spot_waist is None):  # pulser/backend/abc.py:106-121
+            raise ValueError(
+                "Combining register noise with a DMM requires"
+                "`detuning_map_spot_waist` to be defined. If not defined,"
+                "atom thermal motion can lead to non-physical effects."
+            )
         kw = dict(sampling_rate=cfg.sampling_rate, noise_model=nm, solver=cfg.solver,
                   n_trajectories=cfg.n_trajectories)
         if hasattr(sequence, "_schedule"):
             self._sim_obj = QutipEmulator.from_sequence(sequence, with_modulation=cfg.with_modulation, **kw)
         else:
             self._sim_obj = QutipEmulator(sequence, **kw)
-        self._sim_obj.set_evaluation_times(cfg._get_legacy_evaluation_times(self._sim_obj.total_duration_ns))
+        self._options = self._prepare(self._sim_obj, cfg)
+
+    @staticmethod
+    def _get_noise_model(cfg: QutipConfig, device: Any) -> Any:
+        """qutip_backend.py: the device's noise model wins when the configuration
+        prefers it and the device has one."""
+        if cfg.prefer_device_noise_model and getattr(device, "noise_model", None):
+            return device.noise_model
+        return cfg.noise_model
+
+    @staticmethod
+    def _prepare(sim: QutipEmulator, cfg: QutipConfig) -> dict[str, Any]:
+        sim.set_evaluation_times(cfg._get_legacy_evaluation_times(sim.total_duration_ns))
         if cfg.initial_state:
-            self._sim_obj.set_initial_state(np.asarray(cfg.initial_state.to_qobj()).reshape(-1))
-        self._options = {"print_progress": cfg.print_progress, "progress_bar": cfg.progress_bar}
-        self._sim_obj._validate_options(dict(self._options))
+            sim.set_initial_state(np.asarray(cfg.initial_state.to_qobj()).reshape(-1))
+        options = {"print_progress": cfg.print_progress, "progress_bar": cfg.progress_bar}
+        sim._validate_options(dict(options))
+        return options
 
     def run(self) -> Results:
         return self._run_raw(self._sim_obj, self._config, dict(self._options))
+
+    @staticmethod
+    def run_from_sequence_samples(sequence_samples: Any, register: Any = None, device: Any = None,
+                                  *, config: QutipConfig | None = None) -> Results:
+        """qutip_backend.py:194-232: emulate already sampled sequences (pulser
+        ``SequenceSamples`` + register + device, or ``SequenceInputs``)."""
+        cfg = config or QutipConfig(observables=[BitStrings(evaluation_times=[1.0]), StateResult()])
+        sim = QutipEmulator(sequence_samples, register, device, sampling_rate=cfg.sampling_rate,
+                            noise_model=QutipBackendV2._get_noise_model(cfg, device),
+                            solver=cfg.solver, n_trajectories=cfg.n_trajectories)
+        return QutipBackendV2._run_raw(sim, cfg, QutipBackendV2._prepare(sim, cfg))
 
     @staticmethod
     def _run_raw(sim: QutipEmulator, config: QutipConfig, options: dict[str, Any]) -> Results:

@@ -167,3 +167,82 @@ def test_backend_v2_multilevel_and_xy_sequences():
         ref = qp.sesolve(ham, psi0, times, **qp.TIGHT)[-1]
         got = np.asarray(res.get_result("state", 1.0).to_qobj())[:, 0]
         assert np.max(np.abs(got - ref)) < 1e-7
+
+
+def _constant_pulse_inputs(n, spacing, duration, amp, det=0.0):
+    coords = np.stack([np.arange(n) * spacing, np.zeros(n)], axis=1)
+    s = dict(amp=np.full(duration, amp), det=np.full(duration, det), phase=np.zeros(duration))
+    return single_global_channel(coords, s, P.C6_LEVEL70, extended=False)
+
+
+@pytest.mark.parametrize("amp_sigma", [0.0, 1.0])
+def test_backend_v2_leakage_populations(amp_sigma):
+    """tests/pulser_simulation/test_qutip_backend_v2.py:288-360: leakage |r> -> |x>,
+    |g> -> |x> at equal rates on two far-apart atoms: the leaked populations follow
+    1 - exp(-rate t) whatever the drive (and its amplitude noise) does."""
+    rate, duration = 0.5, 500
+    bx, bg, br = np.eye(3)[2][:, None], np.eye(3)[1][:, None], np.eye(3)[0][:, None]
+    nm = NoiseModel(eff_noise_rates=[rate, rate], eff_noise_opers=[bx @ br.T, bx @ bg.T],
+                    with_leakage=True, amp_sigma=amp_sigma)
+    cfg = QutipConfig(default_evaluation_times=[1.0], observables=[StateResult(evaluation_times=[1.0])],
+                      noise_model=nm, solver="mesolve", n_trajectories=1)
+    np.random.seed(4)
+    res = QutipBackendV2(_constant_pulse_inputs(2, 1000.0, duration, np.pi), config=cfg).run()
+    rho = np.asarray(res.state[-1].to_qobj())
+    assert rho.shape == (9, 9) and res.state[-1].eigenstates == ("r", "g", "x")
+    px = bx @ bx.T
+    keep = np.diag([1.0, 1.0, 0.0])
+    e = np.exp(-rate * duration / 1000)
+    ex = lambda op: float(np.real(np.trace(op @ rho)))  # noqa: E731
+    assert ex(np.kron(px, keep) + np.kron(keep, px)) == pytest.approx(2 * (1 - e) * e)
+    assert ex(np.kron(keep, keep)) == pytest.approx(e * e)
+    assert ex(np.kron(px, px)) == pytest.approx((1 - e) ** 2)
+
+
+def test_backend_v2_register_and_detuning_noise_give_a_mixed_state_and_fresh_draws():
+    """test_qutip_backend_v2.py:363-393 (register + detuning noise -> averaged density
+    matrix) and :558-580 (a second run draws new trajectories)."""
+    nm = NoiseModel(trap_depth=1.0, trap_waist=1.0, temperature=50.0, disable_doppler=True,
+                    detuning_sigma=5.0)
+    assert set(nm.noise_types) == {"register", "detuning"}
+    cfg = QutipConfig(default_evaluation_times=[1.0], observables=[StateResult(evaluation_times=[1.0])],
+                      noise_model=nm, n_trajectories=10)
+    np.random.seed(21)
+    backend = QutipBackendV2(_constant_pulse_inputs(2, 1000.0, 500, np.pi), config=cfg)
+    s1 = np.asarray(backend.run().state[-1].to_qobj())
+    s2 = np.asarray(backend.run().state[-1].to_qobj())
+    assert s1.shape == (4, 4) and abs(np.trace(s1) - 1) < 1e-9
+    assert np.trace(s1 @ s1).real < 1 - 1e-6  # mixed
+    overlap = np.trace(s1.conj().T @ s2) / (np.linalg.norm(s1) * np.linalg.norm(s2))
+    assert overlap != pytest.approx(1.0)
+
+
+def test_backend_v2_evaluation_time_rounding():
+    """test_qutip_backend_v2.py:257-285 (100 relative times must give 100 states for
+    durations that do not divide nicely) and :469-492 (a time that differs from a
+    grid point by one rounding error is not duplicated)."""
+    times = np.linspace(0, 1, 100).tolist()
+    for duration in (400, 428, 472, 516, 596):
+        coords = np.array([[-5.0, 0.0], [5.0, 0.0]])
+        s = dict(amp=np.full(duration, np.pi), det=np.zeros(duration), phase=np.zeros(duration))
+        inputs = single_global_channel(coords, s, P.C6_LEVEL70, extended=False)
+        res = QutipBackendV2(inputs, config=QutipConfig(observables=[StateResult(evaluation_times=times)])).run()
+        assert len(res.state) == 100
+    inputs = _constant_pulse_inputs(1, 1.0, 1000, 1.0)
+    cfg = QutipConfig(observables=[BitStrings(evaluation_times=np.linspace(0.0, 1.0, 1001)),
+                                   BitStrings(evaluation_times=[0.49299999999999994], tag_suffix="mod")])
+    res = QutipBackendV2(inputs, config=cfg).run()
+    assert len(res.bitstrings) == 1001 and len(res.bitstrings_mod) == 1
+
+
+def test_backend_v2_run_from_sequence_samples_is_the_same_run():
+    """test_qutip_backend_v2.py:616-655: running from already sampled sequences gives
+    bit-identical states."""
+    inputs = _constant_pulse_inputs(1, 1.0, 1000, 1.0)
+    cfg = QutipConfig(observables=[StateResult()],
+                      initial_state=RydState.from_state_amplitudes(eigenstates=("r", "g"),
+                                                                   amplitudes={"g": 1.0}))
+    for config in (None, cfg):
+        s1 = np.asarray(QutipBackendV2(inputs, config=config).run().state[-1].to_qobj())
+        s2 = np.asarray(QutipBackendV2.run_from_sequence_samples(inputs, config=config).state[-1].to_qobj())
+        assert np.array_equal(s1, s2)

@@ -1126,6 +1126,18 @@ def test_multichannel_noisy_samples_follow_pulser_core(name):
         assert np.all(q1[:120] == f2) and np.all(q1[-121:-1] == f1)
 
 
+def test_backend_v2_refuses_register_noise_with_a_dmm_without_spot_waist():
+    """tests/pulser_simulation/test_qutip_backend_v2.py:583-613 (pulser/backend/abc.py:106-121)."""
+    from pulser_amd.backend import QutipBackendV2, QutipConfig, StateResult
+
+    inputs = SequenceInputs.from_dict(load_fixture("dmm_square4.npz")[0]["inputs"])
+    cfg = QutipConfig(noise_model=NoiseModel(trap_waist=1.0, trap_depth=1.0, temperature=0.5),
+                      observables=[StateResult(evaluation_times=[1.0])])
+    with pytest.raises(ValueError, match="Combining register noise with a DMM requires"):
+        QutipBackendV2(inputs, config=cfg)
+    assert callable(QutipBackendV2.run_from_sequence_samples)
+
+
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
     + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
