@@ -36,8 +36,8 @@ __all__ = ["QutipEmulator", "Solver", "SimConfig", "NoiseModel"]
 
 
 class Solver(str, Enum):
-    """simulation.py:67-81.  The Monte-Carlo wavefunction solver is not part
-    of this backend; requesting it raises ``NotImplementedError``."""
+    """simulation.py:67-81.  DEFAULT picks the Schroedinger or master-equation
+    kernels from the noise model; MCSOLVER runs quantum-jump trajectories."""
 
     DEFAULT = "default"
     MESOLVER = "MasterEquation"
