@@ -216,7 +216,8 @@ class StateResult(Result):
         tol: float = 1e-6,
         normalize: bool = True,
     ) -> QState:
-        """qutip_result.py:160-242 (``reduce_to_basis`` only for 2-level)."""
+        """qutip_result.py:160-242: optional global-phase removal and reduction of a
+        multi-level ket to one of its two-level bases (kets only, like the reference)."""
         state = QState(self.state.copy())
         if ignore_global_phase and state.isket:
             full = state.full()
@@ -229,9 +230,37 @@ class StateResult(Result):
                     + f" to the {reduce_to_basis} basis."
                 )
         elif reduce_to_basis is not None:
-            raise NotImplementedError(
-                "reduce_to_basis for multi-level bases is not supported by the MI355X backend yet."
-            )
+            if not state.isket:
+                raise NotImplementedError(
+                    "Reduce to basis not implemented for density matrix states."
+                )
+            if reduce_to_basis not in EIGENSTATES:
+                raise ValueError(
+                    "'reduce_to_basis' must be 'ground-rydberg', "
+                    f"'XY', or 'digital', not '{reduce_to_basis}'."
+                )
+            eigenbasis = self._eigenbasis
+            target = set(EIGENSTATES[reduce_to_basis])
+            if not target.issubset(eigenbasis):
+                raise ValueError(
+                    f"Can't reduce a state expressed in {self._basis_name}"
+                    f" into {reduce_to_basis}"
+                )
+            # basis states with every qudit inside the target basis survive
+            d, n = self._dim, self._size
+            kept_level = np.array([lvl in target for lvl in eigenbasis])
+            digits = (np.arange(d**n)[:, None] // d ** np.arange(n - 1, -1, -1)[None, :]) % d
+            keep = kept_level[digits].all(axis=1)
+            amps = state.full()
+            if not np.all(np.isclose(np.abs(amps[~keep]) ** 2, 0, atol=tol)):
+                raise TypeError(
+                    "Can't reduce to chosen basis because the population of a "
+                    "state to eliminate is above the allowed tolerance."
+                )
+            reduced = amps[keep]
+            if normalize:
+                reduced = reduced / np.linalg.norm(reduced)
+            state = QState(reduced)
         arr = np.asarray(state).copy()
         arr[np.abs(arr) < 1e-12] = 0  # Qobj.tidyup default atol
         return QState(arr)

@@ -1,0 +1,224 @@
+"""GPU: the SimulationResults API (CoherentResults / NoisyResults) on runs of the
+HIP engine, following tests/pulser_simulation/test_simresults.py case by case."""
+from collections import Counter
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+from helpers import load_fixture
+
+from pulser_amd import NoiseModel, QutipEmulator
+from pulser_amd import problem as P
+from pulser_amd.hamiltonian_data import ChannelInput, SequenceInputs, Slot, single_global_channel
+from pulser_amd.results import CoherentResults, NoisyResults, QState
+
+pytestmark = pytest.mark.gpu
+
+COORDS = np.array([[0.0, 0.0], [0.0, 10.0]])  # test_simresults.py:33-40
+
+
+def _pi_amp():
+    """BlackmanWaveform(1000, pi) as pulser sampled it (captured in results_noisy.npz)."""
+    return np.asarray(load_fixture("results_noisy.npz")[0]["inputs"]["channels"][0]["amp"], float)[:1000]
+
+
+def _two_atoms(measurement="ground-rydberg"):
+    inputs = SequenceInputs.from_dict(load_fixture("results_noisy.npz")[0]["inputs"])
+    return replace(inputs, measurement=measurement)
+
+
+def _run(inputs, **kw):
+    run_kw = kw.pop("run", {})
+    emu = QutipEmulator(inputs, **kw)
+    with pytest.warns(DeprecationWarning, match="QutipEmulator is deprecated as of pulser 1.9"):
+        return emu, emu.run(**run_kw)
+
+
+def _three_level_inputs():
+    """rydberg_global + raman_local on atom A: two Raman pi pulses, then the global
+    Rydberg pi pulse (test_simresults.py:206-212)."""
+    amp, z = _pi_amp(), np.zeros(1000)
+    ram = ChannelInput("ram", "Local", "digital", np.concatenate((amp, amp, z)), np.zeros(3000),
+                       np.zeros(3000), slots=[Slot(0, 1000, (0,)), Slot(1000, 2000, (0,))])
+    ryd = ChannelInput("ryd", "Global", "ground-rydberg", np.concatenate((z, z, amp)), np.zeros(3000),
+                       np.zeros(3000), slots=[Slot(2000, 3000, (0, 1))])
+    return SequenceInputs(COORDS, ("A", "B"), [ryd, ram], P.C6_LEVEL70)
+
+
+def test_initialization_checks_and_fields():
+    """test_simresults.py:108-160."""
+    state = QState(np.array([1.0, 0, 0, 0], dtype=complex))
+    with pytest.raises(ValueError, match="`basis_name` must be"):
+        CoherentResults([], 2, "bad_basis", None, [0])
+    with pytest.raises(ValueError, match="`meas_basis` must be 'ground-rydberg' or 'digital'."):
+        CoherentResults([], 1, "all", None, "XY")
+    for basis in ("ground-rydberg", "digital", "XY"):
+        with pytest.raises(ValueError, match=f"`meas_basis` associated to basis_name '{basis}' must be"):
+            CoherentResults([], 1, basis, [0], "wrong_measurement_basis")
+        with pytest.raises(ValueError, match="only values of 'epsilon' and 'epsilon_prime'"):
+            CoherentResults([], 1, basis, [0], basis, {"eta": 0.1, "epsilon": 0.0, "epsilon_prime": 0.4})
+    with pytest.raises(ValueError, match="`basis_name` must be"):
+        NoisyResults([], 2, "bad_basis", [0], 123)
+    for basis, exp in (("ground-rydberg_with_error", "ground-rydberg"), ("digital_with_error", "digital"),
+                       ("all_with_error", "digital"), ("all", "digital"), ("XY_with_error", "XY")):
+        assert NoisyResults([], 2, basis, [0], 100)._basis_name == exp
+    _, results = _run(_two_atoms())
+    assert (results._dim, results._size) == (2, 2)
+    assert results._basis_name == "ground-rydberg" and results._meas_basis == "ground-rydberg"
+    assert np.array_equal(np.asarray(results.states[0]).ravel(), [0, 0, 0, 1])  # |gg>
+    assert state.isket
+
+
+@pytest.mark.parametrize("noisychannel", [True, False])
+def test_get_final_state(noisychannel):
+    """test_simresults.py:163-241."""
+    kw = dict(noise_model=NoiseModel(dephasing_rate=0.01)) if noisychannel else {}
+    _, res = _run(_two_atoms(), **kw)
+    assert isinstance(res, CoherentResults)
+    final = res.get_final_state()
+    assert final.isoper if noisychannel else final.isket
+    with pytest.raises(TypeError, match="Can't reduce"):
+        res.get_final_state(reduce_to_basis="digital")
+    last = np.asarray(res.states[-1])
+    same = np.asarray(res.get_final_state(reduce_to_basis="ground-rydberg", ignore_global_phase=False))
+    assert np.allclose(same, np.where(np.abs(last) < 1e-12, 0, last), atol=0, rtol=0)
+    for flag in (False, True):
+        assert np.allclose(np.abs(np.asarray(res.get_final_state(ignore_global_phase=flag))), np.abs(last))
+    if noisychannel:
+        return
+    _, res3 = _run(_three_level_inputs())
+    assert res3._basis_name == "all" and res3._dim == 3
+    with pytest.raises(ValueError, match="'reduce_to_basis' must be"):
+        res3.get_final_state(reduce_to_basis="all")
+    with pytest.raises(TypeError, match="Can't reduce to chosen basis"):
+        res3.get_final_state(reduce_to_basis="digital")
+    h_states = np.asarray(res3.get_final_state(reduce_to_basis="digital", tol=1, normalize=False))[1:]
+    assert np.linalg.norm(h_states) < 3e-6
+    reduced = np.asarray(res3.get_final_state(reduce_to_basis="ground-rydberg"))
+    assert np.allclose(np.abs(reduced), np.abs(last), atol=1e-5)
+
+
+def test_get_state_float_time():
+    """test_simresults.py:278-286."""
+    _, res = _run(_two_atoms())
+    with pytest.raises(IndexError, match="is absent from"):
+        res.get_state(-1.0)
+    mean = (res._sim_times[-1] + res._sim_times[-2]) / 2
+    diff = (res._sim_times[-1] - res._sim_times[-2]) / 2
+    with pytest.raises(IndexError, match="is absent from"):
+        res.get_state(mean, t_tol=diff / 2)
+    state = res.get_state(mean, t_tol=3 * diff / 2)
+    assert np.array_equal(np.asarray(state), np.asarray(res.get_state(res._sim_times[-2])))
+
+
+def test_expect():
+    """test_simresults.py:289-380, including the reference's leakage golden 0.7804005."""
+    _, res = _run(_two_atoms())
+    with pytest.raises(TypeError, match="must be a list"):
+        res.expect("bad_observable")
+    with pytest.raises(TypeError, match="Incompatible type"):
+        res.expect(["bad_observable"])
+    with pytest.raises(ValueError, match="Incompatible shape"):
+        res.expect([np.array(3)])
+    amp = np.concatenate((_pi_amp(), [0.0]))
+    single = single_global_channel(np.zeros((1, 2)), dict(amp=amp, det=0 * amp, phase=0 * amp), P.C6_LEVEL70)
+    proj_r = np.diag([1.0, 0.0]).astype(complex)
+    _, r1 = _run(single)
+    exp = r1.expect([proj_r])[0]
+    assert np.isclose(exp[-1], 1) and len(exp) == 1001
+    np.testing.assert_almost_equal(np.asarray(r1._calc_pseudo_density(-1)), np.diag([1.0, 0.0]))
+    # with SPAM errors
+    nm = NoiseModel(p_false_pos=0.01, p_false_neg=0.05)
+    emu = QutipEmulator(single, noise_model=nm)
+    emu.set_evaluation_times("Minimal")
+    with pytest.warns(DeprecationWarning):
+        r2 = emu.run()
+    exp = r2.expect([proj_r])[0]
+    assert len(exp) == 2 and isinstance(r2, CoherentResults)
+    assert r2._meas_errors == {"epsilon": 0.01, "epsilon_prime": 0.05}
+    assert np.isclose(exp[0], 0.01) and np.isclose(exp[-1], 0.95)
+    np.testing.assert_almost_equal(np.asarray(r2._calc_pseudo_density(-1)), np.diag([0.95, 0.05]))
+    # with leakage (3 levels r, g, x; |x><g| at rate 0.5)
+    op = np.zeros((3, 3), dtype=complex)
+    op[2, 1] = 1.0
+    emu = QutipEmulator(single, sampling_rate=0.1,
+                        noise_model=NoiseModel(eff_noise_rates=[0.5], eff_noise_opers=[op], with_leakage=True))
+    emu.set_evaluation_times(0.5)
+    with pytest.warns(DeprecationWarning):
+        r3 = emu.run()
+    assert isinstance(r3, CoherentResults)
+    assert np.isclose(r3.expect([np.diag([1.0, 0, 0]).astype(complex)])[0][-1], 0.7804005, atol=1e-6)
+    # 3-level "all" basis: atom A never reaches |r> (Raman pi pulse first, blockade next)
+    amp2, z = _pi_amp(), np.zeros(1000)
+    ram = ChannelInput("ram", "Local", "digital", np.concatenate((amp2, z)), np.zeros(2000), np.zeros(2000),
+                       slots=[Slot(0, 1000, (0,))])
+    ryd = ChannelInput("ryd", "Global", "ground-rydberg", np.concatenate((z, amp2)), np.zeros(2000),
+                       np.zeros(2000), slots=[Slot(1000, 2000, (0, 1))])
+    _, r4 = _run(SequenceInputs(COORDS, ("A", "B"), [ryd, ram], P.C6_LEVEL70))
+    e3 = r4.expect([np.kron(np.diag([1.0, 0, 0]), np.eye(3)).astype(complex)])[0][-1]
+    assert abs(e3) < 1e-9
+
+
+def test_plot_and_sampling(monkeypatch):
+    """test_simresults.py:393-420."""
+    import matplotlib
+
+    matplotlib.use("Agg")
+    from test_host_logic import _results_noisy_emulator
+
+    _, res = _run(_two_atoms())
+    emu, _ = _results_noisy_emulator()
+    with pytest.warns(DeprecationWarning):
+        noisy = emu.run()
+    op = np.kron(np.eye(2), np.diag([1.0, 0.0])).astype(complex)
+    noisy.plot(op)
+    noisy.plot(op, error_bars=False)
+    res.plot(op)
+    sampling = res.sample_final_state(1234)
+    assert len(sampling) == 4  # all states observed
+    res[-1].matching_meas_basis = False
+    assert res.sample_final_state(N_samples=911) == Counter({"00": 911})
+
+
+def test_sample_final_state_three_level():
+    """test_simresults.py:422-443: the Raman pi pulse on B does not affect A."""
+    amp, z = _pi_amp(), np.zeros(1000)
+    ryd = ChannelInput("ryd", "Global", "ground-rydberg", np.concatenate((amp, z)), np.zeros(2000),
+                       np.zeros(2000), slots=[Slot(0, 1000, (0, 1))])
+    ram = ChannelInput("raman", "Local", "digital", np.concatenate((z, amp)), np.zeros(2000), np.zeros(2000),
+                       slots=[Slot(1000, 2000, (1,))])
+    inputs = SequenceInputs(COORDS, ("A", "B"), [ryd, ram], P.C6_LEVEL70)
+    np.random.seed(0)
+    _, r = _run(inputs)
+    assert len(r.sample_final_state()) == 2
+    _, r = _run(replace(inputs, measurement="ground-rydberg"))
+    assert len(r.sample_final_state()) == 4
+
+
+def test_results_xy():
+    """test_simresults.py:486-529."""
+    amp = np.concatenate((_pi_amp(), [0.0]))
+    inputs = single_global_channel(COORDS, dict(amp=amp, det=0 * amp, phase=0 * amp), P.C6_LEVEL70,
+                                   basis="XY", name="ch0")
+    inputs = replace(inputs, measurement="XY", interaction_coeff_xy=3700.0, magnetic_field=(0.0, 0.0, 30.0))
+    _, r = _run(inputs)
+    assert (r._dim, r._size, r._basis_name, r._meas_basis) == (2, 2, "XY", "XY")
+    assert np.array_equal(np.asarray(r.states[0]).ravel(), [1, 0, 0, 0])
+    for basis in ("all", "ground-rydberg", "digital"):
+        with pytest.raises(TypeError, match="Can't reduce a system in"):
+            r.get_final_state(reduce_to_basis=basis)
+    state = np.asarray(r.get_final_state(reduce_to_basis="XY"))
+    assert np.allclose(np.abs(state), np.abs(np.asarray(r.states[-1])), atol=1e-5)
+    assert np.array_equal(r._meas_projector(0), np.diag([1.0, 0.0]))
+    assert np.array_equal(r._meas_projector(1), np.diag([0.0, 1.0]))
+
+
+def test_false_positive():
+    """test_simresults.py:532-557: a pulse after a long idle start still acts."""
+    coords = P.register_coords(P.square_rect(2, 2), 5.0)
+    amp = np.concatenate((np.zeros(2500), _pi_amp(), np.zeros(500), [0.0]))
+    inputs = single_global_channel(coords, dict(amp=amp, det=0 * amp, phase=0 * amp), P.C6_LEVEL70)
+    emu, r = _run(inputs)
+    final = np.asarray(r.get_final_state()).ravel()
+    assert np.max(np.abs(final - np.asarray(emu.initial_state).ravel())) > 0.1

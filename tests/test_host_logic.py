@@ -1138,6 +1138,39 @@ def test_backend_v2_refuses_register_noise_with_a_dmm_without_spot_waist():
     assert callable(QutipBackendV2.run_from_sequence_samples)
 
 
+def test_state_result_reduce_to_basis():
+    """qutip_result.py:160-242: global phase, reduction of a 3-level ket to a
+    two-level basis, the population tolerance and the reference's error messages."""
+    # "all" basis (r, g, h), two atoms: amplitude on |gg>, |gh>, |hg> only
+    psi = np.zeros(9, dtype=complex)
+    psi[4], psi[5], psi[7] = 0.6j, 0.48j, 0.64j  # gg, gh, hg
+    psi[0] = 1e-5  # a little Rydberg population
+    res = StateResult(("a", "b"), "digital", QState(psi), False)
+    assert res._basis_name == "all" and res._eigenbasis == ["r", "g", "h"]
+    red = np.asarray(res.get_state(reduce_to_basis="digital", normalize=False)).ravel()
+    assert red.shape == (4,)  # gg, gh, hg, hh with the global phase of the largest term removed
+    assert np.allclose(red, [0.6, 0.48, 0.64, 0.0]) and abs(red[2].imag) < 1e-15
+    unit = np.asarray(res.get_state(reduce_to_basis="digital")).ravel()
+    assert abs(np.linalg.norm(unit) - 1) < 1e-15
+    with pytest.raises(TypeError, match="Can't reduce to chosen basis because the population"):
+        res.get_state(reduce_to_basis="ground-rydberg")
+    with pytest.raises(TypeError, match="Can't reduce to chosen basis because the population"):
+        res.get_state(reduce_to_basis="digital", tol=1e-12)
+    with pytest.raises(ValueError, match="'reduce_to_basis' must be 'ground-rydberg', 'XY', or 'digital'"):
+        res.get_state(reduce_to_basis="all")
+    with pytest.raises(ValueError, match="Can't reduce a state expressed in all into XY"):
+        res.get_state(reduce_to_basis="XY")
+    rho = QState(np.outer(psi, psi.conj()))
+    with pytest.raises(NotImplementedError, match="not implemented for density matrix"):
+        StateResult(("a", "b"), "digital", rho, False).get_state(reduce_to_basis="digital")
+    two = StateResult(("a",), "ground-rydberg", QState(np.array([0.6, 0.8j])), True)
+    with pytest.raises(TypeError, match="Can't reduce a system in ground-rydberg to the digital basis"):
+        two.get_state(reduce_to_basis="digital")
+    kept = np.asarray(two.get_state(ignore_global_phase=False)).ravel()
+    assert np.array_equal(kept, [0.6, 0.8j])
+    assert np.allclose(np.asarray(two.get_state()).ravel(), [-0.6j, 0.8])
+
+
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
     + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
