@@ -121,8 +121,9 @@ def test_expect():
         res.expect(["bad_observable"])
     with pytest.raises(ValueError, match="Incompatible shape"):
         res.expect([np.array(3)])
-    amp = np.concatenate((_pi_amp(), [0.0]))
-    single = single_global_channel(np.zeros((1, 2)), dict(amp=amp, det=0 * amp, phase=0 * amp), P.C6_LEVEL70)
+    amp = _pi_amp()
+    single = single_global_channel(np.zeros((1, 2)), dict(amp=amp, det=0 * amp, phase=0 * amp), P.C6_LEVEL70,
+                                   extended=False)
     proj_r = np.diag([1.0, 0.0]).astype(complex)
     _, r1 = _run(single)
     exp = r1.expect([proj_r])[0]
@@ -198,9 +199,9 @@ def test_sample_final_state_three_level():
 
 def test_results_xy():
     """test_simresults.py:486-529."""
-    amp = np.concatenate((_pi_amp(), [0.0]))
+    amp = _pi_amp()
     inputs = single_global_channel(COORDS, dict(amp=amp, det=0 * amp, phase=0 * amp), P.C6_LEVEL70,
-                                   basis="XY", name="ch0")
+                                   basis="XY", name="ch0", extended=False)
     inputs = replace(inputs, measurement="XY", interaction_coeff_xy=3700.0, magnetic_field=(0.0, 0.0, 30.0))
     _, r = _run(inputs)
     assert (r._dim, r._size, r._basis_name, r._meas_basis) == (2, 2, "XY", "XY")
@@ -217,8 +218,11 @@ def test_results_xy():
 def test_false_positive():
     """test_simresults.py:532-557: a pulse after a long idle start still acts."""
     coords = P.register_coords(P.square_rect(2, 2), 5.0)
-    amp = np.concatenate((np.zeros(2500), _pi_amp(), np.zeros(500), [0.0]))
-    inputs = single_global_channel(coords, dict(amp=amp, det=0 * amp, phase=0 * amp), P.C6_LEVEL70)
+    amp = np.concatenate((np.zeros(2500), _pi_amp(), np.zeros(500)))
+    inputs = single_global_channel(coords, dict(amp=amp, det=0 * amp, phase=0 * amp), P.C6_LEVEL70,
+                                   extended=False)
     emu, r = _run(inputs)
     final = np.asarray(r.get_final_state()).ravel()
-    assert np.max(np.abs(final - np.asarray(emu.initial_state).ravel())) > 0.1
+    # four blockaded atoms: the "pi" pulse is a collective 2 pi rotation, so the state
+    # comes back close to - but, unlike the old bug, not exactly at - the initial state
+    assert np.max(np.abs(final - np.asarray(emu.initial_state).ravel())) > 1e-3
