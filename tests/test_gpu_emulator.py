@@ -459,6 +459,62 @@ def test_relaxation_noise_population_decays(capsys):
     assert abs(rho[0, 0].real - np.asarray(res.get_state(1.0))[0, 0].real * np.exp(-0.5)) < 1e-6
 
 
+def _blackman(duration, area):
+    w = np.clip(np.blackman(duration), 0, np.inf)
+    return w * area / (w.sum() * 1e-3)
+
+
+def test_pulses_between_long_delays_are_not_skipped():
+    """test_simulation.py:612-633: delay, pi pulse, delay, pi/2 pulse on one atom ends
+    at population 1/2.  (The reference's other half - with ``max_step=1`` QuTiP's
+    adaptive integrator steps over both pulses and returns 0 - is an artefact this
+    engine does not reproduce: a larger ``max_step`` never skips samples here.)"""
+    amp = np.concatenate((np.zeros(1500), _blackman(600, np.pi), np.zeros(2000), _blackman(600, np.pi / 2)))
+    inputs = single_global_channel(np.zeros((1, 2)), dict(amp=amp, det=0 * amp, phase=0 * amp),
+                                   P.C6_LEVEL70, extended=False)
+    emu = QutipEmulator(inputs)
+    proj = np.diag([1.0, 0.0]).astype(complex)
+    for kw in ({}, {"max_step": 1}):
+        with pytest.warns(DeprecationWarning):
+            occ = emu.run(**kw).expect([proj])[0]
+        assert np.isclose(occ[-1], 0.5, 1e-4)
+        assert np.isclose(occ[2100], 1.0, 1e-6)
+
+
+def test_single_atom_and_empty_sequences():
+    """test_simulation.py:434-472, 591-609."""
+    from pulser_amd.hamiltonian_data import ChannelInput, SequenceInputs, Slot
+
+    amp = np.ones(16)
+    one = single_global_channel(np.zeros((1, 2)), dict(amp=amp, det=amp, phase=0 * amp), P.C6_LEVEL70,
+                                extended=False)
+    for ev in ("Full", "Minimal"):
+        with pytest.warns(DeprecationWarning):
+            res = QutipEmulator(one, evaluation_times=ev).run()
+        assert res._size == 1 and len(res) == (17 if ev == "Full" else 2)
+    empty = SequenceInputs(np.zeros((1, 2)), ("q0",), [ChannelInput("ch0", "Global", "XY", np.zeros(0),
+                                                                    np.zeros(0), np.zeros(0))], 1.0)
+    with pytest.raises(ValueError, match="SequenceSamples is empty"):
+        QutipEmulator(empty)
+    # only delays + SPAM: every sample of every atom is zero, the run still works
+    coords = np.array([[-4.0, 0.0], [0.0, 4.0], [4.0, 0.0]])
+    z = np.zeros(100)
+    idle = SequenceInputs(coords, ("control1", "target", "control2"),
+                          [ChannelInput("test", "Local", "digital", z, z, z, slots=[Slot(0, 100, (1,))]),
+                           ChannelInput("test2", "Global", "ground-rydberg", z, z, z)], P.C6_LEVEL70)
+    np.random.seed(1)
+    emu = QutipEmulator(idle, noise_model=NoiseModel(samples_per_run=1, state_prep_error=0.005,
+                                                     p_false_pos=0.01, p_false_neg=0.05), n_trajectories=15)
+    nested = emu._current_problem["samples"]
+    assert not nested["Global"]
+    for per_atom in nested["Local"].values():
+        for entry in per_atom.values():
+            assert not any(np.any(v) for v in entry.values())
+    with pytest.warns(DeprecationWarning):
+        r = emu.run()
+    assert sum(r[-1].bitstring_counts.values()) == 15
+
+
 def test_sharded_ensemble_on_the_gpu_equals_the_serial_run():
     """pulser_amd.distributed.run_ensemble with the real HIP solver (world size 1):
     same Counters as QutipEmulator.run() for the same seed (all random numbers are

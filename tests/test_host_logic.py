@@ -1171,6 +1171,41 @@ def test_state_result_reduce_to_basis():
     assert np.allclose(np.asarray(two.get_state()).ravel(), [-0.6j, 0.8])
 
 
+def test_evaluation_times_instructions():
+    """test_simulation.py:721-815 (``set_evaluation_times``) on the CCZ sequence."""
+    inputs = SequenceInputs.from_dict(load_fixture("noise_spam_all.npz")[0]["inputs"])
+
+    def fresh():
+        return QutipEmulator(inputs, sampling_rate=1.0)
+
+    with pytest.raises(ValueError, match="evaluation_times float must be between 0 and 1."):
+        fresh().set_evaluation_times(3.0)
+    for bad in (123, "Best"):
+        with pytest.raises(ValueError, match="Wrong evaluation time label."):
+            fresh().set_evaluation_times(bad)
+    sim = fresh()
+    st, end = sim.sampling_times, sim._tot_duration / 1000
+    with pytest.raises(ValueError, match="Provided evaluation-time list contains negative values."):
+        sim.set_evaluation_times([-1, 0, st[-2]])
+    with pytest.raises(ValueError, match="Provided evaluation-time list extends further than sequence duration."):
+        sim.set_evaluation_times([0, st[-1] + 10])
+    sim.set_evaluation_times("Full")
+    assert sim._eval_times_instruction == "Full"
+    np.testing.assert_almost_equal(sim._eval_times_array, st)
+    sim.set_evaluation_times("Minimal")
+    np.testing.assert_almost_equal(sim._eval_times_array, [st[0], end])
+    sim.set_evaluation_times([0, st[-3], end])
+    np.testing.assert_almost_equal(sim._eval_times_array, [0, st[-3], end])
+    for empty in ([], 0.0001):
+        sim.set_evaluation_times(empty)
+        np.testing.assert_almost_equal(sim._eval_times_array, [0, end])
+    sim.set_evaluation_times([st[-10], st[-3]])
+    np.testing.assert_almost_equal(sim._eval_times_array, [0, st[-10], st[-3], end])
+    sim.set_evaluation_times(0.4)
+    np.testing.assert_almost_equal(
+        st[np.linspace(0, len(st) - 1, int(0.4 * len(st)), dtype=int)], sim._eval_times_array)
+
+
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
     + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
