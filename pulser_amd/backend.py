@@ -17,7 +17,9 @@ matrix-free generator kernel on the device (``ryd_apply_generator``).
 
 from __future__ import annotations
 
+import collections.abc
 import json
+import math
 import uuid
 import warnings
 from collections import Counter, defaultdict
@@ -38,15 +40,52 @@ __all__ = [
 _ONE_STATE = {("r", "g"): "r", ("g", "h"): "h", ("u", "d"): "d"}
 
 
+def _validate_eigenstates(eigenstates: Any) -> None:
+    """pulser/backend/state.py:196-208."""
+    if not isinstance(eigenstates, collections.abc.Sequence):
+        raise TypeError(
+            "'eigenstates' must be a 'collections.Sequence' "
+            f"(list or tuple), not {type(eigenstates).__name__}."
+        )
+    if any(not isinstance(s, str) or len(s) != 1 for s in eigenstates):
+        raise ValueError("All eigenstates must be represented by single characters.")
+    if len(eigenstates) != len(set(eigenstates)):
+        raise ValueError("'eigenstates' can't contain repeated entries.")
+
+
+def _validate_shape(shape: tuple[int, ...], qudit_dim: int) -> None:
+    """qutip_state.py:272-280."""
+    n = math.log(shape[0], qudit_dim)
+    if not np.isclose(n, round(n)):
+        raise ValueError(
+            f"An array with shape {tuple(shape)} is incompatible with "
+            f"a system of {qudit_dim}-level qudits."
+        )
+
+
 # ------------------------------------------------------------------- state
 class RydState:
     """``QutipState`` (pulser_simulation/qutip_state.py:38-281) on a NumPy state."""
 
     def __init__(self, state: Any, *, eigenstates: Sequence[str]) -> None:
+        _validate_eigenstates(eigenstates)
         self.eigenstates = tuple(eigenstates)
-        self._state = QState(state)
-        d = len(self.eigenstates)
-        self._n = int(round(np.log(self._state.shape[0]) / np.log(d)))
+        arr = np.asarray(state)
+        if isinstance(state, (str, bytes)) or arr.dtype == object or arr.ndim not in (1, 2):
+            raise TypeError(
+                "'state' must be a state vector (ket or bra) or a density matrix, "
+                f"not {state!r}."
+            )
+        if arr.ndim == 2 and arr.shape[0] == 1 and arr.shape[1] > 1:  # a bra
+            arr = arr.conj().T
+        if arr.ndim == 2 and arr.shape[1] not in (1, arr.shape[0]):
+            raise TypeError(
+                "'state' must be a state vector (ket or bra) or a density matrix, "
+                f"not an array of shape {arr.shape}."
+            )
+        self._state = QState(arr)
+        _validate_shape(self._state.shape, len(self.eigenstates))
+        self._n = int(round(math.log(self._state.shape[0], len(self.eigenstates))))
         self._amplitudes: Mapping[str, complex] | None = None
 
     def _to_abstract_repr(self) -> dict[str, Any]:
@@ -86,6 +125,8 @@ class RydState:
         raise RuntimeError(f"Failed to infer the 'one state' from the eigenstates: {self.eigenstates}")
 
     def get_basis_state_from_index(self, index: int) -> str:
+        if index < 0:
+            raise ValueError(f"'index' must be a non-negative integer; got {index} instead.")
         d = self.qudit_dim
         digits = np.base_repr(index, base=d).zfill(self._n)
         return "".join(self.eigenstates[int(c)] for c in digits)
@@ -94,6 +135,18 @@ class RydState:
         """qutip_state.py:86-110."""
         if not isinstance(other, RydState):
             raise TypeError(f"'RydState.overlap()' expects another 'RydState', not {type(other)}.")
+        if self.n_qudits != other.n_qudits or self.qudit_dim != other.qudit_dim:
+            raise ValueError(
+                "Can't calculate the overlap between a state with "
+                f"{self.n_qudits} {self.qudit_dim}-dimensional qudits and "
+                f"another with {other.n_qudits} {other.qudit_dim}-dimensional qudits."
+            )
+        if self.eigenstates != other.eigenstates:
+            msg = ("Can't calculate the overlap between states with eigenstates "
+                   f"{self.eigenstates} and {other.eigenstates}.")
+            if set(self.eigenstates) != set(other.eigenstates):
+                raise ValueError(msg)
+            raise NotImplementedError(msg)
         ov = self._state.overlap(other._state)
         if self._state.isket and other._state.isket:
             ov = np.abs(ov) ** 2
@@ -144,18 +197,40 @@ class RydState:
     @classmethod
     def from_state_amplitudes(cls, *, eigenstates: Sequence[str],
                               amplitudes: Mapping[str, complex]) -> "RydState":
-        """pulser/backend/state.py:100-176: {"rgr": a, ...} -> normalised ket."""
-        n = len(next(iter(amplitudes)))
+        """pulser/backend/state.py:143-176, 217-232: {"rgr": a, ...} -> ket with exactly
+        these amplitudes (no normalisation, like the reference)."""
+        _validate_eigenstates(eigenstates)
+        keys = list(amplitudes)
+        n = len(keys[0])
+        if not all(len(k) == n and set(k) <= set(eigenstates) for k in keys):
+            raise ValueError(
+                "All basis states must be combinations of eigenstates with the"
+                f" same length. Expected combinations of {eigenstates}, each "
+                f"with {n} elements."
+            )
         d = len(eigenstates)
         vec = np.zeros(d**n, dtype=complex)
-        for key, amp in amplitudes.items():
+        amps = {k: complex(v) for k, v in amplitudes.items()}
+        for key, amp in amps.items():
             idx = 0
             for ch in key:
                 idx = idx * d + list(eigenstates).index(ch)
-            vec[idx] = amp
-        out = cls(QState(vec).unit(), eigenstates=eigenstates)
-        out._amplitudes = dict(amplitudes)
+            vec[idx] += amp
+        out = cls(QState(vec), eigenstates=eigenstates)
+        out._amplitudes = amps
         return out
+
+    def __repr__(self) -> str:
+        return "\n".join(["RydState", "--------", f"Eigenstates: {self.eigenstates}",
+                          repr(np.asarray(self._state))])
+
+    def __eq__(self, other: Any) -> bool:
+        if not isinstance(other, RydState):
+            return False
+        return (self.eigenstates == other.eigenstates and self._state.shape == other._state.shape
+                and np.allclose(np.asarray(self._state), np.asarray(other._state), rtol=0, atol=1e-12))
+
+    __hash__ = None  # type: ignore[assignment]
 
 
 class RydOperator:
@@ -165,10 +240,14 @@ class RydOperator:
     def __init__(self, operator: Any, *, eigenstates: Sequence[str]) -> None:
         import scipy.sparse as sp
 
+        _validate_eigenstates(eigenstates)
         self.eigenstates = tuple(eigenstates)
+        if isinstance(operator, (str, bytes)) or (not sp.issparse(operator) and np.asarray(operator).ndim != 2):
+            raise TypeError(f"'operator' must be a square matrix (dense or sparse), not {operator!r}.")
         self._operator = sp.csr_matrix(operator, dtype=complex)
         if self._operator.shape[0] != self._operator.shape[1]:
-            raise ValueError("An operator must be a square matrix.")
+            raise TypeError(f"'operator' must be a square matrix, not one of shape {self._operator.shape}.")
+        _validate_shape(self._operator.shape, len(self.eigenstates))
         self._n_qudits: int | None = None
         self._operations: Any = None
 

@@ -70,9 +70,15 @@ class QState(np.ndarray):
         return QState(np.asarray(self) / self.norm())
 
     def overlap(self, other: Any) -> complex:
-        a, b = np.asarray(self), np.asarray(QState(other))
-        if self.isket and b.shape[1] == 1:
+        """``Qobj.overlap``: <a|b>, <a|B|a>, <b|A|b> or Tr(A^dag B)."""
+        other = QState(other)
+        a, b = np.asarray(self), np.asarray(other)
+        if self.isket and other.isket:
             return complex(np.vdot(a, b))
+        if self.isket:
+            return complex(np.vdot(a, b @ a))
+        if other.isket:
+            return complex(np.vdot(b, a @ b))
         return complex(np.trace(a.conj().T @ b))
 
 
