@@ -650,9 +650,9 @@ def test_results_abstract_repr_and_aggregation_match_pulser_core():
     with pytest.raises(ValueError, match="same atom order"):
         Results.aggregate([mine[0], other])
     # states serialise only when built from amplitudes (backend/state.py:234-254)
-    st = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rg": 1.0, "gr": 1j})
+    st = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rg": 0.6, "gr": 0.8j})
     d = json.loads(json.dumps({"s": st}, cls=type(agg)._encoder()))
-    assert d["s"]["eigenstates"] == ["r", "g"] and d["s"]["amplitudes"]["gr"] == {"real": 0.0, "imag": 1.0}
+    assert d["s"]["eigenstates"] == ["r", "g"] and d["s"]["amplitudes"]["gr"] == {"real": 0.0, "imag": 0.8}
     with pytest.raises(ValueError, match="from_state_amplitudes"):
         RydState(np.array([1.0, 0.0]), eigenstates=("r", "g"))._to_abstract_repr()
 
