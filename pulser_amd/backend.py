@@ -867,6 +867,25 @@ class QutipConfig:
                  sampling_rate: float = 1.0, solver: Solver = Solver.DEFAULT,
                  default_num_shots: int = 1000, progress_bar: bool = False,
                  print_progress: bool = False, **backend_options: Any) -> None:
+        if unexpected := set(backend_options) - {"interaction_matrix"}:  # config.py:80-90
+            raise ValueError(
+                f"'QutipConfig' received unexpected keyword arguments: {unexpected}; only the "
+                f"following keyword arguments are expected: {self._expected_kwargs()}. "
+            )
+        if initial_state and not isinstance(initial_state, RydState):
+            raise TypeError(
+                "If provided, `initial_state` must be an instance of "
+                f"`RydState`, not {type(initial_state)}."
+            )
+        if noise_model is not None and noise_model.samples_per_run not in (None, 1):
+            warnings.warn(
+                f"The number of samples per run (`samples_per_run` = {noise_model.samples_per_run}) "
+                "is ignored when using QutipBackendV2.", stacklevel=2)
+        try:
+            solver = Solver(solver)
+        except ValueError:
+            raise ValueError(f"Invalid solver '{solver}'. Allowed solvers are: "
+                             + ", ".join(v.value for v in Solver) + ".") from None
         tags = [o.tag for o in observables]
         if len(set(tags)) != len(tags):
             raise ValueError("Some of the provided 'observables' share identical tags. Use 'tag_suffix' to make them unique.")
@@ -898,6 +917,16 @@ class QutipConfig:
         if backend_options.get("interaction_matrix") is not None:
             raise NotImplementedError("'QutipBackendV2' does not handle custom interaction matrices.")
         self._extra = dict(backend_options)
+
+    state_type = RydState  # config.py:409-417
+    operator_type = RydOperator
+
+    @staticmethod
+    def _expected_kwargs() -> set[str]:
+        """config.py:396-407 + qutip_config.py:143-149."""
+        return {"callbacks", "observables", "default_evaluation_times", "initial_state",
+                "with_modulation", "interaction_matrix", "prefer_device_noise_model", "noise_model",
+                "n_trajectories", "sampling_rate", "solver", "print_progress", "progress_bar"}
 
     # -- read-only views / JSON abstract representation (config.py:116-118, 438-470)
     @property

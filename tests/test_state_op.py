@@ -296,3 +296,46 @@ def test_operator_abstract_repr():
             "Failed to serialize state of type 'RydOperator' because it was not created via "
             "'RydOperator.from_operator_repr()'")):
         json.dumps(RydOperator(op.to_qobj(), eigenstates=op.eigenstates), cls=_AbstractReprEncoder)
+
+
+# ---------------------------------------------------------------- QutipConfig
+def test_qutip_config_validation():
+    """tests/pulser_simulation/test_qutip_config.py:17-147."""
+    import warnings
+
+    from pulser_amd import NoiseModel, Solver
+    from pulser_amd.backend import BitStrings, QutipConfig, StateResult
+
+    obs = lambda: [StateResult(evaluation_times=[1.0])]  # noqa: E731
+    with pytest.raises(NotImplementedError, match="'QutipBackendV2' does not handle custom interaction matrices."):
+        QutipConfig(observables=obs(), interaction_matrix=np.eye(4))
+    with pytest.raises(ValueError, match="be greater than 0 and less than or equal to 1"):
+        QutipConfig(observables=obs(), sampling_rate=1.2)
+    cfg = QutipConfig(observables=obs(), sampling_rate=0.5, progress_bar=True)
+    assert {"sampling_rate", "progress_bar"} <= cfg._expected_kwargs() and cfg.progress_bar
+    with pytest.raises(ValueError, match="received unexpected keyword arguments"):
+        QutipConfig(observables=obs(), not_an_option=3)
+    with pytest.warns(UserWarning, match="The number of samples per run .* is ignored when using QutipBackendV2."):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", DeprecationWarning)
+            QutipConfig(observables=obs(), noise_model=NoiseModel(temperature=45, samples_per_run=5))
+    with pytest.raises(TypeError, match=re.escape("If provided, `initial_state` must be an instance of `RydState`")):
+        QutipConfig(observables=obs(), initial_state="all-ground")
+    assert QutipConfig.state_type is RydState and QutipConfig.operator_type is RydOperator
+    # evaluation times given as arrays
+    default_times = np.array([0.0, 0.25, 0.5, 0.75, 1.0])
+    t1, t2 = np.array([0.2, 0.4, 0.8]), np.array([0.15, 0.35, 0.65, 0.95])
+    cfg = QutipConfig(observables=[StateResult(evaluation_times=t1),
+                                   StateResult(evaluation_times=t2, tag_suffix="second")],
+                      default_evaluation_times=default_times)
+    np.testing.assert_almost_equal(cfg._get_legacy_evaluation_times(1000),
+                                   np.union1d(np.union1d(default_times, t1), t2))
+    # solver round trip through the JSON document
+    for solver in Solver:
+        for given in (solver, str(solver.value)):
+            cfg = QutipConfig(observables=[BitStrings(evaluation_times=[1.0])], solver=given)
+            text = cfg.to_abstract_repr()
+            assert json.loads(text)["solver"] == str(solver.value)
+            assert QutipConfig.from_abstract_repr(text).solver is solver
+    with pytest.raises(ValueError, match="Invalid solver 'fakesolver'"):
+        QutipConfig(observables=[BitStrings(evaluation_times=[1.0])], solver="fakesolver")
