@@ -78,6 +78,40 @@ def _to_tuple(obj: Any) -> Any:
     return obj
 
 
+def check_eff_noise(rates: Any, opers: Any, check_contents: bool, with_leakage: bool) -> None:
+    """pulser/noise_model.py:585-644: lengths and rate types always; when the noise
+    type is active also non-empty, non-negative rates and 2-D operators of the
+    single-qudit dimension (or one more, for the extra level of a larger basis)."""
+    if len(opers) != len(rates):
+        raise ValueError(
+            f"The operators list length({len(opers)}) and rates list length"
+            f"({len(rates)}) must be equal."
+        )
+    for rate in rates:
+        if not isinstance(rate, (float, int)):
+            raise TypeError(f"eff_noise_rates is a list of floats, it must not contain a {type(rate)}.")
+    if not check_contents:
+        return
+    if not opers or not rates:
+        raise ValueError("The effective noise parameters have not been filled.")
+    if np.any(np.array(rates) < 0):
+        raise ValueError("The provided rates must be greater than 0.")
+    smallest = 3 if with_leakage else 2
+    allowed = [(smallest, smallest), (smallest + 1, smallest + 1)]
+    for op in opers:
+        try:
+            arr = np.array(op, dtype=complex)
+        except (TypeError, ValueError) as e:
+            raise TypeError(f"Operator {op!r} is not castable to a Numpy array.") from e
+        if arr.ndim != 2:
+            raise ValueError(f"Operator '{op!r}' is not a 2D array.")
+        if arr.shape not in allowed:
+            raise ValueError(
+                f"With{'' if with_leakage else 'out'} leakage, operator's "
+                f"shape must be {allowed[0]}, not {arr.shape}."
+            )
+
+
 @dataclass(frozen=True)
 class NoiseModel:
     noise_types: tuple[str, ...] = field(init=False, default=())
@@ -126,10 +160,8 @@ class NoiseModel:
                 "At least one effective noise operator must be defined to "
                 "simulate leakage."
             )
-        if len(vals["eff_noise_rates"]) != len(vals["eff_noise_opers"]):
-            raise ValueError(
-                "The operators list length must be equal to the rates list length."
-            )
+        check_eff_noise(vals["eff_noise_rates"], vals["eff_noise_opers"], "eff_noise" in types,
+                        bool(vals["with_leakage"]))
         if len(vals["detuning_hf_psd"]) != len(vals["detuning_hf_omegas"]):
             raise ValueError(
                 "'detuning_hf_psd' and 'detuning_hf_omegas' must have the same length."

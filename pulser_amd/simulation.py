@@ -27,7 +27,7 @@ import numpy as np
 
 from .hamiltonian_data import HamiltonianData, SequenceInputs
 from .noise_model import (LEGACY_DEFAULTS, NoiseModel, _NOISE_TYPE_PARAMS,
-                          has_stochastic_noise)
+                          check_eff_noise, has_stochastic_noise)
 from .results import (CoherentResults, NoisyResults, QState, SampledResult,
                       SimulationResults, StateResult)
 from .terms import sampling_times
@@ -111,10 +111,13 @@ class SimConfig:
             if value > 1 or value < 0:
                 raise ValueError(f"SPAM parameter {param} = {value} must be"
                                  + " greater than 0 and less than 1.")
-        if len(self.eff_noise_opers) != len(self.eff_noise_rates):
-            raise ValueError(
-                f"The operators list length({len(self.eff_noise_opers)}) and rates list length"
-                f"({len(self.eff_noise_rates)}) must be equal.")
+        for operator in self.eff_noise_opers:  # simconfig.py:253-268
+            if not isinstance(operator, np.ndarray) and not hasattr(operator, "full"):
+                raise TypeError(f"{operator} is not a matrix (NumPy array or Qobj).")
+            if np.asarray(operator).ndim != 2 or np.asarray(operator).shape[0] != np.asarray(operator).shape[1]:
+                raise TypeError("Operators are supposed to be square matrices (Qutip type 'oper').")
+        check_eff_noise(self.eff_noise_rates, [np.asarray(o) for o in self.eff_noise_opers],
+                        "eff_noise" in noise, self.with_leakage)
 
     @property
     def with_leakage(self) -> bool:

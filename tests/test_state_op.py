@@ -339,3 +339,52 @@ def test_qutip_config_validation():
             assert QutipConfig.from_abstract_repr(text).solver is solver
     with pytest.raises(ValueError, match="Invalid solver 'fakesolver'"):
         QutipConfig(observables=[BitStrings(evaluation_times=[1.0])], solver="fakesolver")
+
+
+def test_density_matrix_aggregator():
+    """tests/pulser_simulation/test_aggregators.py:4-47."""
+    from pulser_amd.backend import density_matrix_aggregator
+
+    s1 = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rgr": 1.0})
+    s2 = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"grr": 1.0})
+    s3 = RydState(proj(np.asarray(RydState.from_state_amplitudes(
+        eigenstates=("r", "g"), amplitudes={"ggr": 1.0}).to_qobj()).ravel()), eigenstates=("r", "g"))
+    acc = density_matrix_aggregator([s1, s2])  # vector and vector
+    res1 = np.zeros((8, 8))
+    res1[2, 2] = res1[4, 4] = 0.5  # |rgr> = index 2, |grr> = index 4
+    assert np.isclose(acc.to_qobj().norm(), 1.0) and np.allclose(np.asarray(acc.to_qobj()), res1)
+    acc = density_matrix_aggregator([acc, s3])  # matrix and matrix from a ket
+    res2 = 0.5 * res1
+    res2[6, 6] = 0.5
+    assert np.isclose(acc.to_qobj().norm(), 1.0) and np.allclose(np.asarray(acc.to_qobj()), res2)
+    acc = density_matrix_aggregator([acc, acc])
+    assert np.isclose(acc.to_qobj().norm(), 1.0) and np.allclose(np.asarray(acc.to_qobj()), res2)
+
+
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")
+def test_simconfig_effective_noise_and_noise_model_conversion():
+    """tests/pulser_simulation/test_simconfig.py:103-172."""
+    from pulser_amd import NoiseModel, SimConfig
+
+    ket = np.array([[1.0], [2.0]])
+    with pytest.raises(ValueError, match="The operators list length"):
+        SimConfig(noise=("eff_noise"), eff_noise_rates=[1.0])
+    with pytest.raises(TypeError, match="eff_noise_rates is a list of floats"):
+        SimConfig(noise=("eff_noise"), eff_noise_rates=["0.1"], eff_noise_opers=[EYE])
+    with pytest.raises(ValueError, match="The effective noise parameters have not been filled."):
+        SimConfig(noise=("eff_noise"))
+    with pytest.raises(TypeError, match="is not a matrix"):
+        SimConfig(noise=("eff_noise"), eff_noise_opers=[2.0], eff_noise_rates=[1.0])
+    with pytest.raises(TypeError, match="type 'oper'"):
+        SimConfig(noise=("eff_noise"), eff_noise_opers=[ket], eff_noise_rates=[1.0])
+    for bad in (EYE, np.eye(5)):
+        with pytest.raises(ValueError, match="With leakage, operator's shape"):
+            SimConfig(noise=("eff_noise", "leakage"), eff_noise_opers=[bad], eff_noise_rates=[1.0])
+    with pytest.raises(ValueError, match="Without leakage, operator's shape"):
+        SimConfig(noise=("eff_noise",), eff_noise_opers=[np.eye(4)], eff_noise_rates=[1.0])
+    SimConfig(noise=("eff_noise"), eff_noise_opers=[SX, EYE], eff_noise_rates=[0.5, 0.5])
+    nm = NoiseModel(p_false_neg=0.4, p_false_pos=0.1, amp_sigma=1e-3, runs=10, samples_per_run=1)
+    expected = SimConfig(noise=("SPAM", "amplitude"), epsilon=0.1, epsilon_prime=0.4, eta=0.0,
+                         amp_sigma=1e-3, laser_waist=float("inf"), runs=10, samples_per_run=1)
+    assert SimConfig.from_noise_model(nm) == expected
+    assert expected.to_noise_model() == nm
