@@ -32,7 +32,7 @@ from .results import QState, multinomial
 from .simulation import QutipEmulator, Solver
 
 __all__ = [
-    "QutipBackendV2", "QutipConfig", "RydState", "RydOperator", "Results", "Observable", "StateResult",
+    "QutipBackendV2", "QutipBackend", "EmulatorConfig", "QutipConfig", "RydState", "RydOperator", "Results", "Observable", "StateResult",
     "BitStrings", "Fidelity", "Expectation", "CorrelationMatrix", "Occupation", "Energy",
     "EnergyVariance", "EnergySecondMoment",
 ]
@@ -1047,6 +1047,74 @@ class QutipConfig:
                                   int(self.sampling_rate * total_duration_ns), dtype=int) / total_duration_ns
             rel = np.union1d(rel, list(extra))
         return "Full" if isinstance(rel, str) else rel * total_duration_ns * 1e-3
+
+
+# ------------------------------------------------------------- legacy backend
+class EmulatorConfig:
+    """``pulser.EmulatorConfig`` (pulser/backend/config.py:477-583): the options of the
+    legacy ``QutipBackend``."""
+
+    _EVAL_LABELS = ("Full", "Minimal", "Final")
+
+    def __init__(self, backend_options: dict[str, Any] | None = None, sampling_rate: float = 1.0,
+                 evaluation_times: Any = "Full", initial_state: Any = "all-ground",
+                 with_modulation: bool = False, prefer_device_noise_model: bool = False,
+                 noise_model: Any = None) -> None:
+        if not (0 < sampling_rate <= 1.0):
+            raise ValueError(f"The sampling rate (`sampling_rate` = {sampling_rate}) must be "
+                             "greater than 0 and less than or equal to 1.")
+        if isinstance(evaluation_times, str):
+            if evaluation_times not in self._EVAL_LABELS:
+                raise ValueError("If provided as a string, 'evaluation_times' must be one "
+                                 f"of the following options: {self._EVAL_LABELS}")
+        elif isinstance(evaluation_times, float):
+            if not (0 < evaluation_times <= 1.0):
+                raise ValueError("If provided as a float, 'evaluation_times' must be"
+                                 " greater than 0 and less than or equal to 1.")
+        elif isinstance(evaluation_times, (list, tuple, np.ndarray)):
+            if np.min(evaluation_times, initial=0) < 0:
+                raise ValueError("If provided as a sequence of values, 'evaluation_times' must not "
+                                 "contain negative values.")
+        else:
+            raise TypeError(f"'{type(evaluation_times)}' is not a valid type for 'evaluation_times'.")
+        if isinstance(initial_state, str) and initial_state != "all-ground":
+            raise ValueError("If provided as a string, 'initial_state' must be 'all-ground'.")
+        self.backend_options = dict(backend_options or {})
+        self.sampling_rate, self.evaluation_times = sampling_rate, evaluation_times
+        self.initial_state, self.with_modulation = initial_state, bool(with_modulation)
+        self.prefer_device_noise_model = bool(prefer_device_noise_model)
+        self.noise_model = noise_model if noise_model is not None else NoiseModel()
+
+
+class QutipBackend:
+    """The deprecated ``QutipBackend`` (qutip_backend.py:44-118): a thin wrapper that
+    builds a ``QutipEmulator`` from a legacy ``EmulatorConfig`` and returns its
+    ``CoherentResults`` / ``NoisyResults``."""
+
+    def __init__(self, sequence: Any, config: Any = None, mimic_qpu: bool = False) -> None:
+        warnings.warn("'QutipBackend' is deprecated. Please use 'QutipBackendV2' instead.",
+                      DeprecationWarning, stacklevel=2)
+        config = EmulatorConfig() if config is None else config
+        needed = ("sampling_rate", "evaluation_times", "initial_state", "with_modulation",
+                  "prefer_device_noise_model", "noise_model")
+        if isinstance(config, QutipConfig) or not all(hasattr(config, a) for a in needed):
+            raise TypeError(f"'config' must be of type 'EmulatorConfig', not {type(config)}.")
+        self._config = config
+        noise_model = None
+        if config.prefer_device_noise_model:
+            noise_model = getattr(getattr(sequence, "device", None), "noise_model", None)
+        kw = dict(sampling_rate=config.sampling_rate, noise_model=noise_model or config.noise_model,
+                  evaluation_times=config.evaluation_times)
+        if hasattr(sequence, "_schedule"):
+            self._sim_obj = QutipEmulator.from_sequence(sequence, with_modulation=config.with_modulation, **kw)
+        else:
+            self._sim_obj = QutipEmulator(sequence, **kw)
+        self._sim_obj.set_initial_state(config.initial_state)
+
+    def run(self, progress_bar: bool = False, **options: Any) -> Any:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", DeprecationWarning)
+            return self._sim_obj.run(progress_bar=progress_bar, **options)
 
 
 # ------------------------------------------------------------------- backend

@@ -248,3 +248,34 @@ def test_backend_v2_run_from_sequence_samples_is_the_same_run():
         s1 = np.asarray(QutipBackendV2(inputs, config=config).run().state[-1].to_qobj())
         s2 = np.asarray(QutipBackendV2.run_from_sequence_samples(inputs, config=config).state[-1].to_qobj())
         assert np.array_equal(s1, s2)
+
+
+def test_legacy_qutip_backend():
+    """tests/pulser_simulation/test_qutip_backend.py:42-100: the deprecated wrapper
+    (one atom, local Raman pi pulse -> |h>; SPAM noise -> NoisyResults)."""
+    from pulser_amd import EmulatorConfig, QutipBackend
+    from pulser_amd.hamiltonian_data import ChannelInput, SequenceInputs, Slot
+    from pulser_amd.results import CoherentResults, NoisyResults
+
+    w = np.clip(np.blackman(1000), 0, np.inf)
+    amp = w * np.pi / (w.sum() * 1e-3)
+    inputs = SequenceInputs(np.zeros((1, 2)), ("q0",),
+                            [ChannelInput("raman_local", "Local", "digital", amp, 0 * amp, 0 * amp,
+                                          slots=[Slot(0, 1000, (0,))])], P.C6_LEVEL70)
+    with pytest.raises(TypeError, match="must be of type 'EmulatorConfig'"), pytest.deprecated_call():
+        QutipBackend(inputs, NoiseModel())
+    with pytest.deprecated_call(match="'QutipBackend' is deprecated"):
+        backend = QutipBackend(inputs)
+    results = backend.run()
+    assert isinstance(results, CoherentResults)
+    assert np.array_equal(np.asarray(results[0].get_state()).ravel(), [1, 0])  # |g> in (g, h)
+    final = np.asarray(results[-1].get_state())
+    assert np.array_equal(final, np.asarray(results.get_final_state()))
+    np.testing.assert_allclose(np.abs(final), [[0], [1]], atol=1e-5)
+    spam = NoiseModel(p_false_pos=0.1, p_false_neg=0.05, state_prep_error=0.1, runs=10, samples_per_run=1)
+    with pytest.deprecated_call():
+        backend = QutipBackend(inputs, config=EmulatorConfig(noise_model=spam, evaluation_times="Minimal"))
+    np.random.seed(2)
+    assert isinstance(backend.run(), NoisyResults) and backend._sim_obj.noise_model == spam
+    with pytest.raises(ValueError, match="'evaluation_times' must be one of the following options"):
+        EmulatorConfig(evaluation_times="Best")
