@@ -10,6 +10,7 @@ passed wherever a NoiseModel is expected - only attribute access is used.
 from __future__ import annotations
 
 import math
+import warnings
 from dataclasses import dataclass, field, fields
 from typing import Any
 
@@ -76,6 +77,34 @@ def _to_tuple(obj: Any) -> Any:
     if isinstance(obj, (tuple, list)):
         return tuple(_to_tuple(el) for el in obj)
     return obj
+
+
+_POSITIVE = {"dephasing_rate", "hyperfine_dephasing_rate", "relaxation_rate", "depolarizing_rate",
+             "temperature", "detuning_sigma", "trap_waist"}
+_STRICT_POSITIVE = {"runs", "samples_per_run", "laser_waist", "trap_depth", "detuning_map_spot_waist"}
+_PROBABILITY_LIKE = {"state_prep_error", "p_false_pos", "p_false_neg", "amp_sigma", "dmm_sigma"}
+_BOOLEAN = {"with_leakage", "disable_doppler"}
+
+
+def _check_detuning_hf_noise(psd: tuple, freqs: tuple) -> None:
+    """pulser/noise_model.py:539-583."""
+    if (psd == ()) ^ (freqs == ()):
+        raise ValueError("`detuning_hf_psd` and `detuning_hf_omegas` must either"
+                         " both be empty tuples or both be provided.")
+    if psd == ():
+        return
+    psd_a, freqs_a = np.asarray(psd), np.asarray(freqs)
+    both = "`detuning_hf_psd` and `detuning_hf_omegas`"
+    if psd_a.ndim != 1 or freqs_a.ndim != 1:
+        raise ValueError(f"{both} are expected to be 1D tuples.")
+    if psd_a.size != freqs_a.size:
+        raise ValueError(f"{both} are expected to have the same length.")
+    if psd_a.size <= 1:
+        raise ValueError(f"{both} are expected to have length > 1.")
+    if not (np.all(psd_a > 0) and np.all(freqs_a > 0)):
+        raise ValueError(f"{both} are expected to have positive values.")
+    if np.any(np.diff(freqs_a) < 0):
+        raise ValueError("`detuning_hf_omegas` are expected to be monotonously growing.")
 
 
 def check_eff_noise(rates: Any, opers: Any, check_contents: bool, with_leakage: bool) -> None:
@@ -145,6 +174,13 @@ class NoiseModel:
             vals[key] = _to_tuple(vals[key])
             object.__setattr__(self, key, vals[key])
 
+        for p in _POSITIVE | _PROBABILITY_LIKE:  # noise_model.py:386-395
+            try:
+                vals[p] = float(vals[p])
+            except (TypeError, ValueError):
+                raise TypeError(f"{p} should be castable to float, not of type {type(vals[p])}.") from None
+            object.__setattr__(self, p, vals[p])
+
         def truthy(v: Any) -> bool:
             if isinstance(v, tuple):
                 return len(v) > 0
@@ -162,17 +198,29 @@ class NoiseModel:
             )
         check_eff_noise(vals["eff_noise_rates"], vals["eff_noise_opers"], "eff_noise" in types,
                         bool(vals["with_leakage"]))
-        if len(vals["detuning_hf_psd"]) != len(vals["detuning_hf_omegas"]):
-            raise ValueError(
-                "'detuning_hf_psd' and 'detuning_hf_omegas' must have the same length."
-            )
-        for p in ("state_prep_error", "p_false_pos", "p_false_neg", "amp_sigma", "dmm_sigma"):
-            if not (0.0 <= float(vals[p]) <= 1.0):
-                raise ValueError(f"'{p}' must be greater than or equal to zero and smaller than or equal to one, not {vals[p]}.")
-        for p in ("dephasing_rate", "hyperfine_dephasing_rate", "relaxation_rate",
-                  "depolarizing_rate", "temperature", "detuning_sigma", "trap_waist"):
-            if float(vals[p]) < 0:
-                raise ValueError(f"'{p}' must be greater than or equal to zero, not {vals[p]}.")
+        _check_detuning_hf_noise(vals["detuning_hf_psd"], vals["detuning_hf_omegas"])
+        relevant = self._find_relevant_params(types, vals["state_prep_error"], vals["amp_sigma"],
+                                              vals["laser_waist"])
+        if vals["runs"] is not None:
+            warnings.warn(
+                "Defining the number of emulation trajectories via 'NoiseModel.runs' is deprecated "
+                "since pulser v1.7. Please favour using 'EmulationConfig.n_trajectories' instead.",
+                category=DeprecationWarning, stacklevel=3)
+        for p, v in vals.items():  # noise_model.py:646-675: only defined or relevant parameters
+            if (v is None and p not in relevant) or (p == "runs" and v is None):
+                continue
+            if p in _POSITIVE and not v >= 0:
+                raise ValueError(f"'{p}' must be greater than or equal to zero, not {v}.")
+            if p in _STRICT_POSITIVE and not (v is not None and v > 0):
+                raise ValueError(f"'{p}' must be greater than zero, not {v}.")
+            if p in _PROBABILITY_LIKE and not 0 <= v <= 1:
+                raise ValueError(f"'{p}' must be greater than or equal to zero and smaller than "
+                                 f"or equal to one, not {v}.")
+            if p in _BOOLEAN and not isinstance(v, bool):
+                raise ValueError(f"'{p}' must be a boolean, not {v}.")
+            if p == "samples_per_run" and v != 1:
+                warnings.warn("Setting samples_per_run different to 1 is deprecated since pulser v1.6.",
+                              DeprecationWarning, stacklevel=3)
         if "register" in types and (
             vals["trap_waist"] == 0.0 or vals["trap_depth"] is None or vals["temperature"] == 0.0
         ):
@@ -183,6 +231,30 @@ class NoiseModel:
         if vals["disable_doppler"]:
             types.discard("doppler")
         object.__setattr__(self, "noise_types", tuple(sorted(types)))
+        defined = [p for p in relevant if truthy(vals[p])]
+        for p, v in vals.items():  # noise_model.py:460-475
+            unused = truthy(v) if p != "samples_per_run" else v != 1
+            if p != "disable_doppler" and p not in relevant and unused:
+                warnings.warn(
+                    f"{p!r} is not used by any active noise type in {self.noise_types} when the "
+                    f"only defined parameters are {defined}.", stacklevel=3)
+
+    @staticmethod
+    def _find_relevant_params(noise_types: Any, state_prep_error: float, amp_sigma: float,
+                              laser_waist: float | None) -> set[str]:
+        """noise_model.py:492-516: the parameters the active noise types read."""
+        relevant: set[str] = set()
+        for nt in noise_types:
+            relevant.update(_NOISE_TYPE_PARAMS[nt])
+            if nt == "register":
+                relevant.add("temperature")
+            if (nt in ("doppler", "detuning", "register", "dmm_sigma")
+                    or (nt == "amplitude" and amp_sigma != 0.0)
+                    or (nt == "SPAM" and state_prep_error != 0.0)):
+                relevant.update(("runs", "samples_per_run"))
+        if laser_waist is None:
+            relevant.discard("laser_waist")
+        return relevant
 
     # -- JSON abstract representation (pulser/noise_model.py:676-699) ----------
     _OPTIONAL_IN_ABSTR_REPR = ("detuning_sigma", "trap_waist", "trap_depth", "detuning_hf_psd",

@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the reference's own deprecations, raised on purpose by the legacy API under test
+    for msg in ("Setting samples_per_run different to 1", ".*'NoiseModel.runs' is deprecated"):
+        config.addinivalue_line("filterwarnings", f"ignore:{msg}:DeprecationWarning")
 
 
 @pytest.fixture(scope="session")
