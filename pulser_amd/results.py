@@ -18,6 +18,7 @@ is what makes sampled bitstring indices bit-exact:
 from __future__ import annotations
 
 import collections.abc
+import warnings
 from collections import Counter
 from dataclasses import dataclass
 from functools import lru_cache
@@ -120,6 +121,30 @@ class Result:
             for i in multinomial(n_samples, self._weights())
         )
 
+    def get_state(self) -> Any:
+        raise NotImplementedError(f"`{self.__class__.__name__}.get_state()` is not implemented.")
+
+    def plot_histogram(self, min_rate: float = 0.001, max_n_bitstrings: int | None = None,
+                       show: bool = True) -> None:
+        """Bar chart of the sampling distribution (result.py:128-153)."""
+        import matplotlib.pyplot as plt
+
+        probs = np.array(Counter(self.sampling_dist).most_common(max_n_bitstrings), dtype=object)
+        probs = probs[probs[:, 1] >= min_rate]
+        plt.bar(probs[:, 0], probs[:, 1])
+        plt.xticks(rotation="vertical")
+        plt.ylabel("Probabilites")
+        if show:
+            plt.show()
+
+    def __str__(self) -> str:
+        return self.__repr__()
+
+    @classmethod
+    def from_final_bitstrings(cls, atom_order: Sequence[str], total_duration: int,
+                              final_bitstrings: Mapping[str, int]) -> "Result":
+        raise NotImplementedError(f"'{cls.__name__}.from_final_bitstrings()' is not implemented.")
+
 
 @dataclass
 class SampledResult(Result):
@@ -132,6 +157,21 @@ class SampledResult(Result):
 
     def __post_init__(self) -> None:
         self.n_samples = sum(self.bitstring_counts.values())
+
+    @property
+    def final_bitstrings(self) -> Counter:
+        """The measured bitstrings themselves (``Results.final_bitstrings``)."""
+        return Counter(self.bitstring_counts)
+
+    def get_samples(self, n_samples: int) -> Counter:
+        warnings.warn(
+            "'SampledResult.get_samples()' resamples a sampling distribution"
+            " derived from the original 'bitstring_counts'. To get the real "
+            "samples, accessing 'SampledResult.final_bitstrings' is "
+            "recommended.",
+            stacklevel=2,
+        )
+        return super().get_samples(n_samples)
 
     @property
     def sampling_errors(self) -> dict[str, float]:
@@ -164,13 +204,22 @@ class StateResult(Result):
         return int(np.rint(full ** (1 / self._size)).astype(int))
 
     @property
+    def sampling_errors(self) -> dict[str, float]:
+        """An exact state has no sampling error (qutip_result.py:49-55)."""
+        return {bitstr: 0.0 for bitstr in self.sampling_dist}
+
+    @property
     def _basis_name(self) -> str:  # qutip_result.py:66-90
         if self.meas_basis == "XY":
-            return "XY_with_error" if self._dim == 3 else "XY"
+            if self._dim == 3:
+                return "XY_with_error"
+            assert self._dim == 2, f"In XY, state's dimension can only be 2 or 3, not {self._dim}."
+            return "XY"
         if self._dim == 4:
             return "all_with_error"
         if self._dim == 3:
             return self.meas_basis + "_with_error" if self.matching_meas_basis else "all"
+        assert self._dim == 2, f"In Ising, state's dimension can be 2, 3 or 4, not {self._dim}."
         if not self.matching_meas_basis:
             return "digital" if self.meas_basis == "ground-rydberg" else "ground-rydberg"
         return self.meas_basis
