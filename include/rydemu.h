@@ -227,7 +227,8 @@ int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr, con
                          double scale_re, double scale_im, double row_norm);
 
 /* Test/bench hook (bit mask): 1 = disable the persistent small-N kernel, 2 =
- * reserved (accepted, ignored), 4 = disable the 2^14
+ * disable the single-launch plan of small states (partner tiles read through
+ * L2; the multi-pass tiling is used instead), 4 = disable the 2^14
  * register-tile kernel and the Hermitian mesolve path, 8 = force them even when
  * the launch has too few tiles to fill the GPU.  Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);

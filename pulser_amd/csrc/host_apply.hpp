@@ -93,13 +93,15 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
     A.n_dbl = (int)p.dbl.size();
     A.include_diag = p.include_diag;
     for (int i = 0; i < A.n_flip; ++i) A.flip_q[i] = (signed char)p.flip_q[i];
+    A.n_oflip = (int)p.oflip.size();
+    for (int i = 0; i < A.n_oflip; ++i) A.oflip_p[i] = (signed char)p.oflip[i];
     for (int i = 0; i < A.n_dbl; ++i) {
       A.dbl_qb[i] = (signed char)p.dbl[i].first;
       A.dbl_qa[i] = (signed char)p.dbl[i].second;
     }
     const int TL = p.T >> 1, TH = p.T - TL;
     const size_t lds = ((size_t)1 << p.T) * sizeof(cplx) + ((1 << TL) + (1 << TH)) * sizeof(double) +
-                       2 * MAXF * sizeof(cplx);
+                       (2 * MAXF + MAXO) * sizeof(cplx);
     dim3 grid((unsigned)(1ull << p.n_outer_bits), h->B);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->timing) { int rc = timing_begin(h, st, ev); if (rc) return rc; }

@@ -7,6 +7,7 @@ struct Pass {
   int T = 0;
   int n_outer_bits = 0;
   std::vector<int> flip_q;
+  std::vector<int> oflip;  // global bits flipped through partner tiles (single-pass plan)
   std::vector<std::pair<int, int>> dbl;  // (qb, qa)
   bool include_diag = false;
   bool use14 = false;  // pass 0 on 2^14 register tiles (k_apply14)
@@ -62,6 +63,7 @@ struct ryd_handle {
   bool force_generic = false;
   bool no_tile14 = false;      // test hook: disable k_apply14 / the Hermitian mesolve path
   bool force_tile14 = false;   // test hook: use them even when too few tiles fill the GPU
+  bool no_outer = false;       // test hook: disable the single-pass partner-tile plan
   bool drive_real = false;     // every drive series is real-valued
   bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
   // Monte-Carlo wavefunction mode (sesolve handles with ryd_set_collapse)
@@ -147,10 +149,33 @@ static bool tile14_pays(const ryd_handle* h) {
   return p14 < p12 && tiles >= 48;
 }
 
+// Small states (the whole batch fits in L2): ONE launch per application.  Each
+// workgroup stages its contiguous 2^T tile in LDS for the low-bit flips and reads
+// the partner amplitude of every higher bit from the same offset of another tile
+// (coalesced, L2-resident): (1 + nb - T) reads + 1 write per tile instead of one
+// read + one write per pass - the same bytes at nb - T = 2, but half the launches
+// of a launch-latency-bound regime (a single 14-atom ket: 7 us per launch).
+static bool single_pass_pays(const ryd_handle* h, int T) {
+  if (h->no_outer || !h->auto_tile || (h->cfg.mode == RYD_MESOLVE && h->has_dbl)) return false;
+  if (h->nb <= T || h->nb - T > MAXO) return false;
+  const size_t bytes = (size_t)h->B * sizeof(cplx) << h->nb;
+  return bytes <= ((size_t)2 << 20);
+}
+
 static void plan_passes(ryd_handle* h) {
   h->passes.clear();
   const int nb = h->nb, N = h->N, T = std::min(h->T, nb);
   const int C = 4;  // run bits (256 B contiguous) kept in every tile
+  if (single_pass_pays(h, T) && !(nb >= 14 && tile14_pays(h))) {
+    Pass p = make_pass(nb, {{0, T}});
+    for (int j = 0; j < T; ++j) p.flip_q.push_back(j);
+    for (int j = T; j < nb; ++j) p.oflip.push_back(j);
+    p.include_diag = true;
+    h->passes.push_back(p);
+    h->stats.passes = 1;
+    h->passes_valid = true;
+    return;
+  }
   if (h->cfg.mode == RYD_MESOLVE && h->has_dbl) {
     // pair passes: both bits of each atom in the same tile
     int done = 0;  // atoms (counted from the low bit end) handled so far

@@ -626,12 +626,13 @@ extern "C" int ryd_mc_get_jumps(ryd_handle* h, int32_t* counts, void* stream) {
 extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
   if (!h) return fail(RYD_ERR_INVALID, "null handle");
   h->force_generic = (force_generic & 1) != 0;
-  // bit 2 (a retired tile-kernel hook) is accepted and ignored
   {
-    const bool nt = (force_generic & 4) != 0, ft = (force_generic & 8) != 0;
-    if (nt != h->no_tile14 || ft != h->force_tile14) {
+    const bool no = (force_generic & 2) != 0, nt = (force_generic & 4) != 0,
+               ft = (force_generic & 8) != 0;
+    if (nt != h->no_tile14 || ft != h->force_tile14 || no != h->no_outer) {
       h->no_tile14 = nt;
       h->force_tile14 = ft;
+      h->no_outer = no;
       plan_passes(h);
     }
   }

@@ -1,6 +1,7 @@
 // Part of librydemu (included by rydemu.hip, one translation unit).
 #define MAXF 16  // flips per pass (<= tile bits)
 #define MAXD 8   // double flips per pass
+#define MAXO 8   // outer flips per pass (partner tiles streamed from global memory)
 
 struct PassArgs {
   const cplx* in;    // x: the vector G is applied to
@@ -24,6 +25,8 @@ struct PassArgs {
   int include_diag, final_pass;
   signed char flip_q[MAXF];  // tile-local bit of each single flip
   signed char dbl_qb[MAXD], dbl_qa[MAXD];
+  int n_oflip;                // single flips on bits outside the tile: the partner
+  signed char oflip_p[MAXO];  // amplitude sits at the same place of another tile
 };
 
 // Global bit position of tile-local bit q.
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
   double* tabHi = tabLo + (1 << TL);
   cplx* c0 = reinterpret_cast<cplx*>(tabHi + (1 << TH));
   cplx* c1 = c0 + MAXF;
+  cplx* oc = c1 + MAXF;  // outer flips: one coefficient each (the bit is fixed per tile)
 
   const int tid = threadIdx.x;
   const int N = A.N;
@@ -90,6 +94,22 @@ __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
     }
     c0[tid] = lo;
     c1[tid] = hi;
+  }
+  if (tid >= 64 && tid - 64 < A.n_oflip) {
+    // same coefficients as above for a global bit p of the output index `base_idx`
+    const int p = A.oflip_p[tid - 64];
+    const bool bit = (base_idx >> p) & 1ull;
+    cplx v;
+    if (MODE == RYD_SESOLVE || p >= N) {
+      const int k = (MODE == RYD_SESOLVE ? N : 2 * N) - 1 - p;
+      const double cr = cf[4 * k], ci = cf[4 * k + 1];
+      v = bit ? make_double2(ci, -cr) : make_double2(-ci, -cr);
+    } else {
+      const int k = N - 1 - p;
+      const double cr = cf[4 * k], ci = cf[4 * k + 1];
+      v = bit ? make_double2(ci, cr) : make_double2(-ci, cr);
+    }
+    oc[tid - 64] = v;
   }
   double eOuter = 0.0;
   if (A.include_diag) {
@@ -160,6 +180,8 @@ __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
       const cplx cc = ((l >> q) & 1) ? c1[f] : c0[f];
       acc = cfma(cc, xv, acc);
     }
+    for (int f = 0; f < A.n_oflip; ++f)  // coalesced: the partner tile has the same layout
+      acc = cfma(oc[f], xin[gi ^ (1ull << A.oflip_p[f])], acc);
     if (MODE == RYD_MESOLVE) {
       for (int d = 0; d < A.n_dbl; ++d) {
         const int qb = A.dbl_qb[d], qa = A.dbl_qa[d];

@@ -228,25 +228,31 @@ def test_persistent_kernel_cfg2_chain12_snapshots():
         assert np.max(np.abs(snaps[i - 1][0] - ref[i])) < AMP_TOL
 
 
+@pytest.mark.parametrize("single_pass", [False, True])
 @pytest.mark.parametrize("mode,n,batch", [("sesolve", 13, 1), ("sesolve", 17, 1), ("sesolve", 13, 300),
-                                          ("mesolve", 6, 1), ("mesolve", 9, 1)])
-def test_tiled_kernel_workgroup_widths_and_pass_plans(mode, n, batch):
+                                          ("mesolve", 6, 1), ("mesolve", 7, 1), ("mesolve", 9, 1)])
+def test_tiled_kernel_workgroup_widths_and_pass_plans(mode, n, batch, single_pass):
     """The tiled kernel in both workgroup widths (1024 threads when a launch has
-    at most 512 tiles, 512 otherwise) and with balanced multi-pass plans, against
-    the oracle's sparse matvec / Lindblad right-hand side."""
+    at most 512 tiles, 512 otherwise), with balanced multi-pass plans and with the
+    single-launch plan of L2-resident states (low bits in LDS, the partner of every
+    higher bit read from the same offset of another tile), against the oracle's
+    sparse matvec / Lindblad right-hand side."""
     from oracle import qutip_path as qp
 
     ops = [(np.sqrt(0.1), "sigma_rr")] if mode == "mesolve" else None
     prob = local_problem(n, seed=1, duration=21, collapse_ops=ops)
     eng = _engine([prob] * batch, mode=mode)
-    eng.set_path(True, no_tile14=True)
+    eng.set_path(True, no_tile14=True, no_single_pass=not single_pass)
     shape = eng.state_shape
     rng = np.random.default_rng(0)
     x = rng.normal(size=shape[1:]) + 1j * rng.normal(size=shape[1:])
     dev = _to_dev(eng, np.broadcast_to(x, shape).copy())
     got = eng.apply_generator(dev, 0.0123).cpu().numpy()
-    # 13-atom kets: two 2^12-tile passes, or one pass of 2^13 tiles when >= 128 tiles remain
-    assert eng.stats()["passes"] == ({13: 2, 17: 2, 6: 1, 9: 2}[n] if batch < 128 else 1)
+    # 13-atom kets: two 2^12-tile passes, or one pass of 2^13 tiles when >= 128 tiles remain;
+    # states of at most 2 MiB (13 / 17-atom kets, 7-atom density matrices): one launch
+    multi = {13: 2, 17: 2, 6: 1, 7: 2, 9: 2}[n] if batch < 128 else 1
+    small = 16 * batch * (2**n if mode == "sesolve" else 4**n) <= 2 << 20
+    assert eng.stats()["passes"] == (1 if single_pass and small else multi)
     ham = qp.build_hamiltonian(prob)
     if mode == "sesolve":
         ref = -1j * ham.apply(0.0123, x)
@@ -297,7 +303,8 @@ def test_register_tile_kernel_sesolve_14_and_16_atoms():
             st = eng.new_state()
             eng.evolve(st, 0.0, 0.003)
             res[no14] = st.cpu().numpy()
-            assert eng.stats()["passes"] == ({14: 1, 16: 2}[n] if not no14 else 2)
+            # without the register tiles: the single-launch plan of small states
+            assert eng.stats()["passes"] == ({14: 1, 16: 2}[n] if not no14 else 1)
         assert np.max(np.abs(res[False] - res[True])) < 1e-13
 
 
