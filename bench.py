@@ -387,7 +387,7 @@ def main() -> None:
         also.append({"workload": "14-atom triangular register, sesolve, single sequence, 100 ns slice at t = 1 us",
                      "value": (t1 - t0) / sec, "unit": "sim-us/s",
                      "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
-                     "roofline": roofline(14, 1, stats, kms, kl, "k_apply<sesolve> (tiled, 2 passes; 256 KiB state: launch-latency-bound)")})
+                     "roofline": roofline(14, 1, stats, kms, kl, "k_apply<sesolve> (single-launch plan: low bits in LDS, 5 partner tiles from L2; 256 KiB state: launch-latency-bound)")})
         eng.close()
         # ... and a batch of 256 such sequences (state batch = 64 MiB): the streaming regime
         eng = Engine.from_problems([tri_problem(2, 7)] * 256, mode="sesolve")
