@@ -230,7 +230,8 @@ int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr, con
  * disable the single-launch plan of small states (partner tiles read through
  * L2; the multi-pass tiling is used instead), 4 = disable the 2^14
  * register-tile kernel and the Hermitian mesolve path, 8 = force them even when
- * the launch has too few tiles to fill the GPU.  Never needed for results. */
+ * the launch has too few tiles to fill the GPU, 16 = use the single-launch plan
+ * whatever the size of the state.  Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);
 
 /* Replaces: QobjEvo.__call__(t) applied to a state (used by

@@ -64,6 +64,7 @@ struct ryd_handle {
   bool no_tile14 = false;      // test hook: disable k_apply14 / the Hermitian mesolve path
   bool force_tile14 = false;   // test hook: use them even when too few tiles fill the GPU
   bool no_outer = false;       // test hook: disable the single-pass partner-tile plan
+  bool force_outer = false;    // test hook: use it whatever the size of the state
   bool drive_real = false;     // every drive series is real-valued
   bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
   // Monte-Carlo wavefunction mode (sesolve handles with ryd_set_collapse)
@@ -149,17 +150,20 @@ static bool tile14_pays(const ryd_handle* h) {
   return p14 < p12 && tiles >= 48;
 }
 
-// Small states (the whole batch fits in L2): ONE launch per application.  Each
-// workgroup stages its contiguous 2^T tile in LDS for the low-bit flips and reads
-// the partner amplitude of every higher bit from the same offset of another tile
-// (coalesced, L2-resident): (1 + nb - T) reads + 1 write per tile instead of one
-// read + one write per pass - the same bytes at nb - T = 2, but half the launches
-// of a launch-latency-bound regime (a single 14-atom ket: 7 us per launch).
+// Cache-resident states (batch <= 32 MiB: in, out and Horner base together stay
+// in the 256 MiB Infinity Cache): ONE launch per application.  Each workgroup
+// stages its contiguous 2^T tile in LDS for the low-bit flips and reads the
+// partner amplitude of every higher bit from the same offset of another tile
+// (coalesced, served by L2 / Infinity Cache): (1 + nb - T) reads + 1 write per
+// tile instead of one read + one write per pass - the same bytes at nb - T = 2,
+// but half the launches of a latency-bound regime (5-13 us per launch).  Measured
+// gains 1.5x (one 14-atom ket) ... 1.2x (one 20-atom ket, 16 x 17-atom kets);
+// beyond that the 2^14 register tiles take over (tile14_pays).
 static bool single_pass_pays(const ryd_handle* h, int T) {
   if (h->no_outer || !h->auto_tile || (h->cfg.mode == RYD_MESOLVE && h->has_dbl)) return false;
   if (h->nb <= T || h->nb - T > MAXO) return false;
   const size_t bytes = (size_t)h->B * sizeof(cplx) << h->nb;
-  return bytes <= ((size_t)2 << 20);
+  return h->force_outer || bytes <= ((size_t)32 << 20);
 }
 
 static void plan_passes(ryd_handle* h) {

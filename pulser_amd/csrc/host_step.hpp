@@ -628,11 +628,12 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
   h->force_generic = (force_generic & 1) != 0;
   {
     const bool no = (force_generic & 2) != 0, nt = (force_generic & 4) != 0,
-               ft = (force_generic & 8) != 0;
-    if (nt != h->no_tile14 || ft != h->force_tile14 || no != h->no_outer) {
+               ft = (force_generic & 8) != 0, fo = (force_generic & 16) != 0;
+    if (nt != h->no_tile14 || ft != h->force_tile14 || no != h->no_outer || fo != h->force_outer) {
       h->no_tile14 = nt;
       h->force_tile14 = ft;
       h->no_outer = no;
+      h->force_outer = fo;
       plan_passes(h);
     }
   }

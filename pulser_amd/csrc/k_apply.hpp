@@ -1,7 +1,7 @@
 // Part of librydemu (included by rydemu.hip, one translation unit).
 #define MAXF 16  // flips per pass (<= tile bits)
 #define MAXD 8   // double flips per pass
-#define MAXO 8   // outer flips per pass (partner tiles streamed from global memory)
+#define MAXO 10  // outer flips per pass (partner tiles streamed from global memory)
 
 struct PassArgs {
   const cplx* in;    // x: the vector G is applied to

@@ -289,14 +289,16 @@ class Engine:
         return counts
 
     def set_path(self, force_generic: bool, no_tile14: bool = False,
-                 force_tile14: bool = False, no_single_pass: bool = False) -> None:
+                 force_tile14: bool = False, no_single_pass: bool = False,
+                 force_single_pass: bool = False) -> None:
         """Test/bench hook: disable the persistent small-N kernel and/or the 2^14
         register-tile kernel with the Hermitian mesolve path (the tiled
         multi-pass kernels are used instead), or force the register tiles;
         ``no_single_pass`` disables the one-launch plan of L2-resident states."""
         _lib.check(self.lib.ryd_set_path(
             self._h, int(bool(force_generic)) | (2 if no_single_pass else 0)
-            | (4 if no_tile14 else 0) | (8 if force_tile14 else 0)))
+            | (4 if no_tile14 else 0) | (8 if force_tile14 else 0)
+            | (16 if force_single_pass else 0)))
 
     def apply_generator(self, x: Any, t: float) -> Any:
         """``G(t) x`` with ``G = -iH`` (sesolve) or the Lindbladian (mesolve)."""

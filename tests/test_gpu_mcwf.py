@@ -224,20 +224,21 @@ def test_exotic_collapse_operators_fall_back_to_the_master_equation():
 
 
 def test_quantum_jumps_on_register_tile_and_tiled_kernels_agree():
-    """14 atoms (beyond the persistent kernel): the 2^14 register-tile kernel and
-    the tiled two-pass kernels, both with the H_eff decay diagonal, give the same
-    trajectories; norms stay 1 and jumps happen."""
+    """14 atoms (beyond the persistent kernel): the 2^14 register-tile kernel, the
+    tiled kernel's single-launch plan and its two-pass plan, all with the H_eff decay
+    diagonal, give the same trajectories; norms stay 1 and jumps happen."""
     prob = _problem(14, seed=31)
     seeds = np.arange(64, dtype=np.uint64) + np.uint64(5)
     tables = lower([prob] * 64)
     out = []
-    for no14 in (False, True):
+    for no14, no_single in ((False, False), (True, False), (True, True)):
         with Engine(tables, mode="mcsolve") as eng:
-            eng.set_path(False, no_tile14=no14)
+            eng.set_path(False, no_tile14=no14, no_single_pass=no_single)
             state = eng.new_state()
             eng.mc_solve(state, np.array([0.0, 0.03]), seeds, store=False)
             out.append((state.cpu().numpy(), eng.mc_jumps(), eng.stats()["passes"]))
-    assert out[0][2] == 1 and out[1][2] == 2
-    assert np.array_equal(out[0][1], out[1][1]) and out[0][1].sum() > 10
-    assert np.max(np.abs(out[0][0] - out[1][0])) < 1e-10
+    assert [o[2] for o in out] == [1, 1, 2]
+    for other in out[1:]:
+        assert np.array_equal(out[0][1], other[1]) and out[0][1].sum() > 10
+        assert np.max(np.abs(out[0][0] - other[0])) < 1e-10
     assert np.allclose(np.linalg.norm(out[0][0], axis=-1), 1.0, atol=1e-12)
