@@ -303,11 +303,11 @@ def main() -> None:
         if args.workload == "cfg3":
             ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
             eng = Engine.from_problems([tri_problem(2, 7, ops)], mode="mesolve")
-            t0, t1, nb, kname = 1.0, 1.0 + 1e-3 * args.slice_ns, 28, "k_apply<mesolve> (tiled, multi-pass)"
+            t0, t1, nb, kname = 1.0, 1.0 + 1e-3 * args.slice_ns, 28, "k_apply14<mesolve> + k_symm (Hermitian path: 2^14 register-tile row pass + tile-pair symmetrisation)"
             wl = f"BASELINE configs[2]: 14-atom triangular register, dephasing mesolve (rho = 4.29 GB), {args.slice_ns} ns slice at t = 1 us"
         else:
             eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")
-            t0, t1, nb, kname = 1.0, 1.0 + 1e-3 * args.slice_ns, 20, "k_apply<sesolve> (tiled, multi-pass)"
+            t0, t1, nb, kname = 1.0, 1.0 + 1e-3 * args.slice_ns, 20, "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)"
             wl = f"BASELINE configs[4]: 20-atom 4x5 register, sesolve, {args.slice_ns} ns slice at t = 1 us"
         sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, t0, t1, args.steps, args.warmup, dist, torch)
         out = {"metric": "sim-us/sec", "value": n_gpus * (t1 - t0) / sec, **common,
@@ -407,7 +407,7 @@ def main() -> None:
                      "value": (t1 - t0) / sec, "unit": "sim-us/s", "ms_per_sim_ns": sec * 1e3 / 2,
                      "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
                      "trace": float(occ[-1].item()),
-                     "roofline": roofline(28, 1, stats, kms, kl, "k_apply<mesolve> (tiled, multi-pass)",
+                     "roofline": roofline(28, 1, stats, kms, kl, "k_apply14<mesolve> + k_symm (Hermitian path: 2^14 register-tile row pass + tile-pair symmetrisation)",
                                           "cfg3:k_apply")})
         eng.close()
         # cfg5: 20-atom sesolve slice
@@ -417,7 +417,7 @@ def main() -> None:
         also.append({"workload": "cfg5: 20-atom 4x5 register, sesolve, 20 ns slice at t = 1 us",
                      "value": (t1 - t0) / sec, "unit": "sim-us/s",
                      "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
-                     "roofline": roofline(20, 1, stats, kms, kl, "k_apply<sesolve> (tiled, multi-pass)")})
+                     "roofline": roofline(20, 1, stats, kms, kl, "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)")})
         eng.close()
         out["also"] = also
 
