@@ -150,27 +150,29 @@ static bool tile14_pays(const ryd_handle* h) {
   return p14 < p12 && tiles >= 48;
 }
 
-// Cache-resident states (batch <= 32 MiB: in, out and Horner base together stay
-// in the 256 MiB Infinity Cache): ONE launch per application.  Each workgroup
-// stages its contiguous 2^T tile in LDS for the low-bit flips and reads the
-// partner amplitude of every higher bit from the same offset of another tile
-// (coalesced, served by L2 / Infinity Cache): (1 + nb - T) reads + 1 write per
-// tile instead of one read + one write per pass - the same bytes at nb - T = 2,
-// but half the launches of a latency-bound regime (5-13 us per launch).  Measured
-// gains 1.5x (one 14-atom ket) ... 1.2x (one 20-atom ket, 16 x 17-atom kets);
-// beyond that the 2^14 register tiles take over (tile14_pays).
+// States up to 128 MiB whose high bits number at most MAXO: ONE launch per
+// application.  Each workgroup stages its contiguous 2^T tile in LDS for the
+// low-bit flips and reads the partner amplitude of every higher bit from the same
+// offset of another tile (coalesced; the re-reads are served by L2 / the 256 MiB
+// Infinity Cache): (1 + nb - T) reads + 1 write per tile instead of one read + one
+// write (+ partial sums) per pass, and half or a third of the launches of a
+// latency-bound regime (5-50 us per launch).  Measured against the best multi-pass
+// plan: 1.5x (one 14-atom ket), 1.4x (one 20-atom ket), 1.3x (21 atoms, 16 x 17),
+// 1.16x (64 x 16 atoms), 1.10x (256 x 15 atoms = 128 MiB), 1.06x (22 atoms).
 static bool single_pass_pays(const ryd_handle* h, int T) {
   if (h->no_outer || !h->auto_tile || (h->cfg.mode == RYD_MESOLVE && h->has_dbl)) return false;
   if (h->nb <= T || h->nb - T > MAXO) return false;
   const size_t bytes = (size_t)h->B * sizeof(cplx) << h->nb;
-  return h->force_outer || bytes <= ((size_t)32 << 20);
+  return h->force_outer || bytes <= ((size_t)128 << 20);
 }
 
 static void plan_passes(ryd_handle* h) {
   h->passes.clear();
   const int nb = h->nb, N = h->N, T = std::min(h->T, nb);
   const int C = 4;  // run bits (256 B contiguous) kept in every tile
-  if (single_pass_pays(h, T) && !(nb >= 14 && tile14_pays(h))) {
+  // (the 2^14 register tiles keep 14-bit states, where they are a single pass too,
+  // and whatever the test hook forces onto them)
+  if (single_pass_pays(h, T) && !(nb >= 14 && tile14_pays(h) && (nb == 14 || h->force_tile14))) {
     Pass p = make_pass(nb, {{0, T}});
     for (int j = 0; j < T; ++j) p.flip_q.push_back(j);
     for (int j = T; j < nb; ++j) p.oflip.push_back(j);

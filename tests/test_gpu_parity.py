@@ -249,9 +249,9 @@ def test_tiled_kernel_workgroup_widths_and_pass_plans(mode, n, batch, single_pas
     dev = _to_dev(eng, np.broadcast_to(x, shape).copy())
     got = eng.apply_generator(dev, 0.0123).cpu().numpy()
     # 13-atom kets: two 2^12-tile passes, or one pass of 2^13 tiles when >= 128 tiles remain;
-    # cache-resident batches (<= 32 MiB: these kets, 7- and 9-atom density matrices): one launch
+    # batches up to 128 MiB (these kets, 7- and 9-atom density matrices): one launch
     multi = {13: 2, 17: 2, 6: 1, 7: 2, 9: 2}[n] if batch < 128 else 1
-    small = 16 * batch * (2**n if mode == "sesolve" else 4**n) <= 32 << 20
+    small = 16 * batch * (2**n if mode == "sesolve" else 4**n) <= 128 << 20
     assert eng.stats()["passes"] == (1 if single_pass and small else multi)
     ham = qp.build_hamiltonian(prob)
     if mode == "sesolve":
