@@ -656,9 +656,39 @@ def _deserialize_complex(obj: Any) -> Any:
     return obj
 
 
+def _check_values(values: Any) -> Any:
+    """pulser/backend/aggregators.py:38-77: a non-empty list; nested elements are
+    numbers, lists of numbers or lists of lists of numbers."""
+    if not isinstance(values, list):
+        raise ValueError("Need to supply a list of values to process.")
+    if values == []:
+        raise ValueError("Cannot process 0 samples.")
+    return values[0]
+
+
+def _check_nested(elt: Any) -> None:
+    if elt == [] or len(elt) == 0:
+        raise ValueError("Cannot process list of empty lists.")
+    if not isinstance(elt[0], (float, complex, list)):
+        raise ValueError(f"Cannot process list of lists of {type(elt[0])}.")
+    if isinstance(elt[0], list):
+        if len(elt[0]) == 0:
+            raise ValueError("Cannot process list of matrices with empty columns.")
+        if not isinstance(elt[0][0], (float, complex)):
+            raise ValueError(f"Cannot process list of matrices of {type(elt[0][0])}.")
+
+
+def _is_torch_tensor(x: Any) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "dim")
+
+
 def _mean_of(values: list[Any]) -> Any:
     """pulser/backend/aggregators.py:119-156."""
-    elt = values[0]
+    elt = _check_values(values)
+    if _is_torch_tensor(elt):
+        import torch
+
+        return torch.stack(values).mean(dim=0)
     if isinstance(elt, np.ndarray):
         return np.stack(values).mean(axis=0)
     if isinstance(elt, (float, int)) and not isinstance(elt, bool):
@@ -667,12 +697,17 @@ def _mean_of(values: list[Any]) -> Any:
         return complex(np.mean(values))
     if not isinstance(elt, (list, tuple)):
         raise ValueError(f"Mean aggregator cannot process data of type {type(elt)}.")
+    _check_nested(elt)
     return list(np.mean(values, axis=0).tolist())
 
 
 def _std_of(values: list[Any]) -> Any:
     """pulser/backend/aggregators.py:80-116 (sample standard deviation, ddof=1)."""
-    elt = values[0]
+    elt = _check_values(values)
+    if _is_torch_tensor(elt):
+        import torch
+
+        return torch.stack(values).std(dim=0)
     if isinstance(elt, np.ndarray):
         return np.stack(values).std(axis=0, ddof=1)
     if isinstance(elt, (float, int)) and not isinstance(elt, bool):
@@ -681,6 +716,7 @@ def _std_of(values: list[Any]) -> Any:
         return complex(np.std(values, ddof=1))
     if not isinstance(elt, (list, tuple)):
         raise ValueError(f"Std aggregator cannot process data of type {type(elt)}.")
+    _check_nested(elt)
     return list(np.std(values, axis=0, ddof=1).tolist())
 
 

@@ -388,3 +388,38 @@ def test_simconfig_effective_noise_and_noise_model_conversion():
                          amp_sigma=1e-3, laser_waist=float("inf"), runs=10, samples_per_run=1)
     assert SimConfig.from_noise_model(nm) == expected
     assert expected.to_noise_model() == nm
+
+
+def test_mean_and_std_aggregators():
+    """/tests/test_aggregators.py:15-160 of the reference (pulser.backend.aggregators)."""
+    import torch
+
+    from pulser_amd.backend import _mean_of, _std_of
+
+    assert _mean_of([1.0, 2.0, 3.0, 4.0]) == 2.5 and _mean_of([1.0j, 2.0j, 3.0j, 4.0j]) == 2.5j
+    arrays = [np.array([1.0, 2.0, 3.0]), np.array([2.0, 3.0, 4.0]), np.array([3.0, 4.0, 5.0])]
+    assert np.all(_mean_of(arrays) == np.array([2.0, 3.0, 4.0]))
+    lists = [a.tolist() for a in arrays]
+    assert _mean_of(lists) == [2.0, 3.0, 4.0]
+    assert _mean_of([[x] for x in lists]) == [[2.0, 3.0, 4.0]]
+    assert torch.allclose(_mean_of([torch.tensor(x) for x in lists]), torch.tensor([2.0, 3.0, 4.0]))
+    assert np.isclose(_std_of([1.0, 2.0, 3.0, 4.0]), 1.2909944487358056)
+    assert np.isclose(_std_of([1.0j, 2.0j, 3.0j, 4.0j]), 1.2909944487358056)
+    assert np.all(_std_of(arrays) == np.array([1.0, 1.0, 1.0]))
+    assert _std_of(lists) == [1.0, 1.0, 1.0] and _std_of([[x] for x in lists]) == [[1.0, 1.0, 1.0]]
+    assert torch.allclose(_std_of([torch.tensor(x) for x in lists]), torch.tensor([1.0, 1.0, 1.0]))
+    for fn, name in ((_mean_of, "Mean"), (_std_of, "Std")):
+        with pytest.raises(ValueError, match="Cannot process 0 samples."):
+            fn([])
+        with pytest.raises(ValueError, match="Cannot process list of empty lists."):
+            fn([[], []])
+        with pytest.raises(ValueError, match="Need to supply a list of values to process."):
+            fn("abcd")
+        with pytest.raises(ValueError, match=f"{name} aggregator cannot process data"):
+            fn([{}, {}])
+        with pytest.raises(ValueError, match=f"Cannot process list of lists of {type({})}."):
+            fn([[{}], [{}]])
+        with pytest.raises(ValueError, match=f"Cannot process list of matrices of {type('a')}."):
+            fn([[["abcd"]], [["efgh"]]])
+        with pytest.raises(ValueError, match="Cannot process list of matrices with empty columns."):
+            fn([[[]], [[]]])
