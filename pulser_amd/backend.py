@@ -392,6 +392,22 @@ class HamiltonianOperator:
 
 
 # --------------------------------------------------------------- observables
+TIME_TOLERANCE = 1e-12  # observable.py:33
+
+
+def _validate_eval_times(evaluation_times: Any) -> np.ndarray:
+    """observable.py:219-242: relative times in [0, 1], distinct up to 1e-12, ascending."""
+    ev = np.array(evaluation_times, dtype=float)
+    if np.any((ev < 0.0) | (ev > 1.0)):
+        raise ValueError(f"All evaluation times must be between 0. and 1. Instead, got {evaluation_times!r}.")
+    if np.any(np.abs(ev[:-1] - ev[1:]) < TIME_TOLERANCE):
+        raise ValueError(f"Evaluation times must be unique up to {TIME_TOLERANCE} but "
+                         f"{evaluation_times!r} has repeated values.")
+    if not np.all(ev[:-1] < ev[1:]):
+        raise ValueError(f"Evaluation times must be in ascending order.Instead, got {evaluation_times!r}.")
+    return ev
+
+
 class Observable:
     """pulser/backend/observable.py:60-215."""
 
@@ -400,12 +416,7 @@ class Observable:
     def __init__(self, *, evaluation_times: Sequence[float] | None = None,
                  tag_suffix: str | None = None) -> None:
         if evaluation_times is not None:
-            ev = np.array(evaluation_times, dtype=float)
-            if ev.ndim != 1 or np.any(ev < 0) or np.any(ev > 1) or np.any(np.diff(ev) <= 0):
-                raise ValueError(
-                    "All evaluation times must be between 0. and 1., unique and sorted in ascending order."
-                )
-            self.evaluation_times: np.ndarray | None = ev
+            self.evaluation_times: np.ndarray | None = _validate_eval_times(evaluation_times)
         else:
             self.evaluation_times = None
         self._tag_suffix = tag_suffix
@@ -913,7 +924,7 @@ class QutipConfig:
                 "If provided, `initial_state` must be an instance of "
                 f"`RydState`, not {type(initial_state)}."
             )
-        if noise_model is not None and noise_model.samples_per_run not in (None, 1):
+        if noise_model is not None and getattr(noise_model, "samples_per_run", None) not in (None, 1):
             warnings.warn(
                 f"The number of samples per run (`samples_per_run` = {noise_model.samples_per_run}) "
                 "is ignored when using QutipBackendV2.", stacklevel=2)
@@ -922,11 +933,26 @@ class QutipConfig:
         except ValueError:
             raise ValueError(f"Invalid solver '{solver}'. Allowed solvers are: "
                              + ", ".join(v.value for v in Solver) + ".") from None
+        if not observables and not callbacks:  # config.py:259-266
+            warnings.warn("'QutipConfig' was initialized without any observables. The corresponding "
+                          "emulation results will be empty.", stacklevel=2)
+        for i, cb in enumerate(callbacks):
+            if isinstance(cb, Observable):
+                raise TypeError("All entries in 'callbacks' must not be instances of Observable, since "
+                                f"those go in 'observables'. Instead, got {cb!r} at index {i}.")
+            if not callable(cb):
+                raise TypeError("All entries in 'callbacks' must be instances of Callback. Instead, got "
+                                f"instance of type {type(cb)} at index {i}: {cb!r}.")
+        for i, obs in enumerate(observables):
+            if not isinstance(obs, Observable):
+                raise TypeError("All entries in 'observables' must be instances of Observable. Instead, "
+                                f"got instance of type {type(obs)} at index {i}: {obs!r}.")
         tags = [o.tag for o in observables]
-        if len(set(tags)) != len(tags):
-            raise ValueError("Some of the provided 'observables' share identical tags. Use 'tag_suffix' to make them unique.")
-        if not all(isinstance(o, Observable) for o in observables):
-            raise TypeError("All entries in 'observables' must be instances of Observable.")
+        if repeated := [k for k, v in Counter(tags).items() if v > 1]:
+            raise ValueError(
+                "Some of the provided 'observables' share identical tags. Use 'tag_suffix' when "
+                "instantiating multiple instances of the same observable so they can be distinguished. "
+                f"Repeated tags found: {repeated}")
         self.observables = tuple(observables)
         self.callbacks = tuple(callbacks)
         if isinstance(default_evaluation_times, str):
@@ -934,15 +960,24 @@ class QutipConfig:
                 raise ValueError(f"'default_evaluation_times' must be 'Full' or a sequence of floats, not {default_evaluation_times!r}.")
             self.default_evaluation_times: Any = "Full"
         else:
-            ev = np.array(default_evaluation_times, dtype=float)
-            if ev.ndim != 1 or np.any(ev < 0) or np.any(ev > 1) or np.any(np.diff(ev) <= 0):
-                raise ValueError("All evaluation times must be between 0. and 1., unique and sorted in ascending order.")
-            self.default_evaluation_times = ev
+            self.default_evaluation_times = _validate_eval_times(list(map(float, default_evaluation_times)))
         self.initial_state = initial_state
         self.with_modulation = bool(with_modulation)
-        self.noise_model = noise_model if noise_model is not None else NoiseModel()
+        if noise_model is None:
+            noise_model = NoiseModel()
+        elif not hasattr(noise_model, "noise_types"):  # pulser.NoiseModel instances are welcome
+            raise TypeError(f"When defined, 'noise_model' must be a NoiseModel instance, not {type(noise_model)}.")
+        self.noise_model = noise_model
         self.prefer_device_noise_model = bool(prefer_device_noise_model)
-        self.n_trajectories = n_trajectories
+        runs = getattr(noise_model, "runs", None)
+        if n_trajectories is not None and runs is not None and n_trajectories != runs:
+            raise ValueError("`EmulationConfig.n_trajectories` and `NoiseModel.runs` can't be simultaneously "
+                             "defined. Please favour using only `EmulationConfig.n_trajectories`.")
+        if n_trajectories is None:  # config.py:368-374
+            n_trajectories = 40 if prefer_device_noise_model else (runs if runs is not None else 1)
+        if n_trajectories < 1 or n_trajectories != int(n_trajectories):
+            raise ValueError(f"`n_trajectories` must be a strictly positive integer, not {n_trajectories}.")
+        self.n_trajectories = int(n_trajectories)
         if not (0 < sampling_rate <= 1.0):
             raise ValueError(f"The sampling rate (`sampling_rate` = {sampling_rate}) must be greater than 0 and less than or equal to 1.")
         self.sampling_rate = sampling_rate

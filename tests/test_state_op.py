@@ -423,3 +423,50 @@ def test_mean_and_std_aggregators():
             fn([[["abcd"]], [["efgh"]]])
         with pytest.raises(ValueError, match="Cannot process list of matrices with empty columns."):
             fn([[[]], [[]]])
+
+
+def test_emulation_config_semantics():
+    """/tests/test_backend.py:570-802 of the reference (``EmulationConfig``), for the
+    parts this backend's ``QutipConfig`` implements."""
+    from pulser_amd import NoiseModel
+    from pulser_amd.backend import BitStrings, QutipConfig
+
+    with pytest.warns(UserWarning, match="'QutipConfig' was initialized without any observables"):
+        QutipConfig()
+    with pytest.raises(TypeError, match="All entries in 'observables' must be instances of Observable"
+                       ".*at index 0.*fidelity"):
+        QutipConfig(observables=["fidelity"])
+    with pytest.raises(TypeError, match="All entries in 'callbacks' must not be instances of Observable"
+                       ".*at index 0"):
+        QutipConfig(callbacks=(BitStrings(),))
+    with pytest.raises(TypeError, match="All entries in 'callbacks' must be instances of Callback"
+                       ".*at index 0.*Hello"):
+        QutipConfig(callbacks=("Hello",), observables=(BitStrings(),))
+    with pytest.raises(ValueError, match="Some of the provided 'observables' share identical tags"):
+        QutipConfig(observables=[BitStrings(), BitStrings(num_shots=200000)])
+    with pytest.raises(ValueError, match="All evaluation times must be between 0. and 1."):
+        QutipConfig(observables=(BitStrings(),), default_evaluation_times=[-1e15, 0.0, 0.5, 1.0])
+    with pytest.raises(ValueError, match="Evaluation times must be unique up to"):
+        QutipConfig(observables=(BitStrings(),), default_evaluation_times=[0.0, 0.5, 0.5 + 1e-14, 1.0])
+    with pytest.raises(ValueError, match="Evaluation times must be in ascending order"):
+        QutipConfig(observables=(BitStrings(),), default_evaluation_times=[0.0, 1.0, 0.5])
+    with pytest.raises(TypeError, match="must be a NoiseModel"):
+        QutipConfig(observables=(BitStrings(),), noise_model={"p_false_pos": 0.1})
+    for bad in (0, 1.001):
+        with pytest.raises(ValueError, match="strictly positive integer"):
+            QutipConfig(observables=(BitStrings(),), n_trajectories=bad)
+    with pytest.deprecated_call():
+        runs_nm = NoiseModel(amp_sigma=0.1, runs=10)
+    with pytest.raises(ValueError, match="`EmulationConfig.n_trajectories` and `NoiseModel.runs` can't be"
+                       " simultaneously defined"):
+        QutipConfig(observables=(BitStrings(),), noise_model=runs_nm, n_trajectories=2)
+    assert QutipConfig(observables=(BitStrings(),), noise_model=runs_nm, n_trajectories=10.0).n_trajectories == 10
+    assert QutipConfig(observables=(BitStrings(),), noise_model=runs_nm).n_trajectories == 10
+    assert QutipConfig(observables=(BitStrings(),), noise_model=runs_nm,
+                       prefer_device_noise_model=True).n_trajectories == 40
+    config = QutipConfig(observables=(BitStrings(),))
+    assert config.n_trajectories == 1
+    assert config.with_changes(n_trajectories=10).n_trajectories == 10 and config.n_trajectories == 1
+    times = np.array([0.5, 1.0])
+    conf = QutipConfig(default_evaluation_times=times, observables=(BitStrings(),))
+    np.testing.assert_equal(conf.default_evaluation_times, times)
