@@ -840,25 +840,36 @@ class Results:
         with each observable's default aggregation (mean, Counter union, mean and
         standard deviation, mean of density matrices) or the function / kind
         name given for the tag; 'skip' / 'skip_warn' tags are dropped."""
-        if not results:
-            raise ValueError("no results to aggregate")
+        if len(results) == 0:
+            raise ValueError("No results to aggregate.")
         first = results[0]
+        if len(results) == 1:
+            return first
+        common = [t for t in first._tagmap if all(t in r._tagmap for r in results)]
+        for r in results:
+            if r._results and not r._aggregation:
+                raise NotImplementedError("You're trying to aggregate results from pulser<1.6,"
+                                          "aggregation is not supported in this case.")
+            for tag, uid in r._tagmap.items():
+                if tag not in common and r._aggregation[uid] not in ("skip", "skip_warn"):
+                    raise ValueError("You're trying to aggregate incompatible results: "
+                                     f"result `{tag}` is not present in all results, "
+                                     "but it's not marked to be skipped.")
+        if not all({t: r._aggregation[r._tagmap[t]] for t in common}
+                   == {t: first._aggregation[first._tagmap[t]] for t in common}
+                   for r in results):
+            raise ValueError("You're trying to aggregate incompatible results: "
+                             "they do not all contain the same aggregation functions.")
         if not all(r.atom_order == first.atom_order for r in results):
             raise ValueError("You're trying to aggregate incompatible results: "
                              "they do not all have the same atom order.")
         if not all(r.total_duration == first.total_duration for r in results):
             raise ValueError("You're trying to aggregate incompatible results: "
                              "they do not all have the same sequence duration.")
-        common = [t for t in first._tagmap if all(t in r._tagmap for r in results)]
-        if not all({t: r._aggregation.get(r._tagmap[t], "mean") for t in common}
-                   == {t: first._aggregation.get(first._tagmap[t], "mean") for t in common}
-                   for r in results):
-            raise ValueError("You're trying to aggregate incompatible results: "
-                             "they do not all contain the same aggregation functions.")
         out = cls(first.atom_order, first.total_duration)
         for tag in common:
             uid = first._tagmap[tag]
-            kind = first._aggregation.get(uid, "mean")
+            kind = first._aggregation[uid]
             agg = aggregators.get(tag, kind)
             if agg in ("skip", "skip_warn"):
                 if agg == "skip_warn":

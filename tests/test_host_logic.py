@@ -647,8 +647,19 @@ def test_results_abstract_repr_and_aggregation_match_pulser_core():
     top = Results.aggregate(mine, energy=max, occupation="skip")
     assert top.get_result("energy", 0.5) == 2 - 3.25 * 0.5 and "occupation" not in top.get_result_tags()
     other = Results(("q0", "q1"), 1000)
+    with pytest.raises(ValueError, match="result `bitstrings` is not present in all results"):
+        Results.aggregate([mine[0], other])
+    other = Results.from_abstract_repr(extra["json_texts"][0])
+    other.atom_order = ("q0", "q1")
     with pytest.raises(ValueError, match="same atom order"):
         Results.aggregate([mine[0], other])
+    other = Results.from_abstract_repr(extra["json_texts"][0])
+    other.total_duration = 2000
+    with pytest.raises(ValueError, match="same sequence duration"):
+        Results.aggregate([mine[0], other])
+    with pytest.raises(ValueError, match="No results to aggregate."):
+        Results.aggregate([])
+    assert Results.aggregate([mine[0]]) is mine[0]
     # states serialise only when built from amplitudes (backend/state.py:234-254)
     st = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rg": 0.6, "gr": 0.8j})
     d = json.loads(json.dumps({"s": st}, cls=type(agg)._encoder()))
