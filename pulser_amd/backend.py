@@ -438,6 +438,13 @@ class Observable:
     def tag(self) -> str:
         return self._base_tag if self._tag_suffix is None else f"{self._base_tag}_{self._tag_suffix}"
 
+    @property
+    def uuid(self) -> uuid.UUID:
+        return self._uuid
+
+    def __repr__(self) -> str:
+        return f"{self.tag}:{self._uuid}"
+
     def __call__(self, config: "QutipConfig", t: float, state: RydState,
                  hamiltonian: HamiltonianOperator, result: "Results") -> None:
         time_tol = (0.5 / result.total_duration) if result.total_duration else 1e-6
@@ -800,10 +807,13 @@ class Results:
         self._times[uid].append(time)
 
     def _find_uuid(self, observable: Observable | str) -> uuid.UUID:
-        tag = observable.tag if isinstance(observable, Observable) else observable
-        if tag not in self._tagmap:
-            raise ValueError(f"{tag!r} is not an Observable instance nor a known observable tag in the results.")
-        return self._tagmap[tag]
+        if isinstance(observable, Observable):
+            if observable._uuid not in self._results:
+                raise ValueError(f"'{observable!r}' has not been stored in the results")
+            return observable._uuid
+        if observable not in self._tagmap:
+            raise ValueError(f"{observable!r} is not an Observable instance nor a known observable tag in the results.")
+        return self._tagmap[observable]
 
     def get_result_tags(self) -> list[str]:
         return list(self._tagmap.keys())
@@ -823,15 +833,67 @@ class Results:
             raise ValueError(f"{observable!r} is not available at time {time}.")
         return self._results[uid][int(hit[0])]
 
-    def __getattr__(self, name: str) -> list[Any]:
-        if name.startswith("_") or name not in self.__dict__.get("_tagmap", {}):
-            raise AttributeError(f"{name!r} is not in the results.")
-        return list(self._results[self._tagmap[name]])
+    _SAMPLED_RESULT_ATTRS = ("sampling_dist", "sampling_errors", "get_samples", "get_state",
+                             "plot_histogram", "n_samples", "evaluation_time", "meas_basis")
+
+    def __getattr__(self, name: str) -> Any:
+        """results.py:156-174: ``results.<tag>`` = the list of stored values."""
+        if not name.startswith("_") and name in self.__dict__.get("_tagmap", {}):
+            return list(self._results[self._tagmap[name]])
+        if name == "bitstring_counts":
+            warnings.warn("'bitstring_counts' is an attribute of the deprecated `SampledResult` class. "
+                          "Please favor acessing the bitstrings via 'final_bitstrings' instead.",
+                          category=FutureWarning, stacklevel=2)
+            return self.final_bitstrings
+        if name in self._SAMPLED_RESULT_ATTRS:
+            raise AttributeError(f"{name} is available only in 'SampledResult', which has been"
+                                 " deprecated and is being phased out.")
+        raise AttributeError(f"{name!r} is not in the results.")
 
     @property
     def final_bitstrings(self) -> Counter:
-        """pulser/backend/results.py: the 'bitstrings' observable at t = 1."""
-        return self.get_result("bitstrings", 1.0)
+        """results.py:176-190: the 'bitstrings' observable at t = 1."""
+        try:
+            return self.get_result("bitstrings", 1.0)
+        except ValueError:
+            raise RuntimeError(
+                "The final bitstrings are not available. Please make sure 'BitStrings()' at relative "
+                "time t=1.0 is included in the observables of your emulator backend's configuration "
+                "(when possible).") from None
+
+    @property
+    def final_state(self) -> RydState:
+        """results.py:192-204: the 'state' observable at t = 1."""
+        try:
+            return self.get_result("state", 1.0)
+        except ValueError:
+            raise RuntimeError(
+                "The final state is not available. Please make sure 'StateResult()' at relative "
+                "time t=1.0 is included in the observables of your emulator backend's configuration "
+                "(when possible).") from None
+
+    @classmethod
+    def from_final_bitstrings(cls, atom_order: Sequence[str], total_duration: int,
+                              final_bitstrings: Mapping[str, int]) -> "Results":
+        """results.py:77-112: a Results holding only final bitstrings (e.g. from a QPU)."""
+        try:
+            bitstrings = Counter(final_bitstrings)
+        except TypeError:
+            raise TypeError("'final_bitstrings' is not a valid bitstrings counter; "
+                            f"got {final_bitstrings}") from None
+        obs = BitStrings(num_shots=sum(bitstrings.values()))
+        obs._uuid = uuid.UUID("00000000-0000-0000-0000-000000000000")
+        res = cls(tuple(atom_order), total_duration)
+        res._store(observable=obs, time=1.0, value=bitstrings)
+        return res
+
+    def __str__(self) -> str:
+        times = {tag: self._times[uid] for tag, uid in self._tagmap.items()}
+        name = self.__class__.__name__
+        return "\n".join([name, "-" * len(name), f"Stored results: {self.get_result_tags()}",
+                          f"Evaluation times per result: {times}",
+                          f"Atom order in states and bitstrings: {self.atom_order}",
+                          f"Total sequence duration: {self.total_duration} ns"])
 
     @classmethod
     def aggregate(cls, results: Sequence["Results"],

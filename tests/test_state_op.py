@@ -470,3 +470,67 @@ def test_emulation_config_semantics():
     times = np.array([0.5, 1.0])
     conf = QutipConfig(default_evaluation_times=times, observables=(BitStrings(),))
     np.testing.assert_equal(conf.default_evaluation_times, times)
+
+
+def test_results_container():
+    """/tests/test_backend.py:1060-1247 of the reference (``pulser.backend.Results``)."""
+    from collections import Counter
+
+    from pulser_amd.backend import BitStrings, QutipConfig, Results, StateResult
+
+    res = Results(atom_order=(), total_duration=100)
+    assert res.get_result_tags() == [] and res.get_tagged_results() == {}
+    template = "\n".join(["Results", "-------", "Stored results: {stored}",
+                          "Evaluation times per result: {times}",
+                          "Atom order in states and bitstrings: ()", "Total sequence duration: 100 ns"])
+    assert str(res) == template.format(stored=[], times={})
+    with pytest.raises(AttributeError, match="'bitstrings' is not in the results"):
+        res.bitstrings
+    with pytest.raises(ValueError, match="'bitstrings' is not an Observable instance nor a known observable tag"):
+        res.get_result_times("bitstrings")
+    obs = BitStrings(num_shots=100, tag_suffix="test")
+    with pytest.raises(ValueError, match=f"'bitstrings_test:{obs.uuid}' has not been stored"):
+        res.get_result(obs, 1.0)
+    state = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rrr": 1.0})
+    ham = RydOperator.from_operator_repr(eigenstates=("r", "g"), n_qudits=3, operations=[(1.0, [])])
+    obs(config=QutipConfig(observables=(obs,)), t=1.0, state=state, hamiltonian=ham, result=res)
+    expected = [Counter({"111": 100})]
+    assert res.get_result_tags() == ["bitstrings_test"]
+    assert res.get_tagged_results() == {"bitstrings_test": expected} and res.bitstrings_test == expected
+    assert res.get_result_times("bitstrings_test") == res.get_result_times(obs) == [1.0]
+    assert res.get_result(obs, 1.0) == res.get_result("bitstrings_test", 1.0) == expected[0]
+    with pytest.raises(ValueError, match="not available at time 0.912"):
+        res.get_result(obs, 0.912)
+    assert str(res) == template.format(stored=["bitstrings_test"], times={"bitstrings_test": [1.0]})
+    # final bitstrings / state
+    empty = Results(atom_order=(), total_duration=0)
+    with pytest.raises(RuntimeError, match="final bitstrings are not available"):
+        empty.final_bitstrings
+    with pytest.raises(RuntimeError, match="final state is not available"):
+        empty.final_state
+    plain = BitStrings()
+    plain(config=QutipConfig(observables=(BitStrings(),)), t=1.0, state=state, hamiltonian=ham, result=empty)
+    assert empty.final_bitstrings == empty.get_result(plain, 1.0)
+    so, holder = StateResult(), Results(atom_order=(), total_duration=0)
+    so(config=QutipConfig(observables=(so,)), t=1.0, state=state, hamiltonian=ham, result=holder)
+    assert holder.final_state == holder.get_result(so, 1.0) == state
+    # from_final_bitstrings
+    counts = {"000": 60, "111": 40}
+    made = Results.from_final_bitstrings(atom_order=("q0", "q1", "q2"), total_duration=1000,
+                                         final_bitstrings=counts)
+    assert made.atom_order == ("q0", "q1", "q2") and made.total_duration == 1000
+    assert made.final_bitstrings == Counter(counts) and made.get_result_times("bitstrings") == [1.0]
+    with pytest.raises(TypeError, match="'final_bitstrings' is not a valid bitstrings counter"):
+        Results.from_final_bitstrings(atom_order=("q0",), total_duration=100, final_bitstrings=42)
+    with pytest.warns(FutureWarning, match="'bitstring_counts' is an attribute of the deprecated"):
+        assert made.bitstring_counts == made.final_bitstrings
+    with pytest.warns(FutureWarning, match="'bitstring_counts'"):
+        with pytest.raises(RuntimeError, match="final bitstrings are not available"):
+            Results(atom_order=("q0",), total_duration=100).bitstring_counts
+    blank = Results(atom_order=("q0",), total_duration=100)
+    for attr in ("sampling_dist", "sampling_errors", "get_samples", "get_state", "plot_histogram",
+                 "n_samples", "evaluation_time", "meas_basis"):
+        with pytest.raises(AttributeError, match=f"{attr} is available only in 'SampledResult'"):
+            getattr(blank, attr)
+    with pytest.raises(AttributeError, match="'not_an_attr' is not in the results"):
+        blank.not_an_attr
