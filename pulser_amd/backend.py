@@ -508,7 +508,7 @@ class Fidelity(Observable):
                  tag_suffix: str | None = None) -> None:
         super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
         if not isinstance(state, RydState):
-            raise TypeError(f"'state' must be a RydState, not {type(state)}.")
+            raise TypeError(f"'state' must be a State instance; got {type(state)} instead.")
         self.state = state
 
     def _to_abstract_repr(self) -> dict[str, Any]:
@@ -609,8 +609,8 @@ class CorrelationMatrix(Observable):
 class Energy(Observable):
     _base_tag = "energy"
 
-    def apply(self, *, state: RydState, hamiltonian: HamiltonianOperator, **kw: Any) -> float:
-        return hamiltonian.expect(state)
+    def apply(self, *, state: RydState, hamiltonian: Any, **kw: Any) -> float:
+        return float(np.real(hamiltonian.expect(state)))
 
 
 class EnergySecondMoment(Observable):
@@ -619,11 +619,10 @@ class EnergySecondMoment(Observable):
     _base_tag = "energy_second_moment"
 
     def apply(self, *, state: RydState, hamiltonian: HamiltonianOperator, **kw: Any) -> float:
-        s = state.to_qobj()
-        if s.isket:
-            hs = hamiltonian._h_on(s)
-            return float(np.real(np.vdot(hs, hs)))
-        return float(np.real(np.trace(np.asarray(hamiltonian.apply_to(state).to_qobj()))))
+        applied = np.asarray(hamiltonian.apply_to(state).to_qobj())  # H|psi> or H rho H
+        if state.to_qobj().isket:
+            return float(np.real(np.vdot(applied, applied)))
+        return float(np.real(np.trace(applied)))
 
 
 class EnergyVariance(Observable):
@@ -632,7 +631,7 @@ class EnergyVariance(Observable):
 
     def apply(self, *, state: RydState, hamiltonian: HamiltonianOperator, **kw: Any) -> float:
         second = EnergySecondMoment.apply(self, state=state, hamiltonian=hamiltonian)  # type: ignore[arg-type]
-        return second - hamiltonian.expect(state) ** 2
+        return second - float(np.real(hamiltonian.expect(state))) ** 2
 
 
 # ------------------------------------------------------------------- results
