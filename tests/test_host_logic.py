@@ -1217,6 +1217,29 @@ def test_evaluation_times_instructions():
         st[np.linspace(0, len(st) - 1, int(0.4 * len(st)), dtype=int)], sim._eval_times_array)
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_two_and_three_dimensional_registers(dim):
+    """tests/pulser_simulation/test_hamiltonian.py:31-80: 2D and 3D registers with a global
+    channel and two local channels build without error; U = C6 / round(r, 6)^6."""
+    from oracle import qutip_path as qp
+
+    coords = np.array([[-4.0, 0.0, 0.0], [0.0, 4.0, 3.0]])[:, :dim]
+    z = np.zeros(20)
+    inputs = SequenceInputs(coords, ("q0", "q1"), [
+        ChannelInput("ch0", "Global", "ground-rydberg", z + 1.0, z, z, slots=[Slot(0, 20, (0, 1))]),
+        ChannelInput("ch1", "Local", "digital", z, z, z, slots=[Slot(0, 10, (0,))]),
+        ChannelInput("ch2", "Local", "digital", z, z, z, slots=[Slot(0, 10, (1,))])], P.C6_LEVEL70)
+    emu = QutipEmulator(inputs, sampling_rate=0.5)
+    prob = emu._current_problem
+    r = round(float(np.linalg.norm(coords[0] - coords[1])), 6)
+    assert prob["interaction_matrix"][0][0, 1] == pytest.approx(P.C6_LEVEL70 / r**6, rel=1e-14)
+    assert qp.build_hamiltonian(prob).matrix(0.005).shape == (4, 4)  # the idle digital basis is unused
+    np.random.seed(1)
+    noisy = QutipEmulator(inputs, sampling_rate=0.5, n_trajectories=2,
+                          noise_model=NoiseModel(temperature=30.0, trap_depth=150.0, trap_waist=1.0))
+    assert [t.coords.shape for t in noisy._hamiltonian_data.noise_trajectories] == [(2, 3), (2, 3)]
+
+
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
     + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
