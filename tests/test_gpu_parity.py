@@ -421,3 +421,25 @@ def test_persistent_density_matrix_kernel_global_real_drive(case, n):
             ham = qp.build_hamiltonian(p)
             ref = qp.mesolve(ham, qp.all_ground_state(n, p["eigenbasis"]), times, max_step=1e-3, **qp.TIGHT)
             assert np.max(np.abs(outs[False][-1][b] - ref[-1])) < AMP_TOL
+
+
+@pytest.mark.parametrize("mode,n", [("sesolve", 13), ("sesolve", 15), ("mesolve", 7)])
+def test_single_launch_plan_with_different_problems_per_batch_entry(mode, n):
+    """Three different local-addressing problems in one batch (own coefficients and own
+    interaction diagonal per entry): the single-launch plan (partner tiles of the high
+    bits read from global memory) against the multi-pass tiling, and - where the
+    persistent kernel exists - against it."""
+    ops = [(np.sqrt(0.1), "sigma_rr")] if mode == "mesolve" else None
+    probs = [local_problem(n, seed=s, duration=31, collapse_ops=ops) for s in (3, 4, 5)]
+    times = np.array([0.0, 0.004, 0.011])
+    outs = {}
+    for name, kw in (("single", {}), ("multi", {"no_single_pass": True})):
+        eng = _engine(probs, mode=mode)
+        eng.set_path(True, no_tile14=True, **kw)
+        outs[name] = eng.solve(eng.new_state(), times).cpu().numpy()
+        assert eng.stats()["passes"] == (1 if name == "single" else 2)
+    assert np.max(np.abs(outs["single"] - outs["multi"])) < 1e-13
+    if mode == "sesolve" and n <= 13:
+        eng = _engine(probs, mode=mode)
+        assert np.max(np.abs(eng.solve(eng.new_state(), times).cpu().numpy() - outs["single"])) < 1e-12
+    assert np.max(np.abs(outs["single"][-1][0] - outs["single"][-1][1])) > 1e-3  # really different problems
