@@ -294,7 +294,7 @@ class Engine:
         """Test/bench hook: disable the persistent small-N kernel and/or the 2^14
         register-tile kernel with the Hermitian mesolve path (the tiled
         multi-pass kernels are used instead), or force the register tiles;
-        ``no_single_pass`` disables the one-launch plan of L2-resident states."""
+        ``no_single_pass`` disables the one-launch plan of states up to 128 MiB."""
         _lib.check(self.lib.ryd_set_path(
             self._h, int(bool(force_generic)) | (2 if no_single_pass else 0)
             | (4 if no_tile14 else 0) | (8 if force_tile14 else 0)

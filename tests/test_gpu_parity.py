@@ -234,7 +234,7 @@ def test_persistent_kernel_cfg2_chain12_snapshots():
 def test_tiled_kernel_workgroup_widths_and_pass_plans(mode, n, batch, single_pass):
     """The tiled kernel in both workgroup widths (1024 threads when a launch has
     at most 512 tiles, 512 otherwise), with balanced multi-pass plans and with the
-    single-launch plan of L2-resident states (low bits in LDS, the partner of every
+    single-launch plan of states up to 128 MiB (low bits in LDS, the partner of every
     higher bit read from the same offset of another tile), against the oracle's
     sparse matvec / Lindblad right-hand side."""
     from oracle import qutip_path as qp

@@ -1,4 +1,4 @@
-"""Single-launch plan of L2-resident states vs the multi-pass tiling (dev probe):
+"""Single-launch plan (partner tiles through L2 / Infinity Cache) vs the multi-pass tiling (dev probe):
 single kets of 14-17 atoms, small batches, 7-8-atom density matrices."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
