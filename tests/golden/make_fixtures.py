@@ -2,7 +2,11 @@
 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 \
         PYTHONPATH=/tmp/shim:/root/reference/pulser-core:/root/repo \
-        python /root/repo/tests/golden/make_fixtures.py
+        python /root/repo/tests/golden/make_fixtures.py [name ...]
+
+Names (default: rydberg digital three cfg1 cfg2 cfg3 cfg4): rydberg, digital, xy, all, three, cfg1..cfg4,
+spam_all, results_noisy, final_state_noisy, slm_effective_size, slm_masks, modulation, eom_limit_det,
+multichannel_noise, dmm, results, waist, config.
 
 * Inputs are captured by importing the reference's ``pulser-core`` (read-only,
   never shipped; needs the no-op ``jsonschema``/``referencing`` stand-in of
