@@ -18,6 +18,7 @@ matrix-free generator kernel on the device (``ryd_apply_generator``).
 from __future__ import annotations
 
 import collections.abc
+import enum
 import json
 import math
 import uuid
@@ -33,7 +34,7 @@ from .simulation import QutipEmulator, Solver
 
 __all__ = [
     "QutipBackendV2", "QutipBackend", "EmulatorConfig", "QutipConfig", "RydState", "RydOperator", "Results", "Observable", "StateResult",
-    "BitStrings", "Fidelity", "Expectation", "CorrelationMatrix", "Occupation", "Energy",
+    "AggregationMethod", "BitStrings", "Fidelity", "Expectation", "CorrelationMatrix", "Occupation", "Energy",
     "EnergyVariance", "EnergySecondMoment",
 ]
 
@@ -414,13 +415,21 @@ class Observable:
     default_aggregation = "mean"
 
     def __init__(self, *, evaluation_times: Sequence[float] | None = None,
-                 tag_suffix: str | None = None) -> None:
+                 tag_suffix: str | None = None, default_aggregation_method: Any = None) -> None:
         if evaluation_times is not None:
             self.evaluation_times: np.ndarray | None = _validate_eval_times(evaluation_times)
         else:
             self.evaluation_times = None
         self._tag_suffix = tag_suffix
         self._uuid = uuid.uuid4()
+        if default_aggregation_method is not None:  # per-instance override (observable.py:100-131)
+            kind = default_aggregation_method
+            self.default_aggregation = kind if isinstance(kind, str) else _AGG_KIND[int(kind)]
+
+    @property
+    def default_aggregation_method(self) -> "AggregationMethod":
+        """How results of this observable are combined over trajectories (read-only)."""
+        return AggregationMethod(_AGG_CODE[self.default_aggregation])
 
     _base_tag = "observable"
 
@@ -479,8 +488,10 @@ class BitStrings(Observable):
 
     def __init__(self, *, evaluation_times: Sequence[float] | None = None,
                  num_shots: int | None = None, one_state: str | None = None,
-                 tag_suffix: str | None = None) -> None:
-        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+                 tag_suffix: str | None = None,
+                 default_aggregation_method: Any = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix,
+                         default_aggregation_method=default_aggregation_method)
         if num_shots is not None and num_shots < 1:
             raise ValueError(f"'num_shots' must be greater than or equal to 1, not {num_shots}.")
         self._num_shots = None if num_shots is None else int(num_shots)
@@ -505,8 +516,10 @@ class Fidelity(Observable):
     _base_tag = "fidelity"
 
     def __init__(self, state: RydState, *, evaluation_times: Sequence[float] | None = None,
-                 tag_suffix: str | None = None) -> None:
-        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+                 tag_suffix: str | None = None,
+                 default_aggregation_method: Any = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix,
+                         default_aggregation_method=default_aggregation_method)
         if not isinstance(state, RydState):
             raise TypeError(f"'state' must be a State instance; got {type(state)} instead.")
         self.state = state
@@ -527,8 +540,10 @@ class Expectation(Observable):
     _base_tag = "expectation"
 
     def __init__(self, operator: Any, *, evaluation_times: Sequence[float] | None = None,
-                 tag_suffix: str | None = None) -> None:
-        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+                 tag_suffix: str | None = None,
+                 default_aggregation_method: Any = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix,
+                         default_aggregation_method=default_aggregation_method)
         if not isinstance(operator, (RydOperator, np.ndarray)):
             raise TypeError(f"'operator' must be an Operator instance; got {type(operator)} instead.")
         self.operator = operator
@@ -571,8 +586,10 @@ class Occupation(Observable):
     _base_tag = "occupation"
 
     def __init__(self, *, evaluation_times: Sequence[float] | None = None,
-                 one_state: str | None = None, tag_suffix: str | None = None) -> None:
-        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+                 one_state: str | None = None, tag_suffix: str | None = None,
+                 default_aggregation_method: Any = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix,
+                         default_aggregation_method=default_aggregation_method)
         self.one_state = one_state
 
     def _to_abstract_repr(self) -> dict[str, Any]:
@@ -591,8 +608,10 @@ class CorrelationMatrix(Observable):
     _base_tag = "correlation_matrix"
 
     def __init__(self, *, evaluation_times: Sequence[float] | None = None,
-                 one_state: str | None = None, tag_suffix: str | None = None) -> None:
-        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix)
+                 one_state: str | None = None, tag_suffix: str | None = None,
+                 default_aggregation_method: Any = None) -> None:
+        super().__init__(evaluation_times=evaluation_times, tag_suffix=tag_suffix,
+                         default_aggregation_method=default_aggregation_method)
         self.one_state = one_state
 
     def _to_abstract_repr(self) -> dict[str, Any]:
@@ -635,7 +654,17 @@ class EnergyVariance(Observable):
 
 
 # ------------------------------------------------------------------- results
-# AggregationMethod (pulser/backend/observable.py:79-86) <-> the kinds used here
+class AggregationMethod(enum.IntEnum):
+    """pulser/backend/observable.py:79-86 (same values, so pulser's own enum compares equal)."""
+
+    SKIP = 0
+    SKIP_WARN = 1
+    MEAN = 2
+    BAG_UNION = 3
+    MEANSTD = 4
+
+
+# AggregationMethod <-> the kinds used here
 _AGG_CODE = {"skip": 0, "skip_warn": 1, "density_matrix": 1, "mean": 2, "bag_union": 3, "meanstd": 4}
 _AGG_KIND = {0: "skip", 1: "skip_warn", 2: "mean", 3: "bag_union", 4: "meanstd"}
 
@@ -932,6 +961,8 @@ class Results:
             uid = first._tagmap[tag]
             kind = first._aggregation[uid]
             agg = aggregators.get(tag, kind)
+            if isinstance(agg, int) and not callable(agg):
+                agg = _AGG_KIND[int(agg)]
             if agg in ("skip", "skip_warn"):
                 if agg == "skip_warn":
                     warnings.warn(f"Skipping aggregation of `{tag}`.")

@@ -161,4 +161,30 @@ def test_expectation_and_fidelity(ghz_state, ham, zzz):
 def test_default_aggregation(obs_cls, default):
     """test_backend.py:886-905 (StateResult: the backend's density-matrix aggregator replaces
     the reference's SKIP_WARN, qutip_backend.py:322-325)."""
+    from pulser_amd.backend import AggregationMethod
+
+    codes = {"density_matrix": AggregationMethod.SKIP_WARN, "bag_union": AggregationMethod.BAG_UNION,
+             "mean": AggregationMethod.MEAN, "skip_warn": AggregationMethod.SKIP_WARN}
     assert obs_cls().default_aggregation == default
+    assert obs_cls().default_aggregation_method == codes[default]
+    with pytest.raises(AttributeError):  # read-only
+        obs_cls().default_aggregation_method = AggregationMethod.SKIP
+    overridden = obs_cls(default_aggregation_method=AggregationMethod.SKIP)
+    assert overridden.default_aggregation_method == AggregationMethod.SKIP
+    assert obs_cls(default_aggregation_method=4).default_aggregation == "meanstd"
+
+
+def test_aggregate_with_enum_methods(config, ghz_state, ham):
+    """test_backend.py:805-884: per-tag aggregation given as an AggregationMethod."""
+    from pulser_amd.backend import AggregationMethod
+
+    runs = []
+    occ = Occupation()
+    for shift in (0.0, 1.0):
+        res = Results(atom_order=("q0", "q1", "q2"), total_duration=1000)
+        res._store(observable=occ, time=1.0, value=[0.5 + shift, 0.5, 0.5])
+        runs.append(res)
+    assert Results.aggregate(runs).occupation == [[1.0, 0.5, 0.5]]
+    both = Results.aggregate(runs, occupation=AggregationMethod.MEANSTD).occupation
+    assert isinstance(both[0], tuple) and np.allclose(both[0][1], [np.sqrt(0.5), 0.0, 0.0])
+    assert "occupation" not in Results.aggregate(runs, occupation=AggregationMethod.SKIP).get_result_tags()
