@@ -1296,14 +1296,14 @@ class QutipBackendV2:
     """qutip_backend.py:121-325 on the MI355X engine.  ``sequence`` is a
     ``pulser.Sequence`` (needs pulser) or a ``pulser_amd.SequenceInputs``."""
 
-    default_config = None  # built lazily (observables carry uuids)
+    default_config: "QutipConfig"  # set right after the class (qutip_backend.py:136-138)
+    config_type: type  # = QutipConfig
 
     def __init__(self, sequence: Any, *, config: QutipConfig | None = None,
                  mimic_qpu: bool = False) -> None:
         if config is not None and not isinstance(config, QutipConfig):
             raise TypeError("'config' must be an instance of 'EmulationConfig'")
-        self._config = config or QutipConfig(observables=[BitStrings(evaluation_times=[1.0]),
-                                                          StateResult()])
+        self._config = config or self.default_config
         cfg = self._config
         nm = self._get_noise_model(cfg, getattr(sequence, "device", None))
         has_dmm = (any(c.is_dmm for c in sequence.channels) if hasattr(sequence, "channels")
@@ -1316,6 +1316,12 @@ class QutipBackendV2:
                 "`detuning_map_spot_waist` to be defined. If not defined,"
                 "atom thermal motion can lead to non-physical effects."
             )
+        device_nm = getattr(getattr(sequence, "device", None), "noise_model", None)
+        if (cfg.prefer_device_noise_model and device_nm is not None
+                and getattr(device_nm, "runs", None) is not None
+                and device_nm.runs != cfg.n_trajectories):  # pulser/backend/abc.py:123-135
+            warnings.warn(f"'sequence.device.noise_model.runs={device_nm.runs}' is being ignored; "
+                          f"'config.n_trajectories={cfg.n_trajectories}' will be used instead.", stacklevel=2)
         kw = dict(sampling_rate=cfg.sampling_rate, noise_model=nm, solver=cfg.solver,
                   n_trajectories=cfg.n_trajectories)
         if hasattr(sequence, "_schedule"):
@@ -1349,7 +1355,7 @@ class QutipBackendV2:
                                   *, config: QutipConfig | None = None) -> Results:
         """qutip_backend.py:194-232: emulate already sampled sequences (pulser
         ``SequenceSamples`` + register + device, or ``SequenceInputs``)."""
-        cfg = config or QutipConfig(observables=[BitStrings(evaluation_times=[1.0]), StateResult()])
+        cfg = config or QutipBackendV2.default_config
         sim = QutipEmulator(sequence_samples, register, device, sampling_rate=cfg.sampling_rate,
                             noise_model=QutipBackendV2._get_noise_model(cfg, device),
                             solver=cfg.solver, n_trajectories=cfg.n_trajectories)
@@ -1395,3 +1401,7 @@ class QutipBackendV2:
                     fill(res, coherent, ham_engine)
                     results.append(res)
             return Results.aggregate(results)
+
+
+QutipBackendV2.default_config = QutipConfig(observables=[BitStrings(evaluation_times=[1.0]), StateResult()])
+QutipBackendV2.config_type = QutipConfig
