@@ -279,3 +279,42 @@ def test_legacy_qutip_backend():
     assert isinstance(backend.run(), NoisyResults) and backend._sim_obj.noise_model == spam
     with pytest.raises(ValueError, match="'evaluation_times' must be one of the following options"):
         EmulatorConfig(evaluation_times="Best")
+
+
+def test_backend_v2_callbacks_and_device_noise_model(capfd):
+    """tests/pulser_simulation/test_qutip_backend_v2.py:91-108 (a callback sees every
+    evaluation time of a "Full" run, noisy or not) and :158-196 (the device's noise model
+    wins when the configuration prefers it; the configuration keeps its own)."""
+    class CountCalls:
+        def __init__(self):
+            self.counter = 0
+
+        def __call__(self, config, t, state, hamiltonian, result):
+            self.counter += 1
+
+    inputs = _constant_pulse_inputs(2, 8.0, 120, np.pi)
+    for kw in ({}, {"noise_model": NoiseModel(amp_sigma=0.1), "n_trajectories": 1}):
+        backend = QutipBackendV2(inputs, config=QutipConfig(callbacks=[CountCalls()], **kw))
+        np.random.seed(3)
+        backend.run()
+        assert backend._config.callbacks[0].counter == 120 + 1
+    with pytest.raises(TypeError, match="'config' must be an instance of 'EmulationConfig'"):
+        QutipBackendV2(inputs, config="tralala")
+
+    class Device:
+        noise_model = NoiseModel(dephasing_rate=0.01, temperature=50.0)
+
+    class Holder:  # a sequence-like object that only carries what the backend reads
+        device = Device()
+        channels = inputs.channels
+
+    cfg = QutipConfig(observables=[StateResult(evaluation_times=[1.0])],
+                      noise_model=NoiseModel(p_false_neg=0.1), prefer_device_noise_model=True,
+                      n_trajectories=2, print_progress=True)
+    assert QutipBackendV2._get_noise_model(cfg, Holder.device) is Device.noise_model
+    assert cfg.noise_model.p_false_neg == 0.1
+    sim_cfg = cfg.with_changes(prefer_device_noise_model=False, noise_model=Device.noise_model)
+    capfd.readouterr()
+    np.random.seed(4)
+    QutipBackendV2(inputs, config=sim_cfg).run()
+    assert capfd.readouterr().out == "Emulating Trajectory 1/2\nEmulating Trajectory 2/2\n"
