@@ -1171,7 +1171,8 @@ class QutipConfig:
                     eigenstates=tuple(st["eigenstates"]), amplitudes=amps), **kw))
             else:
                 observables.append(kinds[o["observable"]](**kw))
-            observables[-1]._uuid = uuid.UUID(o["uuid"])
+            if "uuid" in o:  # optional in the schema
+                observables[-1]._uuid = uuid.UUID(o["uuid"])
             if "default_aggregation_method" in o:
                 observables[-1].default_aggregation = _AGG_KIND[int(o["default_aggregation_method"])]
         init = obj.get("initial_state")
