@@ -98,3 +98,46 @@ def test_config_documents():
             assert back.noise_model == config.noise_model
             assert (back.sampling_rate, back.solver, back.progress_bar, back.n_trajectories) == (
                 config.sampling_rate, config.solver, config.progress_bar, config.n_trajectories)
+
+
+@pytest.mark.parametrize("use_torch", [False, True])
+def test_result_serialization(use_torch):
+    """test_backend_abstract_repr.py:585-666: arrays / tensors become lists, complex
+    entries survive, times, tags and aggregation methods come back."""
+    import torch
+
+    from pulser_amd.backend import Results
+
+    rng = np.random.default_rng(7)
+    bitstrings, corr, energy, occ = BitStrings(), CorrelationMatrix(), Energy(), Occupation()
+    results = Results(atom_order=(), total_duration=100)
+    results._store(observable=bitstrings, time=0.1, value="rgrgrg")
+    cor_mat = torch.from_numpy(rng.normal(size=(6, 6))) if use_torch else rng.normal(size=(6, 6))
+    results._store(observable=corr, time=0.2, value=cor_mat)
+    results._store(observable=energy, time=0.3, value=5.0)
+    occ_vec = rng.normal(size=6).astype(complex)
+    occ_vec[0] += 1j
+    occ_vec = torch.from_numpy(occ_vec) if use_torch else occ_vec
+    results._store(observable=occ, time=0.4, value=occ_vec)
+    d = results._to_abstract_repr()
+    assert d["results"][str(bitstrings.uuid)] == ["rgrgrg"] and d["results"][str(energy.uuid)] == [5.0]
+    assert type(d["results"][str(corr.uuid)][0]) is type(cor_mat)
+    assert d["tagmap"] == {o.tag: str(o.uuid) for o in (bitstrings, corr, energy, occ)}
+    assert d["times"] == {str(bitstrings.uuid): [0.1], str(corr.uuid): [0.2], str(energy.uuid): [0.3],
+                          str(occ.uuid): [0.4]}
+    assert d["aggregation_methods"] == {str(bitstrings.uuid): AggregationMethod.BAG_UNION,
+                                        str(corr.uuid): AggregationMethod.MEAN,
+                                        str(energy.uuid): AggregationMethod.MEAN,
+                                        str(occ.uuid): AggregationMethod.MEAN}
+    text = results.to_abstract_repr()
+    assert text == json.dumps(d, cls=_AbstractReprEncoder)
+    back = Results.from_abstract_repr(text)
+    assert results.energy == back.energy and results.bitstrings == back.bitstrings
+    assert [x.tolist() for x in results.occupation] == back.occupation
+    assert isinstance(back.occupation[0][0], complex)
+    assert all(isinstance(v, float) for v in back.occupation[0][1:])
+    assert [x.tolist() for x in results.correlation_matrix] == back.correlation_matrix
+    for o in (bitstrings, occ, corr, energy):
+        assert results.get_result_times(o) == back.get_result_times(o)
+    assert results.get_result_tags() == back.get_result_tags()
+    assert results._aggregation == back._aggregation
