@@ -137,11 +137,16 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
     }
     {
       const bool wide = (size_t)grid.x * grid.y <= 512 && p.T >= 10;
+      const bool pre = A.n_oflip > 0 && (1 << p.T) <= (wide ? 1024 : 512);
       if (h->cfg.mode == RYD_SESOLVE) {
-        if (wide) hipLaunchKernelGGL((k_apply<RYD_SESOLVE, 1024>), grid, dim3(1024), lds, st, A);
+        if (pre && wide) hipLaunchKernelGGL((k_apply<RYD_SESOLVE, 1024, true>), grid, dim3(1024), lds, st, A);
+        else if (pre) hipLaunchKernelGGL((k_apply<RYD_SESOLVE, 512, true>), grid, dim3(512), lds, st, A);
+        else if (wide) hipLaunchKernelGGL((k_apply<RYD_SESOLVE, 1024>), grid, dim3(1024), lds, st, A);
         else hipLaunchKernelGGL((k_apply<RYD_SESOLVE, 512>), grid, dim3(512), lds, st, A);
       } else {
-        if (wide) hipLaunchKernelGGL((k_apply<RYD_MESOLVE, 1024>), grid, dim3(1024), lds, st, A);
+        if (pre && wide) hipLaunchKernelGGL((k_apply<RYD_MESOLVE, 1024, true>), grid, dim3(1024), lds, st, A);
+        else if (pre) hipLaunchKernelGGL((k_apply<RYD_MESOLVE, 512, true>), grid, dim3(512), lds, st, A);
+        else if (wide) hipLaunchKernelGGL((k_apply<RYD_MESOLVE, 1024>), grid, dim3(1024), lds, st, A);
         else hipLaunchKernelGGL((k_apply<RYD_MESOLVE, 512>), grid, dim3(512), lds, st, A);
       }
     }

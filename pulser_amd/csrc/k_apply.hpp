@@ -46,7 +46,10 @@ __device__ __forceinline__ int tile_bit_pos(const Segs& s, int q) {
 
 // out = post * (base + scale * (kin + G~_pass x))        (final pass)
 // kout = kin + G~_pass x                                  (other passes)
-template <int MODE, int NT>
+// PRE (single-launch plan with at most one amplitude per thread): the partner
+// amplitudes of the outer bits are fetched into registers before the barrier, so
+// their global-memory latency overlaps the LDS staging instead of following it.
+template <int MODE, int NT, bool PRE = false>
 __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = A.T;
@@ -70,6 +73,14 @@ __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
   // ---- stage the tile (coalesced 16 B / lane) ----
   for (int l = tid; l < tileSize; l += NT)
     xs[l] = xin[base_idx | deposit((unsigned long long)l, A.tile)];
+
+  cplx pre[PRE ? MAXO : 1];
+  if (PRE && tid < tileSize) {
+    const unsigned long long g0 = base_idx | deposit((unsigned long long)tid, A.tile);
+#pragma unroll
+    for (int f = 0; f < MAXO; ++f)
+      if (f < A.n_oflip) pre[f] = xin[g0 ^ (1ull << A.oflip_p[f])];
+  }
 
   // ---- per-pass coefficient tables ----
   if (tid < A.n_flip) {
@@ -180,8 +191,14 @@ __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
       const cplx cc = ((l >> q) & 1) ? c1[f] : c0[f];
       acc = cfma(cc, xv, acc);
     }
-    for (int f = 0; f < A.n_oflip; ++f)  // coalesced: the partner tile has the same layout
-      acc = cfma(oc[f], xin[gi ^ (1ull << A.oflip_p[f])], acc);
+    if (PRE) {
+#pragma unroll
+      for (int f = 0; f < MAXO; ++f)
+        if (f < A.n_oflip) acc = cfma(oc[f], pre[f], acc);
+    } else {
+      for (int f = 0; f < A.n_oflip; ++f)  // coalesced: the partner tile has the same layout
+        acc = cfma(oc[f], xin[gi ^ (1ull << A.oflip_p[f])], acc);
+    }
     if (MODE == RYD_MESOLVE) {
       for (int d = 0; d < A.n_dbl; ++d) {
         const int qb = A.dbl_qb[d], qa = A.dbl_qa[d];
