@@ -160,7 +160,8 @@ static bool tile14_pays(const ryd_handle* h) {
 // plan: 1.5x (one 14-atom ket), 1.4x (one 20-atom ket), 1.3x (21 atoms, 16 x 17),
 // 1.16x (64 x 16 atoms), 1.10x (256 x 15 atoms = 128 MiB), 1.06x (22 atoms).
 static bool single_pass_pays(const ryd_handle* h, int T) {
-  if (h->no_outer || !h->auto_tile || (h->cfg.mode == RYD_MESOLVE && h->has_dbl)) return false;
+  if (h->no_outer || (!h->auto_tile && !h->force_outer) || (h->cfg.mode == RYD_MESOLVE && h->has_dbl))
+    return false;
   if (h->nb <= T || h->nb - T > MAXO) return false;
   const size_t bytes = (size_t)h->B * sizeof(cplx) << h->nb;
   return h->force_outer || bytes <= ((size_t)128 << 20);
@@ -170,12 +171,25 @@ static void plan_passes(ryd_handle* h) {
   h->passes.clear();
   const int nb = h->nb, N = h->N, T = std::min(h->T, nb);
   const int C = 4;  // run bits (256 B contiguous) kept in every tile
+  // Tile size of the single-launch plan: about one tile per CU (256 tiles), between
+  // 2^9 and 2^12 amplitudes - smaller tiles mean more partner reads but more
+  // workgroups in flight (measured, tools/single_pass_bench2.py: 17 atoms 4.0 -> 5.6
+  // sim-us/s at 2^9 instead of 2^11, 18 atoms 3.6 -> 4.3 at 2^10; 20 atoms is best
+  // at 2^12).  States that fit one tile anyway are left alone.
+  int Ts = T;
+  if (h->auto_tile && nb > T) {
+    int logB = 0;
+    while ((1 << logB) < h->B) ++logB;
+    Ts = std::min(12, std::max(9, nb + logB - 8));
+    Ts = std::max(Ts, nb - MAXO);
+  }
   // (the 2^14 register tiles keep 14-bit states, where they are a single pass too,
   // and whatever the test hook forces onto them)
-  if (single_pass_pays(h, T) && !(nb >= 14 && tile14_pays(h) && (nb == 14 || h->force_tile14))) {
-    Pass p = make_pass(nb, {{0, T}});
-    for (int j = 0; j < T; ++j) p.flip_q.push_back(j);
-    for (int j = T; j < nb; ++j) p.oflip.push_back(j);
+  if (nb > T && single_pass_pays(h, Ts) &&
+      !(nb >= 14 && tile14_pays(h) && (nb == 14 || h->force_tile14))) {
+    Pass p = make_pass(nb, {{0, Ts}});
+    for (int j = 0; j < Ts; ++j) p.flip_q.push_back(j);
+    for (int j = Ts; j < nb; ++j) p.oflip.push_back(j);
     p.include_diag = true;
     h->passes.push_back(p);
     h->stats.passes = 1;

@@ -1,17 +1,10 @@
-"""Where does the single-launch plan stop paying? (dev probe)"""
+"""Tile size of the single-launch plan: more, smaller tiles (more partner reads) vs fewer, larger ones (dev probe)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quick_bench import run
 
 if __name__ == "__main__":
-    # density matrices: Hermitian path (2^14 register-tile row pass + symmetrisation) vs one launch
-    run(11, "mesolve", 0.006)
-    run(11, "mesolve", 0.006, no14=True)
-    run(10, "mesolve", 0.012)
-    run(10, "mesolve", 0.012, force14=True)
-    run(9, "mesolve", 0.012, batch=16)
-    run(9, "mesolve", 0.012, batch=16, no14=True)
-    # defaults after the policy change
-    run(21, "sesolve", 0.032)
-    run(15, "sesolve", 0.012, batch=256)
-    run(14, "sesolve", 0.022, batch=256)
+    for n, t1, tiles in ((15, 0.102, (9, 10, 11)), (16, 0.082, (9, 10, 11)), (17, 0.062, (9, 10, 11, 12)),
+                         (18, 0.052, (10, 11, 12)), (20, 0.032, (10, 11, 12))):
+        for t in tiles:
+            run(n, "sesolve", t1, tile_bits=t, force_single=True)
