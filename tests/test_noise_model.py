@@ -185,3 +185,39 @@ def test_register_noise_parameters():
     assert set(nm.noise_types) == {"doppler", "register"}
     with pytest.raises(ValueError, match="trap_waist, trap_depth, and temperature must be defined"):
         NoiseModel(trap_waist=1.0, trap_depth=150.0, runs=1)
+
+
+def test_register_sigma_and_shot_to_shot_classification():
+    """/tests/test_hamiltonian_data.py:25-33 (sigma_xy = 0.158, sigma_z = 0.826 um at 15 uK,
+    1 um waist, 150 uK depth) and :648-675 (which noise types vary from shot to shot)."""
+    from types import SimpleNamespace
+
+    from pulser_amd.noise_model import has_shot_to_shot_except_spam, register_sigma_xy_z
+
+    sxy, sz = register_sigma_xy_z(15.0, 1.0, 150.0)
+    assert 0.158 == pytest.approx(sxy, abs=1e-2) and 0.826 == pytest.approx(sz, abs=1e-2)
+    for data, expected in ((dict(noise_types="doppler"), True),
+                           (dict(noise_types="amplitude", amp_sigma=1), True),
+                           (dict(noise_types="amplitude", amp_sigma=0), False),
+                           (dict(noise_types="detuning"), True), (dict(noise_types="register"), True),
+                           (dict(noise_types="dmm_sigma"), True), (dict(noise_types="SPAM"), False),
+                           (dict(noise_types="other"), False),
+                           (dict(noise_types={"other", "doppler"}), True)):
+        assert has_shot_to_shot_except_spam(SimpleNamespace(**data)) is expected
+
+
+def test_high_frequency_detuning_noise_formula():
+    """/tests/test_hamiltonian_data.py:616-645: delta_hf(t) = sum_i sqrt(2 df_i S_i) cos(w_i t + phi_i)."""
+    from pulser_amd.hamiltonian_data import generate_detuning_fluctuations
+
+    psd, freqs = [1, 2, 3], [3, 4, 5]
+    times = np.arange(0, 10, 0.1)
+    rng = np.random.default_rng(3)
+    phases = rng.uniform(0, 2 * np.pi, size=2)
+    nm = NoiseModel(detuning_hf_psd=psd, detuning_hf_omegas=freqs)
+    got = generate_detuning_fluctuations(nm, 0.0, phases, times)
+    want = np.zeros_like(times)
+    for i, s in enumerate(psd[1:]):
+        want += np.sqrt(2 * (freqs[i + 1] - freqs[i]) * s) * np.cos(freqs[i + 1] * times * 1e-3 + phases[i])
+    assert got.size == times.size and np.allclose(got, want)
+    assert np.allclose(generate_detuning_fluctuations(nm, 0.25, phases, times), want + 0.25)
