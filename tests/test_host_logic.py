@@ -1240,6 +1240,48 @@ def test_two_and_three_dimensional_registers(dim):
     assert [t.coords.shape for t in noisy._hamiltonian_data.noise_trajectories] == [(2, 3), (2, 3)]
 
 
+def test_noisy_interaction_matrix_seeded_golden_and_dmm_detuning():
+    """/tests/test_hamiltonian_data.py:511-560 (seed 0xDEADBEEF, state_prep_error 0.5: bad atoms
+    [batman, aquaman], U(superman, ironman) = 26.4198) and :678-759 (DMM detuning with dmm_sigma:
+    det_q = det + factor x weight_q x dmm_det)."""
+    c6_level60 = 865723.02  # AnalogDevice (rydberg_level 60), pulser/devices/interaction_coefficients
+    coords = np.array([[-4.0, 0.0], [4.0, 0.0], [0.0, 4.0], [0.0, -4.0]])
+    w = np.clip(np.blackman(200), 0, np.inf)
+    amp = w * (np.pi / 5) / (w.sum() * 1e-3)
+    inputs = SequenceInputs(coords, ("batman", "superman", "ironman", "aquaman"),
+                            [ChannelInput("ch0", "Global", "ground-rydberg", amp, 0 * amp, 0 * amp,
+                                          slots=[Slot(0, 200, (0, 1, 2, 3))])], c6_level60)
+    np.random.seed(0xDEADBEEF)
+    hd = HamiltonianData(inputs.extend_duration(201), NoiseModel(state_prep_error=0.5), 1)
+    traj = hd.noise_trajectories[0]
+    assert list(traj.bad_atoms) == [True, False, False, True]
+    mat = hd.problem(traj, 1.0)["interaction_matrix"]
+    expected = np.zeros((1, 4, 4))
+    expected[0, 1, 2] = expected[0, 2, 1] = 26.4198
+    assert np.allclose(mat, expected, atol=1e-4)
+    # DMM: two atoms with weights 1.0 / 0.5, constant detunings
+    xy = np.array([[0.0, 0.0], [0.0, 5.0]])
+    ones = np.ones(100)
+    ryd = ChannelInput("ch0", "Global", "ground-rydberg", ones, -1.0 * ones, 0 * ones, slots=[Slot(0, 100, (0, 1))])
+    dmm = ChannelInput("dmm_0", "Global", "ground-rydberg", 0 * ones, -10.0 * ones, 0 * ones,
+                       slots=[Slot(0, 100, (0, 1))], dmm_trap_coords=xy, dmm_weights=np.array([1.0, 0.5]),
+                       dmm_qubit_coords=xy)
+    seq = SequenceInputs(xy, ("q0", "q1"), [ryd, dmm], c6_level60)
+    np.random.seed(0xDEADBEEF)
+    clean = HamiltonianData(seq.extend_duration(101), NoiseModel(), 1)
+    nested = clean.problem(clean.noise_trajectories[0], 1.0)["samples"]
+    loc = nested["Local"]["ground-rydberg"]  # noiseless: the Rydberg channel stays global
+    assert np.allclose(nested["Global"]["ground-rydberg"]["det"][:100], -1.0)
+    assert np.allclose(loc[0]["det"][:100], -10 * 1.0) and np.allclose(loc[1]["det"][:100], -10 * 0.5)
+    noisy = HamiltonianData(seq.extend_duration(101), NoiseModel(dmm_sigma=0.5), 1)
+    t0 = noisy.noise_trajectories[0]
+    factor = t0.dmm_det_fluctuation["dmm_0"]
+    assert isinstance(t0.dmm_det_fluctuation, dict) and factor >= 0 and not np.isclose(factor, 1.0)
+    loc = noisy.problem(t0, 1.0)["samples"]["Local"]["ground-rydberg"]
+    assert np.allclose(loc[0]["det"][:100], -1 - 10 * 1.0 * factor)
+    assert np.allclose(loc[1]["det"][:100], -1 - 10 * 0.5 * factor)
+
+
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
     + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
