@@ -1282,6 +1282,70 @@ def test_noisy_interaction_matrix_seeded_golden_and_dmm_detuning():
     assert np.allclose(loc[1]["det"][:100], -1 - 10 * 0.5 * factor)
 
 
+@pytest.mark.parametrize("leakage", [False, True])
+def test_building_basis_and_projection_operators(leakage):
+    """tests/pulser_simulation/test_simulation.py:253-430: eigenbasis and dimension per
+    addressed basis (with / without the leakage level), ``build_operator`` and its errors."""
+    def noise(dim):
+        return (NoiseModel(with_leakage=True, eff_noise_opers=[np.eye(dim)], eff_noise_rates=[0.0])
+                if leakage else NoiseModel())
+
+    def kets(dim, names):
+        return {s: np.eye(dim)[:, [i]] for i, s in enumerate(names)}
+
+    amp = np.ones(100)
+    z = np.zeros(100)
+    coords = np.array([[-4.0, 0.0], [0.0, 4.0], [4.0, 0.0]])
+    ids = ("control1", "target", "control2")
+
+    def emulator(channels, dim, **kw):
+        return QutipEmulator(SequenceInputs(coords, ids, channels, P.C6_LEVEL70, **kw), sampling_rate=0.1,
+                             noise_model=noise(dim))
+
+    ryd = ChannelInput("ryd", "Local", "ground-rydberg", amp, z, z, slots=[Slot(0, 100, (1,))])
+    ram = ChannelInput("ram", "Local", "digital", amp, z, z, slots=[Slot(0, 100, (1,))])
+    glob = ChannelInput("glob", "Global", "ground-rydberg", amp, z, z, slots=[Slot(0, 100, (0, 1, 2))])
+    mw = ChannelInput("mw", "Global", "XY", amp, z, z, slots=[Slot(0, 100, (0, 1, 2))])
+    suffix = "_with_error" if leakage else ""
+    x = ["x"] if leakage else []
+    for channels, name, states, kw in (
+            ([ryd, ram], "all", ["r", "g", "h"], {}),
+            ([glob], "ground-rydberg", ["r", "g"], {}),
+            ([ram], "digital", ["g", "h"], {}),
+            ([ryd], "ground-rydberg", ["r", "g"], {}),
+            ([mw], "XY", ["u", "d"], dict(interaction_coeff_xy=3700.0, magnetic_field=(0.0, 0.0, 30.0)))):
+        dim = len(states) + leakage
+        sim = emulator(channels, dim, **kw)
+        assert sim.basis_name == name + suffix and sim.dim == dim
+        want = kets(dim, states + x)
+        assert list(sim.basis) == states + x
+        for s in want:
+            assert np.array_equal(np.asarray(sim.basis[s]), want[s])
+        a, b = states[0], states[1]
+        proj = sim.build_operator([(f"sigma_{a}{a}", ["target"])])
+        assert np.array_equal(proj, np.kron(np.kron(np.eye(dim), want[a] @ want[a].T), np.eye(dim)))
+        low = sim.build_operator([(f"sigma_{b}{a}", ["control2"])])
+        assert np.array_equal(low, np.kron(np.eye(dim * dim), want[b] @ want[a].T))
+        if leakage:
+            assert np.array_equal(sim.build_operator([(f"sigma_x{a}", ["control1"])]),
+                                  np.kron(want["x"] @ want[a].T, np.eye(dim * dim)))
+    sim = emulator([ryd, ram], 3 + leakage)
+    with pytest.raises(ValueError, match="Duplicate atom"):
+        sim.build_operator([("sigma_gg", ["target", "target"])])
+    with pytest.raises(ValueError, match="not a valid operator"):
+        sim.build_operator([("wrong", ["target"])])
+    with pytest.raises(ValueError, match="Invalid qubit names: {'wrong'}"):
+        sim.build_operator([("sigma_gg", ["wrong"])])
+    one = sim.build_operator(("sigma_gg", ["target"]))
+    assert np.array_equal(one, sim.build_operator([("sigma_gg", ["target"])]))
+    total = sim.build_operator([("sigma_rr", "global")])
+    assert np.array_equal(total, sum(sim.build_operator([("sigma_rr", [q])]) for q in ids))
+    zz = sim.build_operator([("sigma_gg", ["control1", "target"]), ("sigma_rr", ["control2"])])
+    d = sim.dim
+    g, r = np.eye(d)[:, [1]], np.eye(d)[:, [0]]
+    assert np.array_equal(zz, np.kron(np.kron(g @ g.T, g @ g.T), r @ r.T))
+
+
 def test_laser_waist_hf_detuning_and_register_noise_follow_pulser_core():
     """amp_sigma x finite laser waist (hamiltonian_data.py:758-780), detuning_sigma
     + high-frequency detuning PSD (:132-169), doppler and register noise (:116-130)
