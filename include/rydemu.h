@@ -100,8 +100,9 @@ typedef struct ryd_dterm {
 
 typedef struct ryd_opts {
   int32_t taylor_order; /* 0 = choose from norm bound and `tol` */
-  int32_t max_order;    /* cap for the automatic choice (default 24) */
-  double tol;           /* per-exponential truncation bound (default 1e-12) */
+  int32_t max_order;    /* cap for the automatic choice (default and maximum 32) */
+  double tol;           /* per-exponential truncation bound (default 1e-10: ends <= 2e-8 from the
+                           tight oracle after a 3.1 us sequence, the stated bar being 1e-7) */
   double max_step;      /* us; 0 = no cap (steps never straddle a spline knot) */
   double magnus_tol;    /* per-interval Magnus error target driving the automatic
                            sub-stepping next to waveform kinks (default 1e-10) */
@@ -134,6 +135,15 @@ int ryd_set_series(ryd_handle* h, int32_t n_series, int32_t n_knots,
 /* Replaces: the per-qubit / global [operator, coefficient] term list of
  * build_coeffs_ops (hamiltonian.py:333-389).  desc[batch][N], host pointer. */
 int ryd_set_qubit_desc(ryd_handle* h, const ryd_qdesc* desc);
+
+/* Replaces: the per-trajectory high-frequency detuning-noise synthesis of
+ * HamiltonianData._generate_detuning_fluctuations
+ * (pulser-core/pulser/_hamiltonian_data/hamiltonian_data.py:132-169, added to
+ * the samples at :464-468).  terms[n_terms] (host pointer; copied) is the table
+ * that ryd_qdesc.extra indexes (1-based); n_terms = 0 removes it.  May be called
+ * before or after ryd_set_qubit_desc; every `extra` is checked against the table
+ * when a solve / apply starts (RYD_ERR_INVALID if it points outside). */
+int ryd_set_detuning_terms(ryd_handle* h, int32_t n_terms, const ryd_dterm* terms);
 
 /* Replaces: make_vdw_term / make_interaction_term (hamiltonian.py:260-274,
  * 296-331).  U float64[n_mats][N][N] symmetric (rows/cols of bad atoms zeroed

@@ -130,7 +130,7 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP library first "
             "(python -c 'import __graft_entry__ as g; g.build()' or "
-            "make -C pulser_amd/csrc). There is no CPU fallback."
+            "make -C pulser_amd/csrc, same command). There is no CPU fallback."
         )
     try:
         # torch ships its own libamdhip64 (same SONAME); load it first so the

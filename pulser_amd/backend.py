@@ -1368,40 +1368,54 @@ class QutipBackendV2:
         from .general import lower_general
 
         eigenstates = sim._hamiltonian_data.eigenbasis
-        noiseless = dict(sim._noiseless_problem)
-        noiseless["collapse_ops"] = []
         qids = tuple(sim.samples_obj.qubit_ids)
         T = sim.total_duration_ns
+        with_leakage = bool(getattr(config.noise_model, "with_leakage", False))
+        holder: list[Any] = []  # the engine of the noiseless H(t), built on first use
 
-        def fill(res: Results, coherent: Any, ham_engine: Any) -> None:
+        def noiseless_engine() -> Any:
+            # qutip_backend.py:259-264: _get_noiseless_hamiltonian(with_leakage) is first
+            # called (and, for the leakage basis, first draws its HamiltonianData) inside
+            # the loop over evaluation times, i.e. after the solver ran; lru_cached after.
+            # Matrix-free for 2-level Ising sequences, explicit sparse terms otherwise
+            # (leakage: the states are 3^N / 4^N dimensional, so is this operator).
+            if not holder:
+                hd = sim._get_noiseless_data(with_leakage)
+                noiseless = dict(hd.problem(hd.noise_trajectories[0], sim._sampling_rate))
+                noiseless["collapse_ops"] = []
+                holder.append(Engine.from_problems([noiseless], mode="sesolve")
+                              if sim._fast_path_ok(noiseless)
+                              else GeneralEngine(lower_general(noiseless, mesolve=False)))
+            return holder[0]
+
+        def fill(res: Results, coherent: Any) -> None:
             for r in coherent:
                 t = r.evaluation_time
                 state = RydState(r.state.unit(), eigenstates=eigenstates)
-                ham = HamiltonianOperator(ham_engine, t * T / 1000, eigenstates)
+                ham = HamiltonianOperator(noiseless_engine(), t * T / 1000, eigenstates)
                 for cb in config.callbacks:
                     cb(config=config, t=float(t), state=state, hamiltonian=ham, result=res)
                 for obs in config.observables:
                     obs(config=config, t=float(t), state=state, hamiltonian=ham, result=res)
 
-        # the noiseless H(t) the observables see (qutip_backend.py:259-264): matrix-free
-        # for 2-level Ising sequences, explicit sparse terms for multi-level / XY ones
-        ham_ctx = (Engine.from_problems([noiseless], mode="sesolve") if sim._fast_path_ok(noiseless)
-                   else GeneralEngine(lower_general(noiseless, mesolve=False)))
-        with ham_ctx as ham_engine:
+        try:
             if not has_stochastic_noise(sim.noise_model):
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore", DeprecationWarning)
                     single = sim.run(**options)
                 res = Results(qids, T)
-                fill(res, single, ham_engine)
+                fill(res, single)
                 return res
             results: list[Results] = []
             for coherent, reps in sim._noisy_runs(**options):
                 for _ in range(reps):
                     res = Results(qids, T)
-                    fill(res, coherent, ham_engine)
+                    fill(res, coherent)
                     results.append(res)
             return Results.aggregate(results)
+        finally:
+            for eng in holder:
+                eng.close()
 
 
 QutipBackendV2.default_config = QutipConfig(observables=[BitStrings(evaluation_times=[1.0]), StateResult()])

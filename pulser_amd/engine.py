@@ -151,8 +151,12 @@ class Engine:
             )
 
     def new_state(self, kets: np.ndarray | None = None) -> Any:
-        """Device state from host ket(s) ``complex[B?, 2^N]``; default = all
-        atoms in the last basis state (``g``), simulation.py:498-505."""
+        """Device state from host ket(s) ``complex[B?, 2^N]``.
+
+        Default (``kets=None``): basis vector ``2^N - 1``, every atom in local state 1.
+        That is ``|g...g>`` in the ground-rydberg order ``[r, g]`` (simulation.py:498-505)
+        - and only there: in the digital order ``[g, h]`` it would be ``|h...h>``, so the
+        front-end (``QutipEmulator``) always passes the initial ket explicitly."""
         torch = self.torch
         if kets is None:
             host = np.zeros((self.batch, self.dim), dtype=np.complex128)
@@ -444,6 +448,11 @@ class GeneralEngine:
         return out
 
     def apply_generator(self, x: Any, t: float) -> Any:
+        # the C side trusts the pointer: a mis-sized vector would read / write out of bounds
+        if (tuple(x.shape) != (1, self.dim) or x.dtype != self.torch.complex128
+                or not x.is_contiguous() or x.device != self.device):
+            raise ValueError(f"state must be a contiguous complex128 tensor of shape (1, {self.dim}) "
+                             f"on {self.device}, got {tuple(x.shape)} {x.dtype} on {x.device}")
         out = self.torch.empty_like(x)
         _lib.check(self.lib.ryd_apply_generator(self._h, x.data_ptr(), out.data_ptr(), float(t),
                                                 self._stream()))

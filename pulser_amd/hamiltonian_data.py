@@ -613,6 +613,12 @@ class HamiltonianData:
         too: cos / sin series shared by the batch, per-trajectory amplitudes)."""
         if len(self.eigenbasis) != 2 or self.interaction_type != "ising":
             return False
+        # a detuning-map modulator weights its detuning per qubit (DMM weights,
+        # dmm_sigma factor, crosstalk spot waist: hamiltonian_data.py:414-421,
+        # 880-888; samples.py DMMSamples) - that is not a (series, scale) pair of
+        # the shared channel samples, so those sequences take lower(problem(...))
+        if any(ch.is_dmm for ch in self.samples.channels):
+            return False
         seen: set[tuple[str, int]] = set()
         for ch in self.samples.channels:
             targets = {t for s in ch.slots for t in s.targets}

@@ -449,17 +449,42 @@ def test_lowering_matches_oracle_terms():
 
 
 # ------------------------------------------------------------------ C ABI
+def _header_prototypes():
+    """Function names with a prototype in include/rydemu.h (comments stripped first,
+    so a mention inside a comment cannot stand in for a declaration)."""
+    header = open(os.path.join(ROOT, "include", "rydemu.h")).read()
+    code = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    code = re.sub(r"//[^\n]*", " ", code)
+    protos = re.findall(r"\b(ryd_[a-z0-9_]+)\s*\(", code)
+    return header, set(protos)
+
+
+def test_header_parser_ignores_comments():
+    _, protos = _header_prototypes()
+    assert "ryd_set_detuning_terms" in protos and "ryd_create" in protos and "ryd_last_error" in protos
+    code = "/* ryd_fake (0 = none) */ int ryd_real(int a);"
+    stripped = re.sub(r"/\*.*?\*/", " ", code, flags=re.S)
+    assert re.findall(r"(ryd_[a-z0-9_]+)\s*\(", stripped) == ["ryd_real"]
+
+
 def test_library_exports_every_declared_symbol():
+    import shutil
+    import subprocess
+
     from pulser_amd import _lib
 
-    header = open(os.path.join(ROOT, "include", "rydemu.h")).read()
-    declared = set(re.findall(r"\b(ryd_[a-z_]+)\s*\(", header))
+    header, declared = _header_prototypes()
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
     assert lib.ryd_abi_version() == _lib.RYD_ABI_VERSION
     assert f"#define RYD_ABI_VERSION {_lib.RYD_ABI_VERSION}" in header
+    # both directions: the dynamic symbol table exports exactly the declared entry points
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("ryd_")}
+    assert exported == declared, exported ^ declared
 
 
 def test_engine_fails_loudly_without_gpu():
@@ -1280,6 +1305,36 @@ def test_noisy_interaction_matrix_seeded_golden_and_dmm_detuning():
     loc = noisy.problem(t0, 1.0)["samples"]["Local"]["ground-rydberg"]
     assert np.allclose(loc[0]["det"][:100], -1 - 10 * 1.0 * factor)
     assert np.allclose(loc[1]["det"][:100], -1 - 10 * 0.5 * factor)
+
+
+def test_dmm_only_sequence_is_not_factored():
+    """A DMM channel scales its detuning per qubit (weights, dmm_sigma factor, spot waist:
+    hamiltonian_data.py:414-421, 880-888) - not a (series, scale) pair of the shared channel
+    samples.  ``device_tables`` must therefore equal ``lower(problem(...))``: the weight-0 atom
+    sees no DMM detuning and the weight-0.5 atom half of it (the factored form gave all three
+    atoms the full detuning)."""
+    from pulser_amd.terms import lower
+
+    xy = np.array([[0.0, 0.0], [0.0, 6.0], [6.0, 0.0]])
+    ones = np.ones(100)
+    dmm = ChannelInput("dmm_0", "Global", "ground-rydberg", 0 * ones, -10.0 * ones, 0 * ones,
+                       slots=[Slot(0, 100, (0, 1, 2))], dmm_trap_coords=xy,
+                       dmm_weights=np.array([1.0, 0.5, 0.0]), dmm_qubit_coords=xy)
+    seq = SequenceInputs(xy, ("q0", "q1", "q2"), [dmm], 865723.02)
+    np.random.seed(5)
+    hd = HamiltonianData(seq.extend_duration(101), NoiseModel(temperature=50.0, dmm_sigma=0.2), 3)
+    assert not hd.factorable()
+    trajs = hd.noise_trajectories
+    fac = hd.device_tables(trajs, 1.0)
+    ref = lower([hd.problem(t, 1.0) for t in trajs])
+    assert np.array_equal(fac.desc, ref.desc) and np.array_equal(fac.pp, ref.pp)
+    assert np.array_equal(fac.tknots, ref.tknots) and np.array_equal(fac.interaction, ref.interaction)
+    # the per-atom detunings really differ by the weights
+    for b, t in enumerate(trajs):
+        loc = hd.problem(t, 1.0)["samples"]["Local"]["ground-rydberg"]
+        f = t.dmm_det_fluctuation["dmm_0"]
+        dop = [loc[q]["det"][50] + 10.0 * w * f for q, w in enumerate((1.0, 0.5, 0.0))]
+        assert np.allclose(dop, np.asarray(t.doppler_detune, float), atol=1e-12), (b, dop)
 
 
 @pytest.mark.parametrize("leakage", [False, True])
