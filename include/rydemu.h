@@ -106,7 +106,10 @@ typedef struct ryd_opts {
   double max_step;      /* us; 0 = no cap (steps never straddle a spline knot) */
   double magnus_tol;    /* per-interval Magnus error target driving the automatic
                            sub-stepping next to waveform kinks (default 1e-10) */
-  double reserved[3];
+  int32_t split_steps;  /* mesolve split-operator path: CF4 steps per Strang block (0 = from the
+                           dissipator rate: 4 / 2 / 1 for rates <= 0.1 / <= 0.5 / above) */
+  int32_t reserved_i;
+  double reserved[2];
 } ryd_opts;
 
 typedef struct ryd_stats {
@@ -241,7 +244,10 @@ int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr, con
  * L2; the multi-pass tiling is used instead), 4 = disable the 2^14
  * register-tile kernel and the Hermitian mesolve path, 8 = force them even when
  * the launch has too few tiles to fill the GPU, 16 = use the single-launch plan
- * whatever the size of the state.  Never needed for results. */
+ * whatever the size of the state, 32 = disable the register-resident ket kernel
+ * (sesolve, 14 atoms) and the split-operator master equation built on it (mesolve,
+ * 12-14 atoms, dephasing-type dissipators), 64 = use both from 10 atoms on.
+ * Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);
 
 /* Replaces: QobjEvo.__call__(t) applied to a state (used by

@@ -70,7 +70,9 @@ class RydOpts(C.Structure):
         ("tol", C.c_double),
         ("max_step", C.c_double),
         ("magnus_tol", C.c_double),
-        ("reserved", C.c_double * 3),
+        ("split_steps", C.c_int32),
+        ("reserved_i", C.c_int32),
+        ("reserved", C.c_double * 2),
     ]
 
 

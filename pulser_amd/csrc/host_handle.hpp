@@ -51,6 +51,8 @@ struct ryd_handle {
   bool passes_valid = false;
   StepDesc* sched_dev = nullptr;
   size_t sched_cap = 0;
+  KetStep* ksched_dev = nullptr;  // schedule of the register-resident ket kernel
+  size_t ksched_cap = 0;
   // general path (explicit CSR terms)
   bool general = false;
   std::vector<GenTermHost> gen_host;
@@ -65,6 +67,8 @@ struct ryd_handle {
   bool force_tile14 = false;   // test hook: use them even when too few tiles fill the GPU
   bool no_outer = false;       // test hook: disable the single-pass partner-tile plan
   bool force_outer = false;    // test hook: use it whatever the size of the state
+  bool no_ket = false;         // test hook: disable the register-resident ket kernel / split-operator rows
+  bool force_ket = false;      // test hook: use them from 10 atoms on (instead of 14 / 12)
   bool drive_real = false;     // every drive series is real-valued
   bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
   // Monte-Carlo wavefunction mode (sesolve handles with ryd_set_collapse)
@@ -372,6 +376,7 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->desc_dev);
   hipFree(h->dterms_dev);
   hipFree(h->sched_dev);
+  hipFree(h->ksched_dev);
   hipFree(h->gen_tcoef);
   hipFree(h->gen_terms_dev);
   hipFree(h->gen_series_dev);

@@ -1,0 +1,252 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+// ---------------------------------------------------------------------------
+// Register-resident ket path (k_ket) and the split-operator master equation
+// ---------------------------------------------------------------------------
+// sesolve, N = 13/14, every drive coefficient real: one workgroup per sequence,
+// the whole schedule in one launch (k_ket).
+//
+// mesolve, N = 12..14, dissipators without double flips (dephasing-type, i.e. the
+// Lindbladian is  -i[H, .] + (real elementwise diagonal)  in the |a><b| basis):
+//
+//     rho(t + tau) = D(tau/2) . U ( D(tau/2) . rho ) U^dagger  + O(tau^3)        (Strang)
+//
+// with D(s)[a,b] = exp(s * d(a,b)) elementwise and U the unitary propagator of
+// H(t) over tau = K CF4 steps.  U rho U^dagger is two passes of the SAME ket kernel
+// over the 2^N rows (each row is a ket that is right-multiplied by U^dagger) with a
+// conjugate transposition between them:  X = rho U^dagger;  Y = X^dagger = U rho;
+// Y U^dagger = U rho U^dagger.  The result is Hermitian again, so there is no
+// transposition back.  Per block of K steps the density matrix crosses HBM three
+// times (96 B per element) instead of 72 B per element per generator application
+// (22 applications per ns at 14 atoms): the path is bound by the fp64 vector pipe,
+// not by HBM.  Splitting error measured against the tight oracle (6-atom
+// triangular register, 3.1 us anneal, tools/split_probe.py): K = 1/2/4/8 ns ->
+// 6e-10 / 5e-10 / 1.2e-9 / 8.7e-9 at gamma = 0.05; it grows with gamma K^2, so K
+// is chosen from the dissipator rate.
+
+static bool ket_path(const ryd_handle* h) {
+  if (h->general || h->cfg.mode != RYD_SESOLVE || !h->drive_real || h->mc || h->no_ket) return false;
+  if (h->force_ket) return h->N >= 10 && h->N <= 14;
+  return h->N == 14 && !h->force_generic;  // <= 13 atoms: the LDS-resident kernel k_traj
+}
+
+static bool row_path(const ryd_handle* h) {
+  if (h->general || h->cfg.mode != RYD_MESOLVE || h->has_dbl || h->N > 14) return false;
+  if (h->N < (h->force_ket ? 10 : 12)) return false;
+  if (!h->drive_real || (h->force_generic && !h->force_ket) || h->no_ket || !h->auto_tile) return false;
+  for (int k = 0; k < 4; ++k)
+    if (h->Sd[k].y != 0.0) return false;  // the elementwise factor must be real
+  return true;
+}
+
+// spectral bound / shift of  w1 H(t1) + w2 H(t2)  as a KET generator (also for mesolve
+// handles, whose rows are kets)
+static void ket_bound(const ryd_handle* h, int idx, double w1, double w2, double* bound, double* shift) {
+  const double wmix = w1 + w2;
+  const double drive = wmix * h->bd_drive[idx];
+  const double dpos = wmix * h->bd_pos[idx], dneg = wmix * h->bd_neg[idx];
+  const double lo = wmix * h->e0_min - dpos, hi = wmix * h->e0_max + dneg;
+  *shift = 0.5 * (lo + hi);
+  *bound = 0.5 * (hi - lo) + drive;
+}
+
+// cheapest (scheme, sub-exponentials) whose fitted interval covers x = h ||H~|| / nsub
+static int pick_scheme(double x, double tol, short* sch, short* nsub) {
+  int best = -1, best_n = 0;
+  double best_cost = 0.0;
+  for (int n = 1; n <= 64; ++n) {
+    for (int s = 0; s < kNumSymp; ++s) {
+      if (kSymp[s].X < x / n || kSymp[s].err > tol) continue;
+      const double cost = (double)n * kSymp[s].m + 0.5;  // + the closing half-stage
+      if (best < 0 || cost < best_cost) { best = s; best_n = n; best_cost = cost; }
+    }
+    if (best >= 0 && n >= best_n + 2) break;
+  }
+  if (best < 0) return fail(RYD_ERR_INVALID, "no in-place exponential scheme for x = %g at tol = %g", x, tol);
+  *sch = (short)best;
+  *nsub = (short)best_n;
+  return RYD_OK;
+}
+
+// the default per-exponential accuracy of the in-place schemes.  Their error is attained (not a
+// worst-case bound like the Taylor remainder), so the default is a decade tighter than kDefaultTol.
+static const double kDefaultSympTol = 2e-11;
+
+static int to_ket_steps(ryd_handle* h, const std::vector<StepDesc>& sched, const ryd_opts& o,
+                        std::vector<KetStep>& out) {
+  const double tol = o.tol > 0 ? o.tol : kDefaultSympTol;
+  int rc;
+  for (const StepDesc& d : sched) {
+    KetStep k;
+    std::memset(&k, 0, sizeof k);
+    k.h = d.h; k.u1 = d.u1; k.u2 = d.u2; k.idx = d.idx; k.snap = d.snap;
+    double ba, bb;
+    ket_bound(h, d.idx, kA1, kA2, &ba, &k.shift_a);
+    ket_bound(h, d.idx, kA2, kA1, &bb, &k.shift_b);
+    if ((rc = pick_scheme(std::fabs(d.h) * ba, tol, &k.sch_a, &k.sub_a))) return rc;
+    if ((rc = pick_scheme(std::fabs(d.h) * bb, tol, &k.sch_b, &k.sub_b))) return rc;
+    h->stats.last_order = kSymp[k.sch_a].m * k.sub_a;
+    h->stats.norm_bound = ba / (kA1 + kA2);
+    out.push_back(k);
+  }
+  return RYD_OK;
+}
+
+static int upload_ket_steps(ryd_handle* h, const std::vector<KetStep>& ks, hipStream_t st) {
+  static_assert(sizeof(KetStep) <= 2 * sizeof(StepDesc), "schedule buffer sizing");
+  const size_t bytes = ks.size() * sizeof(KetStep);
+  if (h->ksched_cap < ks.size()) {
+    if (h->ksched_dev) hipFree(h->ksched_dev);
+    h->ksched_dev = nullptr;
+    h->ksched_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->ksched_dev, bytes * 2));
+    h->ksched_cap = ks.size() * 2;
+  }
+  HIPCHK(hipStreamSynchronize(st));  // the buffer may still be read by an earlier launch
+  HIPCHK(hipMemcpyAsync(h->ksched_dev, ks.data(), bytes, hipMemcpyHostToDevice, st));
+  return RYD_OK;
+}
+
+static int ket_init_device(ryd_handle* h) {
+  static bool done[64] = {};
+  const int dev = h->cfg.device;
+  if (dev >= 0 && dev < 64 && done[dev]) return RYD_OK;
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(kSympDev), kSymp, sizeof(kSymp)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (dev >= 0 && dev < 64) done[dev] = true;
+  return RYD_OK;
+}
+
+static int launch_ket(ryd_handle* h, const KetArgs& A, size_t n_rows, hipStream_t st) {
+  const size_t D = (size_t)1 << h->N;
+  const size_t lds = D * sizeof(double) + (64 + 64 + 2 * (D / 512) + 32 + 128 + (D / 512)) * sizeof(double);
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  int rc;
+  if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+  switch (h->N) {
+    case 10: hipLaunchKernelGGL(k_ket<10>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    case 11: hipLaunchKernelGGL(k_ket<11>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    case 12: hipLaunchKernelGGL(k_ket<12>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    case 13: hipLaunchKernelGGL(k_ket<13>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    case 14: hipLaunchKernelGGL(k_ket<14>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    default: return fail(RYD_ERR_INVALID, "k_ket needs 10 <= N <= 14");
+  }
+  HIPCHK(hipGetLastError());
+  if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
+  h->stats.n_launches++;
+  return RYD_OK;
+}
+
+static void fill_ket_args(const ryd_handle* h, KetArgs& A) {
+  std::memset(&A, 0, sizeof A);
+  A.pp = h->pp_dev;
+  A.desc = h->desc_dev;
+  A.dterms = h->dterms_dev;
+  A.e0 = h->e0_dev;
+  A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << h->N);
+  A.n_int = h->n_knots - 1;
+  A.a1 = kA1;
+  A.a2 = kA2;
+  A.conj_sign = 1.0;
+}
+
+static void count_ket_work(ryd_handle* h, const std::vector<KetStep>& ks, size_t i0, size_t i1, int passes) {
+  for (size_t i = i0; i < i1; ++i) {
+    // m stages = m generator applications (+ the closing half-stage)
+    h->stats.n_applications += (int64_t)passes * (kSymp[ks[i].sch_a].m * ks[i].sub_a + kSymp[ks[i].sch_b].m * ks[i].sub_b + 1);
+  }
+}
+
+// sesolve: one launch for the whole schedule, one workgroup per sequence
+static int run_ket(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
+                   const ryd_opts& o, hipStream_t st) {
+  if (sched.empty()) return RYD_OK;
+  int rc;
+  if ((rc = ket_init_device(h))) return rc;
+  std::vector<KetStep> ks;
+  if ((rc = to_ket_steps(h, sched, o, ks))) return rc;
+  if ((rc = upload_ket_steps(h, ks, st))) return rc;
+  KetArgs A;
+  fill_ket_args(h, A);
+  A.state = state;
+  A.snaps = snaps;
+  A.steps = h->ksched_dev;
+  A.n_steps = (int)ks.size();
+  A.rows_log2 = 0;
+  if ((rc = launch_ket(h, A, (size_t)h->B, st))) return rc;
+  count_ket_work(h, ks, 0, ks.size(), 1);
+  h->stats.n_steps += (int64_t)ks.size();
+  return RYD_OK;
+}
+
+// CF4 steps per Strang block from the dissipator rate (splitting error ~ gamma K^2)
+static int row_block_steps(const ryd_handle* h, const ryd_opts& o) {
+  if (o.split_steps > 0) return o.split_steps;
+  double g = 0.0;
+  for (int k = 0; k < 4; ++k) g = std::max(g, std::fabs(h->Sd[k].x));
+  if (g <= 0.1) return 4;
+  if (g <= 0.5) return 2;
+  return 1;
+}
+
+// mesolve: Strang blocks of K CF4 steps; see the header of this file
+static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
+                    const ryd_opts& o, hipStream_t st) {
+  if (sched.empty()) return RYD_OK;
+  int rc;
+  if ((rc = ket_init_device(h))) return rc;
+  std::vector<KetStep> ks;
+  if ((rc = to_ket_steps(h, sched, o, ks))) return rc;
+  for (KetStep& k : ks) k.snap = -1;  // snapshots are whole-matrix copies between blocks
+  if ((rc = upload_ket_steps(h, ks, st))) return rc;
+  const int K = row_block_steps(h, o);
+  const size_t D = (size_t)1 << h->N;
+  const size_t n_rows = D * (size_t)h->B;
+  const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  const unsigned nt = (unsigned)(D / 32);
+  cplx* cur = state;
+  cplx* other = h->wA;
+  size_t i = 0;
+  while (i < sched.size()) {
+    size_t j = i;
+    double tau = 0.0;
+    while (j < sched.size() && (int)(j - i) < K) {
+      tau += sched[j].h;
+      ++j;
+      if (sched[j - 1].snap >= 0) break;  // a requested evaluation time ends the block
+    }
+    KetArgs A;
+    fill_ket_args(h, A);
+    A.steps = h->ksched_dev + i;
+    A.n_steps = (int)(j - i);
+    A.rows_log2 = h->N;
+    A.conj_sign = -1.0;
+    A.state = cur;
+    for (int k = 0; k < 4; ++k) A.pre[k] = 0.5 * tau * h->Sd[k].x;
+    A.use_pre = 1;
+    if ((rc = launch_ket(h, A, n_rows, st))) return rc;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+    hipLaunchKernelGGL(k_transpose_conj, dim3(nt, nt, h->B), dim3(256), 0, st, cur, other, h->N);
+    HIPCHK(hipGetLastError());
+    if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
+    h->stats.n_launches++;
+    std::swap(cur, other);
+    A.state = cur;
+    A.use_pre = 0;
+    for (int k = 0; k < 4; ++k) A.post[k] = 0.5 * tau * h->Sd[k].x;
+    A.use_post = 1;
+    if ((rc = launch_ket(h, A, n_rows, st))) return rc;
+    count_ket_work(h, ks, i, j, 1);  // one Lindbladian application ~ one two-sided ket stage
+    h->stats.n_steps += (int64_t)(j - i);
+    const int snap = sched[j - 1].snap;
+    if (snap >= 0 && snaps)
+      HIPCHK(hipMemcpyAsync(snaps + (size_t)snap * h->dim * h->B, cur, bytes, hipMemcpyDeviceToDevice, st));
+    i = j;
+  }
+  if (cur != state) HIPCHK(hipMemcpyAsync(state, cur, bytes, hipMemcpyDeviceToDevice, st));
+  return RYD_OK;
+}

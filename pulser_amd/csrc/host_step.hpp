@@ -2,137 +2,6 @@
 // ---------------------------------------------------------------------------
 // stepping: schedule (host) -> generic multi-launch path or persistent kernel
 // ---------------------------------------------------------------------------
-static const double kS3 = 1.7320508075688772;
-static const double kC1 = 0.5 - kS3 / 6.0, kC2 = 0.5 + kS3 / 6.0;  // Gauss nodes
-static const double kA1 = 0.25 + kS3 / 6.0, kA2 = 0.25 - kS3 / 6.0;  // CF4 weights
-// Default truncation bound per exponential.  The stated parity bar is 1e-7 on amplitudes after a
-// whole sequence: 1e-10 per exponential ends 5e-9 .. 1.2e-8 from the tight oracle on the
-// 8- and 12-atom anneal sequences (tools/stepper_model.py, tools/order_probe.py); 1e-12 bought 2e-10
-// for 14 % more generator applications.
-static const double kDefaultTol = 1e-10;
-
-// Smallest Taylor degree m with rho^(m+1)/(m+1)! <= tol (the remainder bound of the
-// Horner polynomial for ||h G~|| <= rho), capped.
-static int taylor_order_for(double rho, const ryd_opts& o) {
-  const int cap = std::min(o.max_order > 0 ? o.max_order : 32, 32);
-  const double tol = o.tol > 0 ? o.tol : kDefaultTol;
-  double term = rho;  // rho^(m+1)/(m+1)! for m = 0
-  int order = 1;
-  while (order < cap) {
-    term *= rho / (order + 1);  // now rho^(order+1)/(order+1)!
-    if (term <= tol) break;
-    ++order;
-  }
-  return order;
-}
-
-// Taylor order and spectral shift of one exponential exp(h (w1 G(t1) + w2 G(t2)))
-// with both Gauss points inside knot interval `idx`.
-static void plan_exp(ryd_handle* h, int idx, double hstep, double w1, double w2,
-                     const ryd_opts& o, int* order_out, double* shift_out) {
-  const double wmix = w1 + w2;
-  const double drive = wmix * h->bd_drive[idx];
-  const double dpos = wmix * h->bd_pos[idx], dneg = wmix * h->bd_neg[idx];
-  const double lo = wmix * h->e0_min - dpos, hi = wmix * h->e0_max + dneg;
-  double bound, shift = 0.0;
-  if (h->general) {
-    bound = drive;  // sum_t |coef_t| ||A_t||_inf; no spectral shift
-  } else if (h->cfg.mode == RYD_SESOLVE) {
-    shift = 0.5 * (lo + hi);  // H' = H - shift: halves the spectral radius
-    bound = 0.5 * (hi - lo) + drive;
-    if (h->mc) bound += wmix * std::fabs(h->mc_b) * 0.5 * h->N;  // centred decay diagonal
-  } else {
-    bound = 2.0 * (0.5 * (hi - lo) + drive) + wmix * h->diss_norm;
-  }
-  h->stats.norm_bound = bound / std::max(wmix, 1e-300);
-  const double rho = std::fabs(hstep) * bound;
-  int order = o.taylor_order;
-  if (order <= 0) order = taylor_order_for(rho, o);
-  if (order < 2) order = 2;
-  if (order > 32) order = 32;
-  h->stats.last_order = order;
-  *order_out = order;
-  *shift_out = shift;
-}
-
-// CF4 steps covering [t0, t1]: never straddling a spline knot (inside a knot
-// interval every coefficient is a single cubic), optionally capped by max_step.
-static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& o,
-                           std::vector<StepDesc>& out) {
-  const double eps = 1e-12;
-  double t = t0;
-  while (t < t1 - eps) {
-    const int idx = find_interval(h, t + eps);
-    double tend = t1;  // the last interval extends to t1 (extrapolation, as scipy does)
-    if (idx < h->n_knots - 2) tend = std::min(t1, h->tknots[idx + 1]);
-    if (tend <= t + eps) tend = t1;
-    const double len = tend - t;
-    int nsub = 1;
-    if (o.max_step > 0) nsub = std::max(1, (int)std::ceil(len / o.max_step - 1e-9));
-    {
-      // The local error of the 4th-order Magnus step is dominated by the
-      // non-linear (quadratic + cubic) part of the spline inside the interval -
-      // large only where it rings next to a kink of the waveform.  Calibrated
-      // against converged references: err ~ 1e-5 * h * curvature,
-      // and it falls as n^-4 with n equal sub-steps.
-      const double dtk = h->tknots[idx + 1] - h->tknots[idx];
-      const double frac = dtk > 0 ? std::min(1.0, len / dtk) : 1.0;
-      const double est = 1e-5 * len * h->bd_curv[idx] * frac * frac;
-      const double mtol = o.magnus_tol > 0 ? o.magnus_tol : 1e-10;
-      if (est > mtol) {
-        const int nm = (int)std::ceil(std::pow(est / mtol, 0.25));
-        nsub = std::max(nsub, std::min(nm, 256));
-      }
-    }
-    {
-      // Sub-steps only where they pay: the Taylor degree grows like e*rho + log(1/tol), so the
-      // number of generator applications per unit time FALLS with rho (about 16 / 11 / 8 per unit
-      // rho at rho = 0.75 / 1.5 / 3 for tol = 1e-12).  Split only to stay under the degree cap and
-      // below rho = 6, where the largest term (e^rho) starts to cost digits.
-      int ord;
-      double sh;
-      plan_exp(h, idx, len / nsub, kA1, kA2, o, &ord, &sh);
-      const double rho = (len / nsub) * h->stats.norm_bound * (kA1 + kA2);
-      if (o.taylor_order <= 0) {
-        const int cap = std::min(o.max_order > 0 ? o.max_order : 32, 32);
-        int best_n = 0;
-        double best_cost = 0.0;
-        for (int k = 1; k <= 64; ++k) {
-          const double r = rho / k;
-          if (r > 6.0) continue;
-          ryd_opts oo = o;
-          const int m = taylor_order_for(r, oo);
-          double term = 1.0;
-          for (int j = 1; j <= m + 1; ++j) term *= r / j;
-          const double tol = o.tol > 0 ? o.tol : kDefaultTol;
-          if (m >= cap && term > tol) continue;  // capped before reaching the tolerance
-          const double cost = (double)k * m;
-          if (best_n == 0 || cost < best_cost) { best_n = k; best_cost = cost; }
-          if (r < 0.25) break;
-        }
-        if (best_n > 1) nsub *= best_n;
-      } else if (rho > 1.5) {
-        nsub *= (int)std::ceil(rho / 1.0);  // fixed order: keep the argument near 1
-      }
-    }
-    const double hs = len / nsub;
-    for (int s = 0; s < nsub; ++s) {
-      const double ta = t + s * hs;
-      StepDesc d;
-      std::memset(&d, 0, sizeof d);
-      d.h = hs;
-      d.idx = idx;
-      d.u1 = ta + kC1 * hs - h->tknots[idx];
-      d.u2 = ta + kC2 * hs - h->tknots[idx];
-      plan_exp(h, idx, hs, kA1, kA2, o, &d.order_a, &d.shift_a);
-      plan_exp(h, idx, hs, kA2, kA1, o, &d.order_b, &d.shift_b);
-      d.snap = -1;
-      out.push_back(d);
-    }
-    t = tend;
-  }
-}
-
 static bool hermitian_path(const ryd_handle* h) {
   return !h->general && h->cfg.mode == RYD_MESOLVE && !h->has_dbl && h->N >= 7 && h->N <= 14 &&
          h->auto_tile && tile14_pays(h);
@@ -504,17 +373,19 @@ static bool use_persistent_dm(const ryd_handle* h) {
 }
 
 static int run_steps(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
-                     hipStream_t st);
+                     hipStream_t st, const ryd_opts& o);
 
 static bool use_persistent(const ryd_handle* h) {
   return !h->general && h->cfg.mode == RYD_SESOLVE && h->N <= 13 && !h->force_generic;
 }
 
 static int run_steps(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
-                     hipStream_t st) {
+                     hipStream_t st, const ryd_opts& o) {
+  if (ket_path(h)) return run_ket(h, state, sched, snaps, o, st);
   if (use_persistent(h)) return run_persistent(h, state, sched, snaps, st);
   if (use_persistent_dm(h)) return run_persistent_dm(h, state, sched, snaps, st);
   if (use_persistent_general(h)) return run_persistent_general(h, state, sched, snaps, st);
+  if (row_path(h)) return run_rows(h, state, sched, snaps, o, st);
   return run_generic(h, state, sched, snaps, st);
 }
 
@@ -534,11 +405,12 @@ extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const 
   cplx* state = (cplx*)state_dev;
   cplx* snaps = (cplx*)out_dev;
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  const bool in_place = ket_path(h) || (row_path(h) && !use_persistent_dm(h));
   std::vector<StepDesc> sched;
   // snapshot slot i-1 receives the state at times[i]
   for (int i = 1; i < n_times; ++i) {
     const size_t before = sched.size();
-    build_schedule(h, times[i - 1], times[i], o, sched);
+    build_schedule(h, times[i - 1], times[i], o, sched, in_place);
     if (snaps) {
       if (sched.size() > before) {
         sched.back().snap = i - 1;
@@ -547,14 +419,14 @@ extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const 
           if ((rc = snapshot_copy(h, state, snaps + (size_t)(i - 1) * h->dim * h->B, st))) return rc;
         } else {
           // duplicate time after at least one step: flush what we have, copy, continue
-          if ((rc = run_steps(h, state, sched, snaps, st))) return rc;
+          if ((rc = run_steps(h, state, sched, snaps, st, o))) return rc;
           sched.clear();
           if ((rc = snapshot_copy(h, state, snaps + (size_t)(i - 1) * h->dim * h->B, st))) return rc;
         }
       }
     }
   }
-  return run_steps(h, state, sched, snaps, st);
+  return run_steps(h, state, sched, snaps, st, o);
 }
 
 extern "C" int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
@@ -661,6 +533,8 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
   {
     const bool no = (force_generic & 2) != 0, nt = (force_generic & 4) != 0,
                ft = (force_generic & 8) != 0, fo = (force_generic & 16) != 0;
+    h->no_ket = (force_generic & 32) != 0;
+    h->force_ket = (force_generic & 64) != 0;
     if (nt != h->no_tile14 || ft != h->force_tile14 || no != h->no_outer || fo != h->force_outer) {
       h->no_tile14 = nt;
       h->force_tile14 = ft;

@@ -1,0 +1,311 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+// ---------------------------------------------------------------------------
+// k_ket<N>: register-resident kets of 12-14 atoms, whole schedules in one launch
+// ---------------------------------------------------------------------------
+// A 14-atom ket is 256 KiB - half of a CU's register file.  A Taylor / Horner
+// exponential needs two copies (the iterate and its base), which no CU can hold;
+// the persistent kernel k_traj therefore stops at 13 atoms (and spills there).
+// For a REAL symmetric H~ (every drive coefficient real: phase 0 or pi) the flow
+// of  i psi' = H~ psi  with  psi = q + i p  is the rotation  q' = H~ p, p' = -H~ q,
+// and a product of shears
+//
+//     q += a_1 x p;  p -= b_1 x q;  ...  p -= b_m x q;  q += a_{m+1} x p     (x = h H~)
+//
+// only ever adds H~ times ONE array to the OTHER: it runs in place on a single
+// copy.  The palindromic coefficients (symp_coefs.hpp, fitted by
+// tools/symplectic_coefs.py) make the 2x2 propagator match the rotation to
+// 1e-10 .. 1e-13 for every eigenvalue inside the spectral bound the stepper
+// computes anyway; m stages cost m generator applications, like a degree-m
+// Taylor polynomial, and reach the accuracy of degree m + 2.
+//
+// Layout: 512 threads, thread t owns the amplitudes t + 512 j (j < R = 2^N / 512)
+// as q[R], p[R] in registers.  Per half-stage the source array (128 KiB of
+// doubles at N = 14) is published to LDS once; partners of index bits 0-8 are
+// ds_read_b128 (two amplitudes per read), bits 9+ are register-to-register.
+// HBM is touched for the initial load, snapshots and the final store only.
+//
+// Two uses:
+//  * sesolve batches of 13/14-atom sequences (one workgroup per sequence);
+//  * the split-operator master equation (host_rowpath.hpp): a density matrix is
+//    2^N rows, each a ket that is right-multiplied by U^dagger (conj = -1); the
+//    dephasing-type diagonal of the dissipator is an elementwise factor applied
+//    at load / store.
+#include "symp_coefs.hpp"
+
+__constant__ SympScheme kSympDev[sizeof(kSymp) / sizeof(kSymp[0])];
+
+struct KetStep {
+  double h, u1, u2;
+  double shift_a, shift_b;
+  int idx;
+  short sch_a, sub_a, sch_b, sub_b;  // scheme index / equal sub-exponentials
+  int snap;                          // snapshot slot written after this step, or -1
+};
+
+struct KetArgs {
+  cplx* state;              // [n_rows][2^N] in/out
+  cplx* snaps;              // [n_slots][n_rows][2^N] or null
+  const cplx* pp;           // [n_series][n_int][4]
+  const ryd_qdesc* desc;    // [B][N]
+  const ryd_dterm* dterms;  // or null
+  const double* e0;
+  long long e0_stride;
+  const KetStep* steps;
+  int n_int, n_steps;
+  int rows_log2;            // rows per batch entry = 2^rows_log2 (0: kets; N: density-matrix rows)
+  double a1, a2;
+  double conj_sign;         // +1: psi <- U psi;  -1: row <- row U^dagger (psi <- conj(U) psi)
+  // elementwise real factor exp(sum_k fac[k] * n_k(row, col)) over the four (row bit, column bit)
+  // counts n00, n01, n10, n11 (dissipator diagonal times a time span); row mode only
+  double pre[4], post[4];
+  int use_pre, use_post;
+};
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int N>
+__global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
+  constexpr int D = 1 << N, NTT = 512, LOGNT = 9;
+  constexpr int R = D / NTT;   // amplitudes per thread (8, 16, 32)
+  constexpr int RP = R / 2;    // pairs
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double2* xs = reinterpret_cast<double2*>(smem);                  // [RP][512] published array
+  double* cfA = reinterpret_cast<double*>(xs + (size_t)RP * NTT);  // [16][4]
+  double* cfB = cfA + 64;
+  double* ehi = cfB + 64;   // [2][R]: high-bit detuning sums minus the shift, exp A / exp B
+  double* hfx = ehi + 2 * R;  // [16][2]
+  double* ftab = hfx + 32;    // [2][4][16] load / store factor tables
+  double* ehh = ftab + 128;   // [R] static diagonal of the register-index bits
+
+  const int tid = threadIdx.x;
+  const size_t row = blockIdx.x;
+  const int b = (int)(row >> A.rows_log2);
+  const unsigned rowidx = (unsigned)(row & ((1ull << A.rows_log2) - 1ull));
+  cplx* st = A.state + row * D;
+  const double* e0g = A.e0 + (size_t)b * A.e0_stride;
+
+  if (A.use_pre || A.use_post) {
+    if (tid < 128) {
+      const int which = tid >> 6, k = (tid >> 4) & 3, n = tid & 15;
+      ftab[tid] = exp((which ? A.post[k] : A.pre[k]) * (double)n);
+    }
+    __syncthreads();
+  }
+  auto factor = [&](const double* tab, unsigned col) -> double {
+    const unsigned m = (1u << N) - 1u;
+    const int n11 = __popc(rowidx & col), n10 = __popc(rowidx & ~col & m), n01 = __popc(~rowidx & col & m);
+    const int n00 = N - n11 - n10 - n01;
+    return tab[n00] * tab[16 + n01] * tab[32 + n10] * tab[48 + n11];
+  };
+
+  // The static interaction diagonal E0 is a quadratic form of the index bits, so with
+  // i = (j: register-index bits 9.., t: thread bits 0-8)
+  //     E0(i) = Ehh(j) + Ell(t) + sum over the high atoms excited in j of V_a(t):
+  // six doubles per thread (read back from the E0 table itself) instead of R, which is
+  // what keeps q, p and the partner reads inside the 256 registers of a lane.
+  constexpr int NH = N - LOGNT;               // register-index bits
+  constexpr unsigned HIMASK = ((1u << NH) - 1u) << LOGNT;
+  const double wst = A.a1 + A.a2;             // the static diagonal always enters with weight a1 + a2
+  const double ell = wst * e0g[tid | HIMASK];
+  double vhi[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) vhi[k] = wst * e0g[tid | (HIMASK ^ (1u << (LOGNT + k)))] - ell;
+  if (tid < R) ehh[tid] = wst * e0g[((unsigned)tid << LOGNT) | (NTT - 1)];
+
+  double q[R], p[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int l = tid + j * NTT;
+    const cplx v = st[l];
+    double f = 1.0;
+    if (A.use_pre) f = factor(ftab, (unsigned)l);
+    q[j] = f * v.x;
+    p[j] = f * v.y;
+  }
+
+  for (int s = 0; s < A.n_steps; ++s) {
+    const KetStep sd = A.steps[s];
+    if (A.dterms) {
+      // extra detuning terms (hf noise): wave w sums the list of atoms w, w + NW, ...
+      constexpr int NW = NTT / 64;
+      const int lane = tid & 63;
+      for (int k = tid >> 6; k < N; k += NW) {
+        const int ex = A.desc[(size_t)b * N + k].extra;
+        double xa = 0.0, xb = 0.0;
+        if (ex > 0) {
+          const int count = A.dterms[ex - 1].remaining + 1;
+          for (int e = lane; e < count; e += 64) {
+            const ryd_dterm t = A.dterms[ex - 1 + e];
+            const cplx* pq = A.pp + ((size_t)t.series * A.n_int + sd.idx) * 4;
+            const double o1 = ((pq[0].x * sd.u1 + pq[1].x) * sd.u1 + pq[2].x) * sd.u1 + pq[3].x;
+            const double o2 = ((pq[0].x * sd.u2 + pq[1].x) * sd.u2 + pq[2].x) * sd.u2 + pq[3].x;
+            xa += t.scale * (A.a1 * o1 + A.a2 * o2);
+            xb += t.scale * (A.a2 * o1 + A.a1 * o2);
+          }
+          for (int o = 32; o > 0; o >>= 1) {
+            xa += __shfl_down(xa, o, 64);
+            xb += __shfl_down(xb, o, 64);
+          }
+        }
+        if (lane == 0) { hfx[2 * k] = xa; hfx[2 * k + 1] = xb; }
+      }
+      __syncthreads();
+    }
+    if (tid < N) {
+      // same arithmetic as k_eval_coefs / k_traj (w1 * val(t1) + w2 * val(t2)); only the real
+      // part of the drive is used (the host routes complex drives elsewhere)
+      const ryd_qdesc d = A.desc[(size_t)b * N + tid];
+      auto val = [&](int ser, double u) -> double {
+        const cplx* pq = A.pp + ((size_t)ser * A.n_int + sd.idx) * 4;
+        double r = pq[0].x;
+        r = fma(r, u, pq[1].x);
+        r = fma(r, u, pq[2].x);
+        r = fma(r, u, pq[3].x);
+        return r;
+      };
+      double c1 = 0, c2 = 0, dlA = 0, dlB = 0;
+      if (d.drive_series >= 0) { c1 = val(d.drive_series, sd.u1); c2 = val(d.drive_series, sd.u2); }
+      if (d.det_series >= 0) {
+        const double d1 = val(d.det_series, sd.u1), d2 = val(d.det_series, sd.u2);
+        dlA += d.det_scale * (A.a1 * d1 + A.a2 * d2);
+        dlB += d.det_scale * (A.a2 * d1 + A.a1 * d2);
+      }
+      if (d.off_series >= 0) {
+        const double o1 = val(d.off_series, sd.u1), o2 = val(d.off_series, sd.u2);
+        dlA += d.off_scale * (A.a1 * o1 + A.a2 * o2);
+        dlB += d.off_scale * (A.a2 * o1 + A.a1 * o2);
+      }
+      if (d.extra > 0 && A.dterms) { dlA += hfx[2 * tid]; dlB += hfx[2 * tid + 1]; }
+      cfA[4 * tid + 0] = d.drive_scale * (A.a1 * c1 + A.a2 * c2);
+      cfA[4 * tid + 2] = dlA;
+      cfB[4 * tid + 0] = d.drive_scale * (A.a2 * c1 + A.a1 * c2);
+      cfB[4 * tid + 2] = dlB;
+    }
+    __syncthreads();
+    if (tid < 2 * R) {
+      // diagonal carried by the register-index bits (9 ..): static part + detunings - shift
+      const int ex = tid / R, j = tid % R;
+      const double* cf = ex ? cfB : cfA;
+      double sdet = 0.0;
+      for (int qb = LOGNT; qb < N; ++qb)
+        if (!((j >> (qb - LOGNT)) & 1)) sdet -= cf[4 * (N - 1 - qb) + 2];
+      ehi[tid] = ehh[j] + sdet - (ex ? sd.shift_b : sd.shift_a);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int ex = 0; ex < 2; ++ex) {
+      const double* cf = ex ? cfB : cfA;
+      const double shift = ex ? sd.shift_b : sd.shift_a;
+      const int sch = ex ? sd.sch_b : sd.sch_a;
+      const int nsub = ex ? sd.sub_b : sd.sub_a;
+      // per-bit drive coefficients (bit f <-> atom N-1-f) -> scalar registers
+      double cq[N];
+#pragma unroll
+      for (int f = 0; f < N; ++f) cq[f] = uniform_d(cf[4 * (N - 1 - f)]);
+      double elo = ell;  // thread-bit part of the diagonal: static + detunings
+#pragma unroll
+      for (int f = 0; f < LOGNT; ++f)
+        if (!((tid >> f) & 1)) elo -= cf[4 * (N - 1 - f) + 2];
+      const double* ehx = ehi + ex * R;
+      const int m = kSympDev[sch].m;
+      const double hs = A.conj_sign * sd.h / (double)nsub;
+
+      // dst += coef * (H~ - shift) src, in place on the register arrays
+      auto half_stage = [&](double (&dst)[R], const double (&src)[R], double coef) {
+        __syncthreads();  // partner reads of the previous half-stage are done
+#pragma unroll
+        for (int jp = 0; jp < RP; ++jp) xs[jp * NTT + tid] = make_double2(src[2 * jp], src[2 * jp + 1]);
+        __syncthreads();
+#pragma unroll
+        for (int jp = 0; jp < RP; ++jp) {
+          double2 pv[LOGNT];
+#pragma unroll
+          for (int f = 0; f < LOGNT; ++f) pv[f] = xs[jp * NTT + (tid ^ (1 << f))];
+          const double2 eh2 = *reinterpret_cast<const double2*>(ehx + 2 * jp);
+          // diagonal of the pair (2jp, 2jp+1): high atoms excited <=> their bit is 0.  Re-derived
+          // per pair (<= 5 additions): hoisted out of the stage loop the R partial sums would live
+          // in scratch and every pair would wait for a scratch load
+          double ec = elo;
+          asm volatile("" : "+v"(ec));
+#pragma unroll
+          for (int k = 1; k < NH; ++k)
+            if (!((jp >> (k - 1)) & 1)) ec += vhi[k];
+          double acc0 = ((ec + vhi[0]) + eh2.x) * src[2 * jp];
+          double acc1 = (ec + eh2.y) * src[2 * jp + 1];
+          // register-index bits: bit 9 pairs (2jp, 2jp+1); bits 10.. pair jp with jp ^ 2^k
+          acc0 = fma(cq[LOGNT], src[2 * jp + 1], acc0);
+          acc1 = fma(cq[LOGNT], src[2 * jp], acc1);
+#pragma unroll
+          for (int k = 0; k + LOGNT + 1 < N; ++k) {
+            const int jo = jp ^ (1 << k);
+            acc0 = fma(cq[LOGNT + 1 + k], src[2 * jo], acc0);
+            acc1 = fma(cq[LOGNT + 1 + k], src[2 * jo + 1], acc1);
+          }
+#pragma unroll
+          for (int f = 0; f < LOGNT; ++f) {
+            acc0 = fma(cq[f], pv[f].x, acc0);
+            acc1 = fma(cq[f], pv[f].y, acc1);
+          }
+          dst[2 * jp] = fma(coef, acc0, dst[2 * jp]);
+          dst[2 * jp + 1] = fma(coef, acc1, dst[2 * jp + 1]);
+          __builtin_amdgcn_sched_barrier(0);  // keep the partner reads of the next pair behind this one
+        }
+      };
+
+      for (int sb = 0; sb < nsub; ++sb) {
+        for (int i = 0; i < m; ++i) {
+          // consecutive sub-exponentials share the boundary shear: a_{m+1} + a_1
+          const double ai = kSympDev[sch].a[i] + ((i == 0 && sb > 0) ? kSympDev[sch].a[m] : 0.0);
+          half_stage(q, p, ai * hs);
+          half_stage(p, q, -kSympDev[sch].b[i] * hs);
+        }
+      }
+      half_stage(q, p, kSympDev[sch].a[m] * hs);
+      // e^{-i h shift} (conjugated for the row form)
+      double sn, cs;
+      sincos(A.conj_sign * sd.h * shift, &sn, &cs);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const double qq = q[j], pp2 = p[j];
+        q[j] = fma(qq, cs, pp2 * sn);
+        p[j] = fma(pp2, cs, -qq * sn);
+      }
+    }
+    if (sd.snap >= 0 && A.snaps) {
+      cplx* o = A.snaps + ((size_t)sd.snap * gridDim.x + row) * D;
+#pragma unroll
+      for (int j = 0; j < R; ++j) o[tid + j * NTT] = make_double2(q[j], p[j]);
+    }
+    __syncthreads();  // cf / ehi are rewritten by the next step
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int l = tid + j * NTT;
+    double f = 1.0;
+    if (A.use_post) f = factor(ftab + 64, (unsigned)l);
+    st[l] = make_double2(f * q[j], f * p[j]);
+  }
+}
+
+// out[b][c][r] = conj(in[b][r][c]) for 2^N x 2^N matrices, 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void k_transpose_conj(const cplx* __restrict__ in, cplx* __restrict__ out, int N) {
+  __shared__ cplx t[32][33];
+  const size_t D = (size_t)1 << N;
+  const size_t boff = (size_t)blockIdx.z * D * D;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t r0 = (size_t)blockIdx.y * 32, c0 = (size_t)blockIdx.x * 32;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[ty + 8 * r][tx] = in[boff + (r0 + ty + 8 * r) * D + c0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const cplx v = t[tx][ty + 8 * r];
+    out[boff + (c0 + ty + 8 * r) * D + r0 + tx] = make_double2(v.x, -v.y);
+  }
+}

@@ -185,6 +185,7 @@ class Engine:
         max_step: float = 0.0,
         max_order: int = 0,
         magnus_tol: float = 0.0,
+        split_steps: int = 0,
     ) -> None:
         """In place: ``state <- U(t1, t0) state`` (times in us)."""
         self._check_state(state)
@@ -194,6 +195,7 @@ class Engine:
             tol=float(tol),
             max_step=float(max_step),
             magnus_tol=float(magnus_tol),
+            split_steps=int(split_steps),
         )
         _lib.check(
             self.lib.ryd_evolve(
@@ -294,15 +296,19 @@ class Engine:
 
     def set_path(self, force_generic: bool, no_tile14: bool = False,
                  force_tile14: bool = False, no_single_pass: bool = False,
-                 force_single_pass: bool = False) -> None:
+                 force_single_pass: bool = False, no_ket: bool = False,
+                 force_ket: bool = False) -> None:
         """Test/bench hook: disable the persistent small-N kernel and/or the 2^14
         register-tile kernel with the Hermitian mesolve path (the tiled
         multi-pass kernels are used instead), or force the register tiles;
-        ``no_single_pass`` disables the one-launch plan of states up to 128 MiB."""
+        ``no_single_pass`` disables the one-launch plan of states up to 128 MiB;
+        ``no_ket`` disables the register-resident ket kernel and the split-operator
+        master equation built on it, ``force_ket`` uses them from 10 atoms on."""
         _lib.check(self.lib.ryd_set_path(
             self._h, int(bool(force_generic)) | (2 if no_single_pass else 0)
             | (4 if no_tile14 else 0) | (8 if force_tile14 else 0)
-            | (16 if force_single_pass else 0)))
+            | (16 if force_single_pass else 0) | (32 if no_ket else 0)
+            | (64 if force_ket else 0)))
 
     def apply_generator(self, x: Any, t: float) -> Any:
         """``G(t) x`` with ``G = -iH`` (sesolve) or the Lindbladian (mesolve)."""

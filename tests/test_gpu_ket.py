@@ -1,0 +1,152 @@
+"""-m gpu: the register-resident ket kernel (k_ket) and the split-operator master equation.
+
+Checkers: the tight oracle fixture (12-atom anneal), the other device paths (LDS-resident
+k_traj, multi-launch tiled kernels, Hermitian mesolve path) and, at full size, the exact
+product-state solution of non-interacting atoms.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+from helpers import blockade_radius, load_fixture, with_anneal_samples
+from pulser_amd import problem as P
+
+pytestmark = pytest.mark.gpu
+
+AMP_TOL = 1e-7  # amplitudes / rho entries vs the tight oracle
+
+
+def _engine(probs, mode):
+    from pulser_amd.engine import Engine
+
+    return Engine.from_problems(probs, mode=mode)
+
+
+def real_local_problem(n, seed=0, duration=61, collapse_ops=None, spacing=7.0):
+    """Per-atom REAL drives (phase 0) and detunings: Local addressing without a phase."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(duration) / 1000.0
+    coords = P.register_coords(P.square_rect(1, n), spacing) + rng.normal(0, 0.3, (n, 2))
+    z = np.zeros(duration)
+    prob = P.make_ising_problem(coords, {"amp": z, "det": z, "phase": z})
+    loc = {}
+    for q in range(n):
+        a, b, c = rng.uniform(2, 12, 3)
+        loc[q] = {"amp": a * (1 + 0.5 * np.sin(2 * np.pi * (q + 1) * t / t[-1])),
+                  "det": b * np.cos(3 * t + q) - c, "phase": z}
+    prob["samples"] = {"Global": {}, "Local": {"ground-rydberg": loc}}
+    prob["collapse_ops"] = list(collapse_ops or [])
+    return prob
+
+
+def tri_problem(rows, cols, collapse_ops=None):
+    coords = P.register_coords(P.triangular_rect(rows, cols), blockade_radius())
+    return P.make_ising_problem(coords, P.anneal_samples(), collapse_ops=collapse_ops)
+
+
+def test_ket_kernel_cfg2_chain12_against_tight_oracle_and_persistent_kernel():
+    prob, extra = load_fixture("cfg2_chain12_anneal.npz")
+    prob = with_anneal_samples(prob)
+    times = np.asarray(extra["eval_times"])
+    ref = np.asarray(extra["oracle_states_tight"])
+    outs = {}
+    for force in (True, False):
+        with _engine([prob], "sesolve") as eng:
+            eng.set_path(False, force_ket=force)
+            st = eng.new_state()
+            snaps = eng.solve(st, times).cpu().numpy()[:, 0]
+            outs[force] = snaps
+            if force:
+                assert eng.stats()["n_launches"] == 1  # the whole sequence is one launch
+    for k in range(1, len(times)):
+        assert np.max(np.abs(outs[True][k - 1] - ref[k])) < AMP_TOL, k
+    assert np.max(np.abs(outs[True] - outs[False])) < 2e-8
+
+
+@pytest.mark.parametrize("n", [10, 13, 14])
+def test_ket_kernel_per_atom_real_drives_against_tiled_kernels(n):
+    probs = [real_local_problem(n, seed=s) for s in range(2)]
+    times = np.array([0.0, 0.017, 0.06])
+    outs = {}
+    for force in (True, False):
+        with _engine(probs, "sesolve") as eng:
+            eng.set_path(not force, force_ket=force, no_ket=not force)
+            outs[force] = eng.solve(eng.new_state(), times).cpu().numpy()
+    assert np.max(np.abs(outs[True] - outs[False])) < 1e-9
+    assert abs(np.linalg.norm(outs[True][-1, 1]) - 1.0) < 1e-10
+
+
+def test_ket_kernel_14_atom_triangular_anneal_against_multi_launch():
+    prob = tri_problem(2, 7)
+    outs = {}
+    for no_ket in (False, True):
+        with _engine([prob], "sesolve") as eng:
+            eng.set_path(False, no_ket=no_ket)
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 0.25)  # first part of the rise: Omega and |delta| both large
+            outs[no_ket] = st.cpu().numpy()[0]
+            if not no_ket:
+                assert eng.stats()["n_launches"] == 1
+    assert np.max(np.abs(outs[False] - outs[True])) < 1e-9
+
+
+@pytest.mark.parametrize("n", [10, 12])
+def test_split_operator_rows_against_hermitian_path(n):
+    """rho(t) by Strang blocks U (D rho) U^dagger on the ket kernel against the multi-launch
+    Lindbladian (k_apply14 row pass + symmetrisation), interacting atoms, per-atom drives."""
+    ops = [(np.sqrt(2 * 0.05), "sigma_rr")]
+    prob = real_local_problem(n, seed=3, duration=41, collapse_ops=ops)
+    times = np.array([0.0, 0.013, 0.04])
+    outs = {}
+    for rows in (True, False):
+        with _engine([prob], "mesolve") as eng:
+            eng.set_path(False, force_ket=rows, no_ket=not rows, force_tile14=not rows)
+            outs[rows] = eng.solve(eng.new_state(), times).cpu().numpy()[:, 0]
+    rho = outs[True][-1]
+    assert np.max(np.abs(outs[True] - outs[False])) < 1e-9
+    assert abs(np.trace(rho).real - 1.0) < 1e-12
+    assert np.max(np.abs(rho - rho.conj().T)) < 1e-14
+
+
+def _single_atom_lindblad(omega, delta, gamma, t):
+    H = np.array([[-delta, omega / 2], [omega / 2, 0.0]], dtype=complex)
+    C = np.sqrt(2 * gamma) * np.diag([1.0, 0.0]).astype(complex)
+    I2 = np.eye(2)
+    L = (-1j * (np.kron(H, I2) - np.kron(I2, H.T)) + np.kron(C, C.conj())
+         - 0.5 * np.kron(C.conj().T @ C, I2) - 0.5 * np.kron(I2, (C.conj().T @ C).T))
+    return (expm(L * t) @ np.array([0, 0, 0, 1.0], dtype=complex)).reshape(2, 2)  # from |g><g|
+
+
+@pytest.mark.parametrize("n, gamma", [(10, 0.5), (14, 0.05)])
+def test_split_operator_rows_product_state_full_size(n, gamma):
+    """Non-interacting atoms under a constant drive: rho(t) is the product of single-atom
+    Lindblad solutions - an exact reference at any size (14 atoms: rho = 4.29 GB)."""
+    import torch
+
+    coords = P.register_coords(P.square_rect(1, n), 60.0)  # U ~ 1e-4 rad/us: negligible
+    T = 12
+    samples = {"amp": np.full(T + 1, 6.0), "det": np.full(T + 1, -2.0), "phase": np.zeros(T + 1)}
+    prob = P.make_ising_problem(coords, samples, collapse_ops=[(np.sqrt(2 * gamma), "sigma_rr")])
+    t_end = 0.008
+    with _engine([prob], "mesolve") as eng:
+        eng.set_path(False, force_ket=True)  # 10 atoms: below the default size of the row path
+        st = eng.new_state()
+        eng.evolve(st, 0.0, t_end)
+        assert eng.stats()["n_launches"] == 3 * (8 // (2 if gamma > 0.1 else 4))  # 2 row passes + 1 transposition per block
+        r1 = _single_atom_lindblad(6.0, -2.0, gamma, t_end)
+        D = 1 << n
+        rng = np.random.default_rng(1)
+        pairs = [(0, 0), (D - 1, D - 1), (1, 2), (D - 1, 0), ((1 << (n - 1)) + 3, 5)]
+        pairs += [tuple(int(v) for v in rng.integers(0, D, 2)) for _ in range(40)]
+        got = np.array([st[0, a, b].item() for a, b in pairs])
+        ref = np.array([np.prod([r1[(a >> (n - 1 - k)) & 1, (b >> (n - 1 - k)) & 1] for k in range(n)])
+                        for a, b in pairs])
+        diag = torch.diagonal(st[0]).real
+        assert abs(float(diag.sum().item()) - 1.0) < 1e-11
+        assert np.max(np.abs(got - ref)) < 2e-9  # residual interaction 1e-4 rad/us x 8 ns
+        a, b = pairs[-1]
+        assert abs(st[0, a, b].item() - np.conj(st[0, b, a].item())) < 1e-15
+        occ = eng.occupations(st).cpu().numpy()[0]
+        assert np.allclose(occ[:n], r1[0, 0].real, atol=1e-9)
