@@ -540,14 +540,26 @@ class CoherentResults(SimulationResults):
 
 
 def spam_flips(sampled_state: Counter, eps: float, eps_p: float) -> Counter:
-    """Per-shot per-bit measurement flips (simresults.py:537-568)."""
-    shots = list(sampled_state.keys())
-    n_detects_list = list(sampled_state.values())
-    shot_arr = np.array([list(shot) for shot in shots], dtype=int)
-    flip_probs = np.where(shot_arr == 1, eps_p, eps)
-    flip_probs_repeated = np.repeat(flip_probs, n_detects_list, axis=0)
-    random_matrix = np.random.uniform(size=(np.sum(n_detects_list), len(shot_arr[0])))
-    flips = random_matrix < flip_probs_repeated
-    new_shots = shot_arr.repeat(n_detects_list, axis=0) ^ flips
-    detected: Counter = Counter(map(tuple, new_shots))
-    return Counter({"".join(map(str, k)): v for k, v in detected.items()})
+    """Measurement errors on already sampled bitstrings (behaviour of simresults.py:537-568).
+
+    Every shot flips each of its bits independently: a measured 0 becomes 1 with
+    probability ``eps`` (false positive), a measured 1 becomes 0 with ``eps_p``.  To
+    reproduce the reference's Counters for a seed, the uniforms are drawn in ONE call of
+    shape (total shots, n bits), rows ordered by the Counter's key order with each key
+    repeated ``count`` times, and the result keeps first-occurrence order.  The
+    bookkeeping is done on integer codes rather than on character arrays.
+    """
+    keys = list(sampled_state)
+    if not keys:
+        return Counter()
+    width = len(keys[0])
+    place = np.left_shift(1, np.arange(width - 1, -1, -1, dtype=np.int64))  # MSB first
+    multiplicity = np.fromiter((sampled_state[k] for k in keys), dtype=np.int64, count=len(keys))
+    codes = np.repeat(np.fromiter((int(k, 2) for k in keys), dtype=np.int64, count=len(keys)), multiplicity)
+    ones = (codes[:, None] & place[None, :]) != 0
+    u = np.random.uniform(size=(int(multiplicity.sum()), width))
+    toggled = u < np.where(ones, eps_p, eps)
+    after = codes ^ (toggled * place[None, :]).sum(axis=1)
+    values, first_seen, counts = np.unique(after, return_index=True, return_counts=True)
+    order = np.argsort(first_seen, kind="stable")
+    return Counter({np.binary_repr(int(values[i]), width): int(counts[i]) for i in order})

@@ -352,79 +352,70 @@ class QutipEmulator:
         return self._tot_duration
 
     # -- deprecated SimConfig surface (simulation.py:348-476) -------------------
-    def set_config(self, cfg: SimConfig) -> None:
-        """Replace the noise configuration (new noise-trajectory draws, initial
-        state re-validated or reset to all-ground when the dimension changes)."""
+    # Same contract as the reference (warnings, exception types and messages, the
+    # all-ground fallback when the level structure changes); the mechanics are ours:
+    # one validator shared by set / add, and the merge is done on NoiseModel fields.
+    def _check_legacy_config(self, candidate: Any, *, colon_space: bool, period: bool) -> NoiseModel:
+        """Deprecation notice + the two rejections of the legacy entry points; returns the
+        candidate as a NoiseModel.  (The reference's two messages differ by a space after
+        the colon and a trailing period; both are asserted by its tests.)"""
         warnings.warn(
             "Supplying a 'SimConfig' to QutipEmulator has been deprecated."
             " Please instantiate with a 'NoiseModel' instead.",
             DeprecationWarning,
-            stacklevel=2,
+            stacklevel=3,
         )
-        if not isinstance(cfg, SimConfig):
-            raise ValueError(f"Object {cfg} is not a valid `SimConfig`.")
-        v = self._hamiltonian_data.interaction_type
-        not_supported = set(cfg.noise) - cfg.supported_noises[v]
-        if not_supported:
+        if not isinstance(candidate, SimConfig):
+            raise ValueError(f"Object {candidate} is not a valid `SimConfig`" + ("." if period else ""))
+        mode = self._hamiltonian_data.interaction_type
+        refused = [kind for kind in candidate.noise if kind not in candidate.supported_noises[mode]]
+        if refused:
             raise NotImplementedError(
-                f"Interaction mode '{v}' "
-                "does not support simulation of noise types:"
-                f"{', '.join(not_supported)}."
+                f"Interaction mode '{mode}' does not support simulation of noise types:"
+                + (" " if colon_space else "") + ", ".join(refused) + "."
             )
-        former_dim = self.dim
-        former_ground = self._all_ground()
-        noise_model = cfg.to_noise_model()
+        return candidate.to_noise_model()
+
+    def _install_noise_model(self, model: NoiseModel) -> None:
+        """Swap the noise model: fresh trajectory draws, caches dropped, and the initial
+        state carried over when the local dimension is unchanged."""
+        dim_before, ground_before = self.dim, np.asarray(self._all_ground())
         self._noise_trajectories_used = False
-        self._hamiltonian_data = HamiltonianData(
-            self.samples_obj, noise_model,
-            self._get_n_trajectories(noise_model, check_value=True),
-        )
         self._problems_cache = None
-        self._current_problem = self._hamiltonian_data.problem(
-            self._hamiltonian_data.noise_trajectories[0], self._sampling_rate)
-        if self.dim == former_dim:
-            self.set_initial_state(np.asarray(self._initial_state))
-            return
-        if not np.array_equal(np.asarray(self._initial_state), np.asarray(former_ground)):
-            warnings.warn(
-                "Current initial state's dimension does not match new"
-                " dimensions. Setting it to 'all-ground'."
-            )
-        self.set_initial_state("all-ground")
+        self._hamiltonian_data = HamiltonianData(
+            self.samples_obj, model, self._get_n_trajectories(model, check_value=True))
+        first = self._hamiltonian_data.noise_trajectories[0]
+        self._current_problem = self._hamiltonian_data.problem(first, self._sampling_rate)
+        kept = np.asarray(self._initial_state)
+        if self.dim == dim_before:
+            self.set_initial_state(kept)
+        else:
+            if not np.array_equal(kept, ground_before):
+                warnings.warn(
+                    "Current initial state's dimension does not match new"
+                    " dimensions. Setting it to 'all-ground'."
+                )
+            self.set_initial_state("all-ground")
+
+    def set_config(self, cfg: SimConfig) -> None:
+        """Replace the noise configuration."""
+        self._install_noise_model(self._check_legacy_config(cfg, colon_space=False, period=True))
 
     def add_config(self, config: SimConfig) -> None:
-        """Merge another configuration into the current one: noise types it adds
-        bring their parameters, noise types present in both keep the current ones."""
-        warnings.warn(
-            "Supplying a 'SimConfig' to QutipEmulator has been deprecated."
-            " Please instantiate with a 'NoiseModel' instead.",
-            DeprecationWarning,
-            stacklevel=2,
-        )
-        if not isinstance(config, SimConfig):
-            raise ValueError(f"Object {config} is not a valid `SimConfig`")
-        v = self._hamiltonian_data.interaction_type
-        not_supported = set(config.noise) - config.supported_noises[v]
-        if not_supported:
-            raise NotImplementedError(
-                f"Interaction mode '{v}' "
-                "does not support simulation of noise types: "
-                f"{', '.join(not_supported)}."
-            )
-        noise_model = config.to_noise_model()
-        current = self._hamiltonian_data.noise_model
-        old_noise_set = set(current.noise_types)
-        diff_noise_set = old_noise_set.union(noise_model.noise_types) - old_noise_set
-        from dataclasses import asdict
+        """Merge another configuration into the current one: only the noise types that
+        are NEW bring their parameters; for types present in both the current values stay."""
+        incoming = self._check_legacy_config(config, colon_space=True, period=False)
+        present = self._hamiltonian_data.noise_model
+        fresh_types = set(incoming.noise_types).difference(present.noise_types)
+        adopted = _find_relevant_params(fresh_types, incoming.state_prep_error,
+                                        incoming.amp_sigma, incoming.laser_waist)
+        import dataclasses
 
-        param_dict: dict[str, Any] = asdict(current)
-        for param in _find_relevant_params(diff_noise_set, noise_model.state_prep_error,
-                                           noise_model.amp_sigma, noise_model.laser_waist):
-            param_dict[param] = getattr(noise_model, param)
-        param_dict.pop("noise_types")
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore", DeprecationWarning)
-            self.set_config(SimConfig.from_noise_model(NoiseModel(**param_dict)))
+        fields = {f.name: getattr(present, f.name) for f in dataclasses.fields(present)
+                  if f.name != "noise_types"}
+        fields.update({name: getattr(incoming, name) for name in adopted})
+        # through SimConfig, as the reference does: its field set (and defaults) decide what survives
+        self._install_noise_model(SimConfig.from_noise_model(NoiseModel(**fields)).to_noise_model())
 
     def show_config(self, solver_options: bool = False) -> None:
         """Prints the current configuration."""
@@ -432,9 +423,7 @@ class QutipEmulator:
 
     def reset_config(self) -> None:
         """Back to the default (noiseless) configuration."""
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore", DeprecationWarning)
-            self.set_config(SimConfig())
+        self._install_noise_model(SimConfig().to_noise_model())
 
     def draw(self, draw_phase_area: bool = False, draw_phase_shifts: bool = False,
              draw_phase_curve: bool = False, fig_name: str | None = None,
