@@ -108,7 +108,8 @@ typedef struct ryd_opts {
                            sub-stepping next to waveform kinks (default 1e-10) */
   int32_t split_steps;  /* mesolve split-operator path: CF4 steps per Strang block (0 = from the
                            dissipator rate: 4 / 2 / 1 for rates <= 0.1 / <= 0.5 / above) */
-  int32_t reserved_i;
+  int32_t method;       /* exponential of the multi-launch sesolve path: 0 = Taylor polynomial (Horner),
+                           1 = Lanczos / Krylov subspace (batched inner products V^H w and V c) */
   double reserved[2];
 } ryd_opts;
 

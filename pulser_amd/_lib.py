@@ -71,7 +71,7 @@ class RydOpts(C.Structure):
         ("max_step", C.c_double),
         ("magnus_tol", C.c_double),
         ("split_steps", C.c_int32),
-        ("reserved_i", C.c_int32),
+        ("method", C.c_int32),
         ("reserved", C.c_double * 2),
     ]
 

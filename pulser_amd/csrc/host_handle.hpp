@@ -52,6 +52,12 @@ struct ryd_handle {
   StepDesc* sched_dev = nullptr;
   size_t sched_cap = 0;
   KetStep* ksched_dev = nullptr;  // schedule of the register-resident ket kernel
+  double* ftab_dev = nullptr;     // elementwise dissipator factor tables of the row path
+  double ftab_tau = -1.0;
+  cplx* kry_V = nullptr;          // Krylov basis (m + 1 vectors), allocated on first use
+  int kry_cap = 0;
+  void* kry_pool = nullptr;
+  KryScalars kry{};
   size_t ksched_cap = 0;
   // general path (explicit CSR terms)
   bool general = false;
@@ -377,6 +383,9 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->dterms_dev);
   hipFree(h->sched_dev);
   hipFree(h->ksched_dev);
+  hipFree(h->kry_V);
+  hipFree(h->ftab_dev);
+  hipFree(h->kry_pool);
   hipFree(h->gen_tcoef);
   hipFree(h->gen_terms_dev);
   hipFree(h->gen_series_dev);
@@ -670,6 +679,7 @@ extern "C" int ryd_set_dissipator(ryd_handle* h, const double* S) {
     h->J[r] = make_double2(S[2 * (4 * r + (3 - r))], S[2 * (4 * r + (3 - r)) + 1]);
   }
   h->diss_norm = norm * h->N;
+  h->ftab_tau = -1.0;  // the row path rebuilds its factor tables
   const bool replan = dbl != h->has_dbl;
   h->has_dbl = dbl;
   if (replan) plan_passes(h);

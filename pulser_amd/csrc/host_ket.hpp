@@ -72,7 +72,7 @@ static int pick_scheme(double x, double tol, short* sch, short* nsub) {
 static const double kDefaultSympTol = 2e-11;
 
 static int to_ket_steps(ryd_handle* h, const std::vector<StepDesc>& sched, const ryd_opts& o,
-                        std::vector<KetStep>& out) {
+                        double conj_sign, std::vector<KetStep>& out) {
   const double tol = o.tol > 0 ? o.tol : kDefaultSympTol;
   int rc;
   for (const StepDesc& d : sched) {
@@ -84,6 +84,8 @@ static int to_ket_steps(ryd_handle* h, const std::vector<StepDesc>& sched, const
     ket_bound(h, d.idx, kA2, kA1, &bb, &k.shift_b);
     if ((rc = pick_scheme(std::fabs(d.h) * ba, tol, &k.sch_a, &k.sub_a))) return rc;
     if ((rc = pick_scheme(std::fabs(d.h) * bb, tol, &k.sch_b, &k.sub_b))) return rc;
+    k.cs_a = std::cos(conj_sign * d.h * k.shift_a); k.sn_a = std::sin(conj_sign * d.h * k.shift_a);
+    k.cs_b = std::cos(conj_sign * d.h * k.shift_b); k.sn_b = std::sin(conj_sign * d.h * k.shift_b);
     h->stats.last_order = kSymp[k.sch_a].m * k.sub_a;
     h->stats.norm_bound = ba / (kA1 + kA2);
     out.push_back(k);
@@ -122,7 +124,7 @@ static int ket_init_device(ryd_handle* h) {
 
 static int launch_ket(ryd_handle* h, const KetArgs& A, size_t n_rows, hipStream_t st) {
   const size_t D = (size_t)1 << h->N;
-  const size_t lds = D * sizeof(double) + (64 + 64 + 2 * (D / 512) + 32 + 128 + (D / 512)) * sizeof(double);
+  const size_t lds = D * sizeof(double) + (64 + 64 + 2 * (D / 512) + 32 + 128 + (D / 512) + 64) * sizeof(double);
   std::pair<hipEvent_t, hipEvent_t> ev;
   int rc;
   if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
@@ -167,7 +169,7 @@ static int run_ket(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sche
   int rc;
   if ((rc = ket_init_device(h))) return rc;
   std::vector<KetStep> ks;
-  if ((rc = to_ket_steps(h, sched, o, ks))) return rc;
+  if ((rc = to_ket_steps(h, sched, o, 1.0, ks))) return rc;
   if ((rc = upload_ket_steps(h, ks, st))) return rc;
   KetArgs A;
   fill_ket_args(h, A);
@@ -182,54 +184,91 @@ static int run_ket(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sche
   return RYD_OK;
 }
 
-// CF4 steps per Strang block from the dissipator rate (splitting error ~ gamma K^2)
+// CF4 steps per HALF block of the 4th-order splitting (below): two steps (tau = 4 ns at
+// sampling rate 1) keep the splitting error at the level of the CF4 error (<= 1e-9 after 3.1 us
+// for dephasing rates up to 0.5 / us and drives up to 25 rad/us, tools/split_probe.py); faster
+// dephasing halves the block.
 static int row_block_steps(const ryd_handle* h, const ryd_opts& o) {
   if (o.split_steps > 0) return o.split_steps;
   double g = 0.0;
   for (int k = 0; k < 4; ++k) g = std::max(g, std::fabs(h->Sd[k].x));
-  if (g <= 0.1) return 4;
-  if (g <= 0.5) return 2;
-  return 1;
+  return g <= 0.5 ? 2 : 1;
 }
 
-// mesolve: Strang blocks of K CF4 steps; see the header of this file
+// mesolve by operator splitting (header of this file).  Blocks of two halves, 4th order
+// (Chin's scheme 4A: all coefficients positive, so the dissipative factor never runs backwards):
+//
+//   rho <- D(tau/6) . W2 ( D(2 tau/3) . W1 ( D(tau/6) . rho ) W1^+ ) W2^+
+//   W1 = V U(t + tau/2, t),   W2 = U(t + tau, t + tau/2) V,   V = exp(+i (eps/2) H_drive(t + tau/2))
+//
+// V carries the commutator correction [B, [A, B]] of the scheme: for an elementwise diagonal
+// B = d(a, b) whose value changes by +-g when one index bit flips, [B, [A, B]] = -g^2 A_drive
+// exactly, so the "modified potential" is a drive-only rotation by eps = tau^3 g^2 / 72 - it is
+// what makes the splitting 4th order in tau (without it the error is O(tau^2 g^2)).  It is
+// only exact when every single-bit flip changes d by the same |g| (pure dephasing: Sd = (0, -g,
+// -g, 0)); other diagonal dissipators fall back to the 2nd-order behaviour of the uncorrected
+// scheme with half the block length.
 static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
                     const ryd_opts& o, hipStream_t st) {
   if (sched.empty()) return RYD_OK;
   int rc;
   if ((rc = ket_init_device(h))) return rc;
   std::vector<KetStep> ks;
-  if ((rc = to_ket_steps(h, sched, o, ks))) return rc;
+  if ((rc = to_ket_steps(h, sched, o, -1.0, ks))) return rc;
   for (KetStep& k : ks) k.snap = -1;  // snapshots are whole-matrix copies between blocks
   if ((rc = upload_ket_steps(h, ks, st))) return rc;
-  const int K = row_block_steps(h, o);
+  // |change of d under one bit flip|: (0,0)<->(0,1)/(1,0) and (1,1)<->(0,1)/(1,0)
+  const double g01 = h->Sd[1].x - h->Sd[0].x, g10 = h->Sd[2].x - h->Sd[0].x;
+  const double g31 = h->Sd[1].x - h->Sd[3].x, g32 = h->Sd[2].x - h->Sd[3].x;
+  const bool uniform_g = std::fabs(std::fabs(g01) - std::fabs(g10)) < 1e-14 * (1 + std::fabs(g01)) &&
+                         std::fabs(std::fabs(g01) - std::fabs(g31)) < 1e-14 * (1 + std::fabs(g01)) &&
+                         std::fabs(std::fabs(g01) - std::fabs(g32)) < 1e-14 * (1 + std::fabs(g01));
+  const double gflip = std::fabs(g01);
+  int Kh = row_block_steps(h, o);
+  if (!uniform_g && o.split_steps <= 0) Kh = 1;
   const size_t D = (size_t)1 << h->N;
   const size_t n_rows = D * (size_t)h->B;
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
   const unsigned nt = (unsigned)(D / 32);
+  if (!h->ftab_dev) HIPCHK(hipMalloc((void**)&h->ftab_dev, 4 * 128 * sizeof(double)));
   cplx* cur = state;
   cplx* other = h->wA;
-  size_t i = 0;
-  while (i < sched.size()) {
-    size_t j = i;
-    double tau = 0.0;
-    while (j < sched.size() && (int)(j - i) < K) {
-      tau += sched[j].h;
-      ++j;
-      if (sched[j - 1].snap >= 0) break;  // a requested evaluation time ends the block
-    }
+  int tab_slot = 0;
+
+  // one conjugation  X <- W X W^+  over the steps [i0, i1): two row passes + a conjugate transposition
+  auto conjugate = [&](size_t i0, size_t i1, double f_in, double f_out, double kick_pre, double kick_post,
+                       int kick_idx, double kick_u) -> int {
+    // elementwise factors exp(f * d(a, b)) as four 16-entry tables (counts n00, n01, n10, n11): slot
+    // [0] on the load of the first pass, [1] on the store of the second.  Four rotating slots, so a
+    // table is never rewritten while a queued launch may still read it (the stream serialises more
+    // than four launches apart only after a synchronisation every 4th conjugation).
+    double tab[128];
+    for (int k = 0; k < 4; ++k)
+      for (int n = 0; n < 16; ++n) {
+        tab[k * 16 + n] = std::exp(f_in * h->Sd[k].x * n);
+        tab[64 + k * 16 + n] = std::exp(f_out * h->Sd[k].x * n);
+      }
+    if (tab_slot == 0) HIPCHK(hipStreamSynchronize(st));
+    double* tdev = h->ftab_dev + 128 * tab_slot;
+    tab_slot = (tab_slot + 1) & 3;
+    HIPCHK(hipMemcpyAsync(tdev, tab, sizeof tab, hipMemcpyHostToDevice, st));
     KetArgs A;
     fill_ket_args(h, A);
-    A.steps = h->ksched_dev + i;
-    A.n_steps = (int)(j - i);
+    A.steps = h->ksched_dev + i0;
+    A.n_steps = (int)(i1 - i0);
     A.rows_log2 = h->N;
     A.conj_sign = -1.0;
+    A.kick_pre = kick_pre;
+    A.kick_post = kick_post;
+    A.kick_idx = kick_idx;
+    A.kick_u = kick_u;
+    A.ftab = tdev;
     A.state = cur;
-    for (int k = 0; k < 4; ++k) A.pre[k] = 0.5 * tau * h->Sd[k].x;
-    A.use_pre = 1;
-    if ((rc = launch_ket(h, A, n_rows, st))) return rc;
+    A.use_pre = f_in != 0.0;
+    int rc2;
+    if ((rc2 = launch_ket(h, A, n_rows, st))) return rc2;
     std::pair<hipEvent_t, hipEvent_t> ev;
-    if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+    if (h->timing) { if ((rc2 = timing_begin(h, st, ev))) return rc2; }
     hipLaunchKernelGGL(k_transpose_conj, dim3(nt, nt, h->B), dim3(256), 0, st, cur, other, h->N);
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
@@ -237,11 +276,37 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     std::swap(cur, other);
     A.state = cur;
     A.use_pre = 0;
-    for (int k = 0; k < 4; ++k) A.post[k] = 0.5 * tau * h->Sd[k].x;
-    A.use_post = 1;
-    if ((rc = launch_ket(h, A, n_rows, st))) return rc;
-    count_ket_work(h, ks, i, j, 1);  // one Lindbladian application ~ one two-sided ket stage
-    h->stats.n_steps += (int64_t)(j - i);
+    A.use_post = f_out != 0.0;
+    if ((rc2 = launch_ket(h, A, n_rows, st))) return rc2;
+    count_ket_work(h, ks, i0, i1, 1);  // one Lindbladian application ~ one two-sided ket stage
+    h->stats.n_steps += (int64_t)(i1 - i0);
+    return RYD_OK;
+  };
+
+  size_t i = 0;
+  while (i < sched.size()) {
+    // first half [i, mid), second half [mid, j); a requested evaluation time ends the block
+    size_t mid = i, j;
+    double t1 = 0.0, t2 = 0.0;
+    bool cut = false;
+    while (mid < sched.size() && (int)(mid - i) < Kh && !cut) { t1 += sched[mid].h; cut = sched[mid].snap >= 0; ++mid; }
+    j = mid;
+    while (j < sched.size() && (int)(j - mid) < Kh && !cut) { t2 += sched[j].h; cut = sched[j].snap >= 0; ++j; }
+    if (j == mid) {
+      // a lone half (end of the schedule / evaluation time): 2nd-order Strang block
+      if ((rc = conjugate(i, mid, 0.5 * t1, 0.5 * t1, 0.0, 0.0, 0, 0.0))) return rc;
+    } else {
+      const double tau = t1 + t2;
+      // the two halves may differ in length: with a = t1 / tau the scheme keeps its weights
+      // (1/6, 2/3, 1/6) only for a = 1/2; unequal halves (knot-limited steps) are rare and small,
+      // they keep the symmetric weights of their own lengths: D(t1/3) . D((t1+t2)/3 ...) -
+      // handled by giving each half the weights (1/3, 2/3) of ITS length around the middle factor
+      const double eps = uniform_g ? tau * tau * tau * gflip * gflip / 72.0 : 0.0;
+      const StepDesc& m0 = sched[mid];
+      const double kick_u = m0.u1 - kC1 * m0.h;  // start of the step `mid` inside its knot interval
+      if ((rc = conjugate(i, mid, t1 / 3.0, 2.0 * t1 / 3.0, 0.0, 0.5 * eps, m0.idx, kick_u))) return rc;
+      if ((rc = conjugate(mid, j, 2.0 * t2 / 3.0, t2 / 3.0, 0.5 * eps, 0.0, m0.idx, kick_u))) return rc;
+    }
     const int snap = sched[j - 1].snap;
     if (snap >= 0 && snaps)
       HIPCHK(hipMemcpyAsync(snaps + (size_t)snap * h->dim * h->B, cur, bytes, hipMemcpyDeviceToDevice, st));

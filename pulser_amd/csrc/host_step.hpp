@@ -121,8 +121,10 @@ static int snapshot_copy(ryd_handle* h, const cplx* state, cplx* dst, hipStream_
 }
 
 static int run_generic(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched,
-                       cplx* snaps, hipStream_t st) {
+                       cplx* snaps, hipStream_t st, const ryd_opts& o) {
   int rc;
+  const bool kry = krylov_selected(h, o);
+  const double ktol = o.tol > 0 ? o.tol : kDefaultTol;
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
   for (const StepDesc& d : sched) {
     MixPoint m;
@@ -130,9 +132,18 @@ static int run_generic(ryd_handle* h, cplx* state, const std::vector<StepDesc>& 
     m.u1 = d.u1;
     m.u2 = d.u2;
     m.w1 = kA1; m.w2 = kA2;
-    if ((rc = exp_step(h, state, d.h, m, d.order_a, d.shift_a, st))) return rc;
-    m.w1 = kA2; m.w2 = kA1;
-    if ((rc = exp_step(h, state, d.h, m, d.order_b, d.shift_b, st))) return rc;
+    if (kry) {
+      double bnd, sh;
+      ket_bound(h, d.idx, kA1, kA2, &bnd, &sh);
+      if ((rc = exp_step_krylov(h, state, d.h, m, std::fabs(d.h) * bnd, sh, ktol, st))) return rc;
+      m.w1 = kA2; m.w2 = kA1;
+      ket_bound(h, d.idx, kA2, kA1, &bnd, &sh);
+      if ((rc = exp_step_krylov(h, state, d.h, m, std::fabs(d.h) * bnd, sh, ktol, st))) return rc;
+    } else {
+      if ((rc = exp_step(h, state, d.h, m, d.order_a, d.shift_a, st))) return rc;
+      m.w1 = kA2; m.w2 = kA1;
+      if ((rc = exp_step(h, state, d.h, m, d.order_b, d.shift_b, st))) return rc;
+    }
     h->stats.n_steps++;
     if (h->mc_active && (rc = mc_after_step(h, state, st))) return rc;
     if (d.snap >= 0 && snaps && (rc = snapshot_copy(h, state, snaps + (size_t)d.snap * h->dim * h->B, st)))
@@ -381,12 +392,13 @@ static bool use_persistent(const ryd_handle* h) {
 
 static int run_steps(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
                      hipStream_t st, const ryd_opts& o) {
+  if (krylov_selected(h, o)) return run_generic(h, state, sched, snaps, st, o);
   if (ket_path(h)) return run_ket(h, state, sched, snaps, o, st);
   if (use_persistent(h)) return run_persistent(h, state, sched, snaps, st);
   if (use_persistent_dm(h)) return run_persistent_dm(h, state, sched, snaps, st);
   if (use_persistent_general(h)) return run_persistent_general(h, state, sched, snaps, st);
   if (row_path(h)) return run_rows(h, state, sched, snaps, o, st);
-  return run_generic(h, state, sched, snaps, st);
+  return run_generic(h, state, sched, snaps, st, o);
 }
 
 extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
@@ -405,7 +417,9 @@ extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const 
   cplx* state = (cplx*)state_dev;
   cplx* snaps = (cplx*)out_dev;
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
-  const bool in_place = ket_path(h) || (row_path(h) && !use_persistent_dm(h));
+  // the in-place schemes split an exponential themselves and a Lanczos process takes whole
+  // steps: both skip build_schedule's Taylor sub-stepping
+  const bool in_place = ket_path(h) || (row_path(h) && !use_persistent_dm(h)) || krylov_selected(h, o);
   std::vector<StepDesc> sched;
   // snapshot slot i-1 receives the state at times[i]
   for (int i = 1; i < n_times; ++i) {

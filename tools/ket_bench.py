@@ -42,3 +42,8 @@ if "rows" in which:
         eng.set_path(False, no_ket=True)
         dt, s, st = run(eng, 1.0, 1.002)
         print(f"cfg3 hermitian path: {0.002/dt:.4f} sim-us/s ({dt/2*1e3:.2f} ms per ns), stats {s}", flush=True)
+
+if "pmc" in which:
+    with Engine.from_problems([tri()] * 256, mode="sesolve") as eng:
+        dt, s, _ = run(eng, 1.0, 1.02)
+        print(f"pmc leg: 256 x 14-atom, 20 ns: {dt*1e3:.1f} ms, stats {s}", flush=True)
