@@ -1,29 +1,36 @@
 #!/usr/bin/env python
 """bench.py - sim-us/s of the emulation hot path on MI355X (driver contract).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload north_star|cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Primary workload (BASELINE.json configs[1]): 12-atom chain at the blockade
-radius, analog Ising anneal (T = 3100 ns), sesolve fp64.  One "step" = one full
-pass of the hot path (all 3.1 us) over a batch of `--batch` independent
-sequences per GPU (default 256 = one per CU; cfg4 uses 128 per GPU), inputs
-(spline tables, interaction diagonal, initial states) resident in HBM before the
-timed region.  value = (GPUs x batch x 3.1 us) / seconds-per-step.  Multi-GPU:
-sequences shard across ranks with no data-path collective; the only RCCL call
-is the all-reduce of the ensemble occupation sums at the end of each step.
+Default workload = the north-star target (BASELINE.json): the 14-atom triangular register
+(2 x 7, spacing R_b), analog Ising anneal of 3100 ns, complex128.
 
-The JSON line also carries
-  roofline      - the dominant kernel of the primary workload, timed live with
-                  HIP events on the launch stream (librydemu's own event pairs);
-  cpu_baseline  - the CPU oracle (SciPy restatement of the QuTiP path, the
-                  reference's algorithm) on one host core, rank 0, N = 1 only;
-  also          - secondary workloads (cfg3 14-atom Lindblad slice, cfg5 20-atom
-                  sesolve slice, single-sequence latency) with their own rooflines.
+  value            Schroedinger leg.  One "step" = the FULL 3.1 us sequence for a batch of
+                   `--batch` (256 = one per CU) independent sequences per GPU; the sequences
+                   differ (amplitude / detuning scale factors spread over +-1 %), their tables and
+                   initial states are resident in HBM before the timed region.
+                   value = GPUs x batch x 3.1 us / seconds-per-step.  Multi-GPU: sequences shard
+                   over the ranks, no data-path collective; one all-reduce (RCCL) of the ensemble
+                   occupation sums per step.
+  single_sequence  ONE 14-atom sequence, full 3.1 us (latency; uses one CU).
+  lindblad         cfg3: 14-atom dephasing master equation (rho = 4.29 GB), `--lindblad-ns` ns slice
+                   (default 100) through the split-operator row path; `--full-lindblad` runs all 3.1 us.
+  setup            handle creation + table upload, timed separately (not inside a step).
+  roofline         the dominant kernel of the headline leg, timed with HIP events on its launch
+                   stream; the bound that binds is named (`valu_f64` for the register-resident
+                   kernels, `hbm` for streaming ones) and `frac` <= 1 by construction.
+  cpu_baseline     the CPU oracle (SciPy restatement of the QuTiP path) on host cores, rank 0,
+                   N = 1 only: primary = one 14-atom sequence on one core; `legs` = the other
+                   baselines SURVEY 8(d) lists.
+  also             secondary workloads (12-atom batch = the round-1 headline, quantum jumps, small
+                   density matrices, ensemble density matrix, cfg5 slice).
 """
 from __future__ import annotations
 
 import argparse
+import dataclasses
 import json
 import os
 import sys
@@ -34,8 +41,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
+HBM_PEAK = 8.0e12      # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+F64_VALU_PEAK = 78.6   # TFLOP/s, fp64 vector peak (256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
 T_SEQ_US = 3.1
+
+# fp64 flops per amplitude per stage of k_ket<14>, counted in the ISA of one half-stage (32 amplitudes
+# per lane): 448 v_fma_f64 + 65 v_mul_f64 + 113 v_add_f64 -> (448 x 2 + 65 + 113) / 32 = 33.6 per
+# amplitude per half-stage, two half-stages per stage (tools/count_isa.py, profiles/r02_kket_isa.md)
+KKET_FLOPS_PER_AMP_STAGE = 2 * (448 * 2 + 65 + 113) / 32.0
+# k_traj<12,1024,1>: 120 fp64 instructions per wave and stage for 4 amplitudes per lane
+# (profiles/r01_ktraj_counters.md), ~85 % of them FMAs
+KTRAJ_FLOPS_PER_AMP_STAGE = 120 * 1.85 / 4.0
 
 
 def blockade_radius() -> float:
@@ -65,52 +81,81 @@ def rect_problem(rows: int, cols: int):
     return P.make_ising_problem(coords, P.anneal_samples())
 
 
-def timed_run(eng, state_fn, t0, t1, steps, warmup, dist=None, torch=None):
-    """W warm-up + K timed passes [t0, t1]; returns (sec/step, stats, kernel ms, launches)."""
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+def spread_tables(prob, batch: int, spread: float = 0.01, seed: int = 7):
+    """Device tables of `batch` DIFFERENT sequences on one register: the shared spline tables of
+    `prob` with per-sequence amplitude and detuning scale factors spread over +-spread (what
+    amplitude / detuning calibration noise does, hamiltonian_data.py:431-468) - no clones."""
+    from pulser_amd.terms import lower
 
+    t = lower([prob])
+    desc = np.repeat(t.desc, batch, axis=0)
+    rng = np.random.default_rng(seed)
+    amp = 1.0 + spread * (2.0 * rng.random(batch) - 1.0)
+    det = 1.0 + spread * (2.0 * rng.random(batch) - 1.0)
+    amp[0] = det[0] = 1.0  # sequence 0 is the nominal one
+    desc["drive_scale"] *= amp[:, None]
+    desc["det_scale"] *= det[:, None]
+    return dataclasses.replace(t, batch=batch, desc=desc)
+
+
+def barrier(torch, dist):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def all_reduce(dist, t, op=None):
+    op = op if op is not None else dist.ReduceOp.SUM
+    if dist.get_backend() == "gloo":  # RYD_BENCH_BACKEND=gloo: 1-GPU check of the N > 1 path
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+
+
+def timed_run(eng, state_fn, t0, t1, steps, warmup, dist=None, torch=None, **opts):
+    """W warm-up + K timed passes over [t0, t1] (no per-launch events inside the timed region),
+    then ONE more pass with the library's HIP-event pairs around every launch for the roofline.
+    Returns (sec/step, stats of one step, kernel ms of one step, launches of one step, last occ)."""
     for _ in range(warmup):
         st = state_fn()
-        eng.evolve(st, t0, t1)
-    barrier()
+        eng.evolve(st, t0, t1, **opts)
+    barrier(torch, dist)
     eng.reset_stats()
-    eng.set_kernel_timing(True)
     states = [state_fn() for _ in range(steps)]
-    barrier()
+    barrier(torch, dist)
     tic = time.perf_counter()
     occ = None
-    def all_reduce(t, op=None):
-        op = op if op is not None else dist.ReduceOp.SUM
-        if dist.get_backend() == "gloo":  # RYD_BENCH_BACKEND=gloo: 1-GPU check of the N > 1 path
-            c = t.cpu()
-            dist.all_reduce(c, op=op)
-            t.copy_(c)
-        else:
-            dist.all_reduce(t, op=op)
-
     for st in states:
-        eng.evolve(st, t0, t1)
-        occ = eng.occupations(st).sum(dim=0)
+        eng.evolve(st, t0, t1, **opts)
+        occ = eng.occupations(st).sum(dim=0)  # evaluation-time reduction of the state on the device
         if dist is not None:
-            all_reduce(occ)  # ensemble sum over ranks (RCCL over xGMI)
-    barrier()
+            all_reduce(dist, occ)  # ensemble sum over ranks (RCCL over xGMI)
+    barrier(torch, dist)
     dt = time.perf_counter() - tic
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        all_reduce(tmax, dist.ReduceOp.MAX)
+        all_reduce(dist, tmax, dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    stats = eng.stats()
+    for k in ("n_applications", "n_launches", "n_steps"):
+        stats[k] //= max(steps, 1)
+    del states
+    # roofline pass: same work, event-timed
+    eng.set_kernel_timing(True)
+    st = state_fn()
+    eng.evolve(st, t0, t1, **opts)
+    torch.cuda.synchronize()
     kms, kl = eng.kernel_timing()
     eng.set_kernel_timing(False)
-    return dt / steps, eng.stats(), kms, kl, occ
+    return dt / steps, stats, kms, kl, occ
 
 
 def measured_traffic(key):
-    """HBM bytes per launch from the separate rocprofv3 --pmc passes of this
-    round (tools/profile.sh -> profiles/*_traffic.json); None if not measured."""
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes of this round
+    (tools/profile.sh -> profiles/*_traffic.json); None if not measured."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
@@ -125,56 +170,143 @@ def measured_traffic(key):
     return None
 
 
-def roofline(nb, batch, stats, kernel_ms, launches, kernel_name, traffic_key=None):
-    """Algorithmic bytes = 32 B x 2^nb per generator application."""
+def roofline_hbm(nb, batch, stats, kernel_ms, launches, kernel_name, traffic_key=None):
+    """Streaming kernels: algorithmic bytes = 32 B x 2^nb per generator application."""
     apps = stats["n_applications"]
     bytes_total = 32.0 * (2.0**nb) * batch * apps
     sec = kernel_ms * 1e-3
     achieved = bytes_total / sec if sec > 0 else 0.0
-    return {
-        "bound": "hbm",
-        "kernel": kernel_name,
-        "achieved": achieved / 1e9,
-        "peak": HBM_PEAK / 1e9,
-        "unit": "GB/s",
-        "frac": achieved / HBM_PEAK,
-        "traffic": measured_traffic(traffic_key) if traffic_key else None,
-        "launches": launches,
-        "avg_launch_ms": kernel_ms / max(launches, 1),
-        "applications": apps,
-        "algorithmic_bytes_per_launch": bytes_total / max(launches, 1),
-    }
+    return {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            "traffic": measured_traffic(traffic_key) if traffic_key else None,
+            "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1), "applications": apps,
+            "algorithmic_bytes_per_launch": bytes_total / max(launches, 1)}
 
 
-def cpu_baseline(n: int):
-    """QuTiP-path restatement (oracle) on ONE host core: full 3.1 us, N atoms."""
-    os.environ.setdefault("OMP_NUM_THREADS", "1")
+def roofline_valu(n_amp, rows, stages, flops_per_amp_stage, kernel_ms, launches, kernel_name,
+                  traffic_key=None, note=None):
+    """Register / LDS-resident kernels: the state never streams through HBM, the fp64 vector pipe
+    binds.  achieved = algorithmic fp64 flops (ISA count per amplitude per stage) / kernel time."""
+    flops = flops_per_amp_stage * n_amp * rows * stages
+    sec = kernel_ms * 1e-3
+    tf = flops / sec / 1e12 if sec > 0 else 0.0
+    out = {"bound": "valu_f64", "kernel": kernel_name, "achieved": tf, "peak": F64_VALU_PEAK,
+           "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK,
+           "traffic": measured_traffic(traffic_key) if traffic_key else None,
+           "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
+           "stages": stages, "flops_per_amplitude_per_stage": flops_per_amp_stage,
+           "algorithmic_flops_per_launch": flops / max(launches, 1),
+           "hbm_equivalent_GBps": 32.0 * n_amp * rows * stages / sec / 1e9 if sec > 0 else 0.0}
+    if note:
+        out["note"] = note
+    return out
+
+
+# ----------------------------------------------------------------------------- CPU baselines
+def _oracle_sesolve_time(prob, t_end, reps=1):
     from oracle import qutip_path as qp
 
-    prob = chain_problem(n)
     ham = qp.build_hamiltonian(prob)
+    n = prob["n_qudits"]
     psi0 = qp.all_ground_state(n, prob["eigenbasis"])
     s = prob["samples"]["Global"]["ground-rydberg"]
     opts = qp.default_options([(s["amp"], s["det"])], 3100)
     counter = [0]
     tic = time.perf_counter()
-    reps = 0
-    while True:
-        qp.sesolve(ham, psi0, np.array([0.0, T_SEQ_US]), counter=counter, **opts)
-        reps += 1
-        if time.perf_counter() - tic > 10.0 or reps >= 5:
-            break
-    dt = (time.perf_counter() - tic) / reps
-    return {
-        "value": T_SEQ_US / dt,
-        "unit": "sim-us/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{reps} x one {n}-atom sequence (3.1 us), SciPy CSR terms + not-a-knot spline + "
-                  f"zvode Adams at QuTiP defaults (atol 1e-8, rtol 1e-6, max_step 1 ns): "
-                  f"{counter[0] // reps} RHS evaluations per run, {dt:.2f} s per run",
-        "host_cpu_count": os.cpu_count(),
-    }
+    for _ in range(reps):
+        qp.sesolve(ham, psi0, np.array([0.0, t_end]), counter=counter, **opts)
+    return (time.perf_counter() - tic) / reps, counter[0] // reps
+
+
+def _oracle_mesolve_time(prob, t_end):
+    from oracle import qutip_path as qp
+
+    ham = qp.build_hamiltonian(prob)
+    psi0 = qp.all_ground_state(prob["n_qudits"], prob["eigenbasis"])
+    s = prob["samples"]["Global"]["ground-rydberg"]
+    opts = qp.default_options([(s["amp"], s["det"])], 3100)
+    counter = [0]
+    tic = time.perf_counter()
+    qp.mesolve(ham, psi0, np.array([0.0, t_end]), counter=counter, **opts)
+    return time.perf_counter() - tic, counter[0]
+
+
+def _pool_trajectory(seed):
+    """One noisy 12-atom trajectory on one core (cfg4 CPU baseline worker)."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    rng = np.random.default_rng(seed)
+    prob = chain_problem(12)
+    s = prob["samples"]["Global"]["ground-rydberg"]
+    s["amp"] = s["amp"] * max(0.0, rng.normal(1.0, 0.05))
+    s["det"] = s["det"] + rng.normal(0.0, 0.3)
+    dt, _ = _oracle_sesolve_time(prob, T_SEQ_US)
+    return dt
+
+
+def cpu_baselines(full: bool):
+    """Oracle (kind 'port') timed on the box's host cores.  Bounded: ~10 s primary + ~60 s of legs."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    ncpu = os.cpu_count() or 1
+    dt14, rhs14 = _oracle_sesolve_time(tri_problem(2, 7), T_SEQ_US)
+    out = {"value": T_SEQ_US / dt14, "unit": "sim-us/s", "cores": 1, "kind": "port",
+           "sample": f"1 x one 14-atom triangular-register sequence (3.1 us), SciPy CSR terms + not-a-knot "
+                     f"spline + zvode Adams at QuTiP defaults (atol 1e-8, rtol 1e-6, max_step 1 ns): "
+                     f"{rhs14} RHS evaluations, {dt14:.2f} s",
+           "host_cpu_count": ncpu}
+    if not full:
+        return out
+    legs = []
+    # sesolve scaling with N (full 3.1 us at 12, slice at 16), one core
+    dt12, rhs12 = _oracle_sesolve_time(chain_problem(12), T_SEQ_US)
+    dt16, rhs16 = _oracle_sesolve_time(rect_problem(4, 4), 0.2)
+    dt16 *= T_SEQ_US / 0.2
+    k = np.polyfit([12, 14, 16], np.log2([dt12, dt14, dt16]), 1)
+    legs.append({"workload": "sesolve, one core, full 3.1 us (16 atoms: 200 ns slice scaled)", "unit": "sim-us/s",
+                 "n_atoms": [12, 14, 16], "value": [T_SEQ_US / dt12, T_SEQ_US / dt14, T_SEQ_US / dt16],
+                 "fitted_time_doubling_per_atom": float(k[0]),
+                 "extrapolated_20_atoms_sim_us_per_s": float(T_SEQ_US / 2 ** np.polyval(k, 20)), "cores": 1})
+    # mesolve (cfg3 physics) at reduced N: the explicit-operator path does not fit at 14 atoms
+    ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
+    dm = []
+    for rows_cols, t_end in (((2, 3), 0.2), ((2, 4), 0.05)):
+        dt, rhs = _oracle_mesolve_time(tri_problem(*rows_cols, ops), t_end)
+        dm.append((2 * rows_cols[1], t_end / dt))
+    k2 = np.polyfit([d[0] for d in dm], np.log2([1.0 / d[1] for d in dm]), 1)
+    legs.append({"workload": "mesolve dephasing (cfg3 physics), one core, slices of 200 / 50 ns",
+                 "unit": "sim-us/s", "n_atoms": [d[0] for d in dm], "value": [d[1] for d in dm],
+                 "fitted_time_doubling_per_atom": float(k2[0]),
+                 "extrapolated_14_atoms_sim_us_per_s": float(1.0 / 2 ** np.polyval(k2, 14)), "cores": 1})
+    # cfg4: all host cores, one trajectory per process
+    from multiprocessing import get_context
+
+    nproc = min(ncpu, 64)
+    n_traj = 2 * nproc
+    tic = time.perf_counter()
+    with get_context("fork").Pool(nproc) as pool:
+        pool.map(_pool_trajectory, range(n_traj))
+    wall = time.perf_counter() - tic
+    legs.append({"workload": "cfg4: 12-atom noisy trajectories, process pool, one trajectory per process",
+                 "unit": "trajectories/s", "value": n_traj / wall, "cores": nproc, "n_trajectories": n_traj,
+                 "sim_us_per_s": n_traj * T_SEQ_US / wall, "wall_s": wall})
+    out["legs"] = legs
+    return out
+
+
+def device_copy_bandwidth(torch):
+    """Measured device-to-device copy bandwidth (read + write bytes / time), 2 GiB buffer."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float64, device="cuda")
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    tic = time.perf_counter()
+    for _ in range(5):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - tic) / 5
+    del a, b
+    return 2.0 * n * 8 / sec / 1e9
 
 
 def main() -> None:
@@ -183,15 +315,24 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="independent sequences per GPU")
-    ap.add_argument("--workload", default="cfg2")
-    ap.add_argument("--slice-ns", type=int, default=2, help="cfg3/cfg5: simulated ns per step")
+    ap.add_argument("--workload", default="north_star")
+    ap.add_argument("--slice-ns", type=int, default=2, help="cfg3/cfg5 workloads: simulated ns per step")
+    ap.add_argument("--lindblad-ns", type=int, default=100, help="north_star: slice of the cfg3 leg")
+    ap.add_argument("--full-lindblad", action="store_true", help="north_star: full 3.1 us cfg3 leg (~1-2 min)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ket", action="store_true", help="disable k_ket / the split-operator rows (A/B runs)")
     args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_result = None
+    if rank == 0 and world_env == 1 and not args.no_cpu and args.workload == "north_star":
+        # host-core baselines first: the process pool forks before any HIP context exists
+        cpu_result = cpu_baselines(full=not args.no_extras)
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
@@ -219,47 +360,113 @@ def main() -> None:
     common = {"n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "dtype": "f64", "data": "synthetic", "unit": "sim-us/s"}
-    if args.workload == "cfg2":
+    extras_ok = rank == 0 and n_gpus == 1 and not args.no_extras
+
+    if args.workload == "north_star":
+        n, B = 14, args.batch
+        tic = time.perf_counter()
+        tables = spread_tables(tri_problem(2, 7), B)
+        lower_s = time.perf_counter() - tic
+        tic = time.perf_counter()
+        eng = Engine(tables, mode="sesolve")
+        torch.cuda.synchronize()
+        create_s = time.perf_counter() - tic
+        if args.no_ket:
+            eng.set_path(False, no_ket=True)
+        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, args.steps, args.warmup, dist, torch)
+        value = n_gpus * B * T_SEQ_US / sec
+        ket = stats["n_launches"] == 1
+        out = {
+            "metric": "sim-us/sec, 14-atom Rydberg anneal sequence, sesolve fp64 (aggregate over independent sequences)",
+            "value": value, **common, "ms_per_step": sec * 1e3,
+            "config": {
+                "workload": "north star (BASELINE.json): 14-atom triangular register (2 x 7, spacing R_b), "
+                            "analog Ising anneal 3100 ns, sesolve complex128; one step = the full 3.1 us for a "
+                            "batch of independent sequences per GPU (amplitude / detuning scale factors spread +-1 %)",
+                "n_atoms": n, "sequences_per_gpu": B, "sim_us_per_sequence": T_SEQ_US,
+                "integrator": "CF4 Magnus; exponentials by the in-place symplectic scheme (k_ket), "
+                              "2e-11 per exponential" if ket else "CF4 Magnus + Taylor(Horner), 1e-10 per exponential",
+                "stages_per_sequence": stats["n_applications"], "cf4_steps": stats["n_steps"],
+                "parallelism": f"dp{n_gpus} (independent sequences shard over ranks; all-reduce of ensemble sums only)",
+            },
+            "setup": {"lowering_ms": lower_s * 1e3, "handle_and_upload_ms": create_s * 1e3,
+                      "note": "spline lowering on the host + ryd_create / ryd_set_* uploads; outside the timed "
+                              "step (done once per sequence batch); the step includes the evaluation-time "
+                              "occupation reduction and its all-reduce"},
+        }
+        if ket:
+            out["roofline"] = roofline_valu(
+                2.0**n, B, stats["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kms, kl,
+                "k_ket<14> (register-resident ket, in-place symplectic exponential; one launch per step)",
+                "north_star:k_ket",
+                note="the state lives in registers / LDS for the whole sequence; HBM sees the initial load, "
+                     "the final store and the tables only ('traffic'). hbm_equivalent_GBps = what a "
+                     "streaming kernel would have to sustain for the same applications")
+        else:
+            out["roofline"] = roofline_hbm(n, B, stats, kms, kl, "k_apply14<sesolve> (2^14 register tiles, 1 pass)")
+        eng.close()
+
+        if rank == 0 and n_gpus == 1:
+            # latency: ONE sequence, full length
+            eng = Engine.from_problems([tri_problem(2, 7)], mode="sesolve")
+            if args.no_ket:
+                eng.set_path(False, no_ket=True)
+            s1, st1, k1, l1, _ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, 1, 1, None, torch)
+            out["single_sequence"] = {
+                "workload": "one 14-atom triangular-register sequence, full 3.1 us, sesolve", "value": T_SEQ_US / s1,
+                "unit": "sim-us/s", "ms_per_sequence": s1 * 1e3, "stages": st1["n_applications"],
+                "launches": st1["n_launches"],
+                "roofline": roofline_valu(2.0**n, 1, st1["n_applications"], KKET_FLOPS_PER_AMP_STAGE, k1, l1,
+                                          "k_ket<14> (one workgroup = one CU of 256)",
+                                          note="a single sequence occupies one CU; frac is against the whole chip")
+                if st1["n_launches"] == 1 else
+                roofline_hbm(n, 1, st1, k1, l1, "k_apply<sesolve> (single-launch plan; launch-latency-bound)")}
+            eng.close()
+            # Lindblad leg (cfg3)
+            ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
+            eng = Engine.from_problems([tri_problem(2, 7, ops)], mode="mesolve")
+            if args.no_ket:
+                eng.set_path(False, no_ket=True)
+            if args.full_lindblad:
+                t0, t1 = 0.0, T_SEQ_US
+            else:
+                t0, t1 = 1.0, 1.0 + 1e-3 * args.lindblad_ns
+            sl, stl, kl_ms, kl_n, occl = timed_run(eng, eng.new_state, t0, t1, 1, 0, None, torch)
+            leg = {"workload": f"cfg3: 14-atom triangular register, dephasing 0.05/us master equation "
+                               f"(rho = 4.29 GB), {'full 3.1 us' if args.full_lindblad else f'{args.lindblad_ns} ns slice at t = 1 us'}",
+                   "value": (t1 - t0) / sl, "unit": "sim-us/s", "ms_per_sim_ns": sl * 1e3 / ((t1 - t0) * 1e3),
+                   "seconds": sl, "trace": float(occl[-1].item()), "launches": stl["n_launches"],
+                   "cf4_steps": stl["n_steps"], "stages": stl["n_applications"],
+                   "extrapolated_full_sequence_s": sl * T_SEQ_US / (t1 - t0)}
+            if not args.no_ket:
+                # two row passes per conjugation, each a full ket stage on 2^14 rows of 2^14 amplitudes
+                leg["integrator"] = ("4th-order operator splitting (Chin 4A + exact commutator kick), blocks of 2 + 2 "
+                                     "CF4 steps; U rho U^+ as two row passes of k_ket + one conjugate transposition")
+                leg["roofline"] = roofline_valu(
+                    2.0**n, 2.0**n * 2, stl["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kl_ms, kl_n,
+                    "k_ket<14> row passes (+ k_transpose_conj)", "cfg3:k_ket",
+                    note="kernel time includes the transpositions (HBM-bound, 8.6 GB each)")
+            else:
+                leg["roofline"] = roofline_hbm(28, 1, stl, kl_ms, kl_n,
+                                               "k_apply14<mesolve> + k_symm (Hermitian path)", "cfg3:k_apply")
+            out["lindblad"] = leg
+            eng.close()
+
+    elif args.workload == "cfg2":
         n, B = 12, args.batch
         eng = Engine.from_problems([chain_problem(n)] * B, mode="sesolve")
-        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, args.steps,
-                                             args.warmup, dist, torch)
-        value = n_gpus * B * T_SEQ_US / sec
+        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, args.steps, args.warmup, dist, torch)
         out = {
             "metric": "sim-us/sec, 12-atom Rydberg anneal sequence, sesolve fp64 (aggregate over sequences)",
-            "value": value,
-            **common,
-            "ms_per_step": sec * 1e3,
-            "config": {
-                "workload": "BASELINE configs[1]: 12-atom chain at the blockade radius, analog Ising "
-                            "anneal 3100 ns, sesolve complex128; batch of independent sequences per GPU",
-                "n_atoms": n,
-                "sequences_per_gpu": B,
-                "sim_us_per_sequence": T_SEQ_US,
-                "integrator": "CF4 Magnus + Taylor(Horner), tol 1e-12/exponential",
-                "taylor_order": stats["last_order"],
-                "generator_applications_per_sequence": stats["n_applications"] // max(args.steps, 1),
-                "parallelism": f"dp{n_gpus} (independent sequences, all-reduce of ensemble sums only)",
-            },
-            "roofline": roofline(n, B, stats, kms, kl, "k_traj<12,1024,1> (persistent, LDS-resident)",
-                                 "cfg2:k_traj"),
-        }
-        out["roofline"]["note"] = (
-            "state vectors stay in LDS/registers for the whole sequence, so the algorithmic 32 B/amp/"
-            "application never reaches HBM; frac > 1 is on-chip reuse, not an HBM measurement - the "
-            "kernel's real limit is the fp64 vector pipe, see 'compute'"
-        )
-        # What actually bounds the persistent kernel: fp64 VALU issue (profiles/r01_ktraj_counters.md).
-        # Algorithmic flops per amplitude per application with a real global drive: diagonal 2,
-        # N partner additions 2N, common coupling 2, Horner update 4 (FMA = 2 flops).
-        flops_amp = 2 + 2 * n + 2 + 4
-        tflops = flops_amp * (2.0**n) * B * stats["n_applications"] / (kms * 1e-3) / 1e12
-        out["roofline"]["compute"] = {
-            "bound": "valu_f64", "flops_per_amplitude_per_application": flops_amp,
-            "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s", "frac": tflops / 78.6,
-            "note": "algorithmic flops only (address arithmetic, LDS traffic and barriers excluded); "
-                    "PMC: ~90 % of the SIMD issue slots busy, 120 of 195 VALU instructions per wave "
-                    "and stage are fp64 arithmetic",
+            "value": n_gpus * B * T_SEQ_US / sec, **common, "ms_per_step": sec * 1e3,
+            "config": {"workload": "BASELINE configs[1]: 12-atom chain at the blockade radius, analog Ising "
+                                   "anneal 3100 ns, sesolve complex128; batch of independent sequences per GPU",
+                       "n_atoms": n, "sequences_per_gpu": B, "sim_us_per_sequence": T_SEQ_US,
+                       "integrator": "CF4 Magnus + Taylor(Horner), tol 1e-10/exponential",
+                       "generator_applications_per_sequence": stats["n_applications"],
+                       "parallelism": f"dp{n_gpus} (independent sequences, all-reduce of ensemble sums only)"},
+            "roofline": roofline_valu(2.0**n, B, stats["n_applications"], KTRAJ_FLOPS_PER_AMP_STAGE, kms, kl,
+                                      "k_traj<12,1024,1> (persistent, LDS-resident)", "cfg2:k_traj"),
         }
         eng.close()
     elif args.workload == "cfg4":
@@ -284,21 +491,15 @@ def main() -> None:
 
         for w in range(args.warmup):
             one_pass(100 + w)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        barrier(torch, dist)
         tic = time.perf_counter()
         for k in range(args.steps):
             res = one_pass(k)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        barrier(torch, dist)
         sec = (time.perf_counter() - tic) / args.steps
         if dist is not None:
-            tmax = torch.tensor([sec], dtype=torch.float64)
-            if dist.get_backend() != "gloo":
-                tmax = tmax.cuda()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tmax = torch.tensor([sec], dtype=torch.float64, device="cuda")
+            all_reduce(dist, tmax, dist.ReduceOp.MAX)
             sec = float(tmax.item())
         out = {"metric": "noise trajectories/s, 12-atom anneal sequence, end to end (draws, lowering, sesolve, sampling)",
                "value": n_traj / sec, **common, "unit": "trajectories/s", "scaling": "strong",
@@ -309,41 +510,59 @@ def main() -> None:
                           "sim_us_per_s": n_traj * T_SEQ_US / sec, "n_measures": int(res["n_measures"]),
                           "parallelism": f"dp{n_gpus} over trajectories"},
                "roofline": None}
-        args.no_extras = True
+        extras_ok = False
         args.no_cpu = True
     elif args.workload in ("cfg3", "cfg5"):
-        # HBM-streaming workloads as the primary line (used for the rocprofv3 passes)
+        # streaming workloads as the primary line (used for the rocprofv3 passes)
         if args.workload == "cfg3":
             ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
             eng = Engine.from_problems([tri_problem(2, 7, ops)], mode="mesolve")
-            t0, t1, nb, kname = 1.0, 1.0 + 1e-3 * args.slice_ns, 28, "k_apply14<mesolve> + k_symm (Hermitian path: 2^14 register-tile row pass + tile-pair symmetrisation)"
+            if args.no_ket:
+                eng.set_path(False, no_ket=True)
+            t0, t1, nb = 1.0, 1.0 + 1e-3 * args.slice_ns, 28
+            kname = ("k_apply14<mesolve> + k_symm (Hermitian path)" if args.no_ket
+                     else "k_ket<14> row passes + k_transpose_conj (split-operator path)")
             wl = f"BASELINE configs[2]: 14-atom triangular register, dephasing mesolve (rho = 4.29 GB), {args.slice_ns} ns slice at t = 1 us"
         else:
             eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")
-            t0, t1, nb, kname = 1.0, 1.0 + 1e-3 * args.slice_ns, 20, "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)"
+            t0, t1, nb = 1.0, 1.0 + 1e-3 * args.slice_ns, 20
+            kname = "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)"
             wl = f"BASELINE configs[4]: 20-atom 4x5 register, sesolve, {args.slice_ns} ns slice at t = 1 us"
         sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, t0, t1, args.steps, args.warmup, dist, torch)
-        out = {"metric": "sim-us/sec", "value": n_gpus * (t1 - t0) / sec, **common,
-               "ms_per_step": sec * 1e3,
-               "config": {"workload": wl, "passes_per_application": stats["passes"],
-                          "taylor_order": stats["last_order"],
+        if args.workload == "cfg3" and not args.no_ket:
+            roof = roofline_valu(2.0**14, 2.0**15, stats["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kms, kl, kname, "cfg3:k_ket")
+        else:
+            roof = roofline_hbm(nb, 1, stats, kms, kl, kname, "cfg3:k_apply" if args.workload == "cfg3" else "cfg5:k_apply")
+        out = {"metric": "sim-us/sec", "value": n_gpus * (t1 - t0) / sec, **common, "ms_per_step": sec * 1e3,
+               "config": {"workload": wl, "passes_per_application": stats["passes"], "order": stats["last_order"],
                           "parallelism": f"replicas x{n_gpus} (a single state does not shard)"},
-               "roofline": roofline(nb, 1, stats, kms, kl, kname,
-                                    "cfg3:k_apply" if args.workload == "cfg3" else None)}
+               "roofline": roof}
         eng.close()
-        args.no_extras = True
+        extras_ok = False
         args.no_cpu = True
     else:
         raise SystemExit(f"unknown workload {args.workload}")
 
-    if rank == 0 and n_gpus == 1 and not args.no_extras:
+    if extras_ok:
         also = []
-        # single-sequence latency (the literal config: one 12-atom sequence)
-        eng = Engine.from_problems([chain_problem(12)], mode="sesolve")
+        # the round-1 headline: 256 x 12-atom sequences (LDS-resident persistent kernel)
+        eng = Engine(spread_tables(chain_problem(12), 256), mode="sesolve")
         sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, 2, 1, None, torch)
-        also.append({"workload": "cfg2 single sequence (latency)", "value": T_SEQ_US / sec,
-                     "unit": "sim-us/s", "ms_per_sequence": sec * 1e3,
-                     "roofline": roofline(12, 1, stats, kms, kl, "k_traj (1 workgroup)")})
+        also.append({"workload": "cfg2: 256 independent 12-atom chain sequences, full 3.1 us", "value": 256 * T_SEQ_US / sec,
+                     "unit": "sim-us/s", "ms_per_batch": sec * 1e3, "applications_per_sequence": stats["n_applications"],
+                     "roofline": roofline_valu(4096.0, 256, stats["n_applications"], KTRAJ_FLOPS_PER_AMP_STAGE, kms, kl,
+                                               "k_traj<12,1024,1> (persistent, LDS-resident)", "cfg2:k_traj")})
+        eng.close()
+        # the same with per-atom complex drives (MODEL 0 of the persistent kernel): local addressing
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import local_problem
+
+        eng = Engine.from_problems([local_problem(12, seed=s, duration=401) for s in range(8)] * 32, mode="sesolve")
+        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, 0.4, 2, 1, None, torch)
+        also.append({"workload": "256 x 12-atom sequences with per-atom complex drives (MODEL 0), 400 ns",
+                     "value": 256 * 0.4 / sec, "unit": "sim-us/s", "ms_per_batch": sec * 1e3,
+                     "applications_per_sequence": stats["n_applications"],
+                     "kernel": "k_traj<12,1024,0> (persistent, per-atom complex coefficients)"})
         eng.close()
         # quantum-jump trajectories (what Solver.DEFAULT runs for dissipation + stochastic noise)
         mc_prob = chain_problem(12)
@@ -393,51 +612,23 @@ def main() -> None:
                                   "note": "measured issue ceiling of the f64 MFMA on this part: 48 TFLOP/s "
                                           "(tools/ubench/mfma_f64.hip); a full ZGEMM would need 2x the flops"}})
         eng.close()
-        # north-star target size, Schroedinger leg: one 14-atom triangular-register sequence
-        eng = Engine.from_problems([tri_problem(2, 7)], mode="sesolve")
-        t0, t1 = 1.0, 1.1
-        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, t0, t1, 2, 1, None, torch)
-        also.append({"workload": "14-atom triangular register, sesolve, single sequence, 100 ns slice at t = 1 us",
-                     "value": (t1 - t0) / sec, "unit": "sim-us/s",
-                     "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
-                     "roofline": roofline(14, 1, stats, kms, kl, "k_apply<sesolve> (single-launch plan: low bits in LDS, 5 partner tiles from L2; 256 KiB state: launch-latency-bound)")})
-        eng.close()
-        # ... and a batch of 256 such sequences (state batch = 64 MiB): the streaming regime
-        eng = Engine.from_problems([tri_problem(2, 7)] * 256, mode="sesolve")
-        t0, t1 = 1.0, 1.02
-        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, t0, t1, 2, 1, None, torch)
-        also.append({"workload": "14-atom triangular register, sesolve, 256 sequences, 20 ns slice at t = 1 us",
-                     "value": 256 * (t1 - t0) / sec, "unit": "sim-us/s",
-                     "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
-                     "roofline": roofline(14, 256, stats, kms, kl, "k_apply14<sesolve> (2^14 register tiles, 1 pass)")})
-        eng.close()
-        # cfg3: 14-atom triangular register, dephasing Lindblad, HBM-streaming tiled kernel
-        ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
-        eng = Engine.from_problems([tri_problem(2, 7, ops)], mode="mesolve")
-        t0, t1 = 1.0, 1.002
-        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, t0, t1, 2, 1, None, torch)
-        also.append({"workload": "cfg3: 14-atom triangular, dephasing mesolve (rho = 4.29 GB), 2 ns slice at t = 1 us",
-                     "value": (t1 - t0) / sec, "unit": "sim-us/s", "ms_per_sim_ns": sec * 1e3 / 2,
-                     "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
-                     "trace": float(occ[-1].item()),
-                     "roofline": roofline(28, 1, stats, kms, kl, "k_apply14<mesolve> + k_symm (Hermitian path: 2^14 register-tile row pass + tile-pair symmetrisation)",
-                                          "cfg3:k_apply")})
-        eng.close()
-        # cfg5: 20-atom sesolve slice
+        del psi, rho
+        # cfg5: 20-atom sesolve slice (CF4 + Taylor; Lanczos comparison: profiles/r02_krylov_vs_taylor.md)
         eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")
-        t0, t1 = 1.0, 1.02
-        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, t0, t1, 2, 1, None, torch)
+        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 1.0, 1.02, 2, 1, None, torch)
         also.append({"workload": "cfg5: 20-atom 4x5 register, sesolve, 20 ns slice at t = 1 us",
-                     "value": (t1 - t0) / sec, "unit": "sim-us/s",
-                     "passes_per_application": stats["passes"], "taylor_order": stats["last_order"],
-                     "roofline": roofline(20, 1, stats, kms, kl, "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)")})
+                     "value": 0.02 / sec, "unit": "sim-us/s", "passes_per_application": stats["passes"],
+                     "taylor_order": stats["last_order"],
+                     "roofline": roofline_hbm(20, 1, stats, kms, kl, "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)", "cfg5:k_apply")})
         eng.close()
         out["also"] = also
+        bw = device_copy_bandwidth(torch)
+        out["device_copy_GBps"] = bw
+        if out.get("lindblad", {}).get("roofline", {}).get("hbm_equivalent_GBps"):
+            out["lindblad"]["hbm_equivalent_over_copy_bandwidth"] = out["lindblad"]["roofline"]["hbm_equivalent_GBps"] / bw
 
-    if rank == 0 and n_gpus == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(12)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    if rank == 0:
+        out["cpu_baseline"] = cpu_result
 
     if rank == 0:
         print(json.dumps(out))

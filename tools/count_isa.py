@@ -1,0 +1,30 @@
+"""Count the fp64 instructions of one half-stage of k_ket<14> in the compiled ISA (the flop
+accounting behind bench.py's roofline): python tools/count_isa.py > profiles/r02_kket_isa.md"""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "pulser_amd", "csrc", "rydemu.hip")
+with tempfile.TemporaryDirectory() as d:
+    asm = os.path.join(d, "r.s")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    "-Wno-unused-value", src, "-o", asm], check=True, stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+m = re.search(r"^_Z5k_ketILi14EEv7KetArgs:(.*?)s_endpgm", text, re.S | re.M)
+body = m.group(1).split("\n")
+bars = [i for i, l in enumerate(body) if "s_barrier" in l]
+# half-stages = the longest barrier-to-barrier regions that contain ds_read_b128 partner reads
+regions = sorted(((b - a, a, b) for a, b in zip(bars, bars[1:])), reverse=True)
+hs = [r for r in regions if sum("ds_read_b128" in l for l in body[r[1]:r[2]]) >= 64][:2]
+print("# r02: fp64 instruction count of one half-stage of `k_ket<14>` (hipcc 7.2, gfx950, -O3)\n")
+print("One half-stage = `dst += coef (H~ - shift) src` for the 32 amplitudes of a lane (16 pairs).")
+print("Counted between the two `s_barrier`s that bracket the consume phase.\n")
+print("| region (ISA lines) | v_fma/v_fmac_f64 | v_mul_f64 | v_add_f64 | ds_read_b128 | v_mov_dpp | other VALU | scratch ops | flops / amplitude |")
+print("|---|---|---|---|---|---|---|---|---|")
+for _, a, b in hs:
+    reg = body[a:b]
+    c = lambda pat: sum(1 for l in reg if re.search(pat, l))
+    fma, mul, add = c(r"v_fmac?_f64"), c(r"v_mul_f64"), c(r"v_add_f64")
+    valu = c(r"^\s+v_")
+    print(f"| {a}..{b} | {fma} | {mul} | {add} | {c('ds_read_b128')} | {c('_dpp')} | {valu - fma - mul - add - c('_dpp')} | {c('scratch_')} | {(2 * fma + mul + add) / 32:.2f} |")
+print("\nTwo half-stages per stage (q += a x p; p -= b x q) -> flops per amplitude per stage = 2 x the last column.")
+print("bench.py uses 2 x (448 x 2 + 65 + 113) / 32 = 67.1; re-run this script after changing the kernel.")
