@@ -83,6 +83,78 @@ class QState(np.ndarray):
         return complex(np.trace(a.conj().T @ b))
 
 
+class DeviceState:
+    """A density matrix that stays on the GPU (mesolve at 13+ atoms: 1 - 4 GiB per state).
+
+    What the results of the reference need from ``qutip.Qobj`` on the sampling path - ``shape``,
+    ``isket``, ``diag()`` (qutip_result.py:101-118) - is served from the diagonal, which is
+    reduced on the device and is all that ever crosses PCIe by itself.  ``full()`` /
+    ``np.asarray`` copy the whole matrix to the host on explicit request.  The initial state
+    of a run (|psi><psi| of a ket) is kept as its ket and expanded on demand only.
+    """
+
+    isket = False
+    isoper = True
+
+    def __init__(self, tensor: Any = None, ket: np.ndarray | None = None) -> None:
+        if (tensor is None) == (ket is None):
+            raise ValueError("give either a device tensor or a ket")
+        self._tensor = tensor
+        self._ket = None if ket is None else np.asarray(ket, dtype=complex).reshape(-1)
+        self._diag: np.ndarray | None = None
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        d = int(self._tensor.shape[-1]) if self._tensor is not None else int(self._ket.size)
+        return (d, d)
+
+    @property
+    def device_tensor(self) -> Any:
+        """The torch tensor on the GPU (None for the expanded-ket form)."""
+        return self._tensor
+
+    def diag(self) -> np.ndarray:
+        if self._diag is None:
+            if self._tensor is not None:
+                import torch
+
+                self._diag = torch.diagonal(self._tensor, dim1=-2, dim2=-1).contiguous().cpu().numpy()
+            else:
+                self._diag = (np.abs(self._ket) ** 2).astype(complex)
+        return self._diag
+
+    def tr(self) -> complex:
+        return complex(np.sum(self.diag()))
+
+    def full(self) -> np.ndarray:
+        if self._tensor is not None:
+            return self._tensor.cpu().numpy()
+        return np.outer(self._ket, self._ket.conj())
+
+    def copy(self) -> np.ndarray:
+        return self.full()
+
+    def __array__(self, dtype: Any = None, copy: Any = None) -> np.ndarray:
+        a = self.full()
+        return a if dtype is None else a.astype(dtype)
+
+    def dag(self) -> "QState":
+        return QState(self.full()).dag()
+
+    def norm(self) -> float:
+        return QState(self.full()).norm()
+
+    def unit(self) -> "QState":
+        return QState(self.full()).unit()
+
+    def overlap(self, other: Any) -> complex:
+        return QState(self.full()).overlap(other)
+
+    def __repr__(self) -> str:
+        where = "device tensor" if self._tensor is not None else "ket form"
+        return f"DeviceState(shape={self.shape}, {where})"
+
+
 def multinomial(n_samples: int, probabilities: np.ndarray) -> np.ndarray:
     """pulser-core/pulser/math/multinomial.py:18-36."""
     rnd = np.random.rand(n_samples)

@@ -28,7 +28,7 @@ import numpy as np
 from .hamiltonian_data import HamiltonianData, SequenceInputs
 from .noise_model import (LEGACY_DEFAULTS, NoiseModel, _NOISE_TYPE_PARAMS,
                           check_eff_noise, has_stochastic_noise)
-from .results import (CoherentResults, NoisyResults, QState, SampledResult,
+from .results import (DeviceState, CoherentResults, NoisyResults, QState, SampledResult,
                       SimulationResults, StateResult)
 from .terms import sampling_times
 
@@ -699,41 +699,75 @@ class QutipEmulator:
                 mode = "mesolve"
         n_batch = tables.batch
         times = self._eval_times_array
+        n = self._hamiltonian_data.n_qudits
+        state_bytes = 16 * (4**n if mode == "mesolve" else 2**n) * n_batch
+        on_device = mode == "mesolve" and state_bytes >= self._DEVICE_STATE_BYTES
+        if on_device:
+            self._check_snapshot_budget(len(times) - 1, state_bytes)
         with Engine(tables, mode=mode) as eng:
             init = np.asarray(self._initial_state)
             if mode == "mcsolve" and init.ndim == 2 and init.shape[0] == init.shape[1] and init.shape[0] > 1:
                 raise NotImplementedError(
                     "Quantum-jump trajectories need a ket as initial state; use "
                     "solver=Solver.MESOLVER with a density matrix.")
+            if on_device and not (init.ndim == 1 or 1 in init.shape):
+                raise NotImplementedError(
+                    f"A density matrix as initial state of a {n}-atom master equation is not supported; "
+                    "give the ket (the density matrix is built on the device).")
             state = eng.new_state(init.reshape(1, -1))
-            first = state.cpu().numpy()
+            first = None if on_device else state.cpu().numpy()
             if mode == "mcsolve":
                 snaps = eng.mc_solve(state, times, self._mc_seeds(n_batch, options), store=True,
                                      **self._engine_kwargs(options))
                 self.last_mc_jumps = eng.mc_jumps()
             else:
                 snaps = eng.solve(state, times, store=True, **self._engine_kwargs(options))
-            host = snaps.cpu().numpy()
+            # large density matrices never cross PCIe as a whole: the results hold the device
+            # tensors and reduce the diagonal (sampling weights, qutip_result.py:101-118) there
+            host = None if on_device else snaps.cpu().numpy()
+            del state
             self.last_engine_stats = eng.stats()
         meas_errors = (
             {"epsilon": self.noise_model.p_false_pos, "epsilon_prime": self.noise_model.p_false_neg}
             if "SPAM" in self.noise_model.noise_types else None
         )
         qids = tuple(self.samples_obj.qubit_ids)
-        n = self._hamiltonian_data.n_qudits
         out = []
         for b in range(n_batch):
             results = []
             for i, t in enumerate(times):
-                st = first[b] if i == 0 else host[i - 1][b]
+                if on_device:
+                    st: Any = (DeviceState(ket=np.asarray(self._initial_state).reshape(-1)) if i == 0
+                               else DeviceState(tensor=snaps[i - 1][b]))
+                else:
+                    st = QState(first[b] if i == 0 else host[i - 1][b])
                 results.append(
-                    StateResult(qids, self._meas_basis, QState(st),
+                    StateResult(qids, self._meas_basis, st,
                                 self._meas_basis in self.basis_name,
                                 evaluation_time=float(t / (self._tot_duration * 1e-3)))
                 )
             out.append(CoherentResults(results, n, self.basis_name, times, self._meas_basis,
                                        meas_errors))
         return out
+
+    # density matrices from this size on stay on the GPU (13 atoms: 1 GiB per state)
+    _DEVICE_STATE_BYTES = 1 << 30
+
+    @staticmethod
+    def _check_snapshot_budget(n_snapshots: int, state_bytes: int) -> None:
+        """Refuse evaluation-time lists whose stored states cannot fit the device (the reference
+        would fail the same way in host memory, after hours): the solver needs 4 work copies, the
+        results one copy per evaluation time."""
+        import torch
+
+        free, total = torch.cuda.mem_get_info()
+        need = (n_snapshots + 5) * state_bytes
+        if need > 0.9 * free:
+            raise MemoryError(
+                f"Storing the state at {n_snapshots} evaluation times needs {need / 2**30:.0f} GiB of "
+                f"device memory ({state_bytes / 2**30:.2f} GiB per density matrix, {free / 2**30:.0f} GiB "
+                "free): use evaluation_times='Minimal' or a short list of times instead of 'Full'."
+            )
 
     @staticmethod
     def _fast_path_ok(problem: dict[str, Any]) -> bool:

@@ -189,3 +189,56 @@ def test_krylov_against_taylor_cfg5_sizes(n, rows, cols, t1):
             outs[method] = st.cpu().numpy()[0]
     assert np.max(np.abs(outs["taylor"] - outs["krylov"])) < 1e-8
     assert abs(np.linalg.norm(outs["krylov"]) - 1.0) < 1e-9
+
+
+# ------------------------------------------------------------- cfg3 through the drop-in API
+def test_cfg3_noise_model_end_to_end_14_atoms_keeps_density_matrices_on_the_device():
+    """BASELINE configs[2] through ``QutipEmulator(...).run().sample_final_state()``
+    (simulation.py:800-883, qutip_result.py:101-158, simresults.py:522-568): dephasing + SPAM
+    NoiseModel on 14 atoms -> the reference picks mesolve; rho (4.29 GB) never reaches the host,
+    the sampling weights are its device-reduced diagonal.  Non-interacting atoms, so the exact
+    diagonal is a product of single-atom Lindblad solutions and the seeded Counter can be replayed
+    with the oracle's sampling chain."""
+    from oracle import sampling as osamp
+    from pulser_amd import NoiseModel, QutipEmulator
+    from pulser_amd.hamiltonian_data import single_global_channel
+    from pulser_amd.results import DeviceState
+
+    n, T, gamma = 14, 12, 0.05
+    coords = P.register_coords(P.square_rect(1, n), 60.0)
+    smp = {"amp": np.full(T, 6.0), "det": np.full(T, -2.0), "phase": np.zeros(T)}
+    inputs = single_global_channel(coords, smp, P.C6_LEVEL70, extended=False)
+    nm = NoiseModel(dephasing_rate=gamma, p_false_pos=0.01, p_false_neg=0.05)
+    np.random.seed(11)
+    sim = QutipEmulator(inputs, noise_model=nm, evaluation_times="Minimal")
+    with pytest.warns(DeprecationWarning):
+        res = sim.run()
+    final = res.states[-1]
+    assert isinstance(final, DeviceState) and final.shape == (1 << n, 1 << n)
+    assert isinstance(res.states[0], DeviceState) and abs(res.states[0].tr() - 1.0) < 1e-14
+    assert abs(final.tr() - 1.0) < 1e-11
+    rng_state = np.random.get_state()
+    counts = res.sample_final_state(N_samples=2000)
+    # replay: exact product diagonal -> weights -> multinomial -> measurement flips (oracle chain).
+    # The extra trailing sample (simulation.py:173) makes the spline ramp the drive down over the
+    # last interval, so the single-atom reference integrates the same not-a-knot spline.
+    from oracle import qutip_path as qp
+
+    one = P.make_ising_problem(np.zeros((1, 2)), {k: np.append(v, 0.0 if k != "phase" else v[-1])
+                                                    for k, v in smp.items()},
+                               collapse_ops=[(np.sqrt(2 * gamma), "sigma_rr")])
+    r1 = qp.mesolve(qp.build_hamiltonian(one), qp.all_ground_state(1, one["eigenbasis"]),
+                    np.array([0.0, T * 1e-3]), **qp.TIGHT)[-1]
+    idx = np.arange(1 << n)
+    diag = np.ones(1 << n)
+    for k in range(n):
+        bit = (idx >> (n - 1 - k)) & 1
+        diag *= np.where(bit == 0, r1[0, 0].real, r1[1, 1].real)
+    assert np.max(np.abs(final.diag().real - diag)) < 5e-9
+    np.random.set_state(rng_state)
+    w = osamp.weights(np.diag(diag) if False else diag.astype(complex) ** 0.5, n, ["r", "g"], "ground-rydberg")
+    expected = osamp.spam_flips(osamp.get_samples(w, 2000, n), 0.01, 0.05)
+    assert counts == expected
+    # "Full" would store 13 density matrices of 4.29 GB: still fits; 3101 of them must be refused
+    with pytest.raises(MemoryError, match="evaluation_times='Minimal'"):
+        sim._check_snapshot_budget(3101, 16 * 4**n)
