@@ -13,8 +13,8 @@ from .results import (CoherentResults, NoisyResults, QState, SampledResult,
                       SimulationResults, StateResult)
 from .simulation import QutipEmulator, SimConfig, Solver
 from . import backend
-from .backend import (EmulatorConfig, QutipBackend, QutipBackendV2, QutipConfig, Results, RydOperator,
-                      RydState)
+from .backend import (EmulatorConfig, QutipBackend, QutipBackendV2, QutipConfig, Results, RydEmuBackend,
+                      RydOperator, RydState, register_with_pulser)
 
 __version__ = "0.1.0"
 
@@ -22,5 +22,5 @@ __all__ = [
     "QutipEmulator", "Solver", "SimConfig", "NoiseModel", "CoherentResults",
     "NoisyResults", "SimulationResults", "StateResult", "SampledResult", "QState",
     "SequenceInputs", "ChannelInput", "Slot", "HamiltonianData", "single_global_channel",
-    "QutipBackendV2", "QutipBackend", "EmulatorConfig", "QutipConfig", "RydState", "RydOperator", "Results", "backend",
+    "QutipBackendV2", "RydEmuBackend", "register_with_pulser", "QutipBackend", "EmulatorConfig", "QutipConfig", "RydState", "RydOperator", "Results", "backend",
 ]

@@ -1292,6 +1292,40 @@ class QutipBackend:
             return self._sim_obj.run(progress_bar=progress_bar, **options)
 
 
+def register_with_pulser() -> bool:
+    """When pulser-core is importable: make ``RydState`` / ``RydOperator`` virtual subclasses of
+    ``pulser.backend.State`` / ``Operator`` (backend/state.py:34, backend/operator.py:38), so that
+    pulser-side ``isinstance`` checks (e.g. ``EmulationConfig(initial_state=...)``,
+    ``Fidelity(state)``) accept them.  Returns False when pulser is absent."""
+    try:
+        import pulser.backend as pb
+    except Exception:
+        return False
+    pb.State.register(RydState)
+    pb.Operator.register(RydOperator)
+    return True
+
+
+def _adopt_pulser_config(config: Any) -> "QutipConfig":
+    """A ``pulser.backend.EmulationConfig`` (backend/config.py:151-470; what
+    ``EmulatorBackend.validate_config`` hands to a backend, backend/abc.py:143-169) converted to
+    this package's ``QutipConfig``: observables by tag through the JSON abstract representation
+    both sides write (json/abstract_repr), callbacks carried over as objects."""
+    if not (hasattr(config, "to_abstract_repr") and hasattr(config, "_backend_options")):
+        raise TypeError("'config' must be an instance of 'EmulationConfig'")
+    register_with_pulser()
+    callbacks = list(getattr(config, "callbacks", ()) or ())
+    bare = config.with_changes(callbacks=[]) if callbacks else config
+    try:
+        text = bare.to_abstract_repr(skip_validation=True)
+    except TypeError:  # older signature
+        text = bare.to_abstract_repr()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # "initialized without any observables" was already issued by pulser
+        mine = QutipConfig.from_abstract_repr(text)
+        return mine.with_changes(callbacks=callbacks) if callbacks else mine
+
+
 # ------------------------------------------------------------------- backend
 class QutipBackendV2:
     """qutip_backend.py:121-325 on the MI355X engine.  ``sequence`` is a
@@ -1303,7 +1337,7 @@ class QutipBackendV2:
     def __init__(self, sequence: Any, *, config: QutipConfig | None = None,
                  mimic_qpu: bool = False) -> None:
         if config is not None and not isinstance(config, QutipConfig):
-            raise TypeError("'config' must be an instance of 'EmulationConfig'")
+            config = _adopt_pulser_config(config)
         self._config = config or self.default_config
         cfg = self._config
         nm = self._get_noise_model(cfg, getattr(sequence, "device", None))
@@ -1417,6 +1451,9 @@ class QutipBackendV2:
             for eng in holder:
                 eng.close()
 
+
+# the name the INTEGRATION.md registry entry resolves (pulser/backends.py:49-58: getattr(module, name))
+RydEmuBackend = QutipBackendV2
 
 QutipBackendV2.default_config = QutipConfig(observables=[BitStrings(evaluation_times=[1.0]), StateResult()])
 QutipBackendV2.config_type = QutipConfig
