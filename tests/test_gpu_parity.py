@@ -344,7 +344,7 @@ def test_large_ket_against_the_product_state_solution():
     samples = {"amp": np.full(T + 1, 6.0), "det": np.full(T + 1, -2.0), "phase": np.zeros(T + 1)}
     eng = _engine([P.make_ising_problem(coords, samples)], mode="sesolve")
     st = eng.new_state()
-    eng.evolve(st, 0.0, 0.004)
+    eng.evolve(st, 0.0, 0.004, tol=1e-14)  # exact reference: tighter than the default 1e-10 per exponential
     assert eng.stats()["passes"] == 3
     h1 = np.array([[2.0, 3.0], [3.0, 0.0]])  # (r, g): -delta n_r + (Omega / 2) sigma_x
     w, v = np.linalg.eigh(h1)
