@@ -270,6 +270,23 @@ int ryd_probabilities(ryd_handle* h, const void* state_dev, double* w_dev,
 int ryd_occupations(ryd_handle* h, const void* state_dev, double* out_dev,
                     void* stream);
 
+/* Replaces: the expectation values behind the default observables of the V2 backend for ONE
+ * state - Occupation / CorrelationMatrix through the number operators n_k = |r><r|_k
+ * (pulser-core/pulser/backend/default_observables.py:291-435) and Energy / EnergySecondMoment /
+ * EnergyVariance through H(t) (:437-580; qutip_backend.py:259-264 materialises H(t) for them) -
+ * in one call, on the device.  `what` = RYD_OBS_* bits.  out_dev float64[batch][N*N + N + 3]:
+ *   [0, N)            <n_k>
+ *   [N]               squared norm / trace  (the caller normalises, like state.unit())
+ *   [N+1, N+1+N*N)    <n_k n_l>, row-major
+ *   [N*N+N+1]         <H(t)>      (RYD_OBS_ENERGY; kets only: one generator application)
+ *   [N*N+N+2]         <H(t)^2>
+ * Entries that were not requested are 0.  No host synchronisation. */
+#define RYD_OBS_OCCUPATION 1
+#define RYD_OBS_CORRELATION 2
+#define RYD_OBS_ENERGY 4
+int ryd_observe(ryd_handle* h, const void* state_dev, double t, int32_t what,
+                double* out_dev, void* stream);
+
 /* Replaces: building rho0 = |psi><psi| inside qutip.mesolve for a ket input.
  * psi_dev complex128[batch][2^N] -> rho_dev complex128[batch][2^N][2^N]. */
 int ryd_ket_to_dm(ryd_handle* h, const void* psi_dev, void* rho_dev,

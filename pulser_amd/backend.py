@@ -366,6 +366,29 @@ class HamiltonianOperator:
 
     def __init__(self, engine: Any, t_us: float, eigenstates: Sequence[str]) -> None:
         self._eng, self._t, self.eigenstates = engine, t_us, tuple(eigenstates)
+        self._observed: tuple[int, dict[str, Any]] | None = None
+
+    def observe(self, state: RydState) -> dict[str, Any] | None:
+        """Device-side values behind Occupation / CorrelationMatrix / Energy* for a ket of a
+        2-level register: ONE ``ryd_observe`` call per (state, evaluation time), shared by every
+        observable asking for it.  None when the state is not a ket of the tuned engine (density
+        matrices, multi-level registers): the host formulas are used then."""
+        if not hasattr(self._eng, "observe") or len(self.eigenstates) != 2:
+            return None
+        if self._observed is not None and self._observed[0] == id(state):
+            return self._observed[1]
+        q = state.to_qobj()
+        if not q.isket or q.shape[0] != self._eng.dim:
+            return None
+        import torch
+
+        x = torch.from_numpy(np.ascontiguousarray(np.asarray(q)[:, 0][None, :])).to(self._eng.device)
+        raw = self._eng.observe(x, self._t)
+        n2 = float(raw["norm2"][0])
+        res = {"occupation": raw["occupation"][0] / n2, "correlation": raw["correlation"][0] / n2,
+               "energy": float(raw["energy"][0]) / n2, "energy2": float(raw["energy2"][0]) / n2}
+        self._observed = (id(state), res)
+        return res
 
     def _h_on(self, arr: np.ndarray) -> np.ndarray:
         """H @ arr for a ket (D,1) or a matrix (D,D) of column vectors."""
@@ -597,7 +620,12 @@ class Occupation(Observable):
         d["one_state"] = self.one_state
         return d
 
-    def apply(self, *, state: RydState, **kw: Any) -> list:
+    def apply(self, *, state: RydState, hamiltonian: Any = None, **kw: Any) -> list:
+        dev = hamiltonian.observe(state) if hasattr(hamiltonian, "observe") else None
+        if dev is not None:  # device reduction; local state 0 is what the kernel counts
+            one = self.one_state or state.infer_one_state()
+            occ0 = dev["occupation"]
+            return [float(v) for v in (occ0 if list(state.eigenstates).index(one) == 0 else 1.0 - occ0)]
         p = _probabilities(state)
         return [float(v) for v in p @ _one_mask(state, self.one_state)]
 
@@ -619,7 +647,15 @@ class CorrelationMatrix(Observable):
         d["one_state"] = self.one_state
         return d
 
-    def apply(self, *, state: RydState, **kw: Any) -> list[list]:
+    def apply(self, *, state: RydState, hamiltonian: Any = None, **kw: Any) -> list[list]:
+        dev = hamiltonian.observe(state) if hasattr(hamiltonian, "observe") else None
+        if dev is not None:
+            one = self.one_state or state.infer_one_state()
+            c0, o0 = dev["correlation"], dev["occupation"]
+            if list(state.eigenstates).index(one) == 0:
+                return c0.tolist()
+            # <(1 - n_i)(1 - n_j)> = 1 - <n_i> - <n_j> + <n_i n_j>
+            return (1.0 - o0[:, None] - o0[None, :] + c0).tolist()
         p = _probabilities(state)
         m = _one_mask(state, self.one_state).astype(float)
         return ((m * p[:, None]).T @ m).tolist()
@@ -629,6 +665,9 @@ class Energy(Observable):
     _base_tag = "energy"
 
     def apply(self, *, state: RydState, hamiltonian: Any, **kw: Any) -> float:
+        dev = hamiltonian.observe(state) if hasattr(hamiltonian, "observe") else None
+        if dev is not None:
+            return dev["energy"]
         return float(np.real(hamiltonian.expect(state)))
 
 
@@ -638,6 +677,9 @@ class EnergySecondMoment(Observable):
     _base_tag = "energy_second_moment"
 
     def apply(self, *, state: RydState, hamiltonian: HamiltonianOperator, **kw: Any) -> float:
+        dev = hamiltonian.observe(state) if hasattr(hamiltonian, "observe") else None
+        if dev is not None:
+            return dev["energy2"]
         applied = np.asarray(hamiltonian.apply_to(state).to_qobj())  # H|psi> or H rho H
         if state.to_qobj().isket:
             return float(np.real(np.vdot(applied, applied)))
@@ -649,6 +691,9 @@ class EnergyVariance(Observable):
     default_aggregation = "skip_warn"  # a variance is not averaged over trajectories (:503-504)
 
     def apply(self, *, state: RydState, hamiltonian: HamiltonianOperator, **kw: Any) -> float:
+        dev = hamiltonian.observe(state) if hasattr(hamiltonian, "observe") else None
+        if dev is not None:
+            return dev["energy2"] - dev["energy"] ** 2
         second = EnergySecondMoment.apply(self, state=state, hamiltonian=hamiltonian)  # type: ignore[arg-type]
         return second - float(np.real(hamiltonian.expect(state))) ** 2
 
@@ -1333,6 +1378,8 @@ class QutipBackendV2:
 
     default_config: "QutipConfig"  # set right after the class (qutip_backend.py:136-138)
     config_type: type  # = QutipConfig
+    last_timing: dict[str, float] | None = None
+    last_observable_engine_stats: dict[str, Any] | None = None
 
     def __init__(self, sequence: Any, *, config: QutipConfig | None = None,
                  mimic_qpu: bool = False) -> None:
@@ -1432,22 +1479,37 @@ class QutipBackendV2:
                 for obs in config.observables:
                     obs(config=config, t=float(t), state=state, hamiltonian=ham, result=res)
 
+        import time as _time
+
+        timing = {"solve_s": 0.0, "observables_s": 0.0}
         try:
             if not has_stochastic_noise(sim.noise_model):
+                tic = _time.perf_counter()
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore", DeprecationWarning)
                     single = sim.run(**options)
+                timing["solve_s"] = _time.perf_counter() - tic
                 res = Results(qids, T)
+                tic = _time.perf_counter()
                 fill(res, single)
+                timing["observables_s"] = _time.perf_counter() - tic
                 return res
             results: list[Results] = []
+            tic = _time.perf_counter()
             for coherent, reps in sim._noisy_runs(**options):
+                timing["solve_s"] += _time.perf_counter() - tic
+                tic = _time.perf_counter()
                 for _ in range(reps):
                     res = Results(qids, T)
                     fill(res, coherent)
                     results.append(res)
+                timing["observables_s"] += _time.perf_counter() - tic
+                tic = _time.perf_counter()
             return Results.aggregate(results)
         finally:
+            # diagnostics of the last run: wall-clock split and the launches of the noiseless-H engine
+            QutipBackendV2.last_timing = timing
+            QutipBackendV2.last_observable_engine_stats = holder[0].stats() if holder else None
             for eng in holder:
                 eng.close()
 

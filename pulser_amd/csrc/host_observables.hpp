@@ -28,6 +28,47 @@ extern "C" int ryd_occupations(ryd_handle* h, const void* state_dev, double* out
   return RYD_OK;
 }
 
+extern "C" int ryd_observe(ryd_handle* h, const void* state_dev, double t, int32_t what,
+                           double* out_dev, void* stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!state_dev || !out_dev) return fail(RYD_ERR_INVALID, "null argument");
+  if (h->general) return fail(RYD_ERR_INVALID, "not available on a general-path handle");
+  const bool dm = h->cfg.mode == RYD_MESOLVE;
+  if ((what & RYD_OBS_ENERGY) && dm)
+    return fail(RYD_ERR_UNSUPPORTED, "energy moments need a ket (sesolve) handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  hipStream_t st = (hipStream_t)stream;
+  const int N = h->N;
+  const int stride = N * N + N + 3;
+  HIPCHK(hipMemsetAsync(out_dev, 0, (size_t)h->B * stride * sizeof(double), st));
+  const size_t D = (size_t)1 << N;
+  if (what & (RYD_OBS_OCCUPATION | RYD_OBS_CORRELATION)) {
+    hipLaunchKernelGGL(k_obs_pairs, dim3((unsigned)((D + 2047) / 2048), h->B), dim3(256), 0, st,
+                       (const cplx*)state_dev, N, dm ? 1 : 0, out_dev, stride);
+    HIPCHK(hipGetLastError());
+    h->stats.n_launches++;
+  }
+  if (what & RYD_OBS_ENERGY) {
+    if (!h->bounds_valid) compute_bounds(h);
+    MixPoint m;
+    m.idx1 = m.idx2 = find_interval(h, t);
+    m.u1 = m.u2 = t - h->tknots[m.idx1];
+    m.w1 = 1.0;
+    m.w2 = 0.0;
+    if ((rc = launch_eval(h, m, st))) return rc;
+    if ((rc = apply_generator(h, (const cplx*)state_dev, nullptr, h->wA, 1.0, 1.0, 0.0,
+                              make_double2(1.0, 0.0), st)))
+      return rc;
+    const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(D >> 10, 1), 1024);
+    hipLaunchKernelGGL(k_obs_energy, dim3(nblk, h->B), dim3(256), 0, st, (const cplx*)state_dev,
+                       (const cplx*)h->wA, h->nb, out_dev, stride, N * N + N + 1);
+    HIPCHK(hipGetLastError());
+    h->stats.n_launches++;
+  }
+  return RYD_OK;
+}
+
 extern "C" int ryd_ket_to_dm(ryd_handle* h, const void* psi_dev, void* rho_dev, void* stream) {
   if (!h || !psi_dev || !rho_dev) return fail(RYD_ERR_INVALID, "null argument");
   if (2 * h->N > RYD_MAX_QUBITS) return fail(RYD_ERR_INVALID, "2N exceeds %d", RYD_MAX_QUBITS);

@@ -1,0 +1,72 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+// ---------------------------------------------------------------------------
+// ryd_observe: the V2 observables of one state in one call, on the device
+// ---------------------------------------------------------------------------
+// Occupations <n_k>, correlations <n_k n_l> (default_observables.py:291-435) and the energy
+// moments <H>, <H^2> (:437-580, through one generator application w = -i H x:
+// <H> = -Im <x|w>, <H^2> = |w|^2).  Replaces N(N+1)/2 + 2 qutip.expect calls and the per-time
+// materialisation of H(t) (qutip_backend.py:259-264).
+
+// out[b][0..N-1] = <n_k>, out[b][N] = sum p, out[b][N+1 + k*N + l] = <n_k n_l>.
+// One block stages a chunk of probabilities in LDS; thread <-> (k, l) pair (several per thread when
+// N(N+1)/2 > blockDim); wave-uniform chunk index -> LDS broadcast reads.
+__global__ __launch_bounds__(256) void k_obs_pairs(const cplx* __restrict__ st, int N, int is_dm,
+                                                   double* __restrict__ out, int out_stride) {
+  constexpr int CH = 2048;
+  __shared__ double ps[CH];
+  const size_t D = (size_t)1 << N;
+  const int b = blockIdx.y;
+  const int npair = N * (N + 1) / 2;
+  const size_t base = (size_t)blockIdx.x * CH;
+  for (int i = threadIdx.x; i < CH; i += blockDim.x) {
+    const size_t g = base + i;
+    double p = 0.0;
+    if (g < D) {
+      if (is_dm) p = st[((size_t)b << (2 * N)) + g * D + g].x;
+      else { const cplx v = st[((size_t)b << N) + g]; p = v.x * v.x + v.y * v.y; }
+    }
+    ps[i] = p;
+  }
+  __syncthreads();
+  double* o = out + (size_t)b * out_stride;
+  for (int pr = threadIdx.x; pr <= npair; pr += blockDim.x) {
+    if (pr == npair) {  // the norm
+      double s = 0.0;
+      for (int i = 0; i < CH; ++i) s += ps[i];
+      atomicAdd(o + N, s);
+      continue;
+    }
+    // pair index -> (k <= l)
+    int k = 0, rem = pr;
+    while (rem >= N - k) { rem -= N - k; ++k; }
+    const int l = k + rem;
+    const unsigned mk = 1u << (N - 1 - k), ml = 1u << (N - 1 - l);
+    double s = 0.0;
+    for (int i = 0; i < CH; ++i) {
+      const unsigned g = (unsigned)(base + i);
+      if (!(g & mk) && !(g & ml)) s += ps[i];  // n = 1 <=> bit 0 (local state 0 = r)
+    }
+    if (k == l) atomicAdd(o + k, s);
+    atomicAdd(o + N + 1 + k * N + l, s);
+    if (k != l) atomicAdd(o + N + 1 + l * N + k, s);
+  }
+}
+
+// o[0] += -Im <x|w>, o[1] += |w|^2
+__global__ __launch_bounds__(256) void k_obs_energy(const cplx* __restrict__ x, const cplx* __restrict__ w, int nb,
+                                                    double* __restrict__ out, int out_stride, int off) {
+  const size_t D = (size_t)1 << nb;
+  const size_t boff = (size_t)blockIdx.y * D;
+  double e = 0.0, e2 = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < D; i += (size_t)gridDim.x * 256) {
+    const cplx a = x[boff + i], c = w[boff + i];
+    e -= a.x * c.y - a.y * c.x;
+    e2 = fma(c.x, c.x, fma(c.y, c.y, e2));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { e += __shfl_down(e, o, 64); e2 += __shfl_down(e2, o, 64); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out + (size_t)blockIdx.y * out_stride + off, e);
+    atomicAdd(out + (size_t)blockIdx.y * out_stride + off + 1, e2);
+  }
+}

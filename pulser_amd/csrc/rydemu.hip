@@ -55,6 +55,7 @@ typedef double2 cplx;
 #include "k_traj_dm.hpp"
 #include "k_ket.hpp"
 #include "k_krylov.hpp"
+#include "k_observe.hpp"
 #include "k_general.hpp"
 #include "host_handle.hpp"
 #include "host_apply.hpp"

@@ -341,6 +341,23 @@ class Engine:
         )
         return w
 
+    def observe(self, state: Any, t: float, occupation: bool = True, correlation: bool = True,
+                energy: bool = True) -> dict[str, np.ndarray]:
+        """``ryd_observe``: occupations, correlation matrix and energy moments of every batch
+        entry in one device call (no per-observable launches, no H(t) materialisation).
+        Returns host arrays: ``norm2`` [B], ``occupation`` [B, N], ``correlation`` [B, N, N],
+        ``energy`` [B], ``energy2`` [B] - NOT normalised (divide by ``norm2``)."""
+        self._check_state(state)
+        n = self.n
+        what = (1 if occupation else 0) | (2 if correlation else 0) | (4 if energy else 0)
+        out = self.torch.empty((self.batch, n * n + n + 3), dtype=self.torch.float64, device=self.device)
+        _lib.check(self.lib.ryd_observe(self._h, state.data_ptr(), float(t), what, out.data_ptr(),
+                                        self._stream()))
+        o = out.cpu().numpy()
+        return {"occupation": o[:, :n], "norm2": o[:, n],
+                "correlation": o[:, n + 1:n + 1 + n * n].reshape(self.batch, n, n),
+                "energy": o[:, n * n + n + 1], "energy2": o[:, n * n + n + 2]}
+
     def occupations(self, state: Any) -> Any:
         """float64[B, N+1]: <n_k> and, last, the squared norm / trace."""
         self._check_state(state)

@@ -318,3 +318,43 @@ def test_backend_v2_callbacks_and_device_noise_model(capfd):
     np.random.seed(4)
     QutipBackendV2(inputs, config=sim_cfg).run()
     assert capfd.readouterr().out == "Emulating Trajectory 1/2\nEmulating Trajectory 2/2\n"
+
+
+def test_device_side_observables_one_call_per_evaluation_time():
+    """Occupation / CorrelationMatrix / Energy / EnergyVariance /
+    EnergySecondMoment of a 12-atom sequence at 100 evaluation times come from ONE ``ryd_observe``
+    call per time (pair reduction + one generator application + one dot), not from per-observable
+    expectation values or a materialised H(t); values against NumPy on the stored states."""
+    from oracle import qutip_path as qp
+    from pulser_amd import problem as P
+    from pulser_amd.backend import EnergySecondMoment, EnergyVariance
+    from pulser_amd.hamiltonian_data import single_global_channel
+
+    n = 12
+    coords = P.register_coords(P.square_rect(1, n), blockade_radius())
+    smp = {k: v[:-1] for k, v in P.anneal_samples().items()}
+    inputs = single_global_channel(coords, smp, P.C6_LEVEL70, extended=False)
+    times = np.linspace(0.01, 1.0, 100).tolist()
+    obs = [StateResult(evaluation_times=[0.25, 1.0]), Occupation(), CorrelationMatrix(), Energy(),
+           EnergyVariance(), EnergySecondMoment()]
+    res = QutipBackendV2(inputs, config=QutipConfig(default_evaluation_times=times, observables=obs)).run()
+    stats = QutipBackendV2.last_observable_engine_stats
+    # per evaluation time: pair reduction + generator application + energy dot = 3 launches
+    assert stats["n_launches"] == 3 * len(times) and stats["n_applications"] == len(times)
+    timing = QutipBackendV2.last_timing
+    assert timing["observables_s"] < 0.5 * timing["solve_s"] + 0.5, timing
+    prob = P.make_ising_problem(coords, P.anneal_samples())
+    ham = qp.build_hamiltonian(prob)
+    idx = np.arange(1 << n)
+    nk = np.stack([1 - ((idx >> (n - 1 - k)) & 1) for k in range(n)], axis=1).astype(float)
+    for t in (0.25, 1.0):
+        psi = np.asarray(res.get_result(obs[0], t).to_qobj())[:, 0]
+        psi = psi / np.linalg.norm(psi)
+        p = np.abs(psi) ** 2
+        assert np.allclose(res.get_result(obs[1], t), p @ nk, atol=1e-12)
+        assert np.allclose(res.get_result(obs[2], t), (nk * p[:, None]).T @ nk, atol=1e-12)
+        h_psi = ham.apply(t * 3.1, psi)
+        e, e2 = np.vdot(psi, h_psi).real, np.vdot(h_psi, h_psi).real
+        assert abs(res.get_result(obs[3], t) - e) < 1e-9 * max(1.0, abs(e))
+        assert abs(res.get_result(obs[5], t) - e2) < 1e-9 * max(1.0, e2)
+        assert abs(res.get_result(obs[4], t) - (e2 - e * e)) < 1e-7 * max(1.0, e2)
