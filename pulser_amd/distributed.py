@@ -16,9 +16,10 @@ reference's order:
 
 and broadcast.  The only collective on the result path is one all-reduce (sum)
 of the per-rank accumulators: bitstring histograms int64[n_eval, 2^N]
-(BAG_UNION of Counters == sum) and reps-weighted occupation sums
-float64[n_eval, N+1].  Backend: ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo``
-in the CPU tests.
+(BAG_UNION of Counters == sum), reps-weighted occupation sums float64[n_eval, N+1]
+and - on request - the trajectory sum of |psi><psi| (density_matrix_aggregator,
+pulser_simulation/aggregators.py:19-37).  Backend: ``nccl`` (= RCCL over xGMI) on
+GPUs, ``gloo`` in the CPU tests.
 """
 
 from __future__ import annotations
@@ -110,61 +111,103 @@ def predraw_sampling(reps: Sequence[int], n_eval: int, samples_per_run: int, n_q
     return out
 
 
+def _broadcast_array(dist: Any, arr: np.ndarray | None, shape: tuple[int, ...], src: int = 0) -> np.ndarray:
+    """One contiguous float64 tensor broadcast (device tensor under nccl, host under gloo)."""
+    import torch
+
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = (torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(dev) if arr is not None
+         else torch.empty(shape, dtype=torch.float64, device=dev))
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
 def run_ensemble(
     emulator: Any,
     solve_fn: Callable[[list[dict[str, Any]]], np.ndarray] | None = None,
     dist: Any = None,
     batch: int = 128,
     mc_seed: int | None = None,
+    options: dict[str, Any] | None = None,
+    density_matrix: bool = False,
 ) -> dict[str, Any]:
     """Sharded equivalent of the stochastic branch of ``QutipEmulator.run``
-    (simulation.py:847-883).
+    (simulation.py:847-883, 885-915); ``QutipEmulator.run`` calls it when
+    ``torch.distributed`` is initialised with more than one rank.
 
-    ``emulator`` must have been constructed identically on every rank *with the
-    same seed* or - preferably - its trajectories are taken from rank 0 (done
-    here by broadcasting ``noise_trajectories``).  ``solve_fn(problems)`` returns
-    host states complex[len(problems), n_eval, dim] (default: the HIP engine).
-    Returns on every rank the total histograms int64[n_eval, 2^N], the Counters
-    and the reps-weighted mean occupations.
+    Rank 0 owns every random draw - the noise trajectories (redrawn on a repeated run, like
+    simulation.py:892-902) and the sampling uniforms - and broadcasts them: the trajectory list as
+    objects (a few KB each), the uniforms as two contiguous float64 tensors.  Every rank solves its
+    contiguous block on its GPU and samples it; ONE all-reduce (sum) per accumulator closes the run:
+    bitstring histograms int64[n_eval, 2^N], measured-bit occupation sums float64[n_eval, N + 1]
+    and, with ``density_matrix``, the reps-weighted sum of |psi><psi| (aggregators.py:19-37) as
+    float64[n_eval, 2, D, D].  ``solve_fn(problems)`` (tests) returns host states
+    complex[len(problems), n_eval, dim] instead of running the HIP engine.
     """
     import torch
 
     rank, _, world = env_world()
     if dist is None:
         world, rank = 1, 0
-    hd = emulator._hamiltonian_data
+    options = dict(options or {})
+    emulator._validate_options(options)  # max_step / nsteps defaults, the SPAM + initial-state refusal
     nm = emulator.noise_model
-    n = hd.n_qudits
     times = emulator._eval_times_array
     n_eval = len(times)
     meas_err = "SPAM" in nm.noise_types and not (nm.p_false_pos == 0.0 and nm.p_false_neg == 0)
     # -- rank 0 owns every random draw ------------------------------------
     payload: list[Any] = [None]
     if rank == 0:
-        trajs = hd.noise_trajectories
-        rnd = predraw_sampling([t.reps for t in trajs], n_eval, nm.samples_per_run, n, meas_err)
+        if emulator._noise_trajectories_used:  # fresh draws on every further run (simulation.py:892-902)
+            from .hamiltonian_data import HamiltonianData
+
+            emulator._hamiltonian_data = HamiltonianData(
+                emulator.samples_obj, nm, emulator._get_n_trajectories(nm, check_value=True))
+            emulator._problems_cache = None
+        trajs = emulator._hamiltonian_data.noise_trajectories
         # quantum-jump seeds (used only when the solver is the Monte-Carlo one):
         # like qutip.mcsolve's, NOT from the global np.random stream
         mc_seeds = np.random.default_rng(mc_seed).integers(0, 2**64, size=len(trajs), dtype=np.uint64)
-        payload = [(trajs, rnd, mc_seeds)]
+        payload = [(trajs, mc_seeds)]
+    emulator._noise_trajectories_used = True
     if dist is not None:
         dist.broadcast_object_list(payload, src=0)
-    trajs, rnd, mc_seeds = payload[0]
-    lo, hi = partition([t.reps for t in trajs], world)[rank]
+    trajs, mc_seeds = payload[0]
+    hd = emulator._hamiltonian_data  # only rank 0's draws (`trajs`) are lowered below
+    n = hd.n_qudits
+    reps = np.array([t.reps for t in trajs], dtype=np.int64)
+    shots = nm.samples_per_run * reps  # per (trajectory, evaluation time)
+    offs = np.concatenate([[0], np.cumsum(np.repeat(shots, n_eval))])  # trajectory-major, time-minor
+    total = int(offs[-1])
+    rnd_all = mat_all = None
+    if rank == 0:  # the reference's call sequence: rand(n), then uniform(size=(n, N)) (simulation.py:853-861)
+        rnd_all = np.empty(total)
+        mat_all = np.empty((total, n)) if meas_err else None
+        for k in range(len(trajs) * n_eval):
+            a, b = offs[k], offs[k + 1]
+            rnd_all[a:b] = np.random.rand(b - a)
+            if meas_err:
+                mat_all[a:b] = np.random.uniform(size=(b - a, n))
+    if dist is not None:
+        rnd_all = _broadcast_array(dist, rnd_all, (total,))
+        if meas_err:
+            mat_all = _broadcast_array(dist, mat_all, (total, n))
+    lo, hi = partition(reps, world)[rank]
     hist = np.zeros((n_eval, 2**n), dtype=np.int64)
     occ_sum = np.zeros((n_eval, n + 1), dtype=np.float64)
+    rho_sum = None
     default_solver = solve_fn is None
     fast = default_solver and emulator._fast_path_ok(emulator._current_problem)
     if default_solver:
         def solve_fn(problems: list[dict[str, Any]]) -> np.ndarray:
-            res = emulator._solve_batch(problems, False, {})
+            res = emulator._solve_batch(problems, False, options)
             return np.stack([[np.asarray(s) for s in r.states] for r in res])
     else:
         mc_seeds = None
     from .results import QState, StateResult
 
     qids = tuple(emulator.samples_obj.qubit_ids)
-    idx_bits = 1 - ((np.arange(2**n)[:, None] >> (n - 1 - np.arange(n))[None, :]) & 1)
+    bit_of = ((np.arange(2**n)[:, None] >> (n - 1 - np.arange(n))[None, :]) & 1).astype(np.float64)
     for start in range(lo, hi, batch):
         block = list(range(start, min(hi, start + batch)))
         if mc_seeds is not None:  # a trajectory's jumps depend on its seed only, not on the sharding
@@ -172,7 +215,7 @@ def run_ensemble(
         try:
             if fast:  # factored lowering: shared spline tables + per-(trajectory, atom) scales
                 tables = hd.device_tables([trajs[i] for i in block], emulator._sampling_rate)
-                res = emulator._solve_batch([], False, {}, tables=tables)
+                res = emulator._solve_batch([], False, options, tables=tables)
                 states = np.stack([[np.asarray(s) for s in r.states] for r in res])
             else:
                 states = solve_fn([hd.problem(trajs[i], emulator._sampling_rate) for i in block])
@@ -183,14 +226,24 @@ def run_ensemble(
                 st = QState(states[j][ti])
                 w = StateResult(qids, emulator._meas_basis, st,
                                 emulator._meas_basis in emulator.basis_name)._weights()
-                r, mat = rnd[i][ti]
-                ind = sample_with(r, w)
-                ind = flips_with(ind, n, mat, nm.p_false_pos, nm.p_false_neg)
+                k = i * n_eval + ti
+                ind = sample_with(rnd_all[offs[k]:offs[k + 1]], w)
+                ind = flips_with(ind, n, mat_all[offs[k]:offs[k + 1]] if meas_err else None,
+                                 nm.p_false_pos, nm.p_false_neg)
                 hist[ti] += np.bincount(ind, minlength=2**n)
-                p = np.abs(np.asarray(st)[:, 0]) ** 2 if st.isket else np.abs(st.diag())
-                occ_sum[ti, :n] += trajs[i].reps * (p @ idx_bits)
-                occ_sum[ti, n] += trajs[i].reps * p.sum()
-    # -- the one collective: sum of the per-rank accumulators -----------------
+                # measured-bit occupations from the 2^N weights: valid for every basis (2-, 3-, 4-level)
+                occ_sum[ti, :n] += reps[i] * (w @ bit_of)
+                occ_sum[ti, n] += reps[i] * (float(np.vdot(st, st).real) if st.isket else float(st.tr().real))
+                if density_matrix:
+                    a = np.asarray(st)
+                    r1 = (a @ a.conj().T) if st.isket else a
+                    if rho_sum is None:
+                        rho_sum = np.zeros((n_eval,) + r1.shape, dtype=np.complex128)
+                    rho_sum[ti] += reps[i] * r1
+    # -- the one collective per accumulator: sum over ranks -----------------
+    if density_matrix and rho_sum is None:  # an empty shard still takes part in the all-reduce
+        d = len(hd.eigenbasis) ** n
+        rho_sum = np.zeros((n_eval, d, d), dtype=np.complex128)
     if dist is not None:
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         th = torch.from_numpy(hist).to(dev)
@@ -198,12 +251,16 @@ def run_ensemble(
         dist.all_reduce(th)
         dist.all_reduce(to)
         hist, occ_sum = th.cpu().numpy(), to.cpu().numpy()
-    n_traj = sum(t.reps for t in trajs)
+        if density_matrix:
+            tr = torch.view_as_real(torch.from_numpy(rho_sum)).contiguous().to(dev)  # float64[..., 2]
+            dist.all_reduce(tr)
+            rho_sum = torch.view_as_complex(tr.cpu().contiguous()).numpy()
+    n_traj = int(reps.sum())
     counters = [
         Counter({np.binary_repr(i, n): int(c) for i, c in enumerate(h) if c})
         for h in hist
     ]
-    return {
+    out = {
         "histograms": hist,
         "counters": counters,
         "mean_occupations": occ_sum[:, :n] / n_traj,
@@ -211,3 +268,6 @@ def run_ensemble(
         "n_measures": n_traj * nm.samples_per_run,
         "block": (lo, hi),
     }
+    if density_matrix:
+        out["density_matrices"] = rho_sum / n_traj
+    return out

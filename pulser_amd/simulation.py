@@ -895,6 +895,22 @@ class QutipEmulator:
             return self._solve_batch([self._current_problem], progress_bar, options,
                                      mc_ntraj=self.n_trajectories or 1)[0]
 
+        sharded = self._distributed()
+        if sharded is not None:
+            # one process per GPU: trajectories shard over the ranks, one all-reduce of the
+            # histograms; every rank returns the same NoisyResults (pulser_amd/distributed.py)
+            from .distributed import run_ensemble
+
+            ens = run_ensemble(self, dist=sharded, options=options)
+            qids = tuple(self.samples_obj.qubit_ids)
+            results = [
+                SampledResult(qids, self._meas_basis, ens["counters"][ind],
+                              evaluation_time=float(t / (self._tot_duration * 1e-3)))
+                for ind, t in enumerate(self._eval_times_array)
+            ]
+            return NoisyResults(results, self._hamiltonian_data.n_qudits, self.basis_name,
+                                self._eval_times_array, int(ens["n_measures"]))
+
         total_count = np.array([Counter() for _ in self._eval_times_array])
         for res, reps in self._noisy_runs(progress_bar, print_progress, **options):
             total_count += np.array(
@@ -912,6 +928,16 @@ class QutipEmulator:
         ]
         return NoisyResults(results, self._hamiltonian_data.n_qudits, self.basis_name,
                             self._eval_times_array, n_measures)
+
+    @staticmethod
+    def _distributed() -> Any:
+        """``torch.distributed`` when this process is one of several ranks, else None."""
+        import sys
+
+        td = sys.modules.get("torch.distributed")
+        if td is None or not td.is_available() or not td.is_initialized() or td.get_world_size() < 2:
+            return None
+        return td
 
     def _noisy_runs(self, progress_bar: Any, print_progress: bool = False,
                     batch: int | None = None, **options: Any

@@ -101,8 +101,8 @@ def _worker(rank, world, port, q):
     if rank != 0:  # other ranks must NOT rely on their own RNG state
         np.random.seed(999 + rank)
     n_eval = len(emu._eval_times_array)
-    out = run_ensemble(emu, lambda probs: _fake_states(probs, n_eval), dist=d, batch=3)
-    q.put((rank, out["histograms"], out["mean_occupations"], out["block"]))
+    out = run_ensemble(emu, lambda probs: _fake_states(probs, n_eval), dist=d, batch=3, density_matrix=True)
+    q.put((rank, out["histograms"], out["mean_occupations"], out["block"], out["density_matrices"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -124,7 +124,14 @@ def test_sharded_ensemble_equals_serial_reference_world1_and_world2(world):
     # world size 1 (same process, fresh emulator with the same seed)
     emu1 = _make_emulator()
     n_eval = len(emu1._eval_times_array)
-    out1 = run_ensemble(emu1, lambda probs: _fake_states(probs, n_eval), dist=None, batch=4)
+    out1 = run_ensemble(emu1, lambda probs: _fake_states(probs, n_eval), dist=None, batch=4, density_matrix=True)
+    # the ensemble density matrix = reps-weighted mean of |psi><psi| (aggregators.py:19-37)
+    rho_ref = np.zeros_like(out1["density_matrices"])
+    for prob in emu1._problems:
+        st = _fake_states([prob], n_eval)[0]
+        rho_ref += prob["reps"] * np.einsum("ti,tj->tij", st, st.conj())
+    assert np.allclose(out1["density_matrices"], rho_ref / 16, atol=1e-14)
+    assert np.allclose(np.trace(out1["density_matrices"], axis1=1, axis2=2), 1.0, atol=1e-13)
     assert out1["counters"] == ref
     assert out1["n_measures"] == 16 * 7
     # world size 2 over gloo
@@ -141,6 +148,7 @@ def test_sharded_ensemble_equals_serial_reference_world1_and_world2(world):
     blocks = sorted(g[3] for g in got)  # contiguous shards covering every trajectory once
     assert blocks[0][0] == 0 and blocks[-1][1] == len(emu._problems)
     assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
-    for _, hist, occ, _ in got:
+    for _, hist, occ, _, rho in got:
         assert np.array_equal(hist, out1["histograms"])
         assert np.allclose(occ, out1["mean_occupations"], atol=1e-14)
+        assert np.allclose(rho, out1["density_matrices"], atol=1e-14)  # the all-reduced sum of |psi><psi|

@@ -1,0 +1,71 @@
+"""-m gpu: ``QutipEmulator.run()`` shards its noise trajectories when ``torch.distributed`` is
+initialised (one process per GPU).  Here two ranks share the one GPU of the test box over gloo -
+the RCCL path differs only in the backend of the one all-reduce."""
+from __future__ import annotations
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _emulator(seed):
+    from pulser_amd import NoiseModel, QutipEmulator, problem as P
+    from pulser_amd.hamiltonian_data import single_global_channel
+
+    coords = P.register_coords(P.square_rect(1, 6), 8.0)
+    s = {k: v[:600] for k, v in P.anneal_samples().items()}
+    inputs = single_global_channel(coords, s, P.C6_LEVEL70, extended=False)
+    nm = NoiseModel(temperature=50.0, amp_sigma=0.05, state_prep_error=0.05, p_false_pos=0.01,
+                    p_false_neg=0.05, samples_per_run=9)
+    np.random.seed(seed)
+    return QutipEmulator(inputs, noise_model=nm, n_trajectories=24, evaluation_times=[0.0, 0.3, 0.6])
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import warnings
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    emu = _emulator(5 if rank == 0 else 1234 + rank)  # only rank 0's random stream may matter
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        res = emu.run()
+    q.put((rank, [dict(r.bitstring_counts) for r in res], res.n_measures if hasattr(res, "n_measures") else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_shards_trajectories_over_ranks_and_matches_the_serial_run():
+    import warnings
+
+    import torch.multiprocessing as mp
+
+    emu = _emulator(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        serial = emu.run()
+    ref = [dict(r.bitstring_counts) for r in serial]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, counters, _ in got:
+        assert counters == ref, rank  # bit-identical Counters on every rank, for any world size
