@@ -76,8 +76,9 @@ __device__ __forceinline__ double dpp_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int N>
+template <int N, int F0 = 4>
 __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
+  static_assert(F0 == 0 || F0 == 4, "index bits below F0 use the DPP crossbar: 0 or 4");
   constexpr int D = 1 << N, NTT = 512, LOGNT = 9;
   constexpr int R = D / NTT;   // amplitudes per thread (8, 16, 32)
   constexpr int RP = R / 2;    // pairs
@@ -259,7 +260,6 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
 #pragma unroll
         for (int jp = 0; jp < RP; ++jp) {
           asm volatile("" : "+v"(ra));
-          constexpr int F0 = 4;  // first bit read from LDS
           double2 pv[LOGNT - F0];
 #pragma unroll
           for (int f = F0; f < LOGNT; ++f) pv[f - F0] = *reinterpret_cast<const double2*>(smem + (ra ^ (16u << f)));
@@ -284,14 +284,16 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
             bcc0 = fma(cq[LOGNT + 1 + k], src[2 * jo], bcc0);
             bcc1 = fma(cq[LOGNT + 1 + k], src[2 * jo + 1], bcc1);
           }
-          bcc0 = fma(cq[0], dpp_f64<0xB1>(s0), bcc0);   // xor 1
-          bcc1 = fma(cq[0], dpp_f64<0xB1>(s1), bcc1);
-          bcc0 = fma(cq[1], dpp_f64<0x4E>(s0), bcc0);   // xor 2
-          bcc1 = fma(cq[1], dpp_f64<0x4E>(s1), bcc1);
-          bcc0 = fma(cq[3], dpp_f64<0x128>(s0), bcc0);  // xor 8 (row rotate by 8)
-          bcc1 = fma(cq[3], dpp_f64<0x128>(s1), bcc1);
-          bcc0 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s0)), bcc0);  // xor 4 = (xor 7) o (xor 3)
-          bcc1 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s1)), bcc1);
+          if constexpr (F0 == 4) {
+            bcc0 = fma(cq[0], dpp_f64<0xB1>(s0), bcc0);   // xor 1
+            bcc1 = fma(cq[0], dpp_f64<0xB1>(s1), bcc1);
+            bcc0 = fma(cq[1], dpp_f64<0x4E>(s0), bcc0);   // xor 2
+            bcc1 = fma(cq[1], dpp_f64<0x4E>(s1), bcc1);
+            bcc0 = fma(cq[3], dpp_f64<0x128>(s0), bcc0);  // xor 8 (row rotate by 8)
+            bcc1 = fma(cq[3], dpp_f64<0x128>(s1), bcc1);
+            bcc0 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s0)), bcc0);  // xor 4 = (xor 7) o (xor 3)
+            bcc1 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s1)), bcc1);
+          }
 #pragma unroll
           for (int f = F0; f < LOGNT; ++f) {
             acc0 = fma(cq[f], pv[f - F0].x, acc0);

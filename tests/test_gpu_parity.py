@@ -2,7 +2,7 @@
 
 Tolerances: amplitudes / rho entries <= 1e-7 max-abs against the
 TIGHT oracle (zvode rtol 1e-13); single generator applications <= 1e-11
-relative; sampling indices bit-exact (tests/test_gpu_sampling.py).
+relative; sampling indices bit-exact (tests/test_gpu_emulator.py, tests/test_gpu_simresults.py).
 """
 import numpy as np
 import pytest

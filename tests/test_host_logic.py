@@ -1538,3 +1538,30 @@ def test_config_abstract_repr_reads_and_rewrites_pulser_core_documents():
         QutipConfig(observables=[StateResult()]).to_abstract_repr()
     with pytest.raises(NotImplementedError, match="custom interaction matrices"):
         QutipConfig(observables=[BitStrings()], interaction_matrix=np.eye(2))
+
+
+def test_default_tolerance_oracle_drift_is_a_measured_quantity():
+    """SURVEY 8(d)(ii) planned to assert agreement with "QuTiP-default" output at 5e-5.  The
+    restated QuTiP path at its defaults (zvode Adams, atol 1e-8, rtol 1e-6, max_step 1 ns) is
+    itself ~1e-3 away from the converged solution on the 12-atom anneal (norm drift -8e-4,
+    ``normalize_output=False``), so a converged solver CANNOT be within 5e-5 of it: the GPU tests
+    assert <= 1e-7 against the tight oracle and <= 5e-3 against the default-tolerance one
+    (tests/test_gpu_parity.py).  This pins the numbers that correction rests on."""
+    _, extra = load_fixture("cfg2_chain12_anneal.npz")
+    tight = np.asarray(extra["oracle_states_tight"])
+    dflt = np.asarray(extra["oracle_states_default"])
+    drift = np.max(np.abs(tight[-1] - dflt[-1]))
+    assert 5e-5 < drift < 5e-3, drift  # measured 1.4e-3
+    assert abs(np.linalg.norm(tight[-1]) - 1.0) < 1e-9
+    assert 1e-4 < 1.0 - np.linalg.norm(dflt[-1]) < 2e-3  # the default run loses ~8e-4 of norm
+    # and it is reproducible: re-running the oracle at its defaults gives the stored states
+    from oracle import qutip_path as qp
+
+    prob, _ = load_fixture("cfg2_chain12_anneal.npz")
+    prob = with_anneal_samples(prob)
+    ham = qp.build_hamiltonian(prob)
+    s = prob["samples"]["Global"]["ground-rydberg"]
+    opts = qp.default_options([(s["amp"], s["det"])], 3100)
+    again = qp.sesolve(ham, qp.all_ground_state(12, prob["eigenbasis"]),
+                       np.asarray(extra["eval_times"])[[0, 1]], **opts)[-1]
+    assert np.max(np.abs(again - dflt[1])) < 1e-9
