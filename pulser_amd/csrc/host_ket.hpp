@@ -118,7 +118,6 @@ static int ket_init_device(ryd_handle* h) {
   HIPCHK(hipFuncSetAttribute((const void*)k_ket<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_ket<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_ket<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_ket<14, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (dev >= 0 && dev < 64) done[dev] = true;
   return RYD_OK;
 }
@@ -134,12 +133,7 @@ static int launch_ket(ryd_handle* h, const KetArgs& A, size_t n_rows, hipStream_
     case 11: hipLaunchKernelGGL(k_ket<11>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
     case 12: hipLaunchKernelGGL(k_ket<12>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
     case 13: hipLaunchKernelGGL(k_ket<13>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
-    case 14: {
-      static const bool all_lds = std::getenv("RYD_KET_ALL_LDS") != nullptr;  // dev knob: partners of bits 0-3 from LDS too
-      if (all_lds) hipLaunchKernelGGL((k_ket<14, 0>), dim3((unsigned)n_rows), dim3(512), lds, st, A);
-      else hipLaunchKernelGGL(k_ket<14>, dim3((unsigned)n_rows), dim3(512), lds, st, A);
-      break;
-    }
+    case 14: hipLaunchKernelGGL(k_ket<14>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
     default: return fail(RYD_ERR_INVALID, "k_ket needs 10 <= N <= 14");
   }
   HIPCHK(hipGetLastError());

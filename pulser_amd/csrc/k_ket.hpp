@@ -76,10 +76,14 @@ __device__ __forceinline__ double dpp_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int N, int F0 = 4>
-__global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
+// F0: index bits below F0 take their partners over the DPP crossbar (4) or from LDS like the
+// others (0); LOGNT: log2 of the workgroup size.  Measured at 14 atoms, 1024 rows (us per stage):
+// <14, 4, 9> 10.6, <14, 0, 9> 10.4 (the DPP moves cost the VALU what the LDS reads cost the LDS
+// pipe), <14, 4, 10> 13.5 (four waves per SIMD but 128 registers per lane: spills in the hot loop).
+template <int N, int F0 = 4, int LOGNT = 9>
+__global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
   static_assert(F0 == 0 || F0 == 4, "index bits below F0 use the DPP crossbar: 0 or 4");
-  constexpr int D = 1 << N, NTT = 512, LOGNT = 9;
+  constexpr int D = 1 << N, NTT = 1 << LOGNT;
   constexpr int R = D / NTT;   // amplitudes per thread (8, 16, 32)
   constexpr int RP = R / 2;    // pairs
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -243,8 +247,7 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
       // Partners: index bits 0, 1, 3 over the DPP crossbar (quad permutes, row rotate by 8),
       // bit 2 as row_half_mirror + reversed quad permute (two moves), bits 4-8 as ds_read_b128
       // from the published copy (two amplitudes per read), bits 9.. register to register.
-      auto half_stage = [&](double (&dst)[R], const double (&src)[R], double coef, auto with_diag) {
-        constexpr bool DIAG = decltype(with_diag)::value;
+      auto half_stage = [&](double (&dst)[R], const double (&src)[R], double coef) {
         __syncthreads();  // partner reads of the previous half-stage are done
         {
           unsigned wa = (unsigned)tid * 16u;  // byte address inside xs
@@ -273,8 +276,8 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
           for (int k = 1; k < NH; ++k)
             if (!((jp >> (k - 1)) & 1)) ec += vhi[k];
           const double s0 = src[2 * jp], s1 = src[2 * jp + 1];
-          double acc0 = DIAG ? ((ec + vhi[0]) + eh2.x) * s0 : 0.0;
-          double acc1 = DIAG ? (ec + eh2.y) * s1 : 0.0;
+          double acc0 = ((ec + vhi[0]) + eh2.x) * s0;
+          double acc1 = (ec + eh2.y) * s1;
           // second chains: the register-index and DPP partners (independent of the LDS reads)
           double bcc0 = cq[LOGNT] * s1;  // bit 9 pairs (2jp, 2jp+1)
           double bcc1 = cq[LOGNT] * s0;
@@ -306,23 +309,47 @@ __global__ __launch_bounds__(512) void k_ket(const KetArgs A) {
         }
       };
 
-      if (kick) {
-        // exp(-i hk F), F = sum_k c_k X_k, hk ~ 1e-11: one symmetric shear triple is exact to hk^3
-        const double hk = ex < 0 ? A.kick_pre : A.kick_post;
-        half_stage(q, p, 0.5 * hk, std::false_type{});
-        half_stage(p, q, -hk, std::false_type{});
-        half_stage(q, p, 0.5 * hk, std::false_type{});
-        continue;
-      }
-      for (int sb = 0; sb < nsub; ++sb) {
-        for (int i = 0; i < m; ++i) {
-          // consecutive sub-exponentials share the boundary shear: a_{m+1} + a_1
-          const double ai = kSympDev[sch].a[i] + ((i == 0 && sb > 0) ? kSympDev[sch].a[m] : 0.0);
-          half_stage(q, p, ai * hs, std::true_type{});
-          half_stage(p, q, -kSympDev[sch].b[i] * hs, std::true_type{});
+      // The exponential as ONE loop of half-stages, so that the hot code exists twice only
+      // (q <- p and p <- q): 2 m nsub + 1 shears of the in-place scheme (consecutive
+      // sub-exponentials share their boundary shear a_{m+1} + a_1), or - for the splitting kick
+      // exp(-i hk F), F = sum_k c_k X_k (drive only), hk ~ 1e-11 - one symmetric shear triple
+      // (exact to hk^3) through the same code, whose diagonal term is taken out again afterwards.
+      const double hk = ex < 0 ? A.kick_pre : A.kick_post;
+      auto undo_diag = [&](double (&dst)[R], const double (&src)[R], double coef) {
+#pragma unroll
+        for (int jp = 0; jp < RP; ++jp) {
+          const double2 eh2 = *reinterpret_cast<const double2*>(ehx + 2 * jp);
+          double ec = elo;
+#pragma unroll
+          for (int k = 1; k < NH; ++k)
+            if (!((jp >> (k - 1)) & 1)) ec += vhi[k];
+          dst[2 * jp] = fma(-coef * ((ec + vhi[0]) + eh2.x), src[2 * jp], dst[2 * jp]);
+          dst[2 * jp + 1] = fma(-coef * (ec + eh2.y), src[2 * jp + 1], dst[2 * jp + 1]);
+        }
+      };
+      const int n_pairs = kick ? 1 : m * nsub;  // (q-shear, p-shear) pairs before the closing q-shear
+      int i = 0, sb = 0;
+#pragma unroll 1
+      for (int t = 0; t <= n_pairs; ++t) {
+        double ca, cb = 0.0;
+        if (kick) {
+          ca = 0.5 * hk;
+          cb = -hk;
+        } else if (t == n_pairs) {
+          ca = kSympDev[sch].a[m] * hs;
+        } else {
+          ca = (kSympDev[sch].a[i] + ((i == 0 && sb > 0) ? kSympDev[sch].a[m] : 0.0)) * hs;
+          cb = -kSympDev[sch].b[i] * hs;
+        }
+        half_stage(q, p, ca);
+        if (kick) undo_diag(q, p, ca);
+        if (t < n_pairs) {
+          half_stage(p, q, cb);
+          if (kick) undo_diag(p, q, cb);
+          if (++i == m) { i = 0; ++sb; }
         }
       }
-      half_stage(q, p, kSympDev[sch].a[m] * hs, std::true_type{});
+      if (kick) continue;
       // e^{-i h shift} (conjugated for the row form)
       const double sn = ex == 1 ? sd.sn_b : sd.sn_a, cs = ex == 1 ? sd.cs_b : sd.cs_a;
 #pragma unroll
