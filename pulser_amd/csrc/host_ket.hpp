@@ -26,7 +26,11 @@
 static bool ket_path(const ryd_handle* h) {
   if (h->general || h->cfg.mode != RYD_SESOLVE || !h->drive_real || h->mc || h->no_ket) return false;
   if (h->force_ket) return h->N >= 10 && h->N <= 14;
-  return h->N == 14 && !h->force_generic;  // <= 13 atoms: the LDS-resident kernel k_traj
+  // <= 13 atoms: the LDS-resident kernel k_traj.  One workgroup evolves one sequence on ONE CU
+  // (10 us per stage), so a handful of sequences is faster on the multi-launch tiled kernels that
+  // spread each ket over the chip (measured, full 3.1 us anneal: 1 sequence 9.5 vs 6.9 sim-us/s;
+  // 8 sequences 48 vs 55; 16 sequences 81 vs 111)
+  return h->N == 14 && h->B >= 8 && !h->force_generic;
 }
 
 static bool row_path(const ryd_handle* h) {

@@ -83,7 +83,7 @@ def test_ket_kernel_14_atom_triangular_anneal_against_multi_launch():
     prob = tri_problem(2, 7)
     outs = {}
     for no_ket in (False, True):
-        with _engine([prob], "sesolve") as eng:
+        with _engine([prob] * 8, "sesolve") as eng:  # from 8 sequences on the ket kernel is the default
             eng.set_path(False, no_ket=no_ket)
             st = eng.new_state()
             eng.evolve(st, 0.0, 0.25)  # first part of the rise: Omega and |delta| both large

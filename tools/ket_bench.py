@@ -22,7 +22,7 @@ if "single" in which:
         with Engine.from_problems([tri()], mode="sesolve") as eng:
             eng.set_path(False, no_ket=no_ket)
             run(eng, 0.0, 0.01)
-            t1 = 3.1 if not no_ket else 0.3
+            t1 = 3.1
             dt, s, _ = run(eng, 0.0, t1)
             print(f"single 14-atom, no_ket={no_ket}: {t1/dt:.2f} sim-us/s ({dt:.3f} s for {t1} us), apps/ns {s['n_applications']/(t1*1e3):.1f}, stats {s}", flush=True)
 if "batch" in which:
