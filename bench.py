@@ -328,6 +328,7 @@ def main() -> None:
     ap.add_argument("--full-lindblad", action="store_true", help="north_star: full 3.1 us cfg3 leg (~1-2 min)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="north_star: headline leg only (profiling runs)")
     ap.add_argument("--no-ket", action="store_true", help="disable k_ket / the split-operator rows (A/B runs)")
     args = ap.parse_args()
 
@@ -413,7 +414,7 @@ def main() -> None:
             out["roofline"] = roofline_hbm(n, B, stats, kms, kl, "k_apply14<sesolve> (2^14 register tiles, 1 pass)")
         eng.close()
 
-        if rank == 0 and n_gpus == 1:
+        if rank == 0 and n_gpus == 1 and not args.no_legs:
             # latency: ONE sequence, full length
             eng = Engine.from_problems([tri_problem(2, 7)], mode="sesolve")
             if args.no_ket:
