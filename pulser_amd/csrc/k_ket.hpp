@@ -107,9 +107,17 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
     if (tid < 128) ftab[tid] = A.ftab[tid];
     __syncthreads();
   }
-  auto factor = [&](const double* tab, unsigned col) -> double {
-    const unsigned m = (1u << N) - 1u;
-    const int n11 = __popc(rowidx & col), n10 = __popc(rowidx & ~col & m), n01 = __popc(~rowidx & col & m);
+  // exp(sum_k fac[k] n_k(row, col)) for col = tid + 512 j: the (row bit, column bit) pair counts split
+  // into a per-thread part (column bits 0-8; three integers kept) and a per-j part (wave-uniform,
+  // scalar unit), so nothing per element stays alive between the load and the store of the kernel
+  const unsigned lomask = (unsigned)NTT - 1u;
+  const int t11 = __popc(rowidx & (unsigned)tid), t10 = __popc(rowidx & ~(unsigned)tid & lomask),
+            t01 = __popc(~rowidx & (unsigned)tid & lomask);
+  auto factor = [&](const double* tab, int j) -> double {
+    const unsigned rh = __builtin_amdgcn_readfirstlane((int)(rowidx >> LOGNT));
+    const unsigned hm = (1u << (N - LOGNT)) - 1u;
+    const int n11 = t11 + __popc(rh & (unsigned)j), n10 = t10 + __popc(rh & ~(unsigned)j & hm),
+              n01 = t01 + __popc(~rh & (unsigned)j & hm);
     const int n00 = N - n11 - n10 - n01;
     return tab[n00] * tab[16 + n01] * tab[32 + n10] * tab[48 + n11];
   };
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
     const int l = tid + j * NTT;
     const cplx v = st[l];
     double f = 1.0;
-    if (A.use_pre) f = factor(ftab, (unsigned)l);
+    if (A.use_pre) f = factor(ftab, j);
     q[j] = f * v.x;
     p[j] = f * v.y;
   }
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
   for (int j = 0; j < R; ++j) {
     const int l = tid + j * NTT;
     double f = 1.0;
-    if (A.use_post) f = factor(ftab + 64, (unsigned)l);
+    if (A.use_post) f = factor(ftab + 64, j);
     st[l] = make_double2(f * q[j], f * p[j]);
   }
 }
