@@ -479,12 +479,16 @@ class Observable:
 
     def __call__(self, config: "QutipConfig", t: float, state: RydState,
                  hamiltonian: HamiltonianOperator, result: "Results") -> None:
-        time_tol = (0.5 / result.total_duration) if result.total_duration else 1e-6
-        if (self.evaluation_times is not None
-                and config.is_time_in_evaluation_times(t, self.evaluation_times, tol=time_tol)) or (
-                self.evaluation_times is None and config.is_evaluation_time(t, tol=time_tol)):
+        if self._fires(config, t, result.total_duration):
             result._store(observable=self, time=t,
                           value=self.apply(config=config, state=state, hamiltonian=hamiltonian))
+
+    def _fires(self, config: "QutipConfig", t: float, total_duration: int) -> bool:
+        """observable.py:178-193: is relative time ``t`` one of this observable's evaluation times."""
+        time_tol = (0.5 / total_duration) if total_duration else 1e-6
+        if self.evaluation_times is not None:
+            return bool(config.is_time_in_evaluation_times(t, self.evaluation_times, tol=time_tol))
+        return bool(config.is_evaluation_time(t, tol=time_tol))
 
     def apply(self, *, config: "QutipConfig", state: RydState,
               hamiltonian: HamiltonianOperator) -> Any:  # pragma: no cover
@@ -525,6 +529,15 @@ class BitStrings(Observable):
         d["num_shots"] = self._num_shots
         d["one_state"] = self.one_state
         return d
+
+    def _skip_draws(self, config: "QutipConfig", n_qudits: int) -> None:
+        """Advance the global ``np.random`` stream exactly as :meth:`apply` would, without a state
+        (``RydState.sample``: ``rand(num_shots)``, then ``uniform(size=(num_shots, N))`` when there
+        are measurement errors) - used by ranks that do not own a trajectory of a sharded run."""
+        shots = self._num_shots if self._num_shots is not None else config.default_num_shots
+        np.random.rand(shots)
+        if not (config.noise_model.p_false_pos == 0.0 and config.noise_model.p_false_neg == 0.0):
+            np.random.uniform(size=(shots, n_qudits))
 
     def apply(self, *, config: "QutipConfig", state: RydState, **kw: Any) -> Counter:
         return state.sample(
@@ -1494,6 +1507,52 @@ class QutipBackendV2:
                 fill(res, single)
                 timing["observables_s"] = _time.perf_counter() - tic
                 return res
+            dist = sim._distributed()
+            builtin = (StateResult, BitStrings, Occupation, CorrelationMatrix, Energy, EnergyVariance,
+                       EnergySecondMoment, Fidelity, Expectation)
+            if dist is not None and not config.callbacks and all(type(o) in builtin for o in config.observables):
+                # one process per GPU: every rank replays rank 0's random stream and trajectory
+                # draws, solves and observes only its block of trajectories, skips the draws of the
+                # others (only BitStrings consumes random numbers), and the per-trajectory Results
+                # are gathered before the aggregation - identical output for any world size
+                from .distributed import partition
+
+                rank, world = dist.get_rank(), dist.get_world_size()
+                payload: list[Any] = [None]
+                if rank == 0:
+                    sim._refresh_trajectories_if_used()
+                    payload = [(sim._hamiltonian_data.noise_trajectories, np.random.get_state())]
+                dist.broadcast_object_list(payload, src=0)
+                trajs, rng_state = payload[0]
+                sim._hamiltonian_data.noise_trajectories = trajs
+                sim._problems_cache = None
+                sim._noise_trajectories_used = False  # already fresh: _noisy_runs must not redraw
+                np.random.set_state(rng_state)
+                lo, hi = partition([t.reps for t in trajs], world)[rank]
+                rel_times = [float(t / (T * 1e-3)) for t in sim._eval_times_array]
+                mine: list[tuple[int, Results]] = []
+                order = 0
+                tic = _time.perf_counter()
+                for coherent, reps in sim._noisy_runs(only=(lo, hi), **options):
+                    timing["solve_s"] += _time.perf_counter() - tic
+                    tic = _time.perf_counter()
+                    for _ in range(reps):
+                        if coherent is None:  # another rank's trajectory: keep the stream in step
+                            for t in rel_times:
+                                for obs in config.observables:
+                                    if isinstance(obs, BitStrings) and obs._fires(config, t, T):
+                                        obs._skip_draws(config, len(qids))
+                        else:
+                            res = Results(qids, T)
+                            fill(res, coherent)
+                            mine.append((order, res))
+                        order += 1
+                    timing["observables_s"] += _time.perf_counter() - tic
+                    tic = _time.perf_counter()
+                gathered: list[Any] = [None] * world
+                dist.all_gather_object(gathered, mine)
+                ordered = [r for _, r in sorted((x for part in gathered for x in part), key=lambda kv: kv[0])]
+                return Results.aggregate(ordered)
             results: list[Results] = []
             tic = _time.perf_counter()
             for coherent, reps in sim._noisy_runs(**options):

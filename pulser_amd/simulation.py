@@ -939,17 +939,22 @@ class QutipEmulator:
             return None
         return td
 
-    def _noisy_runs(self, progress_bar: Any, print_progress: bool = False,
-                    batch: int | None = None, **options: Any
-                    ) -> Iterator[tuple[CoherentResults, int]]:
-        """simulation.py:885-915; trajectories are solved in GPU batches but
-        yielded (and therefore sampled) in the reference's serial order."""
-        n_trajectories = self.n_trajectories
-        if self._noise_trajectories_used:  # fresh draws on every further run (:892-900)
+    def _refresh_trajectories_if_used(self) -> None:
+        """Fresh noise-trajectory draws on every run after the first (simulation.py:892-900)."""
+        if self._noise_trajectories_used:
             nm = self._hamiltonian_data.noise_model
             self._hamiltonian_data = HamiltonianData(
                 self.samples_obj, nm, self._get_n_trajectories(nm, check_value=True))
             self._problems_cache = None
+
+    def _noisy_runs(self, progress_bar: Any = False, print_progress: bool = False,
+                    batch: int | None = None, only: tuple[int, int] | None = None, **options: Any
+                    ) -> Iterator[tuple[CoherentResults | None, int]]:
+        """simulation.py:885-915; trajectories are solved in GPU batches but
+        yielded (and therefore sampled) in the reference's serial order.  ``only = (lo, hi)``
+        (sharded runs): trajectories outside the block are yielded as ``(None, reps)`` unsolved."""
+        n_trajectories = self.n_trajectories
+        self._refresh_trajectories_if_used()
         self._noise_trajectories_used = True
         hd = self._hamiltonian_data
         trajs = hd.noise_trajectories
@@ -961,6 +966,23 @@ class QutipEmulator:
         if batch is None:  # keep the snapshot tensor under ~8 GB
             batch = int(max(1, min(256, (8 << 30) // max(1, dim_bytes * n_eval))))
         traj_nb = 0
+        if only is not None:
+            lo, hi = only
+            for tr in trajs[:lo]:
+                yield None, tr.reps
+            for start in range(lo, hi, batch):
+                chunk = trajs[start:min(hi, start + batch)]
+                if self._fast_path_ok(self._current_problem):
+                    solved = self._solve_batch([], progress_bar, options,
+                                               tables=hd.device_tables(chunk, self._sampling_rate))
+                else:
+                    solved = self._solve_batch([hd.problem(t, self._sampling_rate) for t in chunk],
+                                               progress_bar, options)
+                for tr, res in zip(chunk, solved):
+                    yield res, tr.reps
+            for tr in trajs[hi:]:
+                yield None, tr.reps
+            return
         for start in range(0, len(trajs), batch):
             chunk = trajs[start:start + batch]
             if self._fast_path_ok(self._current_problem):

@@ -69,3 +69,59 @@ def test_run_shards_trajectories_over_ranks_and_matches_the_serial_run():
         assert p.exitcode == 0
     for rank, counters, _ in got:
         assert counters == ref, rank  # bit-identical Counters on every rank, for any world size
+
+
+def _v2_run(seed):
+    from pulser_amd import NoiseModel, QutipBackendV2, QutipConfig, problem as P
+    from pulser_amd.backend import BitStrings, Occupation
+    from pulser_amd.hamiltonian_data import single_global_channel
+
+    coords = P.register_coords(P.square_rect(1, 5), 8.0)
+    s = {k: v[:500] for k, v in P.anneal_samples().items()}
+    inputs = single_global_channel(coords, s, P.C6_LEVEL70, extended=False)
+    nm = NoiseModel(temperature=50.0, amp_sigma=0.05, state_prep_error=0.05, p_false_pos=0.02, p_false_neg=0.06)
+    obs = [BitStrings(evaluation_times=[0.5, 1.0], num_shots=40), Occupation(evaluation_times=[1.0])]
+    cfg = QutipConfig(observables=obs, noise_model=nm, n_trajectories=12)
+    np.random.seed(seed)
+    res = QutipBackendV2(inputs, config=cfg).run()
+    return (dict(res.get_result(obs[0], 0.5)), dict(res.get_result(obs[0], 1.0)),
+            [float(v) for v in res.get_result(obs[1], 1.0)])
+
+
+def _v2_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = _v2_run(9 if rank == 0 else 777 + rank)  # only rank 0's stream may matter
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_backend_v2_run_shards_trajectories_and_matches_the_serial_run():
+    """QutipBackendV2.run() under torch.distributed: ranks replay rank 0's random stream, observe
+    only their own trajectories (skipping the BitStrings draws of the others) and gather the
+    per-trajectory Results before aggregation (qutip_backend.py:266-325)."""
+    import torch.multiprocessing as mp
+
+    ref = _v2_run(9)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_v2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in got:
+        assert out[0] == ref[0] and out[1] == ref[1], rank  # bit-identical bag-union Counters
+        assert np.allclose(out[2], ref[2], atol=1e-12)      # mean occupations
