@@ -881,6 +881,19 @@ class Results:
         self._tagmap: dict[str, uuid.UUID] = {}
         self._aggregation: dict[uuid.UUID, str] = {}
 
+    def _rekey(self, tag_to_uuid: Mapping[str, uuid.UUID]) -> "Results":
+        """The same results under the uuids of ANOTHER set of observables with the same tags
+        (sharded runs: every rank built its own observables; tags are unique inside a configuration)."""
+        for tag, new_uid in tag_to_uuid.items():
+            old = self._tagmap.get(tag)
+            if old is None or old == new_uid:
+                continue
+            for table in (self._results, self._times, self._aggregation):
+                if old in table:
+                    table[new_uid] = table.pop(old)
+            self._tagmap[tag] = new_uid
+        return self
+
     def _store(self, *, observable: Observable, time: float, value: Any) -> None:
         uid = observable._uuid
         self._tagmap[observable.tag] = uid
@@ -1551,7 +1564,9 @@ class QutipBackendV2:
                     tic = _time.perf_counter()
                 gathered: list[Any] = [None] * world
                 dist.all_gather_object(gathered, mine)
-                ordered = [r for _, r in sorted((x for part in gathered for x in part), key=lambda kv: kv[0])]
+                mine_tags = {o.tag: o._uuid for o in config.observables}
+                ordered = [r._rekey(mine_tags) for _, r in
+                           sorted((x for part in gathered for x in part), key=lambda kv: kv[0])]
                 return Results.aggregate(ordered)
             results: list[Results] = []
             tic = _time.perf_counter()

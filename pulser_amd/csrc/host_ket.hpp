@@ -30,12 +30,15 @@ static bool ket_path(const ryd_handle* h) {
   // (10 us per stage), so a handful of sequences is faster on the multi-launch tiled kernels that
   // spread each ket over the chip (measured, full 3.1 us anneal: 1 sequence 9.5 vs 6.9 sim-us/s;
   // 8 sequences 48 vs 55; 16 sequences 81 vs 111)
-  return h->N == 14 && h->B >= 8 && !h->force_generic;
+  // 13 atoms, 256 sequences: 2 950 sim-us/s here vs 1 280 on k_traj<13> (which spills); 12 atoms: equal
+  return (h->N == 13 || h->N == 14) && h->B >= 8 && !h->force_generic;
 }
 
 static bool row_path(const ryd_handle* h) {
   if (h->general || h->cfg.mode != RYD_MESOLVE || h->has_dbl || h->N > 14) return false;
-  if (h->N < (h->force_ket ? 10 : 12)) return false;
+  // measured against the multi-launch Lindbladian (Hermitian path), ms per simulated ns, dephasing:
+  // 10 atoms 0.10 vs 0.41, 11: 0.32 vs 1.08, 12: 1.40 vs 5.41, 13: 5.85 vs 20.7, 14: 23.7 vs 89
+  if (h->N < 10) return false;
   if (!h->drive_real || (h->force_generic && !h->force_ket) || h->no_ket || !h->auto_tile) return false;
   for (int k = 0; k < 4; ++k)
     if (h->Sd[k].y != 0.0) return false;  // the elementwise factor must be real
