@@ -178,8 +178,12 @@ int ryd_evolve(ryd_handle* h, void* state_dev, double t0, double t1,
  * i-1 of out_dev, complex128[n_times-1][batch][dim].  For sesolve with N <= 13
  * (and for mesolve with N <= 6: a density matrix of at most 4096 entries) the
  * whole call is ONE launch of the persistent LDS-resident trajectory kernel
- * (one workgroup per batch entry); otherwise the tiled multi-pass kernels run
- * once per Taylor stage. */
+ * (one workgroup per batch entry); batches of >= 8 kets of 13-14 atoms with real
+ * drive coefficients run in ONE launch of the register-resident kernel (in-place
+ * symplectic exponential); a master equation of 10-14 atoms with a dephasing-type
+ * dissipator runs as 4th-order operator-splitting blocks (two row passes of that
+ * kernel + one conjugate transposition per half block); otherwise the tiled
+ * multi-pass kernels run once per Taylor stage. */
 int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
               void* out_dev, const ryd_opts* opts, void* stream);
 
@@ -246,8 +250,9 @@ int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr, con
  * register-tile kernel and the Hermitian mesolve path, 8 = force them even when
  * the launch has too few tiles to fill the GPU, 16 = use the single-launch plan
  * whatever the size of the state, 32 = disable the register-resident ket kernel
- * (sesolve, 14 atoms) and the split-operator master equation built on it (mesolve,
- * 12-14 atoms, dephasing-type dissipators), 64 = use both from 10 atoms on.
+ * (sesolve, 13-14 atoms, >= 8 sequences, real drives) and the split-operator master
+ * equation built on it (mesolve, 10-14 atoms, dephasing-type dissipators), 64 = use
+ * the ket kernel from 10 atoms and any batch size on.
  * Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);
 
