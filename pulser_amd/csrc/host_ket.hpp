@@ -82,6 +82,7 @@ static int to_ket_steps(ryd_handle* h, const std::vector<StepDesc>& sched, const
                         double conj_sign, std::vector<KetStep>& out) {
   const double tol = o.tol > 0 ? o.tol : kDefaultSympTol;
   int rc;
+  double phase = 0.0;  // accumulated spectral shifts: a global phase, applied at snapshots / final stores
   for (const StepDesc& d : sched) {
     KetStep k;
     std::memset(&k, 0, sizeof k);
@@ -91,8 +92,10 @@ static int to_ket_steps(ryd_handle* h, const std::vector<StepDesc>& sched, const
     ket_bound(h, d.idx, kA2, kA1, &bb, &k.shift_b);
     if ((rc = pick_scheme(std::fabs(d.h) * ba, tol, &k.sch_a, &k.sub_a))) return rc;
     if ((rc = pick_scheme(std::fabs(d.h) * bb, tol, &k.sch_b, &k.sub_b))) return rc;
-    k.cs_a = std::cos(conj_sign * d.h * k.shift_a); k.sn_a = std::sin(conj_sign * d.h * k.shift_a);
-    k.cs_b = std::cos(conj_sign * d.h * k.shift_b); k.sn_b = std::sin(conj_sign * d.h * k.shift_b);
+    phase += conj_sign * d.h * (k.shift_a + k.shift_b);
+    k.cum_phase = phase;
+    k.cum_cs = std::cos(phase);
+    k.cum_sn = std::sin(phase);
     h->stats.last_order = kSymp[k.sch_a].m * k.sub_a;
     h->stats.norm_bound = ba / (kA1 + kA2);
     out.push_back(k);
@@ -160,6 +163,7 @@ static void fill_ket_args(const ryd_handle* h, KetArgs& A) {
   A.a1 = kA1;
   A.a2 = kA2;
   A.conj_sign = 1.0;
+  A.fin_cs = 1.0;
 }
 
 static void count_ket_work(ryd_handle* h, const std::vector<KetStep>& ks, size_t i0, size_t i1, int passes) {
@@ -185,6 +189,8 @@ static int run_ket(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sche
   A.steps = h->ksched_dev;
   A.n_steps = (int)ks.size();
   A.rows_log2 = 0;
+  A.fin_cs = ks.back().cum_cs;
+  A.fin_sn = ks.back().cum_sn;
   if ((rc = launch_ket(h, A, (size_t)h->B, st))) return rc;
   count_ket_work(h, ks, 0, ks.size(), 1);
   h->stats.n_steps += (int64_t)ks.size();
@@ -269,6 +275,11 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     A.kick_post = kick_post;
     A.kick_idx = kick_idx;
     A.kick_u = kick_u;
+    {
+      const double ph = ks[i1 - 1].cum_phase - (i0 > 0 ? ks[i0 - 1].cum_phase : 0.0);
+      A.fin_cs = std::cos(ph);
+      A.fin_sn = std::sin(ph);
+    }
     A.ftab = tdev;
     A.state = cur;
     A.use_pre = f_in != 0.0;

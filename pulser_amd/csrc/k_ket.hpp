@@ -40,9 +40,11 @@ struct KetStep {
   int idx;
   short sch_a, sub_a, sch_b, sub_b;  // scheme index / equal sub-exponentials
   int snap;                          // snapshot slot written after this step, or -1
-  // e^{-i h shift} of both exponentials (sign of the launch folded in), from the host: a
-  // double-precision sincos inside the kernel spills the whole register-resident state
-  double cs_a, sn_a, cs_b, sn_b;
+  // The spectral shifts only contribute a global phase e^{-i sum h shift}: it is not applied per
+  // exponential but accumulated on the host (sign of the launch folded in) and applied to
+  // snapshots / the final store - cos and sin come from the host because a double-precision
+  // sincos inside the kernel spills the whole register-resident state.
+  double cum_phase, cum_cs, cum_sn;  // through the end of this step, from the start of the schedule
 };
 
 struct KetArgs {
@@ -66,6 +68,7 @@ struct KetArgs {
   double kick_pre, kick_post;
   int kick_idx;
   double kick_u;
+  double fin_cs, fin_sn;    // global phase of this launch's steps, applied at the final store
   const double* ftab;       // [2][4][16] = exp(pre[k] n), exp(post[k] n)  (host-computed, device memory)
 };
 
@@ -255,65 +258,103 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
       // Partners: index bits 0, 1, 3 over the DPP crossbar (quad permutes, row rotate by 8),
       // bit 2 as row_half_mirror + reversed quad permute (two moves), bits 4-8 as ds_read_b128
       // from the published copy (two amplitudes per read), bits 9.. register to register.
-      auto half_stage = [&](double (&dst)[R], const double (&src)[R], double coef) {
-        __syncthreads();  // partner reads of the previous half-stage are done
-        {
-          unsigned wa = (unsigned)tid * 16u;  // byte address inside xs
+      // One pair (2jp, 2jp+1) of  dst += coef * (H~ - shift) src ; `ra` = byte address of this
+      // thread's slot of pair jp inside the published copy.
+      auto do_pair = [&](double (&dst)[R], const double (&src)[R], double coef, int jp, unsigned ra) {
+        double2 pv[LOGNT - F0];
 #pragma unroll
-          for (int jp = 0; jp < RP; ++jp) {
-            asm volatile("" : "+v"(wa));  // one running address instead of RP spilled ones
-            *reinterpret_cast<double2*>(smem + wa) = make_double2(src[2 * jp], src[2 * jp + 1]);
-            wa += NTT * 16u;
-          }
+        for (int f = F0; f < LOGNT; ++f) pv[f - F0] = *reinterpret_cast<const double2*>(smem + (ra ^ (16u << f)));
+        const double2 eh2 = *reinterpret_cast<const double2*>(ehx + 2 * jp);
+        // diagonal of the pair: high atoms excited <=> their bit is 0.  Re-derived per pair (<= 5
+        // additions): hoisted out of the stage loop the R partial sums would live in scratch and
+        // every pair would wait for a scratch load
+        double ec = elo;
+        asm volatile("" : "+v"(ec));
+#pragma unroll
+        for (int k = 1; k < NH; ++k)
+          if (!((jp >> (k - 1)) & 1)) ec += vhi[k];
+        const double s0 = src[2 * jp], s1 = src[2 * jp + 1];
+        double acc0 = ((ec + vhi[0]) + eh2.x) * s0;
+        double acc1 = (ec + eh2.y) * s1;
+        // second chains: the register-index and DPP partners (independent of the LDS reads)
+        double bcc0 = cq[LOGNT] * s1;  // bit 9 pairs (2jp, 2jp+1)
+        double bcc1 = cq[LOGNT] * s0;
+#pragma unroll
+        for (int k = 0; k + LOGNT + 1 < N; ++k) {  // bits 10..: jp <-> jp ^ 2^k
+          const int jo = jp ^ (1 << k);
+          bcc0 = fma(cq[LOGNT + 1 + k], src[2 * jo], bcc0);
+          bcc1 = fma(cq[LOGNT + 1 + k], src[2 * jo + 1], bcc1);
         }
-        __syncthreads();
-        unsigned ra = (unsigned)tid * 16u;
+        if constexpr (F0 == 4) {
+          bcc0 = fma(cq[0], dpp_f64<0xB1>(s0), bcc0);   // xor 1
+          bcc1 = fma(cq[0], dpp_f64<0xB1>(s1), bcc1);
+          bcc0 = fma(cq[1], dpp_f64<0x4E>(s0), bcc0);   // xor 2
+          bcc1 = fma(cq[1], dpp_f64<0x4E>(s1), bcc1);
+          bcc0 = fma(cq[3], dpp_f64<0x128>(s0), bcc0);  // xor 8 (row rotate by 8)
+          bcc1 = fma(cq[3], dpp_f64<0x128>(s1), bcc1);
+          bcc0 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s0)), bcc0);  // xor 4 = (xor 7) o (xor 3)
+          bcc1 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s1)), bcc1);
+        }
 #pragma unroll
-        for (int jp = 0; jp < RP; ++jp) {
-          asm volatile("" : "+v"(ra));
-          double2 pv[LOGNT - F0];
+        for (int f = F0; f < LOGNT; ++f) {
+          acc0 = fma(cq[f], pv[f - F0].x, acc0);
+          acc1 = fma(cq[f], pv[f - F0].y, acc1);
+        }
+        dst[2 * jp] = fma(coef, acc0 + bcc0, dst[2 * jp]);
+        dst[2 * jp + 1] = fma(coef, acc1 + bcc1, dst[2 * jp + 1]);
+      };
+
+      // dst += coef * (H~ - shift) src, in place on the register arrays.
+      // Partners: index bits 0, 1, 3 over the DPP crossbar (quad permutes, row rotate by 8),
+      // bit 2 as row_half_mirror + reversed quad permute (two moves), bits 4-8 as ds_read_b128
+      // from the published copy (two amplitudes per read), bits 9.. register to register.
+      //
+      // The published copy of `src` lives in two halves: A = pairs [0, H), B = pairs [H, RP).
+      // Invariant on entry: A holds src[0, H).  First half: pairs [0, H) are computed from A while
+      // src[H, RP) is written into B; second half: pairs [H, RP) are computed from B while the
+      // finished dst[0, H) is written into A for the next half-stage (q <- p and p <- q alternate
+      // inside an exponential; its first half-stage re-publishes p, see below).  The LDS stores ride along with the arithmetic instead of forming a store-only
+      // phase (17 % of a stage before), and there are still two barriers per half-stage.
+      auto half_stage = [&](double (&dst)[R], const double (&src)[R], double coef) {
+        constexpr int H = RP / 2;
+        if constexpr (RP >= 2) {
+          unsigned ra = (unsigned)tid * 16u;
 #pragma unroll
-          for (int f = F0; f < LOGNT; ++f) pv[f - F0] = *reinterpret_cast<const double2*>(smem + (ra ^ (16u << f)));
-          const double2 eh2 = *reinterpret_cast<const double2*>(ehx + 2 * jp);
-          // diagonal of the pair (2jp, 2jp+1): high atoms excited <=> their bit is 0.  Re-derived
-          // per pair (<= 5 additions): hoisted out of the stage loop the R partial sums would live
-          // in scratch and every pair would wait for a scratch load
-          double ec = elo;
-          asm volatile("" : "+v"(ec));
-#pragma unroll
-          for (int k = 1; k < NH; ++k)
-            if (!((jp >> (k - 1)) & 1)) ec += vhi[k];
-          const double s0 = src[2 * jp], s1 = src[2 * jp + 1];
-          double acc0 = ((ec + vhi[0]) + eh2.x) * s0;
-          double acc1 = (ec + eh2.y) * s1;
-          // second chains: the register-index and DPP partners (independent of the LDS reads)
-          double bcc0 = cq[LOGNT] * s1;  // bit 9 pairs (2jp, 2jp+1)
-          double bcc1 = cq[LOGNT] * s0;
-#pragma unroll
-          for (int k = 0; k + LOGNT + 1 < N; ++k) {  // bits 10..: jp <-> jp ^ 2^k
-            const int jo = jp ^ (1 << k);
-            bcc0 = fma(cq[LOGNT + 1 + k], src[2 * jo], bcc0);
-            bcc1 = fma(cq[LOGNT + 1 + k], src[2 * jo + 1], bcc1);
+          for (int jp = 0; jp < H; ++jp) {
+            asm volatile("" : "+v"(ra));
+            *reinterpret_cast<double2*>(smem + ra + (unsigned)H * NTT * 16u) =
+                make_double2(src[2 * (jp + H)], src[2 * (jp + H) + 1]);
+            do_pair(dst, src, coef, jp, ra);
+            ra += NTT * 16u;
+            __builtin_amdgcn_sched_barrier(0);  // keep the partner reads of the next pair behind this one
           }
-          if constexpr (F0 == 4) {
-            bcc0 = fma(cq[0], dpp_f64<0xB1>(s0), bcc0);   // xor 1
-            bcc1 = fma(cq[0], dpp_f64<0xB1>(s1), bcc1);
-            bcc0 = fma(cq[1], dpp_f64<0x4E>(s0), bcc0);   // xor 2
-            bcc1 = fma(cq[1], dpp_f64<0x4E>(s1), bcc1);
-            bcc0 = fma(cq[3], dpp_f64<0x128>(s0), bcc0);  // xor 8 (row rotate by 8)
-            bcc1 = fma(cq[3], dpp_f64<0x128>(s1), bcc1);
-            bcc0 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s0)), bcc0);  // xor 4 = (xor 7) o (xor 3)
-            bcc1 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s1)), bcc1);
-          }
+          __syncthreads();  // B complete; every read of A done
 #pragma unroll
-          for (int f = F0; f < LOGNT; ++f) {
-            acc0 = fma(cq[f], pv[f - F0].x, acc0);
-            acc1 = fma(cq[f], pv[f - F0].y, acc1);
+          for (int jp = H; jp < RP; ++jp) {
+            asm volatile("" : "+v"(ra));
+            *reinterpret_cast<double2*>(smem + ra - (unsigned)H * NTT * 16u) =
+                make_double2(dst[2 * (jp - H)], dst[2 * (jp - H) + 1]);
+            do_pair(dst, src, coef, jp, ra);
+            ra += NTT * 16u;
+            __builtin_amdgcn_sched_barrier(0);
           }
-          dst[2 * jp] = fma(coef, acc0 + bcc0, dst[2 * jp]);
-          dst[2 * jp + 1] = fma(coef, acc1 + bcc1, dst[2 * jp + 1]);
-          ra += NTT * 16u;
-          __builtin_amdgcn_sched_barrier(0);  // keep the partner reads of the next pair behind this one
+          __syncthreads();  // A complete (next source); every read of B done
+        } else {
+          __syncthreads();
+          *reinterpret_cast<double2*>(smem + (unsigned)tid * 16u) = make_double2(src[0], src[1]);
+          __syncthreads();
+          do_pair(dst, src, coef, 0, (unsigned)tid * 16u);
+        }
+      };
+      // slow path (kernel start, kicks): make A hold arr[0, H) whatever was there
+      auto republish_low = [&](const double (&arr)[R]) {
+        if constexpr (RP >= 2) {
+          __syncthreads();
+#pragma unroll
+          for (int jp = 0; jp < RP / 2; ++jp)
+            *reinterpret_cast<double2*>(smem + (unsigned)tid * 16u + (unsigned)jp * NTT * 16u) =
+                make_double2(arr[2 * jp], arr[2 * jp + 1]);
+          __syncthreads();
         }
       };
 
@@ -349,28 +390,21 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
           ca = (kSympDev[sch].a[i] + ((i == 0 && sb > 0) ? kSympDev[sch].a[m] : 0.0)) * hs;
           cb = -kSympDev[sch].b[i] * hs;
         }
+        if (kick || t == 0) republish_low(p);  // the exponential (or kick shear) starts from p
         half_stage(q, p, ca);
-        if (kick) undo_diag(q, p, ca);
+        if (kick) { undo_diag(q, p, ca); republish_low(q); }
         if (t < n_pairs) {
           half_stage(p, q, cb);
           if (kick) undo_diag(p, q, cb);
           if (++i == m) { i = 0; ++sb; }
         }
       }
-      if (kick) continue;
-      // e^{-i h shift} (conjugated for the row form)
-      const double sn = ex == 1 ? sd.sn_b : sd.sn_a, cs = ex == 1 ? sd.cs_b : sd.cs_a;
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const double qq = q[j], pp2 = p[j];
-        q[j] = fma(qq, cs, pp2 * sn);
-        p[j] = fma(pp2, cs, -qq * sn);
-      }
     }
     if (sd.snap >= 0 && A.snaps) {
       cplx* o = A.snaps + ((size_t)sd.snap * gridDim.x + row) * D;
 #pragma unroll
-      for (int j = 0; j < R; ++j) o[tid + j * NTT] = make_double2(q[j], p[j]);
+      for (int j = 0; j < R; ++j)  // psi * e^{-i phase}: the accumulated spectral shifts
+        o[tid + j * NTT] = make_double2(fma(q[j], sd.cum_cs, p[j] * sd.cum_sn), fma(p[j], sd.cum_cs, -q[j] * sd.cum_sn));
     }
     __syncthreads();  // cf / ehi are rewritten by the next step
   }
@@ -379,7 +413,7 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
     const int l = tid + j * NTT;
     double f = 1.0;
     if (A.use_post) f = factor(ftab + 64, j);
-    st[l] = make_double2(f * q[j], f * p[j]);
+    st[l] = make_double2(f * fma(q[j], A.fin_cs, p[j] * A.fin_sn), f * fma(p[j], A.fin_cs, -q[j] * A.fin_sn));
   }
 }
 
