@@ -35,11 +35,12 @@ static bool ket_path(const ryd_handle* h) {
 }
 
 static bool row_path(const ryd_handle* h) {
-  if (h->general || h->cfg.mode != RYD_MESOLVE || h->has_dbl || h->N > 14) return false;
+  if (h->general || h->cfg.mode != RYD_MESOLVE || h->N > 14) return false;
   // measured against the multi-launch Lindbladian (Hermitian path), ms per simulated ns, dephasing:
   // 10 atoms 0.10 vs 0.41, 11: 0.32 vs 1.08, 12: 1.40 vs 5.41, 13: 5.85 vs 20.7, 14: 23.7 vs 89
   if (h->N < 10) return false;
   if (!h->drive_real || (h->force_generic && !h->force_ket) || h->no_ket || !h->auto_tile) return false;
+  if (h->has_dbl) return true;  // dissipator factor by k_local_exp (any complex 4x4 with this sparsity)
   for (int k = 0; k < 4; ++k)
     if (h->Sd[k].y != 0.0) return false;  // the elementwise factor must be real
   return true;
@@ -197,6 +198,78 @@ static int run_ket(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sche
   return RYD_OK;
 }
 
+// exp(f S) of the local 4x4 superoperator (diagonal + double-flip entries): 00 <-> 11 and 01 <-> 10
+// are independent 2x2 blocks; scaling-and-squaring Taylor series on each.
+static void local_super_exp(const ryd_handle* h, double f, cplx Mdiag[4], cplx Mflip[4]) {
+  typedef std::complex<double> cd;
+  for (int blk = 0; blk < 2; ++blk) {
+    const int r0 = blk == 0 ? 0 : 1, r1 = 3 - r0;
+    cd a[2][2] = {{cd(h->Sd[r0].x, h->Sd[r0].y) * f, cd(h->J[r0].x, h->J[r0].y) * f},
+                  {cd(h->J[r1].x, h->J[r1].y) * f, cd(h->Sd[r1].x, h->Sd[r1].y) * f}};
+    double nrm = 0.0;
+    for (auto& row : a) for (auto& v : row) nrm = std::max(nrm, std::abs(v));
+    int sq = 0;
+    while (nrm > 0.25) { nrm *= 0.5; ++sq; }
+    const double sc = std::ldexp(1.0, -sq);
+    for (auto& row : a) for (auto& v : row) v *= sc;
+    cd e[2][2] = {{1.0, 0.0}, {0.0, 1.0}}, term[2][2] = {{1.0, 0.0}, {0.0, 1.0}};
+    for (int k = 1; k <= 18; ++k) {
+      cd nt[2][2];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) nt[i][j] = (term[i][0] * a[0][j] + term[i][1] * a[1][j]) / (double)k;
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) { term[i][j] = nt[i][j]; e[i][j] += nt[i][j]; }
+    }
+    for (int s = 0; s < sq; ++s) {
+      cd n2[2][2];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) n2[i][j] = e[i][0] * e[0][j] + e[i][1] * e[1][j];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) e[i][j] = n2[i][j];
+    }
+    Mdiag[r0] = make_double2(e[0][0].real(), e[0][0].imag());
+    Mflip[r0] = make_double2(e[0][1].real(), e[0][1].imag());
+    Mflip[r1] = make_double2(e[1][0].real(), e[1][0].imag());
+    Mdiag[r1] = make_double2(e[1][1].real(), e[1][1].imag());
+  }
+}
+
+// rho <- exp(f * dissipator) rho by the pair passes (k_local_exp), in place
+static int launch_local_exp(ryd_handle* h, cplx* rho, double f, hipStream_t st) {
+  if (!h->passes_valid) plan_passes(h);
+  LocalExpArgs A;
+  std::memset(&A, 0, sizeof A);
+  local_super_exp(h, f, A.Mdiag, A.Mflip);
+  A.rho = rho;
+  A.nb = h->nb;
+  static bool attr_set[64] = {};
+  const int dev = h->cfg.device;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_local_exp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  for (const Pass& p : h->passes) {
+    if (p.dbl.empty()) return fail(RYD_ERR_STATE, "pair passes expected for a double-flip dissipator");
+    A.tile = p.tile;
+    A.outer = p.outer;
+    A.T = p.T;
+    A.n_dbl = (int)p.dbl.size();
+    for (int i = 0; i < A.n_dbl; ++i) {
+      A.dbl_qb[i] = (signed char)p.dbl[i].first;
+      A.dbl_qa[i] = (signed char)p.dbl[i].second;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    int rc;
+    if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+    hipLaunchKernelGGL(k_local_exp, dim3((unsigned)(1ull << p.n_outer_bits), h->B), dim3(512),
+                       ((size_t)1 << p.T) * sizeof(cplx), st, A);
+    HIPCHK(hipGetLastError());
+    if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
+    h->stats.n_launches++;
+  }
+  return RYD_OK;
+}
+
 // CF4 steps per HALF block of the 4th-order splitting (below): two steps (tau = 4 ns at
 // sampling rate 1) keep the splitting error at the level of the CF4 error (<= 1e-9 after 3.1 us
 // for dephasing rates up to 0.5 / us and drives up to 25 rad/us, tools/split_probe.py); faster
@@ -238,7 +311,9 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
                          std::fabs(std::fabs(g01) - std::fabs(g32)) < 1e-14 * (1 + std::fabs(g01));
   const double gflip = std::fabs(g01);
   int Kh = row_block_steps(h, o);
-  if (!uniform_g && o.split_steps <= 0) Kh = 1;
+  if ((!uniform_g || h->has_dbl) && o.split_steps <= 0) Kh = 1;
+  const bool dbl = h->has_dbl;  // the dissipator factor is not elementwise: k_local_exp passes
+  double pending = 0.0;         // dissipator time not applied yet (adjacent factors merge)
   const size_t D = (size_t)1 << h->N;
   const size_t n_rows = D * (size_t)h->B;
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
@@ -261,6 +336,12 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
         tab[k * 16 + n] = std::exp(f_in * h->Sd[k].x * n);
         tab[64 + k * 16 + n] = std::exp(f_out * h->Sd[k].x * n);
       }
+    if (dbl) {
+      pending += f_in;
+      int rcl;
+      if (pending != 0.0 && (rcl = launch_local_exp(h, cur, pending, st))) return rcl;
+      pending = 0.0;
+    }
     if (tab_slot == 0) HIPCHK(hipStreamSynchronize(st));
     double* tdev = h->ftab_dev + 128 * tab_slot;
     tab_slot = (tab_slot + 1) & 3;
@@ -282,7 +363,7 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     }
     A.ftab = tdev;
     A.state = cur;
-    A.use_pre = f_in != 0.0;
+    A.use_pre = !dbl && f_in != 0.0;
     int rc2;
     if ((rc2 = launch_ket(h, A, n_rows, st))) return rc2;
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -294,8 +375,9 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     std::swap(cur, other);
     A.state = cur;
     A.use_pre = 0;
-    A.use_post = f_out != 0.0;
+    A.use_post = !dbl && f_out != 0.0;
     if ((rc2 = launch_ket(h, A, n_rows, st))) return rc2;
+    if (dbl) pending += f_out;
     count_ket_work(h, ks, i0, i1, 1);  // one Lindbladian application ~ one two-sided ket stage
     h->stats.n_steps += (int64_t)(i1 - i0);
     return RYD_OK;
@@ -319,13 +401,17 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
       // (1/6, 2/3, 1/6) only for a = 1/2; unequal halves (knot-limited steps) are rare and small,
       // they keep the symmetric weights of their own lengths: D(t1/3) . D((t1+t2)/3 ...) -
       // handled by giving each half the weights (1/3, 2/3) of ITS length around the middle factor
-      const double eps = uniform_g ? tau * tau * tau * gflip * gflip / 72.0 : 0.0;
+      const double eps = (uniform_g && !dbl) ? tau * tau * tau * gflip * gflip / 72.0 : 0.0;
       const StepDesc& m0 = sched[mid];
       const double kick_u = m0.u1 - kC1 * m0.h;  // start of the step `mid` inside its knot interval
       if ((rc = conjugate(i, mid, t1 / 3.0, 2.0 * t1 / 3.0, 0.0, 0.5 * eps, m0.idx, kick_u))) return rc;
       if ((rc = conjugate(mid, j, 2.0 * t2 / 3.0, t2 / 3.0, 0.5 * eps, 0.0, m0.idx, kick_u))) return rc;
     }
     const int snap = sched[j - 1].snap;
+    if (dbl && pending != 0.0 && (snap >= 0 || j >= sched.size())) {
+      if ((rc = launch_local_exp(h, cur, pending, st))) return rc;
+      pending = 0.0;
+    }
     if (snap >= 0 && snaps)
       HIPCHK(hipMemcpyAsync(snaps + (size_t)snap * h->dim * h->B, cur, bytes, hipMemcpyDeviceToDevice, st));
     i = j;

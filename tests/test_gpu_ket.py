@@ -242,3 +242,70 @@ def test_cfg3_noise_model_end_to_end_14_atoms_keeps_density_matrices_on_the_devi
     # "Full" would store 13 density matrices of 4.29 GB: still fits; 3101 of them must be refused
     with pytest.raises(MemoryError, match="evaluation_times='Minimal'"):
         sim._check_snapshot_budget(3101, 16 * 4**n)
+
+
+# ------------------------------------------- double-flip dissipators on the split-operator path
+from helpers import DEPOL_PAULIS  # noqa: E402
+
+DBL_CASES = {
+    "relaxation": ([(np.sqrt(0.04), "sigma_gr")], None),
+    "relaxation+dephasing": ([(np.sqrt(2 * 0.05), "sigma_rr"), (np.sqrt(0.03), "sigma_gr")], None),
+    "depolarizing": ([(np.sqrt(0.06 / 4), "x"), (np.sqrt(0.06 / 4), "y"), (np.sqrt(0.06 / 4), "z")], DEPOL_PAULIS),
+}
+
+
+@pytest.mark.parametrize("case", list(DBL_CASES))
+@pytest.mark.parametrize("n", [10, 12])
+def test_split_operator_rows_with_double_flip_dissipators(case, n):
+    """Relaxation / depolarizing (C rho C^+ terms) on the row path: the dissipator factor is the
+    product over atoms of exp(tau S_local) (k_local_exp pair passes) between the unitary row passes;
+    against the multi-launch Lindbladian (three pair passes per application)."""
+    ops, paulis = DBL_CASES[case]
+    prob = real_local_problem(n, seed=5, duration=41, collapse_ops=ops)
+    prob["depolarizing_pauli_2ds"] = dict(paulis or {})
+    times = np.array([0.0, 0.011, 0.04])
+    outs = {}
+    for rows in (True, False):
+        with _engine([prob], "mesolve") as eng:
+            eng.set_path(False, no_ket=not rows)
+            outs[rows] = eng.solve(eng.new_state(), times).cpu().numpy()[:, 0]
+            if rows:
+                s = eng.stats()
+                assert s["n_launches"] < 12 * s["n_steps"], s  # not one launch set per application
+    rho = outs[True][-1]
+    assert np.max(np.abs(outs[True] - outs[False])) < 5e-8
+    assert abs(np.trace(rho).real - 1.0) < 1e-9
+    assert np.max(np.abs(rho - rho.conj().T)) < 1e-12
+
+
+def test_split_operator_rows_relaxation_product_state_12_atoms():
+    """Non-interacting atoms with relaxation + dephasing: exact product of single-atom solutions."""
+    import torch
+    from scipy.linalg import expm
+
+    n, gam_d, gam_r = 12, 0.05, 0.2
+    coords = P.register_coords(P.square_rect(1, n), 60.0)
+    T = 12
+    samples = {"amp": np.full(T + 1, 6.0), "det": np.full(T + 1, -2.0), "phase": np.zeros(T + 1)}
+    prob = P.make_ising_problem(coords, samples, collapse_ops=[(np.sqrt(2 * gam_d), "sigma_rr"),
+                                                               (np.sqrt(gam_r), "sigma_gr")])
+    t_end = 0.008
+    H = np.array([[2.0, 3.0], [3.0, 0.0]], dtype=complex)
+    cs = [np.sqrt(2 * gam_d) * np.diag([1.0, 0.0]).astype(complex),
+          np.sqrt(gam_r) * np.array([[0, 0], [1.0, 0]], dtype=complex)]  # sigma_gr = |g><r|
+    I2 = np.eye(2)
+    L = -1j * (np.kron(H, I2) - np.kron(I2, H.T))
+    for C in cs:
+        L = L + np.kron(C, C.conj()) - 0.5 * np.kron(C.conj().T @ C, I2) - 0.5 * np.kron(I2, (C.conj().T @ C).T)
+    r1 = (expm(L * t_end) @ np.array([0, 0, 0, 1.0], dtype=complex)).reshape(2, 2)
+    with _engine([prob], "mesolve") as eng:
+        st = eng.new_state()
+        eng.evolve(st, 0.0, t_end)
+        D = 1 << n
+        rng = np.random.default_rng(2)
+        pairs = [(0, 0), (D - 1, D - 1), (1, 2), (D - 1, 0)] + [tuple(int(v) for v in rng.integers(0, D, 2)) for _ in range(40)]
+        got = np.array([st[0, a, b].item() for a, b in pairs])
+        ref = np.array([np.prod([r1[(a >> (n - 1 - k)) & 1, (b >> (n - 1 - k)) & 1] for k in range(n)])
+                        for a, b in pairs])
+        assert abs(float(torch.diagonal(st[0]).real.sum().item()) - 1.0) < 1e-11
+        assert np.max(np.abs(got - ref)) < 5e-8
