@@ -47,3 +47,14 @@ if "pmc" in which:
     with Engine.from_problems([tri()] * 256, mode="sesolve") as eng:
         dt, s, _ = run(eng, 1.0, 1.02)
         print(f"pmc leg: 256 x 14-atom, 20 ns: {dt*1e3:.1f} ms, stats {s}", flush=True)
+
+if "relax" in which:
+    ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr"), (float(np.sqrt(0.02)), "sigma_gr")]
+    with Engine.from_problems([tri(ops)], mode="mesolve") as eng:
+        run(eng, 1.0, 1.002)
+        dt, s, st = run(eng, 1.0, 1.008)
+        tr = float(torch.diagonal(st[0]).real.sum().item())
+        print(f"14 atoms dephasing + relaxation, rows: {dt/8*1e3:.2f} ms per ns, trace {tr:.15f}, stats {s}", flush=True)
+        eng.set_path(False, no_ket=True)
+        dt, s, st = run(eng, 1.0, 1.001)
+        print(f"14 atoms dephasing + relaxation, multi-launch pair passes: {dt/1*1e3:.2f} ms per ns, stats {s}", flush=True)
