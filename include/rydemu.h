@@ -283,12 +283,16 @@ int ryd_occupations(ryd_handle* h, const void* state_dev, double* out_dev,
  *   [0, N)            <n_k>
  *   [N]               squared norm / trace  (the caller normalises, like state.unit())
  *   [N+1, N+1+N*N)    <n_k n_l>, row-major
- *   [N*N+N+1]         <H(t)>      (RYD_OBS_ENERGY; kets only: one generator application)
- *   [N*N+N+2]         <H(t)^2>
- * Entries that were not requested are 0.  No host synchronisation. */
+ *   [N*N+N+1]         <H(t)>      (RYD_OBS_ENERGY; kets: one generator application + one dot;
+ *   [N*N+N+2]         <H(t)^2>     density matrices: a gather of the elements of rho within two
+ *                                  bit flips of the diagonal - H(t) is never materialised)
+ * RYD_OBS_DENSITY: state_dev is a density matrix complex128[batch][2^N][2^N] even though the
+ * handle is a ket (sesolve) handle - the V2 backend's noiseless-Hamiltonian engine observing the
+ * states of a master-equation run.  Entries that were not requested are 0.  No host synchronisation. */
 #define RYD_OBS_OCCUPATION 1
 #define RYD_OBS_CORRELATION 2
 #define RYD_OBS_ENERGY 4
+#define RYD_OBS_DENSITY 8
 int ryd_observe(ryd_handle* h, const void* state_dev, double t, int32_t what,
                 double* out_dev, void* stream);
 

@@ -371,19 +371,24 @@ class HamiltonianOperator:
     def observe(self, state: RydState) -> dict[str, Any] | None:
         """Device-side values behind Occupation / CorrelationMatrix / Energy* for a ket of a
         2-level register: ONE ``ryd_observe`` call per (state, evaluation time), shared by every
-        observable asking for it.  None when the state is not a ket of the tuned engine (density
-        matrices, multi-level registers): the host formulas are used then."""
+        observable asking for it (kets: pair reduction + one generator application + one dot;
+        density matrices: pair reduction on the diagonal + one gather kernel for Tr(H rho), Tr(H^2 rho)).
+        None for multi-level registers: the host formulas are used then."""
         if not hasattr(self._eng, "observe") or len(self.eigenstates) != 2:
             return None
         if self._observed is not None and self._observed[0] == id(state):
             return self._observed[1]
         q = state.to_qobj()
-        if not q.isket or q.shape[0] != self._eng.dim:
+        if q.shape[0] != self._eng.dim:
             return None
         import torch
 
-        x = torch.from_numpy(np.ascontiguousarray(np.asarray(q)[:, 0][None, :])).to(self._eng.device)
-        raw = self._eng.observe(x, self._t)
+        if q.isket:
+            x = torch.from_numpy(np.ascontiguousarray(np.asarray(q)[:, 0][None, :])).to(self._eng.device)
+            raw = self._eng.observe(x, self._t)
+        else:  # density matrix of a master-equation run, observed with the noiseless ket engine's H(t)
+            x = torch.from_numpy(np.ascontiguousarray(np.asarray(q)[None, :, :])).to(self._eng.device)
+            raw = self._eng.observe(x, self._t, density=True)
         n2 = float(raw["norm2"][0])
         res = {"occupation": raw["occupation"][0] / n2, "correlation": raw["correlation"][0] / n2,
                "energy": float(raw["energy"][0]) / n2, "energy2": float(raw["energy2"][0]) / n2}

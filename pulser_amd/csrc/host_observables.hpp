@@ -34,9 +34,8 @@ extern "C" int ryd_observe(ryd_handle* h, const void* state_dev, double t, int32
   if (rc) return rc;
   if (!state_dev || !out_dev) return fail(RYD_ERR_INVALID, "null argument");
   if (h->general) return fail(RYD_ERR_INVALID, "not available on a general-path handle");
-  const bool dm = h->cfg.mode == RYD_MESOLVE;
-  if ((what & RYD_OBS_ENERGY) && dm)
-    return fail(RYD_ERR_UNSUPPORTED, "energy moments need a ket (sesolve) handle");
+  const bool dm = h->cfg.mode == RYD_MESOLVE || (what & RYD_OBS_DENSITY) != 0;
+  if (2 * h->N > RYD_MAX_QUBITS && dm) return fail(RYD_ERR_INVALID, "2N exceeds %d", RYD_MAX_QUBITS);
   HIPCHK(hipSetDevice(h->cfg.device));
   hipStream_t st = (hipStream_t)stream;
   const int N = h->N;
@@ -57,6 +56,18 @@ extern "C" int ryd_observe(ryd_handle* h, const void* state_dev, double t, int32
     m.w1 = 1.0;
     m.w2 = 0.0;
     if ((rc = launch_eval(h, m, st))) return rc;
+    if (dm) {
+      // Tr(H rho), Tr(H^2 rho) from the elements of rho within two bit flips of the diagonal
+      const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(D >> 8, 1), 1024);
+      hipLaunchKernelGGL(k_obs_energy_dm, dim3(nblk, h->B), dim3(256), 0, st, (const cplx*)state_dev, N,
+                         (const double*)h->coefs_dev, (const double*)h->e0_dev,
+                         h->e0_mats == 1 ? 0ll : (long long)D, out_dev, stride, N * N + N + 1);
+      HIPCHK(hipGetLastError());
+      h->stats.n_launches++;
+      return RYD_OK;
+    }
+    if (h->cfg.mode != RYD_SESOLVE)
+      return fail(RYD_ERR_UNSUPPORTED, "ket energy moments need a sesolve handle");
     if ((rc = apply_generator(h, (const cplx*)state_dev, nullptr, h->wA, 1.0, 1.0, 0.0,
                               make_double2(1.0, 0.0), st)))
       return rc;

@@ -70,3 +70,58 @@ __global__ __launch_bounds__(256) void k_obs_energy(const cplx* __restrict__ x, 
     atomicAdd(out + (size_t)blockIdx.y * out_stride + off + 1, e2);
   }
 }
+
+// Density matrices: <H> = Tr(H rho) and <H^2> = Tr(H^2 rho) only touch the matrix elements of H
+// and H^2 around the diagonal: with h_k(a) = H_{a, a^k} = (bit_k(a) ? c_k : conj c_k),
+//   (H)_{aa} = E(a);            (H^2)_{aa}      = E(a)^2 + sum_k |c_k|^2
+//   (H)_{a,a^k} = h_k(a);       (H^2)_{a,a^k}   = h_k(a) (E(a) + E(a^k))
+//                               (H^2)_{a,a^k^l} = 2 h_k(a) h_l(a)      (k != l)
+// so one thread per row index a gathers 1 + N + N(N-1)/2 elements of column a.  No H(t) is built
+// (qutip_backend.py:259-264 materialises it) and rho is not multiplied by anything dense.
+__global__ __launch_bounds__(256) void k_obs_energy_dm(const cplx* __restrict__ rho, int N,
+                                                       const double* __restrict__ coefs,
+                                                       const double* __restrict__ e0, long long e0_stride,
+                                                       double* __restrict__ out, int out_stride, int off) {
+  const size_t D = (size_t)1 << N;
+  const int b = blockIdx.y;
+  const cplx* r = rho + ((size_t)b << (2 * N));
+  const double* cf = coefs + (size_t)b * N * 4;
+  const double* e0b = e0 + (size_t)b * e0_stride;
+  double e1 = 0.0, e2 = 0.0;
+  for (size_t a = (size_t)blockIdx.x * 256 + threadIdx.x; a < D; a += (size_t)gridDim.x * 256) {
+    auto energy = [&](size_t s) {
+      double e = e0b[s];
+      for (int k = 0; k < N; ++k)
+        if (!((s >> (N - 1 - k)) & 1)) e -= cf[4 * k + 2];
+      return e;
+    };
+    const double Ea = energy(a);
+    double c2 = 0.0;
+    for (int k = 0; k < N; ++k) c2 += cf[4 * k] * cf[4 * k] + cf[4 * k + 1] * cf[4 * k + 1];
+    const double raa = r[a * D + a].x;
+    e1 += Ea * raa;
+    e2 += (Ea * Ea + c2) * raa;
+    for (int k = 0; k < N; ++k) {
+      const size_t ak = a ^ ((size_t)1 << (N - 1 - k));
+      const bool bk = (a >> (N - 1 - k)) & 1;
+      const cplx hk = make_double2(cf[4 * k], bk ? cf[4 * k + 1] : -cf[4 * k + 1]);
+      const cplx x = r[ak * D + a];  // rho_{a^k, a}
+      const double re = hk.x * x.x - hk.y * x.y;  // Re(h_k rho_{a^k,a}); the imaginary parts cancel in the trace
+      e1 += re;
+      e2 += re * (Ea + energy(ak));
+      for (int l = k + 1; l < N; ++l) {
+        const bool bl = (a >> (N - 1 - l)) & 1;
+        const cplx hl = make_double2(cf[4 * l], bl ? cf[4 * l + 1] : -cf[4 * l + 1]);
+        const cplx hh = cmul(hk, hl);
+        const cplx y = r[(ak ^ ((size_t)1 << (N - 1 - l))) * D + a];
+        e2 += 2.0 * (hh.x * y.x - hh.y * y.y);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { e1 += __shfl_down(e1, o, 64); e2 += __shfl_down(e2, o, 64); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out + (size_t)b * out_stride + off, e1);
+    atomicAdd(out + (size_t)b * out_stride + off + 1, e2);
+  }
+}

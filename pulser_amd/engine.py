@@ -342,14 +342,22 @@ class Engine:
         return w
 
     def observe(self, state: Any, t: float, occupation: bool = True, correlation: bool = True,
-                energy: bool = True) -> dict[str, np.ndarray]:
+                energy: bool = True, density: bool = False) -> dict[str, np.ndarray]:
         """``ryd_observe``: occupations, correlation matrix and energy moments of every batch
         entry in one device call (no per-observable launches, no H(t) materialisation).
-        Returns host arrays: ``norm2`` [B], ``occupation`` [B, N], ``correlation`` [B, N, N],
-        ``energy`` [B], ``energy2`` [B] - NOT normalised (divide by ``norm2``)."""
-        self._check_state(state)
+        ``density``: ``state`` is a density matrix ``[B, D, D]`` observed with this (ket) engine's
+        Hamiltonian.  Returns host arrays: ``norm2`` [B] (trace for density matrices),
+        ``occupation`` [B, N], ``correlation`` [B, N, N], ``energy`` [B], ``energy2`` [B] - NOT
+        normalised (divide by ``norm2``)."""
+        if density and self.mode != RYD_MESOLVE:
+            want = (self.batch, self.dim, self.dim)
+            if (tuple(state.shape) != want or state.dtype != self.torch.complex128
+                    or not state.is_contiguous() or state.device != self.device):
+                raise ValueError(f"density matrix must be a contiguous complex128 tensor of shape {want} on {self.device}")
+        else:
+            self._check_state(state)
         n = self.n
-        what = (1 if occupation else 0) | (2 if correlation else 0) | (4 if energy else 0)
+        what = (1 if occupation else 0) | (2 if correlation else 0) | (4 if energy else 0) | (8 if density else 0)
         out = self.torch.empty((self.batch, n * n + n + 3), dtype=self.torch.float64, device=self.device)
         _lib.check(self.lib.ryd_observe(self._h, state.data_ptr(), float(t), what, out.data_ptr(),
                                         self._stream()))

@@ -358,3 +358,40 @@ def test_device_side_observables_one_call_per_evaluation_time():
         assert abs(res.get_result(obs[3], t) - e) < 1e-9 * max(1.0, abs(e))
         assert abs(res.get_result(obs[5], t) - e2) < 1e-9 * max(1.0, e2)
         assert abs(res.get_result(obs[4], t) - (e2 - e * e)) < 1e-7 * max(1.0, e2)
+
+
+def test_device_side_observables_of_density_matrices():
+    """Master-equation run (dephasing, no stochastic noise -> mesolve): the observables of the
+    density matrices come from the same one-call device path - occupations / correlations from the
+    diagonal, Tr(H rho) and Tr(H^2 rho) from the elements within two bit flips of it - against
+    dense NumPy with the oracle's H(t)."""
+    from oracle import qutip_path as qp
+    from pulser_amd import problem as P
+    from pulser_amd.backend import EnergySecondMoment, EnergyVariance
+    from pulser_amd.hamiltonian_data import single_global_channel
+
+    n = 6
+    coords = P.register_coords(P.triangular_rect(2, 3), blockade_radius())
+    smp = {k: v[:-1] for k, v in P.anneal_samples().items()}
+    inputs = single_global_channel(coords, smp, P.C6_LEVEL70, extended=False)
+    times = [0.2, 0.6, 1.0]
+    obs = [StateResult(), Occupation(), CorrelationMatrix(), Energy(), EnergyVariance(), EnergySecondMoment()]
+    cfg = QutipConfig(default_evaluation_times=times, observables=obs, noise_model=NoiseModel(dephasing_rate=0.3))
+    res = QutipBackendV2(inputs, config=cfg).run()
+    stats = QutipBackendV2.last_observable_engine_stats
+    assert stats["n_launches"] == 2 * len(times)  # pair reduction + the Tr(H rho) gather per time
+    ham = qp.build_hamiltonian(P.make_ising_problem(coords, P.anneal_samples()))
+    idx = np.arange(1 << n)
+    nk = np.stack([1 - ((idx >> (n - 1 - k)) & 1) for k in range(n)], axis=1).astype(float)
+    for t in times:
+        rho = np.asarray(res.get_result(obs[0], t).to_qobj())
+        assert rho.shape == (64, 64)
+        rho = rho / np.trace(rho).real
+        p = np.real(np.diag(rho))
+        H = ham.matrix(t * 3.1).toarray()
+        e, e2 = np.trace(H @ rho).real, np.trace(H @ H @ rho).real
+        assert np.allclose(res.get_result(obs[1], t), p @ nk, atol=1e-12)
+        assert np.allclose(res.get_result(obs[2], t), (nk * p[:, None]).T @ nk, atol=1e-12)
+        assert abs(res.get_result(obs[3], t) - e) < 1e-9 * max(1.0, abs(e))
+        assert abs(res.get_result(obs[5], t) - e2) < 1e-9 * max(1.0, e2)
+        assert abs(res.get_result(obs[4], t) - (e2 - e * e)) < 1e-7 * max(1.0, e2)
