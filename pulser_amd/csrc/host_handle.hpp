@@ -53,7 +53,6 @@ struct ryd_handle {
   size_t sched_cap = 0;
   KetStep* ksched_dev = nullptr;  // schedule of the register-resident ket kernel
   double* ftab_dev = nullptr;     // elementwise dissipator factor tables of the row path
-  double ftab_tau = -1.0;
   cplx* kry_V = nullptr;          // Krylov basis (m + 1 vectors), allocated on first use
   int kry_cap = 0;
   void* kry_pool = nullptr;
@@ -679,7 +678,6 @@ extern "C" int ryd_set_dissipator(ryd_handle* h, const double* S) {
     h->J[r] = make_double2(S[2 * (4 * r + (3 - r))], S[2 * (4 * r + (3 - r)) + 1]);
   }
   h->diss_norm = norm * h->N;
-  h->ftab_tau = -1.0;  // the row path rebuilds its factor tables
   const bool replan = dbl != h->has_dbl;
   h->has_dbl = dbl;
   if (replan) plan_passes(h);

@@ -69,7 +69,14 @@ static int pick_scheme(double x, double tol, short* sch, short* nsub) {
     }
     if (best >= 0 && n >= best_n + 2) break;
   }
-  if (best < 0) return fail(RYD_ERR_INVALID, "no in-place exponential scheme for x = %g at tol = %g", x, tol);
+  if (best < 0) {
+    // tighter than any fitted scheme: the most accurate one that covers the argument (the table
+    // bottoms out at a few 1e-13 per exponential), sub-divided until its interval fits
+    for (int n = 1; n <= 4096 && best < 0; n *= 2)
+      for (int s = 0; s < kNumSymp; ++s)
+        if (kSymp[s].X >= x / n && (best < 0 || kSymp[s].err < kSymp[best].err)) { best = s; best_n = n; }
+    if (best < 0) return fail(RYD_ERR_INVALID, "no in-place exponential scheme covers x = %g", x);
+  }
   *sch = (short)best;
   *nsub = (short)best_n;
   return RYD_OK;
