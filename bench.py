@@ -36,7 +36,12 @@ import os
 import sys
 import time
 
-import numpy as np
+# the CPU baselines are single-threaded per process by definition (QuTiP's CSR matvec and zvode are):
+# pin the BLAS / OpenMP pools BEFORE numpy loads, or 64 pool workers oversubscribe the host
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
