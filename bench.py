@@ -50,10 +50,10 @@ HBM_PEAK = 8.0e12      # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 F64_VALU_PEAK = 78.6   # TFLOP/s, fp64 vector peak (256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
 T_SEQ_US = 3.1
 
-# fp64 flops per amplitude per stage of k_ket<14>, counted in the ISA of one half-stage (32 amplitudes
-# per lane): 448 v_fma_f64 + 65 v_mul_f64 + 113 v_add_f64 -> (448 x 2 + 65 + 113) / 32 = 33.6 per
-# amplitude per half-stage, two half-stages per stage (tools/count_isa.py, profiles/r02_kket_isa.md)
-KKET_FLOPS_PER_AMP_STAGE = 2 * (448 * 2 + 65 + 113) / 32.0
+# fp64 flops per amplitude per stage of k_ket<14>, counted in the ISA (tools/count_isa.py ->
+# profiles/r02_kket_isa.md): per 16 amplitudes of a lane 224 v_fma_f64 + 32 v_mul_f64 + 52..60 v_add_f64
+# = 33.25 / 33.75 flops per amplitude per half-stage (second / first half), two half-stages per stage
+KKET_FLOPS_PER_AMP_STAGE = 2 * 0.5 * (33.25 + 33.75)
 # k_traj<12,1024,1>: 120 fp64 instructions per wave and stage for 4 amplitudes per lane
 # (profiles/r01_ktraj_counters.md), ~85 % of them FMAs
 KTRAJ_FLOPS_PER_AMP_STAGE = 120 * 1.85 / 4.0

@@ -80,10 +80,14 @@ __device__ __forceinline__ double dpp_f64(double v) {
 }
 
 // F0: index bits below F0 take their partners over the DPP crossbar (4) or from LDS like the
-// others (0); LOGNT: log2 of the workgroup size.  Measured at 14 atoms, 1024 rows (us per stage):
-// <14, 4, 9> 10.6, <14, 0, 9> 10.4 (the DPP moves cost the VALU what the LDS reads cost the LDS
-// pipe), <14, 4, 10> 13.5 (four waves per SIMD but 128 registers per lane: spills in the hot loop).
-template <int N, int F0 = 4, int LOGNT = 9>
+// others (0); LOGNT: log2 of the workgroup size.  Measured at 14 atoms, 1024 rows (us per stage),
+// final (software-pipelined) form: <14, 4, 9> 9.9, <14, 0, 9> 10.7 (ten b128 reads per pair, twice
+// for the pipeline); before pipelining 10.6 vs 10.4; <14, 4, 10> 13.5 (four waves per SIMD but 128
+// registers per lane: spills in the hot loop).
+#ifndef RYD_KET_F0
+#define RYD_KET_F0 4
+#endif
+template <int N, int F0 = RYD_KET_F0, int LOGNT = 9>
 __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
   static_assert(F0 == 0 || F0 == 4, "index bits below F0 use the DPP crossbar: 0 or 4");
   constexpr int D = 1 << N, NTT = 1 << LOGNT;
@@ -260,11 +264,14 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
       // from the published copy (two amplitudes per read), bits 9.. register to register.
       // One pair (2jp, 2jp+1) of  dst += coef * (H~ - shift) src ; `ra` = byte address of this
       // thread's slot of pair jp inside the published copy.
-      auto do_pair = [&](double (&dst)[R], const double (&src)[R], double coef, int jp, unsigned ra) {
-        double2 pv[LOGNT - F0];
+      constexpr int NLD = LOGNT - F0 + 1;  // partner reads + the diagonal table entry of a pair
+      auto load_pair = [&](double2 (&pv)[NLD], int jp, unsigned ra) {
 #pragma unroll
         for (int f = F0; f < LOGNT; ++f) pv[f - F0] = *reinterpret_cast<const double2*>(smem + (ra ^ (16u << f)));
-        const double2 eh2 = *reinterpret_cast<const double2*>(ehx + 2 * jp);
+        pv[NLD - 1] = *reinterpret_cast<const double2*>(ehx + 2 * jp);
+      };
+      auto do_pair = [&](double (&dst)[R], const double (&src)[R], double coef, int jp, const double2 (&pv)[NLD]) {
+        const double2 eh2 = pv[NLD - 1];
         // diagonal of the pair: high atoms excited <=> their bit is 0.  Re-derived per pair (<= 5
         // additions): hoisted out of the stage loop the R partial sums would live in scratch and
         // every pair would wait for a scratch load
@@ -318,23 +325,32 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
       auto half_stage = [&](double (&dst)[R], const double (&src)[R], double coef) {
         constexpr int H = RP / 2;
         if constexpr (RP >= 2) {
+          // software pipeline: the LDS reads of pair jp + 1 are in flight while pair jp is computed
+          // (two register sets; with two waves per SIMD the read latency was not covered otherwise)
+          double2 pvs[2][NLD];
           unsigned ra = (unsigned)tid * 16u;
+          load_pair(pvs[0], 0, ra);
 #pragma unroll
           for (int jp = 0; jp < H; ++jp) {
             asm volatile("" : "+v"(ra));
             *reinterpret_cast<double2*>(smem + ra + (unsigned)H * NTT * 16u) =
                 make_double2(src[2 * (jp + H)], src[2 * (jp + H) + 1]);
-            do_pair(dst, src, coef, jp, ra);
+            if (jp + 1 < H) load_pair(pvs[(jp + 1) & 1], jp + 1, ra + NTT * 16u);
+            __builtin_amdgcn_sched_barrier(0);  // issue order: next pair's reads, then this pair's arithmetic
+            do_pair(dst, src, coef, jp, pvs[jp & 1]);
             ra += NTT * 16u;
-            __builtin_amdgcn_sched_barrier(0);  // keep the partner reads of the next pair behind this one
+            __builtin_amdgcn_sched_barrier(0);
           }
           __syncthreads();  // B complete; every read of A done
+          load_pair(pvs[H & 1], H, ra);
 #pragma unroll
           for (int jp = H; jp < RP; ++jp) {
             asm volatile("" : "+v"(ra));
             *reinterpret_cast<double2*>(smem + ra - (unsigned)H * NTT * 16u) =
                 make_double2(dst[2 * (jp - H)], dst[2 * (jp - H) + 1]);
-            do_pair(dst, src, coef, jp, ra);
+            if (jp + 1 < RP) load_pair(pvs[(jp + 1) & 1], jp + 1, ra + NTT * 16u);
+            __builtin_amdgcn_sched_barrier(0);
+            do_pair(dst, src, coef, jp, pvs[jp & 1]);
             ra += NTT * 16u;
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -343,7 +359,9 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
           __syncthreads();
           *reinterpret_cast<double2*>(smem + (unsigned)tid * 16u) = make_double2(src[0], src[1]);
           __syncthreads();
-          do_pair(dst, src, coef, 0, (unsigned)tid * 16u);
+          double2 pv1[NLD];
+          load_pair(pv1, 0, (unsigned)tid * 16u);
+          do_pair(dst, src, coef, 0, pv1);
         }
       };
       // slow path (kernel start, kicks): make A hold arr[0, H) whatever was there

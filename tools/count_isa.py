@@ -9,15 +9,16 @@ with tempfile.TemporaryDirectory() as d:
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                     "-Wno-unused-value", src, "-o", asm], check=True, stderr=subprocess.DEVNULL)
     text = open(asm).read()
-m = re.search(r"^_Z5k_ketILi14EEv7KetArgs:(.*?)s_endpgm", text, re.S | re.M)
+m = re.search(r"^_Z5k_ketILi14E\w*EEv7KetArgs:(.*?)s_endpgm", text, re.S | re.M)
 body = m.group(1).split("\n")
 bars = [i for i, l in enumerate(body) if "s_barrier" in l]
 # half-stages = the longest barrier-to-barrier regions that contain ds_read_b128 partner reads
 regions = sorted(((b - a, a, b) for a, b in zip(bars, bars[1:])), reverse=True)
-hs = [r for r in regions if sum("ds_read_b128" in l for l in body[r[1]:r[2]]) >= 64][:2]
+# since the LDS publishes ride along, a half-stage is two barrier-to-barrier regions of 8 pairs each
+hs = sorted([r for r in regions if sum("ds_read_b128" in l for l in body[r[1]:r[2]]) >= 40][:4], key=lambda r: r[1])
 print("# r02: fp64 instruction count of one half-stage of `k_ket<14>` (hipcc 7.2, gfx950, -O3)\n")
-print("One half-stage = `dst += coef (H~ - shift) src` for the 32 amplitudes of a lane (16 pairs).")
-print("Counted between the two `s_barrier`s that bracket the consume phase.\n")
+print("One half-stage = `dst += coef (H~ - shift) src` for the 32 amplitudes of a lane (16 pairs), in two")
+print("barrier-to-barrier halves of 8 pairs (16 amplitudes) each; the two hot copies are q <- p and p <- q.\n")
 print("| region (ISA lines) | v_fma/v_fmac_f64 | v_mul_f64 | v_add_f64 | ds_read_b128 | v_mov_dpp | other VALU | scratch ops | flops / amplitude |")
 print("|---|---|---|---|---|---|---|---|---|")
 for _, a, b in hs:
@@ -25,6 +26,6 @@ for _, a, b in hs:
     c = lambda pat: sum(1 for l in reg if re.search(pat, l))
     fma, mul, add = c(r"v_fmac?_f64"), c(r"v_mul_f64"), c(r"v_add_f64")
     valu = c(r"^\s+v_")
-    print(f"| {a}..{b} | {fma} | {mul} | {add} | {c('ds_read_b128')} | {c('_dpp')} | {valu - fma - mul - add - c('_dpp')} | {c('scratch_')} | {(2 * fma + mul + add) / 32:.2f} |")
+    print(f"| {a}..{b} | {fma} | {mul} | {add} | {c('ds_read_b128')} | {c('_dpp')} | {valu - fma - mul - add - c('_dpp')} | {c('scratch_')} | {(2 * fma + mul + add) / 16:.2f} |")
 print("\nTwo half-stages per stage (q += a x p; p -= b x q) -> flops per amplitude per stage = 2 x the last column.")
-print("bench.py uses 2 x (448 x 2 + 65 + 113) / 32 = 67.1; re-run this script after changing the kernel.")
+print("bench.py uses KKET_FLOPS_PER_AMP_STAGE = 2 x the mean of the last column; re-run this script after changing the kernel.")
