@@ -404,10 +404,9 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
       if ((rc = conjugate(i, mid, 0.5 * t1, 0.5 * t1, 0.0, 0.0, 0, 0.0))) return rc;
     } else {
       const double tau = t1 + t2;
-      // the two halves may differ in length: with a = t1 / tau the scheme keeps its weights
-      // (1/6, 2/3, 1/6) only for a = 1/2; unequal halves (knot-limited steps) are rare and small,
-      // they keep the symmetric weights of their own lengths: D(t1/3) . D((t1+t2)/3 ...) -
-      // handled by giving each half the weights (1/3, 2/3) of ITS length around the middle factor
+      // Weights D(t1/3) W1 D(2 t1/3 + 2 t2/3) W2 D(t2/3): Chin's (1/6, 2/3, 1/6) when the halves are
+      // equal; when a knot or an evaluation time makes them unequal the scheme stays consistent (the
+      // factor times add up to tau) and symmetric enough for the few such blocks of a schedule.
       const double eps = (uniform_g && !dbl) ? tau * tau * tau * gflip * gflip / 72.0 : 0.0;
       const StepDesc& m0 = sched[mid];
       const double kick_u = m0.u1 - kC1 * m0.h;  // start of the step `mid` inside its knot interval
