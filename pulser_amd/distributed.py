@@ -158,12 +158,7 @@ def run_ensemble(
     # -- rank 0 owns every random draw ------------------------------------
     payload: list[Any] = [None]
     if rank == 0:
-        if emulator._noise_trajectories_used:  # fresh draws on every further run (simulation.py:892-902)
-            from .hamiltonian_data import HamiltonianData
-
-            emulator._hamiltonian_data = HamiltonianData(
-                emulator.samples_obj, nm, emulator._get_n_trajectories(nm, check_value=True))
-            emulator._problems_cache = None
+        emulator._refresh_trajectories_if_used()  # fresh draws on every further run (simulation.py:892-902)
         trajs = emulator._hamiltonian_data.noise_trajectories
         # quantum-jump seeds (used only when the solver is the Monte-Carlo one):
         # like qutip.mcsolve's, NOT from the global np.random stream
