@@ -14,7 +14,7 @@ Default workload = the north-star target (BASELINE.json): the 14-atom triangular
                    value = GPUs x batch x 3.1 us / seconds-per-step.  Multi-GPU: sequences shard
                    over the ranks, no data-path collective; one all-reduce (RCCL) of the ensemble
                    occupation sums per step.
-  single_sequence  ONE 14-atom sequence, full 3.1 us (latency; uses one CU).
+  single_sequence  ONE 14-atom sequence, full 3.1 us (latency; split-operator passes, 4 tiles).
   lindblad         cfg3: 14-atom dephasing master equation (rho = 4.29 GB), `--lindblad-ns` ns slice
                    (default 100) through the split-operator row path; `--full-lindblad` runs all 3.1 us.
   setup            handle creation + table upload, timed separately (not inside a step).
@@ -57,6 +57,11 @@ KKET_FLOPS_PER_AMP_STAGE = 2 * 0.5 * (33.25 + 33.75)
 # k_traj<12,1024,1>: 120 fp64 instructions per wave and stage for 4 amplitudes per lane
 # (profiles/r01_ktraj_counters.md), ~85 % of them FMAs
 KTRAJ_FLOPS_PER_AMP_STAGE = 120 * 1.85 / 4.0
+
+
+KSPLIT_NAME = ("k_split12 (split-operator passes: exact diagonal phase x single-atom rotations, 2^12-amplitude "
+               "register / LDS tiles, one pass per stage; algorithmic bytes = 32 B per amplitude and stage)")
+KAPPLY_NAME = "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)"
 
 
 def blockade_radius() -> float:
@@ -329,6 +334,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="independent sequences per GPU")
     ap.add_argument("--workload", default="north_star")
     ap.add_argument("--slice-ns", type=int, default=2, help="cfg3/cfg5 workloads: simulated ns per step")
+    ap.add_argument("--method", default="auto", choices=["auto", "taylor", "krylov", "split"],
+                    help="cfg5 workload: propagator (auto = split-operator passes)")
     ap.add_argument("--lindblad-ns", type=int, default=100, help="north_star: slice of the cfg3 leg")
     ap.add_argument("--full-lindblad", action="store_true", help="north_star: full 3.1 us cfg3 leg (~1-2 min)")
     ap.add_argument("--no-extras", action="store_true")
@@ -433,7 +440,8 @@ def main() -> None:
                                           "k_ket<14> (one workgroup = one CU of 256)",
                                           note="a single sequence occupies one CU; frac is against the whole chip")
                 if st1["n_launches"] == 1 else
-                roofline_hbm(n, 1, st1, k1, l1, "k_apply<sesolve> (single-launch plan; launch-latency-bound)")}
+                roofline_hbm(n, 1, st1, k1, l1, KSPLIT_NAME + "; 4 tiles: launch-latency-bound"),
+                "local_error_estimate": st1["reserved"][0]}
             eng.close()
             # Lindblad leg (cfg3)
             ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
@@ -539,9 +547,10 @@ def main() -> None:
         else:
             eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")
             t0, t1, nb = 1.0, 1.0 + 1e-3 * args.slice_ns, 20
-            kname = "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)"
+            kname = KSPLIT_NAME if args.method == "auto" else KAPPLY_NAME
             wl = f"BASELINE configs[4]: 20-atom 4x5 register, sesolve, {args.slice_ns} ns slice at t = 1 us"
-        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, t0, t1, args.steps, args.warmup, dist, torch)
+        mopt = {"method": args.method} if args.workload == "cfg5" else {}
+        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, t0, t1, args.steps, args.warmup, dist, torch, **mopt)
         if args.workload == "cfg3" and not args.no_ket:
             roof = roofline_valu(2.0**14, 2.0**15, stats["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kms, kl, kname, "cfg3:k_ket")
         else:
@@ -626,14 +635,21 @@ def main() -> None:
                                           "(tools/ubench/mfma_f64.hip); a full ZGEMM would need 2x the flops"}})
         eng.close()
         del psi, rho
-        # cfg5: 20-atom sesolve slice (CF4 + Taylor; Lanczos comparison: profiles/r02_krylov_vs_taylor.md)
-        eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")
-        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 1.0, 1.02, 2, 1, None, torch)
-        also.append({"workload": "cfg5: 20-atom 4x5 register, sesolve, 20 ns slice at t = 1 us",
-                     "value": 0.02 / sec, "unit": "sim-us/s", "passes_per_application": stats["passes"],
-                     "taylor_order": stats["last_order"],
-                     "roofline": roofline_hbm(20, 1, stats, kms, kl, "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)", "cfg5:k_apply")})
-        eng.close()
+        # cfg5: 20-atom sesolve slice: split-operator passes (default) and CF4 + Taylor on the generator
+        # kernels (Lanczos comparison: profiles/r02_krylov_vs_taylor.md); 24 atoms = the HBM-bound regime
+        for n_at, shape, ns in ((20, (4, 5), 100), (24, (4, 6), 10)):
+            eng = Engine.from_problems([rect_problem(*shape)], mode="sesolve")
+            sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 1.0, 1.0 + ns * 1e-3, 2, 1, None, torch)
+            leg = {"workload": f"cfg5: {n_at}-atom {shape[0]}x{shape[1]} register, sesolve, {ns} ns slice at t = 1 us",
+                   "value": ns * 1e-3 / sec, "unit": "sim-us/s", "stages": stats["n_applications"],
+                   "passes_per_stage": stats["passes"], "local_error_estimate": stats["reserved"][0],
+                   "roofline": roofline_hbm(n_at, 1, stats, kms, kl, KSPLIT_NAME, "cfg5:k_split" if n_at == 20 else None)}
+            if n_at == 20:
+                sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 1.0, 1.02, 2, 1, None, torch, method="taylor")
+                leg["taylor"] = {"value": 0.02 / sec, "unit": "sim-us/s", "taylor_order": stats["last_order"],
+                                 "roofline": roofline_hbm(20, 1, stats, kms, kl, KAPPLY_NAME, "cfg5:k_apply")}
+            also.append(leg)
+            eng.close()
         out["also"] = also
         bw = device_copy_bandwidth(torch)
         out["device_copy_GBps"] = bw

@@ -108,19 +108,27 @@ typedef struct ryd_opts {
                            sub-stepping next to waveform kinks (default 1e-10) */
   int32_t split_steps;  /* mesolve split-operator path: CF4 steps per Strang block (0 = from the
                            dissipator rate: 4 / 2 / 1 for rates <= 0.1 / <= 0.5 / above) */
-  int32_t method;       /* exponential of the multi-launch sesolve path: 0 = Taylor polynomial (Horner),
-                           1 = Lanczos / Krylov subspace (batched inner products V^H w and V c) */
+  int32_t method;       /* propagator of the multi-launch sesolve path: 0 = the library's choice (the
+                           split-operator passes for two-level kets without collapse operators from 15
+                           atoms on - and for fewer than 8 sequences of 14 atoms - else the Taylor
+                           polynomial), 1 = Lanczos / Krylov subspace (batched inner products V^H w and
+                           V c), 2 = split-operator (exact diagonal phases x exact single-atom rotations,
+                           4th-order 6-stage composition; `tol` x 500 = target of the accumulated
+                           local-error estimate of a whole pulse sequence, default 5e-8),
+                           3 = Taylor polynomial (Horner) */
   double reserved[2];
 } ryd_opts;
 
 typedef struct ryd_stats {
-  int64_t n_applications; /* generator applications G.x since creation/reset */
+  int64_t n_applications; /* generator applications G.x (split-operator path: stages) since creation/reset */
   int64_t n_launches;     /* kernel launches of the apply kernel */
   int64_t n_steps;        /* CF4 steps */
   int32_t passes;         /* memory passes per application */
   int32_t last_order;     /* Taylor order used by the last step */
   double norm_bound;      /* last spectral-norm bound (rad/us) */
-  double reserved[4];
+  double reserved[4];     /* split-operator path: [0] accumulated local-error estimate of the last
+                             solve (largest amplitude), [1] last measured local error, [2] its
+                             sub-step (us), [3] checkpoint restores */
 } ryd_stats;
 
 /* Replaces: construction of Hamiltonian/QobjEvo objects
@@ -252,7 +260,10 @@ int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr, con
  * whatever the size of the state, 32 = disable the register-resident ket kernel
  * (sesolve, 13-14 atoms, >= 8 sequences, real drives) and the split-operator master
  * equation built on it (mesolve, 10-14 atoms, dephasing-type dissipators), 64 = use
- * the ket kernel from 10 atoms and any batch size on.
+ * the ket kernel from 10 atoms and any batch size on, 128 = keep the Taylor
+ * polynomial where ryd_opts.method 0 would choose the split-operator ket passes,
+ * 256 = switch their step-size control off (one sub-step per schedule step),
+ * 512 = 12-atom kets pass by pass instead of the one-launch loop over the stages.
  * Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);
 

@@ -58,6 +58,19 @@ struct ryd_handle {
   void* kry_pool = nullptr;
   KryScalars kry{};
   size_t ksched_cap = 0;
+  // split-operator ket path (host_split.hpp)
+  std::vector<Pass> split_tilings;
+  double* split_coefs = nullptr;  // [stages][B][N][4]
+  size_t split_cap = 0;
+  double* split_err = nullptr;    // [B] local-error accumulators
+  bool no_split = false;          // test hook: keep the Taylor polynomial for 15+ atoms
+  bool split_fixed = false;       // test hook: no step-size control (sub-step = schedule step)
+  bool split_no_loop = false;     // test hook: 12-atom kets pass by pass instead of the one-launch loop
+  bool split_known = false;       // controller state below is valid for the current tables
+  double split_tau = 1e300;       // target sub-step (us); 1e300 = whole schedule steps
+  double split_rate = 0.0;        // last measured local error per us at that sub-step
+  double split_eps = 0.0;         // tolerance the state was measured for
+  int split_since = 0;            // schedule steps since the last check
   // general path (explicit CSR terms)
   bool general = false;
   std::vector<GenTermHost> gen_host;
@@ -373,6 +386,8 @@ extern "C" int ryd_create(const ryd_config* cfg, ryd_handle** out) {
 extern "C" void ryd_destroy(ryd_handle* h) {
   if (!h) return;
   hipFree(h->wA);
+  hipFree(h->split_coefs);
+  hipFree(h->split_err);
   hipFree(h->wB);
   hipFree(h->kbuf);
   hipFree(h->coefs_dev);
@@ -608,6 +623,7 @@ static void compute_bounds(ryd_handle* h) {
     if (d.drive_series >= 0 && !series_real[d.drive_series]) { dreal = false; break; }
   h->drive_real = dreal;
   h->bounds_valid = true;
+  h->split_known = false;  // new tables: the split-operator controller starts over
 }
 
 extern "C" int ryd_set_interaction(ryd_handle* h, const double* U, int32_t n_mats) {

@@ -1,0 +1,343 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+// ---------------------------------------------------------------------------
+// Split-operator ket path (k_split.hpp): tilings, pass pipeline, step-size controller (host)
+// ---------------------------------------------------------------------------
+// Symmetric 4th-order composition with 6 stages (Blanes & Moan, J. Comput. Appl. Math. 142 (2002),
+// scheme S6 of table 2):  D(a1) R(b1) D(a2) R(b2) D(a3) R(b3) D(a4) R(b3) D(a3) R(b2) D(a2) R(b1) D(a1).
+static const double kSplitA[7] = {0.0792036964311957, 0.353172906049774, -0.0420650803577195,
+                                  1.0 - 2.0 * (0.0792036964311957 + 0.353172906049774 - 0.0420650803577195),
+                                  -0.0420650803577195, 0.353172906049774, 0.0792036964311957};
+static const double kSplitB[6] = {0.209515106613362, -0.143851773179818,
+                                  0.5 - (0.209515106613362 - 0.143851773179818),
+                                  0.5 - (0.209515106613362 - 0.143851773179818),
+                                  -0.143851773179818, 0.209515106613362};
+static const int kSplitStages = 6;
+static const int kSplitMaxSub = SPLIT_MAX_SUB;
+// Target of the accumulated local-error estimate (sum over the steps of the largest amplitude of the
+// local error) over a whole pulse sequence when ryd_opts.tol is 0 (else 500 tol).  The stated parity bar
+// is 1e-7 on amplitudes.
+static const double kSplitTolTotal = 5e-8;
+
+static int snapshot_copy(ryd_handle* h, const cplx* state, cplx* dst, hipStream_t st);
+
+struct SubStep {
+  int idx;     // knot interval
+  double u0;   // start - tknots[idx]
+  double tau;
+};
+
+static bool split_capable(const ryd_handle* h) {
+  return !h->general && h->cfg.mode == RYD_SESOLVE && !h->mc && h->N >= 4;
+}
+
+// ryd_opts.method: 0 = library default (split-operator for two-level kets of 15+ atoms, else the
+// Taylor polynomial), 1 = Lanczos, 2 = split-operator, 3 = Taylor polynomial
+static bool split_selected(const ryd_handle* h, const ryd_opts& o) {
+  if (!split_capable(h)) return false;
+  if (o.method == 2) return true;
+  if (o.method != 0 || o.taylor_order > 0 || h->force_generic || h->no_split) return false;
+  // 14 atoms: batches of >= 8 real-drive sequences stay on the register-resident k_ket
+  return h->N >= 15 || (h->N == 14 && !ket_path(h));
+}
+
+// Tilings: the low T bits, then tilings of the remaining high bits (at most 8 each) that keep
+// the low T - n_high bits for coalescing (runs of >= 16 amplitudes = 256 B).
+static void split_plan(ryd_handle* h) {
+  if (!h->split_tilings.empty()) return;
+  const int N = h->N, T = std::min(N, SPLIT_TMAX);
+  h->split_tilings.push_back(make_pass(N, {{0, T}}));
+  int rem = N - T, at = T;
+  if (rem > 0) {
+    const int cap = T - 4;
+    const int extra = (rem + cap - 1) / cap;
+    for (int e = 0; e < extra; ++e) {
+      const int nh = rem / (extra - e);  // spread evenly
+      h->split_tilings.push_back(make_pass(N, {{0, T - nh}, {at, nh}}));
+      at += nh;
+      rem -= nh;
+    }
+  }
+}
+
+static unsigned long long tiling_bits(const Pass& p) {
+  unsigned long long m = 0;
+  for (int i = 0; i < 3; ++i)
+    if (p.tile.len[i] > 0) m |= ((1ull << p.tile.len[i]) - 1ull) << p.tile.lo[i];
+  return m;
+}
+
+static int split_ensure_tables(ryd_handle* h, int n_stages) {
+  const size_t need = (size_t)n_stages * h->B * h->N * 4;
+  if (need > h->split_cap) {
+    if (h->split_coefs) HIPCHK(hipFree(h->split_coefs));
+    h->split_coefs = nullptr;
+    HIPCHK(hipMalloc((void**)&h->split_coefs, need * sizeof(double)));
+    h->split_cap = need;
+  }
+  if (!h->split_err) HIPCHK(hipMalloc((void**)&h->split_err, (size_t)h->B * sizeof(double)));
+  return RYD_OK;
+}
+
+// Largest number of sub-steps whose coefficient tables stay under 32 MiB.
+static int split_max_sub(const ryd_handle* h) {
+  const size_t per_sub = (size_t)kSplitStages * h->B * h->N * 4 * sizeof(double);
+  return (int)std::min<size_t>(kSplitMaxSub, std::max<size_t>(1, ((size_t)32 << 20) / per_sub));
+}
+
+// Advance `buf` over `subs` (consecutive sub-steps, at most split_max_sub) from a closed state to
+// a closed state: one k_split_coefs launch, then one k_split launch per pass.
+static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hipStream_t st) {
+  int rc;
+  split_plan(h);
+  const int N = h->N, B = h->B;
+  const int n_stages = kSplitStages * nsub + 1;
+  if ((rc = split_ensure_tables(h, n_stages))) return rc;
+  SplitRun R;
+  std::memset(&R, 0, sizeof R);
+  R.nsub = nsub;
+  for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[s].idx; R.u0[s] = subs[s].u0; R.tau[s] = subs[s].tau; }
+  const int total = B * N;
+  hipLaunchKernelGGL(k_split_coefs, dim3((total + 3) / 4, n_stages), dim3(256), 0, st, h->pp_dev,
+                     h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);
+  HIPCHK(hipGetLastError());
+
+  // weight of E0 in the D of every stage
+  std::vector<double> wE(n_stages);
+  for (int j = 0; j < n_stages; ++j) {
+    const int s = j / kSplitStages, i = j % kSplitStages;
+    double w = 0.0;
+    if (j < n_stages - 1) w += kSplitA[i] * subs[s].tau;
+    if (i == 0 && s > 0) w += kSplitA[6] * subs[s - 1].tau;  // carried over from the previous sub-step
+    wE[j] = w;
+  }
+
+  const std::vector<Pass>& til = h->split_tilings;
+  const int m = (int)til.size();
+  if (m == 1 && N == 12 && !h->split_no_loop) {
+    // the whole ket is one tile: every stage of the run in one launch, the ket stays in registers
+    SplitArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.state = buf;
+    A.e0 = h->e0_dev;
+    A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << N);
+    A.ccur = h->split_coefs;
+    A.N = N;
+    A.T = 12;
+    const size_t lds = ((size_t)16 << 12) + 64 * 16 + 2 * SPLIT_TMAX * 4 * 8 + 128 * 8 + 2 * SPLIT_NMAX * 4 * 8;
+    std::pair<hipEvent_t, hipEvent_t> ev1;
+    if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
+    if (h->drive_real)
+      hipLaunchKernelGGL(k_split12_loop<true>, dim3(1, B), dim3(SPLIT_NT), lds, st, A, R, (long long)B * N * 4);
+    else
+      hipLaunchKernelGGL(k_split12_loop<false>, dim3(1, B), dim3(SPLIT_NT), lds, st, A, R, (long long)B * N * 4);
+    HIPCHK(hipGetLastError());
+    if (h->timing) { HIPCHK(hipEventRecord(ev1.second, st)); h->ev_used.push_back(ev1); }
+    h->stats.n_launches++;
+    h->stats.n_applications += n_stages - 1;
+    h->stats.passes = 1;
+    return RYD_OK;
+  }
+  const unsigned long long ALL = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
+  unsigned long long done = ALL;
+  int x = 0, si = 0, fin_stage = 0;
+  const size_t stride = (size_t)B * N * 4;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  while (!(si == n_stages && done == ALL)) {
+    const Pass& p = til[x];
+    const unsigned long long bits = tiling_bits(p);
+    const unsigned long long F = bits & ~done;
+    done |= F;
+    SplitArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.state = buf;
+    A.e0 = h->e0_dev;
+    A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << N);
+    A.tile = p.tile;
+    A.outer = p.outer;
+    A.N = N;
+    A.T = p.T;
+    A.cfin = h->split_coefs + (size_t)fin_stage * stride;
+    A.ccur = h->split_coefs;
+    for (int b = 0; b < N; ++b)
+      if ((F >> b) & 1ull) A.fin_mask |= 1u << local_of(p.tile, b);
+    if (done == ALL && si < n_stages) {
+      A.do_diag = 1;
+      A.ccur = h->split_coefs + (size_t)si * stride;
+      A.wE = wE[si];
+      if (si < n_stages - 1) {  // a rotation follows (the last stage only closes)
+        A.cur_mask = (1u << p.T) - 1u;
+        done = bits;
+        fin_stage = si;
+      }
+      ++si;
+    }
+    if (A.fin_mask || A.do_diag) {
+      const size_t lds = ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TMAX * 4 * 8 + 128 * 8 + 2 * SPLIT_NMAX * 4 * 8;
+      if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
+      const dim3 grid(1u << (N - p.T), B);
+      if (p.T == 12 && !(A.fin_mask & 0xFu)) {
+        if (h->drive_real) hipLaunchKernelGGL(k_split12<true>, grid, dim3(SPLIT_NT), lds, st, A);
+        else hipLaunchKernelGGL(k_split12<false>, grid, dim3(SPLIT_NT), lds, st, A);
+      } else {
+        hipLaunchKernelGGL(k_split, grid, dim3(SPLIT_NT), lds, st, A);
+      }
+      HIPCHK(hipGetLastError());
+      if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
+      h->stats.n_launches++;
+    }
+    x = (x + 1) % m;
+  }
+  h->stats.n_applications += n_stages - 1;
+  h->stats.passes = m > 1 ? m - 1 : 1;
+  return RYD_OK;
+}
+
+// Advance over any number of sub-steps (closed runs of at most split_max_sub).
+static int split_advance(ryd_handle* h, cplx* buf, const std::vector<SubStep>& subs, hipStream_t st) {
+  const int cap = split_max_sub(h);
+  for (size_t at = 0; at < subs.size(); at += cap) {
+    const int n = (int)std::min<size_t>(cap, subs.size() - at);
+    int rc = split_run(h, buf, subs.data() + at, n, st);
+    if (rc) return rc;
+  }
+  return RYD_OK;
+}
+
+// Sub-steps of target length tau_t covering the part of step d after offset `off`.
+static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, double tau_t,
+                           std::vector<SubStep>& out) {
+  const double rem = d.h - off;
+  const int k = std::max(1, (int)std::ceil(rem / tau_t - 1e-9));
+  const double tau = rem / k;
+  const double u_start = d.u1 - kC1 * d.h + off;  // step start relative to its knot
+  for (int s = 0; s < k; ++s) out.push_back({d.idx, u_start + s * tau, tau});
+}
+
+// The solve loop of the split-operator path.  Step-size control: every kSplitCheckEvery steps one
+// sub-step is taken twice - once whole (scratch copy), once as two halves (kept) - and the largest
+// amplitude of the difference (15/16 of the local error, 4th order) sets the sub-step length so that the
+// local errors of a whole pulse sequence add up to the tolerance; a check that finds the last stretch more
+// than 4x over its allowance restores the checkpoint taken at the previous check and repeats the
+// stretch with the shorter sub-step.
+static const int kSplitCheckEvery = 48;
+
+static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
+                     const ryd_opts& o, hipStream_t st) {
+  int rc;
+  if (sched.empty()) return RYD_OK;
+  const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  double t_total = 0.0;
+  for (const StepDesc& d : sched) t_total += d.h;
+  // the budget is per pulse sequence: a solve over a slice gets its share
+  t_total = std::max(t_total, h->tknots.back() - h->tknots.front());
+  const double eps = o.tol > 0 ? 500.0 * o.tol : kSplitTolTotal;
+  const bool control = !h->split_fixed;
+  // the controller's state survives between calls on the same tables (a front end that advances
+  // from evaluation time to evaluation time must not pay a check per call)
+  if (!h->split_known || h->split_eps != eps) {
+    h->split_known = false;
+    h->split_tau = 1e300;
+    h->split_rate = 0.0;
+    h->split_since = 0;
+  }
+  double tau_t = control ? h->split_tau : 1e300;  // target sub-step (us); 1e300 = whole steps
+  int since = h->split_since;                     // schedule steps since the last check
+  size_t i = 0;
+  double off = 0.0;
+  bool have_ck = false;
+  size_t ck_i = 0;
+  double ck_off = 0.0;
+  int retries = 0;
+  std::vector<SubStep> subs;
+  std::vector<double> errs(h->B);
+  h->stats.reserved[0] = 0.0;  // accumulated local-error estimate of this solve
+  double err_rate = control ? h->split_rate : 0.0;  // last measured local error per us
+  auto finish_step = [&](size_t k) -> int {
+    if (snaps && sched[k].snap >= 0)
+      return snapshot_copy(h, state, snaps + (size_t)sched[k].snap * h->dim * h->B, st);
+    return RYD_OK;
+  };
+  while (i < sched.size()) {
+    if (control && (!h->split_known || since >= kSplitCheckEvery)) {
+      // ---- check: one sub-step whole (wA) against two halves (state) ----
+      const StepDesc& d = sched[i];
+      subs.clear();
+      split_substeps(h, d, off, tau_t, subs);
+      const SubStep s0 = subs[0];
+      HIPCHK(hipMemcpyAsync(h->wA, state, bytes, hipMemcpyDeviceToDevice, st));
+      if ((rc = split_run(h, h->wA, &s0, 1, st))) return rc;
+      const SubStep halves[2] = {{s0.idx, s0.u0, 0.5 * s0.tau}, {s0.idx, s0.u0 + 0.5 * s0.tau, 0.5 * s0.tau}};
+      if ((rc = split_run(h, state, halves, 2, st))) return rc;
+      HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)h->B * sizeof(double), st));
+      const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(h->dim >> 10, 1), 256);
+      hipLaunchKernelGGL(k_split_diff, dim3(nblk, h->B), dim3(256), 0, st, state, h->wA, h->nb, h->split_err);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(errs.data(), h->split_err, (size_t)h->B * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      double e = 0.0;
+      for (double v : errs) e = std::max(e, std::sqrt(std::max(v, 0.0)));
+      e *= 16.0 / 15.0;
+      const double allowed = eps * s0.tau / t_total;
+      double fac = std::pow(0.5 * allowed / std::max(e, 1e-300), 0.25);
+      fac = std::min(std::max(fac, 0.2), 4.0);
+      const double tau_new = s0.tau * fac;
+      h->stats.reserved[1] = e;
+      h->stats.reserved[2] = s0.tau;
+      if (e > 4.0 * allowed && have_ck && retries < 4) {
+        // the stretch since the last checkpoint ran with a sub-step that has become too long
+        HIPCHK(hipMemcpyAsync(state, h->wB, bytes, hipMemcpyDeviceToDevice, st));
+        i = ck_i;
+        off = ck_off;
+        tau_t = tau_new;
+        ++retries;
+        h->stats.reserved[3] += 1.0;  // rollbacks
+        continue;
+      }
+      retries = 0;
+      if (fac < 0.9 || fac > 1.6) tau_t = tau_new;
+      if (tau_t > 0.99 * d.h && fac >= 1.0) tau_t = 1e300;
+      h->stats.reserved[0] += e / 16.0;  // the two halves are what was kept
+      off += s0.tau;
+      if (off >= d.h * (1.0 - 1e-12)) {
+        h->stats.n_steps++;
+        if ((rc = finish_step(i))) return rc;
+        ++i;
+        off = 0.0;
+      }
+      HIPCHK(hipMemcpyAsync(h->wB, state, bytes, hipMemcpyDeviceToDevice, st));
+      ck_i = i;
+      ck_off = off;
+      have_ck = true;
+      err_rate = (e / s0.tau) * std::pow(std::min(tau_t, s0.tau) / s0.tau, 4.0);
+      since = 0;
+      h->split_known = true;
+      h->split_eps = eps;
+    }
+    // ---- the stretch up to the next check ----
+    const size_t stop = control ? std::min(sched.size(), i + (size_t)std::max(kSplitCheckEvery - since, 1))
+                                : sched.size();
+    subs.clear();
+    while (i < stop) {
+      const StepDesc& d = sched[i];
+      const size_t before = subs.size();
+      split_substeps(h, d, off, tau_t, subs);
+      for (size_t q = before; q < subs.size(); ++q) h->stats.reserved[0] += err_rate * subs[q].tau;
+      off = 0.0;
+      h->stats.n_steps++;
+      ++since;
+      const bool snap = snaps && d.snap >= 0;
+      if (snap || i + 1 == stop) {
+        if ((rc = split_advance(h, state, subs, st))) return rc;
+        subs.clear();
+        if ((rc = finish_step(i))) return rc;
+      }
+      ++i;
+    }
+  }
+  if (control) {
+    h->split_tau = tau_t;
+    h->split_rate = err_rate;
+    h->split_since = since;
+  }
+  return RYD_OK;
+}

@@ -393,6 +393,7 @@ static bool use_persistent(const ryd_handle* h) {
 static int run_steps(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
                      hipStream_t st, const ryd_opts& o) {
   if (krylov_selected(h, o)) return run_generic(h, state, sched, snaps, st, o);
+  if (split_selected(h, o)) return run_split(h, state, sched, snaps, o, st);
   if (ket_path(h)) return run_ket(h, state, sched, snaps, o, st);
   if (use_persistent(h)) return run_persistent(h, state, sched, snaps, st);
   if (use_persistent_dm(h)) return run_persistent_dm(h, state, sched, snaps, st);
@@ -419,7 +420,8 @@ extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const 
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
   // the in-place schemes split an exponential themselves and a Lanczos process takes whole
   // steps: both skip build_schedule's Taylor sub-stepping
-  const bool in_place = ket_path(h) || (row_path(h) && !use_persistent_dm(h)) || krylov_selected(h, o);
+  const bool in_place = ket_path(h) || (row_path(h) && !use_persistent_dm(h)) || krylov_selected(h, o) ||
+                        split_selected(h, o);
   std::vector<StepDesc> sched;
   // snapshot slot i-1 receives the state at times[i]
   for (int i = 1; i < n_times; ++i) {
@@ -549,6 +551,9 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
                ft = (force_generic & 8) != 0, fo = (force_generic & 16) != 0;
     h->no_ket = (force_generic & 32) != 0;
     h->force_ket = (force_generic & 64) != 0;
+    h->no_split = (force_generic & 128) != 0;
+    h->split_fixed = (force_generic & 256) != 0;
+    h->split_no_loop = (force_generic & 512) != 0;
     if (nt != h->no_tile14 || ft != h->force_tile14 || no != h->no_outer || fo != h->force_outer) {
       h->no_tile14 = nt;
       h->force_tile14 = ft;

@@ -1,0 +1,672 @@
+// Part of librydemu (included by rydemu.hip, one translation unit).
+// ---------------------------------------------------------------------------
+// Split-operator ket propagator for registers beyond one CU (15+ atoms): k_split
+// ---------------------------------------------------------------------------
+// Replaces the same seam as the Taylor / Lanczos exponentials (qutip.sesolve behind
+// simulation.py:729-735) for two-level kets.  H(t) = D(t) + X(t):
+//   D(t) = E0(s) - sum_k delta_k(t) n_k(s)      diagonal (hamiltonian.py:260-331 + detuning terms)
+//   X(t) = sum_k c_k(t) |1><0|_k + h.c.         a SUM OF COMMUTING single-atom terms
+// so exp(-i b X) = (x)_k R_k is an exact product of 2x2 rotations and exp(-i int D) an exact
+// phase.  A symmetric composition  D(a_1) R(b_1) D(a_2) ... R(b_s) D(a_{s+1})  (4th order, 6 stages:
+// Blanes & Moan 2002; time advances with the D flows, the drive is frozen at the current time) needs
+// NO generator application: one stage = every amplitude read once and written once.
+// One launch = one memory pass over the state, tile by tile: a workgroup holds 2^T amplitudes
+// (16 per lane, 4 "register bits"), rotates the register bits in registers and turns the tile
+// through LDS (XOR-swizzled 16-B slots) to make the next 4 bits the register bits.  Two tilings
+// alternate (low bits | low 2T-N bits + high bits); a pass finishes the previous stage's rotation on the
+// bits its tiling has and the previous one lacked, applies D, and starts the next rotation on all of its
+// bits - so a stage costs ONE pass (32 B per amplitude + 8 B of E0) whatever N <= 2T - 3.
+// Roofline: HBM / Infinity-Cache streaming, 40 B per amplitude and stage.
+
+#define SPLIT_TMAX 12
+#define SPLIT_NT 256
+#define SPLIT_NMAX 32
+
+struct SplitArgs {
+  cplx* state;           // [B][2^N] in place
+  const double* e0;      // [n_mats][2^N]
+  long long e0_stride;   // 0 when shared by the batch
+  const double* cfin;    // [B][N][4]: C, Re g, Im g, -    rotation to finish (previous stage)
+  const double* ccur;    // [B][N][4]: C, Re g, Im g, Delta   this stage's rotation + detuning integral of D
+  double wE;             // weight of E0 in D (us)
+  Segs tile, outer;
+  int N, T;
+  unsigned fin_mask, cur_mask;  // tile-local bits to rotate before / after D
+  int do_diag;
+};
+
+// One closed run of the composition: consecutive sub-steps (knot interval, start offset, length),
+// by value in the kernel arguments.  Stage j = 6 s + i is D(a_i) R(b_i) of sub-step s (its D also
+// carries the last D(a_7) of sub-step s - 1); stage 6 nsub only closes with D(a_7).
+#define SPLIT_MAX_SUB 64
+struct SplitRun {
+  int nsub;
+  int idx[SPLIT_MAX_SUB];
+  double u0[SPLIT_MAX_SUB];
+  double tau[SPLIT_MAX_SUB];
+};
+
+__device__ static const double kSplitADev[7] = {
+    0.0792036964311957, 0.353172906049774, -0.0420650803577195,
+    1.0 - 2.0 * (0.0792036964311957 + 0.353172906049774 - 0.0420650803577195),
+    -0.0420650803577195, 0.353172906049774, 0.0792036964311957};
+__device__ static const double kSplitBDev[6] = {
+    0.209515106613362, -0.143851773179818, 0.5 - (0.209515106613362 - 0.143851773179818),
+    0.5 - (0.209515106613362 - 0.143851773179818), -0.143851773179818, 0.209515106613362};
+
+// out[stage][b][k] = (C, Re g, Im g, Delta): the rotation exp(-i beta (c |1><0| + conj(c) |0><1|)) =
+// C + g |1><0| + g' |0><1| with the drive frozen at the stage's time, and the integral of the
+// detuning over the stage's D intervals (2-point Gauss: exact on the cubic pieces).
+__global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp, int n_int,
+                                                     const ryd_qdesc* __restrict__ desc,
+                                                     const ryd_dterm* __restrict__ dterms, int total,
+                                                     const SplitRun R, double* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= total) return;
+  const int j = blockIdx.y;
+  const int ns = R.nsub;
+  const bool closing = j == 6 * ns;
+  const int s = closing ? ns - 1 : j / 6, st = closing ? 6 : j % 6;
+  // D intervals: (knot interval, start offset, length)
+  int idx_d[2] = {R.idx[s], 0};
+  double us_d[2], len_d[2] = {0.0, 0.0};
+  double cum = 0.0;
+  for (int l = 0; l < st; ++l) cum += kSplitADev[l];
+  us_d[0] = R.u0[s] + cum * R.tau[s];
+  len_d[0] = kSplitADev[st] * R.tau[s];
+  us_d[1] = 0.0;
+  if (!closing && st == 0 && s > 0) {
+    idx_d[1] = R.idx[s - 1];
+    us_d[1] = R.u0[s - 1] + (1.0 - kSplitADev[6]) * R.tau[s - 1];
+    len_d[1] = kSplitADev[6] * R.tau[s - 1];
+  }
+  const int idx_c = R.idx[s];
+  const double u_c = us_d[0] + len_d[0];
+  const double beta = closing ? 0.0 : kSplitBDev[st] * R.tau[s];
+
+  const ryd_qdesc d = desc[i];
+  auto val = [&](int sr, int idx, double u) -> cplx {
+    const cplx* p = pp + ((size_t)sr * n_int + idx) * 4;
+    cplx r = p[0];
+    r = make_double2(fma(r.x, u, p[1].x), fma(r.y, u, p[1].y));
+    r = make_double2(fma(r.x, u, p[2].x), fma(r.y, u, p[2].y));
+    r = make_double2(fma(r.x, u, p[3].x), fma(r.y, u, p[3].y));
+    return r;
+  };
+  double dl = 0.0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (len_d[q] == 0.0) continue;
+    const double ua = us_d[q] + len_d[q] * 0.21132486540518713, ub = us_d[q] + len_d[q] * 0.7886751345948129;
+    double x = 0.0;
+    if (lane == 0) {
+      if (d.det_series >= 0)
+        x += d.det_scale * (val(d.det_series, idx_d[q], ua).x + val(d.det_series, idx_d[q], ub).x);
+      if (d.off_series >= 0)
+        x += d.off_scale * (val(d.off_series, idx_d[q], ua).x + val(d.off_series, idx_d[q], ub).x);
+    }
+    if (d.extra > 0 && dterms) {
+      const int count = dterms[d.extra - 1].remaining + 1;
+      for (int e = lane; e < count; e += 64) {
+        const ryd_dterm t = dterms[d.extra - 1 + e];
+        x += t.scale * (val(t.series, idx_d[q], ua).x + val(t.series, idx_d[q], ub).x);
+      }
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    }
+    dl += 0.5 * len_d[q] * x;
+  }
+  if (lane == 0) {
+    double C = 1.0, gr = 0.0, gi = 0.0;
+    if (d.drive_series >= 0 && beta != 0.0) {
+      const cplx a = val(d.drive_series, idx_c, u_c);
+      const double cr = d.drive_scale * a.x, ci = d.drive_scale * a.y;
+      const double m = sqrt(cr * cr + ci * ci);
+      double sn, cs;
+      sincos(beta * m, &sn, &cs);
+      const double S = m > 1e-300 ? sn / m : beta;  // sin(beta |c|) / |c|
+      C = cs;
+      gr = S * ci;  // g = -i S c
+      gi = -S * cr;
+    }
+    double* o = out + ((size_t)j * total + i) * 4;
+    o[0] = C;
+    o[1] = gr;
+    o[2] = gi;
+    o[3] = dl;
+  }
+}
+
+__device__ static const double kSplitTrig[64][2] = {
+    {1.0, 0.0}, {0.9951847266721969, 0.0980171403295606},
+    {0.9807852804032304, 0.19509032201612825}, {0.9569403357322088, 0.29028467725446233},
+    {0.9238795325112867, 0.3826834323650898}, {0.881921264348355, 0.47139673682599764},
+    {0.8314696123025452, 0.5555702330196022}, {0.773010453362737, 0.6343932841636455},
+    {0.7071067811865476, 0.7071067811865475}, {0.6343932841636455, 0.773010453362737},
+    {0.5555702330196023, 0.8314696123025452}, {0.4713967368259978, 0.8819212643483549},
+    {0.38268343236508984, 0.9238795325112867}, {0.29028467725446233, 0.9569403357322089},
+    {0.19509032201612833, 0.9807852804032304}, {0.09801714032956077, 0.9951847266721968},
+    {6.123233995736766e-17, 1.0}, {-0.09801714032956065, 0.9951847266721969},
+    {-0.1950903220161282, 0.9807852804032304}, {-0.29028467725446216, 0.9569403357322089},
+    {-0.3826834323650897, 0.9238795325112867}, {-0.4713967368259977, 0.881921264348355},
+    {-0.555570233019602, 0.8314696123025455}, {-0.6343932841636454, 0.7730104533627371},
+    {-0.7071067811865475, 0.7071067811865476}, {-0.773010453362737, 0.6343932841636455},
+    {-0.8314696123025453, 0.5555702330196022}, {-0.8819212643483549, 0.47139673682599786},
+    {-0.9238795325112867, 0.3826834323650899}, {-0.9569403357322088, 0.2902846772544624},
+    {-0.9807852804032304, 0.1950903220161286}, {-0.9951847266721968, 0.09801714032956083},
+    {-1.0, 1.2246467991473532e-16}, {-0.9951847266721969, -0.09801714032956059},
+    {-0.9807852804032304, -0.19509032201612836}, {-0.9569403357322089, -0.2902846772544621},
+    {-0.9238795325112868, -0.38268343236508967}, {-0.881921264348355, -0.47139673682599764},
+    {-0.8314696123025455, -0.555570233019602}, {-0.7730104533627371, -0.6343932841636453},
+    {-0.7071067811865477, -0.7071067811865475}, {-0.6343932841636459, -0.7730104533627367},
+    {-0.5555702330196022, -0.8314696123025452}, {-0.47139673682599786, -0.8819212643483549},
+    {-0.38268343236509034, -0.9238795325112865}, {-0.29028467725446244, -0.9569403357322088},
+    {-0.19509032201612866, -0.9807852804032303}, {-0.09801714032956045, -0.9951847266721969},
+    {-1.8369701987210297e-16, -1.0}, {0.09801714032956009, -0.9951847266721969},
+    {0.1950903220161283, -0.9807852804032304}, {0.29028467725446205, -0.9569403357322089},
+    {0.38268343236509, -0.9238795325112866}, {0.4713967368259976, -0.881921264348355},
+    {0.5555702330196018, -0.8314696123025455}, {0.6343932841636456, -0.7730104533627369},
+    {0.7071067811865474, -0.7071067811865477}, {0.7730104533627367, -0.6343932841636459},
+    {0.8314696123025452, -0.5555702330196022}, {0.8819212643483548, -0.4713967368259979},
+    {0.9238795325112865, -0.3826834323650904}, {0.9569403357322088, -0.2902846772544625},
+    {0.9807852804032303, -0.19509032201612872}, {0.9951847266721969, -0.0980171403295605},
+};
+
+// exp(-i phi) by a 64-entry table of exp(i k pi/32) and a short series on |r| <= pi/64
+__device__ __forceinline__ void split_sincos(double phi, const cplx* __restrict__ tab, double& c, double& s) {
+  const double k = rint(phi * 10.185916357881302);  // 32 / pi
+  double r = fma(-k, 0.09817477042468103, phi);
+  r = fma(-k, 3.827021247335479e-18, r);  // pi/32 - double(pi/32)
+  const int ki = ((int)k) & 63;
+  const double r2 = r * r;
+  const double cr = fma(r2, fma(r2, fma(r2, fma(r2, 2.48015873015873e-05, -1.388888888888889e-03),
+                                        4.1666666666666664e-02), -0.5), 1.0);
+  const double sr = r * fma(r2, fma(r2, fma(r2, fma(r2, 2.7557319223985893e-06, -1.984126984126984e-04),
+                                            8.333333333333333e-03), -1.6666666666666666e-01), 1.0);
+  const cplx t = tab[ki];
+  c = fma(t.x, cr, -t.y * sr);
+  s = fma(t.y, cr, t.x * sr);
+}
+
+__global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = A.T;
+  const int G = (T + 3) >> 2;  // register-bit groups
+  cplx* xs = reinterpret_cast<cplx*>(smem);                       // [2^T] swizzled slots
+  cplx* trig = xs + ((size_t)1 << T);                             // [64] exp(i k pi/32)
+  double* rot = reinterpret_cast<double*>(trig + 64);             // [2][SPLIT_TMAX][4]
+  double* dlo = rot + 2 * SPLIT_TMAX * 4;                         // [64]
+  double* dhi = dlo + 64;                                         // [64]
+  double* cfs = dhi + 64;                                         // [2][SPLIT_NMAX][4] staged coefficients
+
+  const int tid = threadIdx.x;
+  const int N = A.N;
+  const int b = blockIdx.y;
+  const int nthr = 1 << (T - 4);
+  const bool active = tid < nthr;
+  const unsigned long long base = deposit((unsigned long long)blockIdx.x, A.outer);
+  cplx* __restrict__ st = A.state + ((size_t)b << N);
+  const double* __restrict__ cfin = A.cfin + (size_t)b * N * 4;
+  const double* __restrict__ ccur = A.ccur + (size_t)b * N * 4;
+
+  auto pos_of = [&](int g) { return min(4 * g, T - 4); };
+  auto idx_of = [&](int r, int pos) -> unsigned {
+    return ((unsigned)tid & ((1u << pos) - 1u)) | ((unsigned)r << pos) | (((unsigned)tid >> pos) << (pos + 4));
+  };
+
+  // bit q belongs to group q/4 below the top group, else to the top group
+  auto group_mask = [&](int gg, unsigned mask) -> unsigned {
+    unsigned m = 0;
+    for (int q = 0; q < T; ++q) {
+      const int owner = (q >> 2) < G - 1 ? (q >> 2) : G - 1;
+      if (owner == gg && ((mask >> q) & 1u)) m |= 1u << q;
+    }
+    return m;
+  };
+
+  // ---- load the tile in the top layout (lanes run over the low tile bits: coalesced) ----
+  int g = G - 1;
+  cplx x[16];
+  {
+    const int pos = pos_of(g);
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = st[base | deposit((unsigned long long)idx_of(r, pos), A.tile)];
+    }
+  }
+  // E0 of the amplitudes in the layout D will find them in (after the finishing rotations)
+  int gD = G - 1;
+  for (int gg = G - 1; gg >= 0; --gg)
+    if (group_mask(gg, A.fin_mask)) gD = gg;
+  double ev[16];
+  if (A.do_diag && active) {
+    const int pos = pos_of(gD);
+    const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ev[r] = e0[base | deposit((unsigned long long)idx_of(r, pos), A.tile)];
+  }
+
+  // ---- per-pass tables: stage the coefficients with one coalesced read, then build from LDS ----
+  if (tid < 4 * N) {
+    cfs[tid] = cfin[tid];
+    cfs[4 * SPLIT_NMAX + tid] = ccur[tid];
+  }
+  if (tid >= 128 && tid < 192) trig[tid - 128] = make_double2(kSplitTrig[tid - 128][0], kSplitTrig[tid - 128][1]);
+  __syncthreads();
+  if (tid < 2 * T) {
+    const int set = tid / T, q = tid % T;
+    const int k = N - 1 - tile_bit_pos(A.tile, q);
+    const double* c = cfs + set * 4 * SPLIT_NMAX + 4 * k;
+    double* o = rot + (set * SPLIT_TMAX + q) * 4;
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+  }
+  double d_outer = 0.0;
+  if (A.do_diag) {
+    const double* cc = cfs + 4 * SPLIT_NMAX;
+    // detuning integral part of the phase: sum_k Delta_k n_k, n_k = 1 - bit
+    if (tid >= 128 && tid < 256) {
+      const int e = tid - 128;
+      const bool hiHalf = e >= 64;
+      const int v = e & 63;
+      const int q0 = hiHalf ? 6 : 0;
+      const int nq = hiHalf ? max(T - 6, 0) : min(T, 6);
+      double s = 0.0;
+      for (int q = 0; q < nq; ++q)
+        if (!((v >> q) & 1)) s += cc[4 * (N - 1 - tile_bit_pos(A.tile, q0 + q)) + 3];
+      (hiHalf ? dhi : dlo)[v] = s;
+    }
+    for (int p = 0; p < N; ++p) {
+      // bits outside the tile are fixed per workgroup
+      bool in_tile = false;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) in_tile |= (p >= A.tile.lo[i] && p < A.tile.lo[i] + A.tile.len[i]);
+      if (!in_tile && !((base >> p) & 1ull)) d_outer += cc[4 * (N - 1 - p) + 3];
+    }
+  }
+  __syncthreads();
+
+  auto rotate = [&](int gg, unsigned mask, int set) {
+    const int pos = pos_of(gg);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = pos + j;
+      // bit q belongs to group q/4 below the top group, else to the top group
+      const int owner = (q >> 2) < G - 1 ? (q >> 2) : G - 1;
+      if (!((mask >> q) & 1u) || owner != gg) continue;
+      const double* c = rot + (set * SPLIT_TMAX + q) * 4;
+      const double C = c[0], gr = c[1], gi = c[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r & (1 << j)) continue;
+        const cplx a0 = x[r], a1 = x[r | (1 << j)];
+        // y0 = C a0 + g' a1,  g' = (-gr, gi);   y1 = C a1 + g a0,  g = (gr, gi)
+        x[r] = make_double2(fma(-gr, a1.x, fma(-gi, a1.y, C * a0.x)), fma(-gr, a1.y, fma(gi, a1.x, C * a0.y)));
+        x[r | (1 << j)] = make_double2(fma(gr, a0.x, fma(-gi, a0.y, C * a1.x)), fma(gr, a0.y, fma(gi, a0.x, C * a1.y)));
+      }
+    }
+  };
+  auto turn = [&](int from, int to) {  // registers -> LDS -> registers in the layout of group `to`
+    const int p0 = pos_of(from), p1 = pos_of(to);
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned i = idx_of(r, p0);
+        xs[i ^ ((i >> 4) & 15u)] = x[r];
+      }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned i = idx_of(r, p1);
+        x[r] = xs[i ^ ((i >> 4) & 15u)];
+      }
+    }
+    __syncthreads();
+  };
+
+  // ---- finish the previous stage's rotation ----
+  for (int s = 0; s < G; ++s) {
+    const int gg = G - 1 - s;
+    if (!group_mask(gg, A.fin_mask)) continue;
+    if (gg != g) { turn(g, gg); g = gg; }
+    rotate(gg, A.fin_mask, 0);
+  }
+
+  // ---- D: exact phase of the diagonal ----
+  if (A.do_diag && active) {
+    const int pos = pos_of(g);  // == gD
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned i = idx_of(r, pos);
+      const double phi = fma(A.wE, ev[r], -(d_outer + dlo[i & 63u] + dhi[i >> 6]));
+      double c, s;
+      split_sincos(phi, trig, c, s);
+      const cplx a = x[r];
+      x[r] = make_double2(fma(a.x, c, a.y * s), fma(a.y, c, -a.x * s));  // a * (c - i s)
+    }
+  }
+
+  // ---- start this stage's rotation on every bit of the tile ----
+  {
+    const int g0 = g;
+    for (int s = 0; s < G; ++s) {
+      const int gg = (g0 - s + G) % G;
+      if (!group_mask(gg, A.cur_mask)) continue;
+      if (gg != g) { turn(g, gg); g = gg; }
+      rotate(gg, A.cur_mask, 1);
+    }
+  }
+  if (g != G - 1) { turn(g, G - 1); g = G - 1; }
+  {
+    const int pos = pos_of(g);
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[base | deposit((unsigned long long)idx_of(r, pos), A.tile)] = x[r];
+    }
+  }
+}
+
+// The same pass for tiles of exactly 2^12 amplitudes with everything static: layouts L2 (register
+// bits 8-11, the load / store layout), L1 (bits 4-7) and L0 (bits 0-3) in the fixed order
+//   L2: finish bits 8-11 | L1: finish bits 4-7, D, start bits 4-7 | L0: start bits 0-3 | L2: start bits 8-11
+// (the tilings keep >= 4 low bits, so a finishing rotation never touches bits 0-3).  LDS slots and
+// global offsets fold into immediates; REAL: every drive coefficient is real (g = -i S c is imaginary).
+template <bool REAL>
+__global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int T = 12;
+  cplx* xs = reinterpret_cast<cplx*>(smem);
+  cplx* trig = xs + (1 << T);
+  double* rot = reinterpret_cast<double*>(trig + 64);
+  double* dlo = rot + 2 * SPLIT_TMAX * 4;
+  double* dhi = dlo + 64;
+  double* cfs = dhi + 64;
+
+  const unsigned tid = threadIdx.x;
+  const int N = A.N;
+  const int b = blockIdx.y;
+  const unsigned long long base = deposit((unsigned long long)blockIdx.x, A.outer);
+  cplx* __restrict__ st = A.state + ((size_t)b << N) + base;
+  const double* __restrict__ cfin = A.cfin + (size_t)b * N * 4;
+  const double* __restrict__ ccur = A.ccur + (size_t)b * N * 4;
+
+  // tile-local index of register r: L2: tid | r << 8;  L1: (tid & 15) | r << 4 | (tid >> 4) << 8;  L0: r | tid << 4
+  const unsigned long long g2 = deposit((unsigned long long)tid, A.tile);
+  const unsigned long long g1 = deposit((unsigned long long)((tid & 15u) | ((tid >> 4) << 8)), A.tile);
+  cplx x[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = st[g2 | deposit((unsigned long long)(r << 8), A.tile)];
+  double ev[16];
+  if (A.do_diag) {
+    const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride + base;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ev[r] = e0[g1 | deposit((unsigned long long)(r << 4), A.tile)];
+  }
+
+  if (tid < 4u * N) {
+    cfs[tid] = cfin[tid];
+    cfs[4 * SPLIT_NMAX + tid] = ccur[tid];
+  }
+  if (tid >= 128 && tid < 192) trig[tid - 128] = make_double2(kSplitTrig[tid - 128][0], kSplitTrig[tid - 128][1]);
+  __syncthreads();
+  if (tid < 2 * T) {
+    const int set = tid / T, q = tid % T;
+    const int k = N - 1 - tile_bit_pos(A.tile, q);
+    const double* c = cfs + set * 4 * SPLIT_NMAX + 4 * k;
+    double* o = rot + (set * SPLIT_TMAX + q) * 4;
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+  }
+  double d_outer = 0.0;
+  if (A.do_diag) {
+    const double* cc = cfs + 4 * SPLIT_NMAX;
+    if (tid >= 128) {
+      const int e = tid - 128;
+      const bool hiHalf = e >= 64;
+      const int v = e & 63;
+      const int q0 = hiHalf ? 6 : 0;
+      double s = 0.0;
+      for (int q = 0; q < 6; ++q)
+        if (!((v >> q) & 1)) s += cc[4 * (N - 1 - tile_bit_pos(A.tile, q0 + q)) + 3];
+      (hiHalf ? dhi : dlo)[v] = s;
+    }
+    for (int p = 0; p < N; ++p) {
+      bool in_tile = false;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) in_tile |= (p >= A.tile.lo[i] && p < A.tile.lo[i] + A.tile.len[i]);
+      if (!in_tile && !((base >> p) & 1ull)) d_outer += cc[4 * (N - 1 - p) + 3];
+    }
+  }
+  __syncthreads();
+
+  // rotations of the 4 register bits at tile-local bits [pos, pos + 4)
+  auto rotate = [&](int pos, unsigned mask, int set) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!((mask >> (pos + j)) & 1u)) continue;
+      const double* c = rot + (set * SPLIT_TMAX + pos + j) * 4;
+      const double C = c[0], gr = c[1], gi = c[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r & (1 << j)) continue;
+        const cplx a0 = x[r], a1 = x[r | (1 << j)];
+        if (REAL) {
+          x[r] = make_double2(fma(-gi, a1.y, C * a0.x), fma(gi, a1.x, C * a0.y));
+          x[r | (1 << j)] = make_double2(fma(-gi, a0.y, C * a1.x), fma(gi, a0.x, C * a1.y));
+        } else {
+          x[r] = make_double2(fma(-gr, a1.x, fma(-gi, a1.y, C * a0.x)), fma(-gr, a1.y, fma(gi, a1.x, C * a0.y)));
+          x[r | (1 << j)] = make_double2(fma(gr, a0.x, fma(-gi, a0.y, C * a1.x)), fma(gr, a0.y, fma(gi, a0.x, C * a1.y)));
+        }
+      }
+    }
+  };
+  // swizzled LDS slot of tile-local index i: i ^ ((i >> 4) & 15)
+  const unsigned s2 = tid ^ ((tid >> 4) & 15u);             // + (r << 8)
+  const unsigned s1 = (tid & 15u) | ((tid >> 4) << 8);      // ((tid & 15) ^ r) | r << 4 | (tid >> 4) << 8
+  const unsigned s0 = tid << 4;                             // (r ^ (tid & 15)) | tid << 4
+
+  rotate(8, A.fin_mask, 0);
+  // ---- L2 -> L1 ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xs[s2 + (r << 8)] = x[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = xs[(s1 ^ (unsigned)r) | (unsigned)(r << 4)];
+  rotate(4, A.fin_mask, 0);
+  if (A.do_diag) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned i = s1 | (unsigned)(r << 4);
+      const double phi = fma(A.wE, ev[r], -(d_outer + dlo[i & 63u] + dhi[i >> 6]));
+      double c, s;
+      split_sincos(phi, trig, c, s);
+      const cplx a = x[r];
+      x[r] = make_double2(fma(a.x, c, a.y * s), fma(a.y, c, -a.x * s));
+    }
+  }
+  rotate(4, A.cur_mask, 1);
+  __syncthreads();
+  // ---- L1 -> L0 ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xs[(s1 ^ (unsigned)r) | (unsigned)(r << 4)] = x[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = xs[s0 | ((unsigned)r ^ (tid & 15u))];
+  rotate(0, A.cur_mask, 1);
+  __syncthreads();
+  // ---- L0 -> L2 ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xs[s0 | ((unsigned)r ^ (tid & 15u))] = x[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = xs[s2 + (r << 8)];
+  rotate(8, A.cur_mask, 1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[g2 | deposit((unsigned long long)(r << 8), A.tile)] = x[r];
+}
+
+// Whole kets of exactly 12 atoms (one tile = one sequence): every stage of a closed run in ONE launch,
+// the ket stays in registers.  A stage is D + the 12 rotations; the layouts alternate
+//   even stages: L2 (D, bits 8-11) -> L0 (bits 0-3) -> L1 (bits 4-7)
+//   odd stages:  L1 (D, bits 4-7)  -> L0 (bits 0-3) -> L2 (bits 8-11)
+// so a stage costs two turns through LDS and no global traffic but its 12 x 4 coefficients.
+// E0 is loaded once, in both layouts D meets.  grid = (1, B).
+template <bool REAL>
+__global__ __launch_bounds__(SPLIT_NT) void k_split12_loop(const SplitArgs A, const SplitRun R, long long stage_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int T = 12;
+  cplx* xs = reinterpret_cast<cplx*>(smem);
+  cplx* trig = xs + (1 << T);
+  double* rot = reinterpret_cast<double*>(trig + 64);  // [SPLIT_TMAX][4]
+  double* dlo = rot + 2 * SPLIT_TMAX * 4;
+  double* dhi = dlo + 64;
+  double* cfs = dhi + 64;
+
+  const unsigned tid = threadIdx.x;
+  const int N = A.N;  // == 12
+  const int b = blockIdx.y;
+  const int n_stages = 6 * R.nsub + 1;
+  cplx* __restrict__ st = A.state + ((size_t)b << N);
+  const double* __restrict__ coefs = A.ccur + (size_t)b * N * 4;
+  const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride;
+
+  const unsigned s2 = tid ^ ((tid >> 4) & 15u);
+  const unsigned s1 = (tid & 15u) | ((tid >> 4) << 8);
+  const unsigned s0 = tid << 4;
+  cplx x[16];
+  double ev1[16], ev2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = st[tid | (r << 8)];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    ev2[r] = e0[tid | (r << 8)];
+    ev1[r] = e0[s1 | (r << 4)];
+  }
+  if (tid < 64) trig[tid] = make_double2(kSplitTrig[tid][0], kSplitTrig[tid][1]);
+  double cnext = tid < 4u * N ? coefs[tid] : 0.0;  // stage 0's coefficients
+
+  auto rotate = [&](int pos) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double* c = rot + (pos + j) * 4;
+      const double C = c[0], gr = c[1], gi = c[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r & (1 << j)) continue;
+        const cplx a0 = x[r], a1 = x[r | (1 << j)];
+        if (REAL) {
+          x[r] = make_double2(fma(-gi, a1.y, C * a0.x), fma(gi, a1.x, C * a0.y));
+          x[r | (1 << j)] = make_double2(fma(-gi, a0.y, C * a1.x), fma(gi, a0.x, C * a1.y));
+        } else {
+          x[r] = make_double2(fma(-gr, a1.x, fma(-gi, a1.y, C * a0.x)), fma(-gr, a1.y, fma(gi, a1.x, C * a0.y)));
+          x[r | (1 << j)] = make_double2(fma(gr, a0.x, fma(-gi, a0.y, C * a1.x)), fma(gr, a0.y, fma(gi, a0.x, C * a1.y)));
+        }
+      }
+    }
+  };
+  auto phase = [&](double wE, const double (&ev)[16], unsigned ibase, int shift) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned i = ibase | (unsigned)(r << shift);
+      const double phi = fma(wE, ev[r], -(dlo[i & 63u] + dhi[i >> 6]));
+      double c, s;
+      split_sincos(phi, trig, c, s);
+      const cplx a = x[r];
+      x[r] = make_double2(fma(a.x, c, a.y * s), fma(a.y, c, -a.x * s));
+    }
+  };
+
+  for (int sgi = 0; sgi < n_stages; ++sgi) {
+    // ---- this stage's tables (the coefficients were fetched during the previous stage) ----
+    __syncthreads();  // previous stage's readers of rot / dlo / dhi / xs are done
+    if (tid < 4u * N) cfs[tid] = cnext;
+    __syncthreads();
+    if (sgi + 1 < n_stages && tid < 4u * N) cnext = coefs[(size_t)(sgi + 1) * stage_stride + tid];
+    if (tid < (unsigned)T) {
+      const double* c = cfs + 4 * (N - 1 - tid);  // tile-local bit q = global bit q
+      double* o = rot + tid * 4;
+      o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+    }
+    if (tid >= 128) {
+      const int e = tid - 128;
+      const bool hiHalf = e >= 64;
+      const int v = e & 63;
+      const int q0 = hiHalf ? 6 : 0;
+      double s = 0.0;
+      for (int q = 0; q < 6; ++q)
+        if (!((v >> q) & 1)) s += cfs[4 * (N - 1 - (q0 + q)) + 3];
+      (hiHalf ? dhi : dlo)[v] = s;
+    }
+    __syncthreads();
+    const bool last = sgi == n_stages - 1;
+    // weight of E0 in this stage's D: a_i tau (+ the a_7 tau carried over from the previous sub-step)
+    double w;
+    {
+      const int sub = last ? R.nsub - 1 : sgi / 6, i = last ? 6 : sgi % 6;
+      w = kSplitADev[i] * R.tau[sub];
+      if (!last && i == 0 && sub > 0) w += kSplitADev[6] * R.tau[sub - 1];
+    }
+    if (!(sgi & 1)) {
+      phase(w, ev2, tid, 8);
+      if (!last) {
+        rotate(8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[s2 + (r << 8)] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = xs[s0 | ((unsigned)r ^ (tid & 15u))];
+        rotate(0);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[s0 | ((unsigned)r ^ (tid & 15u))] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = xs[(s1 ^ (unsigned)r) | (unsigned)(r << 4)];
+        rotate(4);
+      }
+    } else {
+      phase(w, ev1, s1, 4);
+      if (!last) {
+        rotate(4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[(s1 ^ (unsigned)r) | (unsigned)(r << 4)] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = xs[s0 | ((unsigned)r ^ (tid & 15u))];
+        rotate(0);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[s0 | ((unsigned)r ^ (tid & 15u))] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = xs[s2 + (r << 8)];
+        rotate(8);
+      }
+    }
+  }
+  // the closing stage (index n_stages - 1) leaves the layout of its parity
+  if ((n_stages - 1) & 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[s1 | (r << 4)] = x[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[tid | (r << 8)] = x[r];
+  }
+}
+
+// err[b] = max |x - y|^2 over the amplitudes (local-error estimate of the step-size controller);
+// non-negative doubles order like their bit patterns
+__global__ __launch_bounds__(256) void k_split_diff(const cplx* __restrict__ x, const cplx* __restrict__ y, int nb,
+                                                    double* err) {
+  const size_t D = (size_t)1 << nb;
+  const size_t boff = (size_t)blockIdx.y * D;
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < D; i += (size_t)gridDim.x * 256) {
+    const cplx a = x[boff + i], c = y[boff + i];
+    const double dx = a.x - c.x, dy = a.y - c.y;
+    s = fmax(s, fma(dx, dx, dy * dy));
+  }
+  for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_down(s, o, 64));
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(err + blockIdx.y), (unsigned long long)__double_as_longlong(s));
+}

@@ -55,6 +55,7 @@ typedef double2 cplx;
 #include "k_traj_dm.hpp"
 #include "k_ket.hpp"
 #include "k_krylov.hpp"
+#include "k_split.hpp"
 #include "k_observe.hpp"
 #include "k_general.hpp"
 #include "host_handle.hpp"
@@ -63,5 +64,6 @@ typedef double2 cplx;
 #include "host_sched.hpp"
 #include "host_ket.hpp"
 #include "host_krylov.hpp"
+#include "host_split.hpp"
 #include "host_step.hpp"
 #include "host_observables.hpp"

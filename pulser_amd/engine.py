@@ -28,8 +28,9 @@ def _torch():
     return torch
 
 
-# ryd_opts.method: exponential of the multi-launch sesolve path
-_METHODS = {"taylor": 0, "krylov": 1}
+# ryd_opts.method: propagator of the multi-launch sesolve path ("auto": split-operator for
+# two-level kets of 15+ atoms, Taylor polynomial otherwise)
+_METHODS = {"auto": 0, "krylov": 1, "split": 2, "taylor": 3}
 
 
 class Engine:
@@ -190,7 +191,7 @@ class Engine:
         max_order: int = 0,
         magnus_tol: float = 0.0,
         split_steps: int = 0,
-        method: str = "taylor",
+        method: str = "auto",
     ) -> None:
         """In place: ``state <- U(t1, t0) state`` (times in us)."""
         self._check_state(state)
@@ -220,7 +221,7 @@ class Engine:
         max_order: int = 0,
         magnus_tol: float = 0.0,
         split_steps: int = 0,
-        method: str = "taylor",
+        method: str = "auto",
     ) -> Any:
         """Advance ``state`` in place through ``times`` (us); with ``store``
         return complex128[len(times)-1, B, dim...] = the states at times[1:]
@@ -307,18 +308,22 @@ class Engine:
     def set_path(self, force_generic: bool, no_tile14: bool = False,
                  force_tile14: bool = False, no_single_pass: bool = False,
                  force_single_pass: bool = False, no_ket: bool = False,
-                 force_ket: bool = False) -> None:
+                 force_ket: bool = False, no_split: bool = False,
+                 split_fixed: bool = False, split_no_loop: bool = False) -> None:
         """Test/bench hook: disable the persistent small-N kernel and/or the 2^14
         register-tile kernel with the Hermitian mesolve path (the tiled
         multi-pass kernels are used instead), or force the register tiles;
         ``no_single_pass`` disables the one-launch plan of states up to 128 MiB;
         ``no_ket`` disables the register-resident ket kernel and the split-operator
-        master equation built on it, ``force_ket`` uses them from 10 atoms on."""
+        master equation built on it, ``force_ket`` uses them from 10 atoms on;
+        ``no_split`` keeps the Taylor polynomial for kets of 15+ atoms, ``split_fixed``
+        switches the step-size control of the split-operator path off."""
         _lib.check(self.lib.ryd_set_path(
             self._h, int(bool(force_generic)) | (2 if no_single_pass else 0)
             | (4 if no_tile14 else 0) | (8 if force_tile14 else 0)
             | (16 if force_single_pass else 0) | (32 if no_ket else 0)
-            | (64 if force_ket else 0)))
+            | (64 if force_ket else 0) | (128 if no_split else 0)
+            | (256 if split_fixed else 0) | (512 if split_no_loop else 0)))
 
     def apply_generator(self, x: Any, t: float) -> Any:
         """``G(t) x`` with ``G = -iH`` (sesolve) or the Lindbladian (mesolve)."""
@@ -400,6 +405,9 @@ class Engine:
             "passes": int(s.passes),
             "last_order": int(s.last_order),
             "norm_bound": float(s.norm_bound),
+            # split-operator path: accumulated local-error estimate of the last solve, last
+            # measured local error, its sub-step (us), checkpoint restores
+            "reserved": [float(v) for v in s.reserved],
         }
 
     def reset_stats(self) -> None:

@@ -301,7 +301,7 @@ def test_register_tile_kernel_sesolve_14_and_16_atoms():
             eng = _engine(probs)
             eng.set_path(False, no_tile14=no14, force_tile14=not no14)
             st = eng.new_state()
-            eng.evolve(st, 0.0, 0.003)
+            eng.evolve(st, 0.0, 0.003, method="taylor")  # the generator kernels (default here: split-operator)
             res[no14] = st.cpu().numpy()
             # without the register tiles: the single-launch plan of small states
             assert eng.stats()["passes"] == ({14: 1, 16: 2}[n] if not no14 else 1)
@@ -344,7 +344,7 @@ def test_large_ket_against_the_product_state_solution():
     samples = {"amp": np.full(T + 1, 6.0), "det": np.full(T + 1, -2.0), "phase": np.zeros(T + 1)}
     eng = _engine([P.make_ising_problem(coords, samples)], mode="sesolve")
     st = eng.new_state()
-    eng.evolve(st, 0.0, 0.004, tol=1e-14)  # exact reference: tighter than the default 1e-10 per exponential
+    eng.evolve(st, 0.0, 0.004, tol=1e-14, method="taylor")  # exact reference: tighter than the default 1e-10
     assert eng.stats()["passes"] == 3
     h1 = np.array([[2.0, 3.0], [3.0, 0.0]])  # (r, g): -delta n_r + (Omega / 2) sigma_x
     w, v = np.linalg.eigh(h1)

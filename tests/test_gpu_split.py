@@ -1,0 +1,198 @@
+"""-m gpu: the split-operator ket path (k_split: exact diagonal phases x exact single-atom rotations,
+4th-order composition, step-size control) - the default propagator of two-level kets from 14 / 15
+atoms on.  Checkers: the tight oracle fixtures (8- and 12-atom anneal), the CF4 + Taylor path at
+sizes the oracle cannot reach, and the step-size controller's own error estimate.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from helpers import blockade_radius, load_fixture, with_anneal_samples
+from pulser_amd import problem as P
+
+pytestmark = pytest.mark.gpu
+
+AMP_TOL = 1e-7  # amplitudes vs the tight oracle
+
+
+def _engine(probs, mode="sesolve"):
+    from pulser_amd.engine import Engine
+
+    return Engine.from_problems(probs, mode=mode)
+
+
+def rect_problem(rows, cols, scale=1.0):
+    coords = P.register_coords(P.square_rect(rows, cols), blockade_radius())
+    smp = P.anneal_samples()
+    smp = {"amp": smp["amp"] * scale, "det": smp["det"] * (2.0 - scale), "phase": smp["phase"]}
+    return P.make_ising_problem(coords, smp)
+
+
+def local_problem(n, seed=0, duration=61, spacing=7.0):
+    """Per-atom COMPLEX drives (time-dependent phases) and detunings."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(duration) / 1000.0
+    coords = P.register_coords(P.square_rect(1, n), spacing) + rng.normal(0, 0.3, (n, 2))
+    z = np.zeros(duration)
+    prob = P.make_ising_problem(coords, {"amp": z, "det": z, "phase": z})
+    loc = {}
+    for q in range(n):
+        a, b, c = rng.uniform(2, 12, 3)
+        loc[q] = {"amp": a * (1 + 0.5 * np.sin(2 * np.pi * (q + 1) * t / t[-1])),
+                  "det": b * np.cos(3 * t + q) - c, "phase": 0.3 * q + 2.0 * t}
+    prob["samples"] = {"Global": {}, "Local": {"ground-rydberg": loc}}
+    return prob
+
+
+@pytest.mark.parametrize("fixture", ["cfg2_chain8_anneal.npz", "cfg2_chain12_anneal.npz"])
+@pytest.mark.parametrize("fixed, no_loop", [(True, False), (False, False), (False, True)])
+def test_split_operator_full_anneal_against_tight_oracle(fixture, fixed, no_loop):
+    """Whole 3.1-us anneal, every evaluation time of the fixture: one sub-step per spline knot
+    (`fixed`) and under the step-size controller - both an order of magnitude inside the bar.  12 atoms:
+    one launch per closed run (the ket stays in registers) or, with `no_loop`, one launch per stage."""
+    prob, extra = load_fixture(fixture)
+    prob = with_anneal_samples(prob)
+    times = np.asarray(extra["eval_times"])
+    ref = np.asarray(extra["oracle_states_tight"])
+    with _engine([prob]) as eng:
+        eng.set_path(False, split_fixed=fixed, split_no_loop=no_loop)
+        snaps = eng.solve(eng.new_state(), times, method="split").cpu().numpy()[:, 0]
+        s = eng.stats()
+    err = max(np.max(np.abs(snaps[k - 1] - ref[k])) for k in range(1, len(times)))
+    assert err < AMP_TOL / 10, err
+    # no generator applications: 6 stages per sub-step, one launch per stage (+ closings, checks)
+    assert s["n_launches"] < 1.6 * s["n_applications"]
+    if "chain12" in fixture and not no_loop:
+        assert s["n_launches"] < s["n_applications"] / 20  # closed runs of up to 64 sub-steps per launch
+    if not fixed:
+        assert 0 < s["reserved"][0] < 5e-8  # the controller's accumulated estimate met its target
+        assert err < s["reserved"][0] * 3 + 1e-9  # ... and the estimate covers the real error
+
+
+def test_split_controller_follows_the_tolerance():
+    prob, extra = load_fixture("cfg2_chain12_anneal.npz")
+    prob = with_anneal_samples(prob)
+    ref = np.asarray(extra["oracle_states_tight"])[-1]
+    t_end = float(np.asarray(extra["eval_times"])[-1])
+    out = {}
+    for tol in (1e-10, 1e-12):
+        with _engine([prob]) as eng:
+            st = eng.new_state()
+            eng.evolve(st, 0.0, t_end, method="split", tol=tol)
+            out[tol] = (np.max(np.abs(st.cpu().numpy()[0] - ref)), eng.stats())
+    assert out[1e-12][0] < 5e-10 < AMP_TOL
+    assert out[1e-12][1]["n_applications"] > 1.5 * out[1e-10][1]["n_applications"]
+    assert out[1e-10][0] < AMP_TOL / 10
+
+
+@pytest.mark.parametrize("n, seed", [(10, 0), (13, 3)])
+def test_split_local_complex_drives_against_taylor(n, seed):
+    """Per-atom complex drives and detunings (MODEL 0 physics); 13 atoms = two tilings."""
+    prob = local_problem(n, seed)
+    outs = {}
+    for method in ("taylor", "split"):
+        with _engine([prob]) as eng:
+            st = eng.new_state()
+            kw = {"tol": 1e-13} if method == "taylor" else {}
+            eng.evolve(st, 0.0, 0.06, method=method, **kw)
+            outs[method] = st.cpu().numpy()[0]
+    assert np.max(np.abs(outs["taylor"] - outs["split"])) < 5e-9
+    assert abs(np.linalg.norm(outs["split"]) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("n, rows, cols, ns", [(15, 3, 5, 40), (16, 4, 4, 40), (20, 4, 5, 30), (22, 2, 11, 6)])
+def test_split_is_the_default_from_15_atoms_and_matches_taylor(n, rows, cols, ns):
+    """cfg5 sizes (20 atoms = BASELINE configs[4]; 22 atoms = three tilings, two passes per stage):
+    the default path is the split-operator one and agrees with CF4 + Taylor far inside the bar."""
+    prob = rect_problem(rows, cols)
+    outs = {}
+    for method in ("taylor", "auto"):
+        with _engine([prob]) as eng:
+            st = eng.new_state()
+            t0 = 1.0
+            eng.evolve(st, 0.0, t0)  # a non-trivial start (the same path for both)
+            eng.reset_stats()
+            eng.evolve(st, t0, t0 + ns * 1e-3, method=method)
+            outs[method] = st.cpu().numpy()[0]
+            s = eng.stats()
+            if method == "auto":
+                assert s["n_applications"] >= 6 * ns and s["reserved"][0] > 0  # stages; error estimate kept
+                assert s["passes"] == (2 if n > 20 else 1)
+    assert np.max(np.abs(outs["taylor"] - outs["auto"])) < 2e-9
+    assert abs(np.linalg.norm(outs["auto"]) - 1.0) < 1e-9
+
+
+def test_split_batch_of_different_sequences_and_snapshots():
+    """Three different 16-atom sequences in one handle, snapshots at uneven times (two inside a knot
+    interval), against the Taylor path."""
+    probs = [rect_problem(4, 4, s) for s in (1.0, 0.93, 1.05)]
+    times = [1.0, 1.0105, 1.0107, 1.03]
+    outs = {}
+    for method in ("taylor", "split"):
+        with _engine(probs) as eng:
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 1.0, method="taylor")
+            outs[method] = eng.solve(st, times, method=method).cpu().numpy()
+    assert outs["split"].shape == (3, 3, 1 << 16)
+    assert np.max(np.abs(outs["taylor"] - outs["split"])) < 2e-9
+    assert np.max(np.abs(outs["split"][-1, 0] - outs["split"][-1, 1])) > 1e-3  # sequences really differ
+
+
+def test_split_controller_state_survives_between_calls():
+    """A front end that advances from evaluation time to evaluation time (one ryd_evolve per time) must
+    not pay a controller check per call, and must end where a single call ends."""
+    prob = rect_problem(3, 5)
+    with _engine([prob]) as eng:
+        a = eng.new_state()
+        eng.evolve(a, 0.0, 1.0, method="taylor")
+        b = a.clone()
+        eng.reset_stats()
+        eng.evolve(a, 1.0, 1.1)
+        one = eng.stats()["n_launches"]
+        eng.reset_stats()
+        for k in range(100):
+            eng.evolve(b, 1.0 + k * 1e-3, 1.0 + (k + 1) * 1e-3)
+        many = eng.stats()["n_launches"]
+    assert np.max(np.abs(a.cpu().numpy() - b.cpu().numpy())) < 1e-9
+    # per call: 6 stages + 1 closing pass (+ the coefficient kernel is not counted); a check costs ~20 more
+    assert many < 100 * 7 + 6 * 25 and one < many
+
+
+def test_split_14_atoms_single_sequence_is_default_and_matches_ket_kernel():
+    """One 14-atom sequence (fewer than the 8 the register-resident k_ket wants): split-operator
+    passes by default, against k_ket (forced) on the north-star register."""
+    coords = P.register_coords(P.triangular_rect(2, 7), blockade_radius())
+    prob = P.make_ising_problem(coords, P.anneal_samples())
+    outs = {}
+    for force in (False, True):
+        with _engine([prob]) as eng:
+            eng.set_path(False, force_ket=force)
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 0.7)
+            outs[force] = st.cpu().numpy()[0]
+            s = eng.stats()
+            assert (s["n_launches"] == 1) == force
+    assert np.max(np.abs(outs[False] - outs[True])) < 2e-8
+
+
+def test_split_large_ket_against_the_product_state_solution():
+    """25 atoms (0.5 GiB ket, three tilings: 64-bit index arithmetic, strided tiles) on the default
+    path: with the atoms far apart every amplitude is a product of single-atom amplitudes."""
+    n, T = 25, 8
+    coords = P.register_coords(P.square_rect(1, n), 40.0)
+    samples = {"amp": np.full(T + 1, 6.0), "det": np.full(T + 1, -2.0), "phase": np.zeros(T + 1)}
+    with _engine([P.make_ising_problem(coords, samples)]) as eng:
+        st = eng.new_state()
+        eng.evolve(st, 0.0, 0.004)
+        s = eng.stats()
+        assert s["passes"] == 2 and s["n_applications"] >= 24
+        h1 = np.array([[2.0, 3.0], [3.0, 0.0]])  # (r, g): -delta n_r + (Omega / 2) sigma_x
+        w, v = np.linalg.eigh(h1)
+        a1 = (v @ np.diag(np.exp(-1j * w * 0.004)) @ v.conj().T) @ np.array([0.0, 1.0])
+        idx = [0, 1, (1 << n) - 1, (1 << (n - 1)) + 5, 0x155AAAA]
+        got = st[0, idx].cpu().numpy()
+        ref = np.array([np.prod([a1[(i >> (n - 1 - k)) & 1] for k in range(n)]) for i in idx])
+        assert np.max(np.abs(got - ref)) < 1e-10
+        import torch
+        assert abs(float(torch.linalg.vector_norm(st).item()) - 1.0) < 1e-12
