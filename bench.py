@@ -334,6 +334,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="independent sequences per GPU")
     ap.add_argument("--workload", default="north_star")
     ap.add_argument("--slice-ns", type=int, default=2, help="cfg3/cfg5 workloads: simulated ns per step")
+    ap.add_argument("--atoms", type=int, default=20, choices=[20, 22, 24], help="cfg5 workload: register size")
     ap.add_argument("--method", default="auto", choices=["auto", "taylor", "krylov", "split"],
                     help="cfg5 workload: propagator (auto = split-operator passes)")
     ap.add_argument("--lindblad-ns", type=int, default=100, help="north_star: slice of the cfg3 leg")
@@ -545,16 +546,21 @@ def main() -> None:
                      else "k_ket<14> row passes + k_transpose_conj (split-operator path)")
             wl = f"BASELINE configs[2]: 14-atom triangular register, dephasing mesolve (rho = 4.29 GB), {args.slice_ns} ns slice at t = 1 us"
         else:
-            eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")
-            t0, t1, nb = 1.0, 1.0 + 1e-3 * args.slice_ns, 20
-            kname = KSPLIT_NAME if args.method == "auto" else KAPPLY_NAME
-            wl = f"BASELINE configs[4]: 20-atom 4x5 register, sesolve, {args.slice_ns} ns slice at t = 1 us"
+            shape = {20: (4, 5), 22: (2, 11), 24: (4, 6)}[args.atoms]
+            eng = Engine.from_problems([rect_problem(*shape)], mode="sesolve")
+            t0, t1, nb = 1.0, 1.0 + 1e-3 * args.slice_ns, args.atoms
+            kname = KSPLIT_NAME if args.method in ("auto", "split") else KAPPLY_NAME
+            wl = (f"BASELINE configs[4]: {args.atoms}-atom {shape[0]}x{shape[1]} register, sesolve, "
+                  f"{args.slice_ns} ns slice at t = 1 us, method {args.method}")
         mopt = {"method": args.method} if args.workload == "cfg5" else {}
         sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, t0, t1, args.steps, args.warmup, dist, torch, **mopt)
         if args.workload == "cfg3" and not args.no_ket:
             roof = roofline_valu(2.0**14, 2.0**15, stats["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kms, kl, kname, "cfg3:k_ket")
         else:
-            roof = roofline_hbm(nb, 1, stats, kms, kl, kname, "cfg3:k_apply" if args.workload == "cfg3" else "cfg5:k_apply")
+            key = "cfg3:k_apply" if args.workload == "cfg3" else (
+                "cfg5_24atoms:k_split" if (args.atoms == 24 and kname == KSPLIT_NAME) else None if args.atoms != 20
+                else "cfg5:k_split" if kname == KSPLIT_NAME else "cfg5:k_apply")
+            roof = roofline_hbm(nb, 1, stats, kms, kl, kname, key)
         out = {"metric": "sim-us/sec", "value": n_gpus * (t1 - t0) / sec, **common, "ms_per_step": sec * 1e3,
                "config": {"workload": wl, "passes_per_application": stats["passes"], "order": stats["last_order"],
                           "parallelism": f"replicas x{n_gpus} (a single state does not shard)"},
@@ -643,7 +649,7 @@ def main() -> None:
             leg = {"workload": f"cfg5: {n_at}-atom {shape[0]}x{shape[1]} register, sesolve, {ns} ns slice at t = 1 us",
                    "value": ns * 1e-3 / sec, "unit": "sim-us/s", "stages": stats["n_applications"],
                    "passes_per_stage": stats["passes"], "local_error_estimate": stats["reserved"][0],
-                   "roofline": roofline_hbm(n_at, 1, stats, kms, kl, KSPLIT_NAME, "cfg5:k_split" if n_at == 20 else None)}
+                   "roofline": roofline_hbm(n_at, 1, stats, kms, kl, KSPLIT_NAME, "cfg5:k_split" if n_at == 20 else "cfg5_24atoms:k_split")}
             if n_at == 20:
                 sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 1.0, 1.02, 2, 1, None, torch, method="taylor")
                 leg["taylor"] = {"value": 0.02 / sec, "unit": "sim-us/s", "taylor_order": stats["last_order"],

@@ -11,14 +11,20 @@ run() { name=$1; shift; echo "== $name: $*"; timeout 900 "$@" > $OUT/$name.log 2
 NS="python bench.py --no-cpu --no-extras --no-legs"
 run ns_stats rocprofv3 --kernel-trace --stats -d $OUT/ns_stats -o ns --output-format csv -- $NS --steps 2 --warmup 1
 run cfg3_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg3_stats -o cfg3 --output-format csv -- python bench.py --workload cfg3 --steps 1 --warmup 0 --slice-ns 8
-run cfg5_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5_stats -o cfg5 --output-format csv -- python bench.py --workload cfg5 --steps 2 --warmup 1 --slice-ns 20
+run cfg5_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5_stats -o cfg5 --output-format csv -- python bench.py --workload cfg5 --steps 2 --warmup 1 --slice-ns 50
+run cfg5t_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5t_stats -o cfg5t --output-format csv -- python bench.py --workload cfg5 --method taylor --steps 2 --warmup 1 --slice-ns 20
+run cfg5b_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5b_stats -o cfg5b --output-format csv -- python bench.py --workload cfg5 --atoms 24 --steps 2 --warmup 1 --slice-ns 10
 run cfg2_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg2_stats -o cfg2 --output-format csv -- python bench.py --workload cfg2 --steps 2 --warmup 1
 run ns_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/ns_fetch -o ns --output-format csv -- $NS --steps 1 --warmup 0
 run ns_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/ns_write -o ns --output-format csv -- $NS --steps 1 --warmup 0
 run cfg3_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg3_fetch -o cfg3 --output-format csv -- python bench.py --workload cfg3 --steps 1 --warmup 0 --slice-ns 4
 run cfg3_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg3_write -o cfg3 --output-format csv -- python bench.py --workload cfg3 --steps 1 --warmup 0 --slice-ns 4
-run cfg5_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg5_fetch -o cfg5 --output-format csv -- python bench.py --workload cfg5 --steps 1 --warmup 0 --slice-ns 4
-run cfg5_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg5_write -o cfg5 --output-format csv -- python bench.py --workload cfg5 --steps 1 --warmup 0 --slice-ns 4
+run cfg5_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg5_fetch -o cfg5 --output-format csv -- python bench.py --workload cfg5 --steps 1 --warmup 0 --slice-ns 8
+run cfg5_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg5_write -o cfg5 --output-format csv -- python bench.py --workload cfg5 --steps 1 --warmup 0 --slice-ns 8
+run cfg5t_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg5t_fetch -o cfg5t --output-format csv -- python bench.py --workload cfg5 --method taylor --steps 1 --warmup 0 --slice-ns 4
+run cfg5t_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg5t_write -o cfg5t --output-format csv -- python bench.py --workload cfg5 --method taylor --steps 1 --warmup 0 --slice-ns 4
+run cfg5b_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg5b_fetch -o cfg5b --output-format csv -- python bench.py --workload cfg5 --atoms 24 --steps 1 --warmup 0 --slice-ns 4
+run cfg5b_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg5b_write -o cfg5b --output-format csv -- python bench.py --workload cfg5 --atoms 24 --steps 1 --warmup 0 --slice-ns 4
 find $OUT -type f | head -60
 # keep only small files for the merge back
 find $OUT -type f -size +4M -delete
