@@ -252,6 +252,23 @@ int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr, con
                          const double* val /* complex128[nnz] */, int32_t series, int32_t conj,
                          double scale_re, double scale_im, double row_norm);
 
+/* Matrix-free terms of the general path (no operator is materialised): every operator of the
+ * reference's term and collapse lists (hamiltonian.py:97-124, 246-439) is a sum of one- and two-site
+ * operators or a diagonal.
+ *   local:    A = sum_g weights[g] * embed(M on the digits with strides[g][0 .. n_per)),
+ *             digit = (index / stride) % local_dim; M is (local_dim^n_per)^2 (row-major digit order for
+ *             n_per = 2), given by its nnz non-zeros (rows, cols, complex vals).
+ *   diagonal: A = diag(values), complex128[dim]  (Ising interaction, detuning projectors).
+ * series / conj / scale / row_norm as for ryd_general_add_term (row_norm = a bound of the largest
+ * absolute row sum of A). */
+int ryd_general_add_local_term(ryd_handle* h, int32_t local_dim, int32_t n_per, int32_t n_groups,
+                               const int64_t* strides, const double* weights, int32_t nnz,
+                               const int32_t* rows, const int32_t* cols, const double* vals,
+                               int32_t series, int32_t conj, double scale_re, double scale_im,
+                               double row_norm);
+int ryd_general_add_diag_term(ryd_handle* h, const double* values, int32_t series, int32_t conj,
+                              double scale_re, double scale_im, double row_norm);
+
 /* Test/bench hook (bit mask): 1 = disable the persistent small-N kernel, 2 =
  * disable the single-launch plan of small states (partner tiles read through
  * L2; the multi-pass tiling is used instead), 4 = disable the 2^14

@@ -107,6 +107,11 @@ SYMBOLS = {
     "ryd_general_create": (C.c_int, [C.POINTER(RydGeneralConfig), C.POINTER(C.c_void_p)]),
     "ryd_general_add_term": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
+    "ryd_general_add_local_term": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                             C.c_double, C.c_double, C.c_double]),
+    "ryd_general_add_diag_term": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                            C.c_double]),
     "ryd_apply_generator": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "ryd_probabilities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ryd_occupations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

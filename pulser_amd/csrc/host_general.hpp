@@ -37,6 +37,26 @@ extern "C" int ryd_general_create(const ryd_general_config* cfg, ryd_handle** ou
   return RYD_OK;
 }
 
+// device copies of the per-term tables after a term was appended
+static int gen_publish_terms(ryd_handle* h) {
+  const int n = (int)h->gen_host.size();
+  std::vector<GenTermDev> devs(n);
+  std::vector<int> ser(n), cj(n);
+  std::vector<cplx> sc(n);
+  for (int i = 0; i < n; ++i) {
+    devs[i] = h->gen_host[i].dev;
+    ser[i] = h->gen_host[i].series;
+    cj[i] = h->gen_host[i].conj;
+    sc[i] = make_double2(h->gen_host[i].scale.real(), h->gen_host[i].scale.imag());
+  }
+  HIPCHK(hipMemcpy(h->gen_terms_dev, devs.data(), n * sizeof(GenTermDev), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->gen_series_dev, ser.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->gen_conj_dev, cj.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->gen_scale_dev, sc.data(), n * sizeof(cplx), hipMemcpyHostToDevice));
+  h->bounds_valid = false;
+  return RYD_OK;
+}
+
 extern "C" int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* row_ptr,
                                     const int32_t* col, const double* val, int32_t series,
                                     int32_t conj, double scale_re, double scale_im,
@@ -67,22 +87,77 @@ extern "C" int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* r
     HIPCHK(hipMemcpy((void*)t.dev.val, val, nnz * sizeof(cplx), hipMemcpyHostToDevice));
   }
   h->gen_host.push_back(t);
-  const int n = (int)h->gen_host.size();
-  std::vector<GenTermDev> devs(n);
-  std::vector<int> ser(n), cj(n);
-  std::vector<cplx> sc(n);
-  for (int i = 0; i < n; ++i) {
-    devs[i] = h->gen_host[i].dev;
-    ser[i] = h->gen_host[i].series;
-    cj[i] = h->gen_host[i].conj;
-    sc[i] = make_double2(h->gen_host[i].scale.real(), h->gen_host[i].scale.imag());
-  }
-  HIPCHK(hipMemcpy(h->gen_terms_dev, devs.data(), n * sizeof(GenTermDev), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->gen_series_dev, ser.data(), n * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->gen_conj_dev, cj.data(), n * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->gen_scale_dev, sc.data(), n * sizeof(cplx), hipMemcpyHostToDevice));
-  h->bounds_valid = false;
-  return RYD_OK;
+  return gen_publish_terms(h);
+}
+
+// Matrix-free term  A = sum_g w_g embed(M on the digits with strides s_g[0 .. n_per))  of the vector
+// index (digit = (index / stride) % local_dim): M is (local_dim^n_per)^2, given by its non-zeros.
+extern "C" int ryd_general_add_local_term(ryd_handle* h, int32_t local_dim, int32_t n_per, int32_t n_groups,
+                                          const int64_t* strides, const double* weights, int32_t nnz,
+                                          const int32_t* rows, const int32_t* cols, const double* vals,
+                                          int32_t series, int32_t conj, double scale_re, double scale_im,
+                                          double row_norm) {
+  if (!h || !h->general) return fail(RYD_ERR_INVALID, "not a general-path handle");
+  if (!strides || !weights || !rows || !cols || !vals) return fail(RYD_ERR_INVALID, "null argument");
+  if (local_dim < 2 || local_dim > 8 || (n_per != 1 && n_per != 2) || n_groups < 1 || nnz < 1)
+    return fail(RYD_ERR_INVALID, "local term: local_dim=%d n_per=%d n_groups=%d nnz=%d out of range", local_dim,
+                n_per, n_groups, nnz);
+  if ((int)h->gen_host.size() >= MAX_GEN_TERMS)
+    return fail(RYD_ERR_INVALID, "too many terms (max %d)", MAX_GEN_TERMS);
+  if (series < -1 || series >= std::max(h->n_series, 1) || (series >= 0 && h->n_series == 0))
+    return fail(RYD_ERR_INVALID, "series index %d out of range (call ryd_set_series first)", series);
+  const int ld = n_per == 2 ? local_dim * local_dim : local_dim;
+  for (int e = 0; e < nnz; ++e)
+    if (rows[e] < 0 || rows[e] >= ld || cols[e] < 0 || cols[e] >= ld)
+      return fail(RYD_ERR_INVALID, "local term: entry %d outside the %d x %d matrix", e, ld, ld);
+  for (int g = 0; g < n_groups * n_per; ++g)
+    if (strides[g] < 1 || (size_t)strides[g] * local_dim > h->dim)
+      return fail(RYD_ERR_INVALID, "local term: stride %lld does not fit the vector", (long long)strides[g]);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  GenTermHost t;
+  t.series = series;
+  t.conj = conj;
+  t.scale = std::complex<double>(scale_re, scale_im);
+  t.row_norm = row_norm;
+  t.dev.kind = 1;
+  t.dev.d = local_dim;
+  t.dev.n_per = n_per;
+  t.dev.n_groups = n_groups;
+  t.dev.nnz = nnz;
+  std::vector<int> ent(2 * (size_t)nnz);
+  for (int e = 0; e < nnz; ++e) { ent[2 * e] = rows[e]; ent[2 * e + 1] = cols[e]; }
+  HIPCHK(hipMalloc((void**)&t.dev.strides, (size_t)n_groups * n_per * sizeof(long long)));
+  HIPCHK(hipMalloc((void**)&t.dev.weights, (size_t)n_groups * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&t.dev.ent, ent.size() * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t.dev.val, (size_t)nnz * sizeof(cplx)));
+  HIPCHK(hipMemcpy((void*)t.dev.strides, strides, (size_t)n_groups * n_per * sizeof(long long), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy((void*)t.dev.weights, weights, (size_t)n_groups * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy((void*)t.dev.ent, ent.data(), ent.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy((void*)t.dev.val, vals, (size_t)nnz * sizeof(cplx), hipMemcpyHostToDevice));
+  h->gen_host.push_back(t);
+  return gen_publish_terms(h);
+}
+
+// Matrix-free diagonal term  A = diag(values)  (complex128[dim]).
+extern "C" int ryd_general_add_diag_term(ryd_handle* h, const double* values, int32_t series, int32_t conj,
+                                         double scale_re, double scale_im, double row_norm) {
+  if (!h || !h->general) return fail(RYD_ERR_INVALID, "not a general-path handle");
+  if (!values) return fail(RYD_ERR_INVALID, "null argument");
+  if ((int)h->gen_host.size() >= MAX_GEN_TERMS)
+    return fail(RYD_ERR_INVALID, "too many terms (max %d)", MAX_GEN_TERMS);
+  if (series < -1 || series >= std::max(h->n_series, 1) || (series >= 0 && h->n_series == 0))
+    return fail(RYD_ERR_INVALID, "series index %d out of range (call ryd_set_series first)", series);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  GenTermHost t;
+  t.series = series;
+  t.conj = conj;
+  t.scale = std::complex<double>(scale_re, scale_im);
+  t.row_norm = row_norm;
+  t.dev.kind = 2;
+  HIPCHK(hipMalloc((void**)&t.dev.val, h->dim * sizeof(cplx)));
+  HIPCHK(hipMemcpy((void*)t.dev.val, values, h->dim * sizeof(cplx), hipMemcpyHostToDevice));
+  h->gen_host.push_back(t);
+  return gen_publish_terms(h);
 }
 
 static void compute_bounds_general(ryd_handle* h) {

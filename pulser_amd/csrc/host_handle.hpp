@@ -14,7 +14,7 @@ struct Pass {
 };
 
 struct GenTermHost {
-  GenTermDev dev{nullptr, nullptr, nullptr};
+  GenTermDev dev{};
   int series = -1, conj = 0;
   std::complex<double> scale{1.0, 0.0};
   double row_norm = 0.0;
@@ -410,6 +410,9 @@ extern "C" void ryd_destroy(ryd_handle* h) {
     hipFree((void*)t.dev.row_ptr);
     hipFree((void*)t.dev.col);
     hipFree((void*)t.dev.val);
+    hipFree((void*)t.dev.strides);
+    hipFree((void*)t.dev.weights);
+    hipFree((void*)t.dev.ent);
   }
   for (auto& p : h->ev_used) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }

@@ -1,13 +1,60 @@
 // Part of librydemu (included by rydemu.hip, one translation unit).
 // ---------------------------------------------------------------------------
-// General path: G(t) = sum_t coef_t(t) A_t with explicit CSR terms (any local
-// dimension; small systems).  One thread per (row, batch entry).
+// General path: G(t) = sum_t coef_t(t) A_t (any local dimension).  One thread per (row, batch
+// entry).  A term is an explicit CSR matrix, or MATRIX-FREE:
+//   local:    A = sum_g w_g embed(M on the digits with strides s_g[0..n_per))   (d x d or d^2 x d^2 M given
+//             by its non-zeros; the embedding is never formed: digit decode + at most nnz gathers per group)
+//   diagonal: A = diag(v)                                          (interaction, detuning projectors)
+// which is what every operator of the reference's Hamiltonian and collapse lists is (hamiltonian.py:97-124,
+// 246-439): sums of one- and two-site operators.
 // ---------------------------------------------------------------------------
 struct GenTermDev {
-  const int* row_ptr;
+  const int* row_ptr;   // CSR (kind 0)
   const int* col;
-  const cplx* val;
+  const cplx* val;      // CSR values | local: [nnz] values | diagonal: [dim]
+  int kind;             // 0 CSR, 1 local, 2 diagonal
+  int d, n_per, n_groups, nnz;
+  const long long* strides;  // [n_groups][n_per]
+  const double* weights;     // [n_groups]
+  const int* ent;            // [nnz][2]: (row, col) of M
 };
+
+// (A_t x)[row]
+__device__ __forceinline__ cplx gen_term_row(const GenTermDev& T, const cplx* __restrict__ x, long long row) {
+  cplx s = make_double2(0.0, 0.0);
+  if (T.kind == 0) {
+    const int lo = T.row_ptr[row], hi = T.row_ptr[row + 1];
+    for (int e = lo; e < hi; ++e) s = cfma(T.val[e], x[T.col[e]], s);
+    return s;
+  }
+  if (T.kind == 2) return cmul(T.val[row], x[row]);
+  const unsigned r32 = (unsigned)row;  // dim <= 2^26
+  const int d = T.d;
+  for (int g = 0; g < T.n_groups; ++g) {
+    const long long s0 = T.strides[(size_t)g * T.n_per];
+    const int a = (int)((r32 / (unsigned)s0) % (unsigned)d);
+    long long s1 = 0;
+    int b = 0, R = a;
+    if (T.n_per == 2) {
+      s1 = T.strides[(size_t)g * 2 + 1];
+      b = (int)((r32 / (unsigned)s1) % (unsigned)d);
+      R = a * d + b;
+    }
+    cplx sg = make_double2(0.0, 0.0);
+    for (int e = 0; e < T.nnz; ++e) {
+      if (T.ent[2 * e] != R) continue;
+      const int Cc = T.ent[2 * e + 1];
+      long long j;
+      if (T.n_per == 2) j = row + (long long)(Cc / d - a) * s0 + (long long)(Cc % d - b) * s1;
+      else j = row + (long long)(Cc - a) * s0;
+      sg = cfma(T.val[e], x[j], sg);
+    }
+    const double w = T.weights[g];
+    s.x = fma(w, sg.x, s.x);
+    s.y = fma(w, sg.y, s.y);
+  }
+  return s;
+}
 
 #define MAX_GEN_TERMS 96
 
@@ -53,10 +100,7 @@ __global__ __launch_bounds__(256) void k_gen_apply(const GenArgs A) {
   cplx acc = make_double2(0.0, 0.0);
   for (int t = 0; t < A.n_terms; ++t) {
     const GenTermDev T = A.terms[t];
-    const int lo = T.row_ptr[row], hi = T.row_ptr[row + 1];
-    cplx s = make_double2(0.0, 0.0);
-    for (int e = lo; e < hi; ++e) s = cfma(T.val[e], x[T.col[e]], s);
-    acc = cfma(A.tcoef[t], s, acc);
+    acc = cfma(A.tcoef[t], gen_term_row(T, x, row), acc);
   }
   cplx r = make_double2(A.scale * acc.x, A.scale * acc.y);
   if (A.base) {
@@ -149,10 +193,7 @@ __global__ __launch_bounds__(1024) void k_gen_traj(const GenTrajArgs A) {
           cplx acc = make_double2(0.0, 0.0);
           for (int t = 0; t < A.n_terms; ++t) {
             const GenTermDev T = A.terms[t];
-            const int lo = T.row_ptr[row], hi = T.row_ptr[row + 1];
-            cplx sum = make_double2(0.0, 0.0);
-            for (int e = lo; e < hi; ++e) sum = cfma(T.val[e], rd[T.col[e]], sum);
-            acc = cfma(tc[t], sum, acc);
+            acc = cfma(tc[t], gen_term_row(T, rd, row), acc);
           }
           w[j] = make_double2(fma(sc, acc.x, psi[j].x), fma(sc, acc.y, psi[j].y));
         }

@@ -450,6 +450,24 @@ class GeneralEngine:
         _lib.check(self.lib.ryd_set_series(self._h, pp.shape[0], len(tk), tk.ctypes.data,
                                            pp.ctypes.data))
         for i in range(len(tables.values)):
+            free = tables.free[i] if getattr(tables, "free", None) is not None else None
+            tail = (int(tables.series[i]), int(tables.conj[i]), float(tables.scale[i].real),
+                    float(tables.scale[i].imag), float(tables.row_norm[i]))
+            if free is not None and free[0] == "diag":
+                v = np.ascontiguousarray(free[1], dtype=np.complex128)
+                _lib.check(self.lib.ryd_general_add_diag_term(self._h, v.ctypes.data, *tail))
+                continue
+            if free is not None:
+                _, d, p, st, w, rr, cc, vals = free
+                st = np.ascontiguousarray(st, dtype=np.int64)
+                w = np.ascontiguousarray(w, dtype=np.float64)
+                rr = np.ascontiguousarray(rr, dtype=np.int32)
+                cc = np.ascontiguousarray(cc, dtype=np.int32)
+                vals = np.ascontiguousarray(vals, dtype=np.complex128)
+                _lib.check(self.lib.ryd_general_add_local_term(
+                    self._h, int(d), int(p), len(w), st.ctypes.data, w.ctypes.data, len(vals), rr.ctypes.data,
+                    cc.ctypes.data, vals.ctypes.data, *tail))
+                continue
             rp, ci, va = tables.row_ptr[i], tables.col_idx[i], tables.values[i]
             _lib.check(self.lib.ryd_general_add_term(
                 self._h, len(va), rp.ctypes.data, ci.ctypes.data if len(va) else None,

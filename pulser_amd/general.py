@@ -1,14 +1,20 @@
-"""General (any local dimension) lowering: explicit sparse terms for small systems.
+"""General (any local dimension) lowering: a term list ``G(t) = sum_t coef_t(t) A_t``.
 
-The tuned matrix-free kernels cover the 2-level Ising problems that dominate
-the workload sizes of BASELINE.json.  Everything else the reference's
-``Hamiltonian`` can express - the 3-level ``"all"`` basis, leakage
-(``*_with_error``, d = 3/4), XY mode incl. the SLM-mask switching terms, and
-arbitrary ``eff_noise`` collapse operators - is lowered here to an explicit
-list ``G(t) = sum_t coef_t(t) A_t`` of CSR matrices with spline coefficients
-and integrated on the GPU by the same CF4/Taylor stepper through the
-``ryd_general_*`` entry points (a row-per-thread CSR kernel; these systems are
-small: d**N, or d**2N for the Liouvillian).
+The tuned kernels cover the 2-level Ising problems that dominate the workload
+sizes of BASELINE.json.  Everything else the reference's ``Hamiltonian`` can
+express - the 3-level ``"all"`` basis, leakage (``*_with_error``, d = 3/4), XY
+mode incl. the SLM-mask switching terms, and arbitrary ``eff_noise`` collapse
+operators - is lowered here and integrated on the GPU by the same CF4/Taylor
+stepper through the ``ryd_general_*`` entry points.
+
+``matrix_free=True`` (default): every operator of the reference's lists is a sum
+of one- and two-site operators or a diagonal, and is handed over AS THAT - a
+d x d or d^2 x d^2 matrix with the digit strides and weights of the sites it acts
+on (``ryd_general_add_local_term``), or a dense diagonal
+(``ryd_general_add_diag_term``); the kernel decodes the digits of a row and
+gathers.  Nothing of size d^N x nnz is built on the host or stored on the device.
+``matrix_free=False``: the same generator as explicit CSR matrices (the round-1
+path, kept as the cross-check).
 
 Term structure restated from
 pulser-simulation/pulser_simulation/hamiltonian.py:246-439 (Hamiltonian) and
@@ -52,6 +58,21 @@ class GeneralTables:
     conj: np.ndarray  # int32[n_terms]
     scale: np.ndarray  # complex128[n_terms]
     row_norm: np.ndarray  # float64[n_terms]: max abs row sum
+    # matrix-free terms (None entries of row_ptr / col_idx / values mark them): per term None (CSR) or
+    # ("diag", complex128[dim]) or ("local", d, n_per, int64[G, n_per] strides, float64[G] weights,
+    #  int32[nnz] rows, int32[nnz] cols, complex128[nnz] vals)
+    free: list | None = None
+
+
+@dataclass
+class _LocalSum:
+    """sum_g w_g embed(M on the sites of group g); sites are digit positions of the evolved vector."""
+
+    mat: np.ndarray  # (d^p, d^p)
+    groups: list  # [(sites tuple of length p, weight)]
+
+    def dagger(self) -> "_LocalSum":
+        return _LocalSum(self.mat.conj().T, self.groups)
 
 
 def _local_ops(eigenbasis: Sequence[str]) -> dict[str, np.ndarray]:
@@ -74,7 +95,225 @@ def _embed(n: int, d: int, factors: Mapping[int, np.ndarray]) -> sp.csr_matrix:
     return out
 
 
-def lower_general(problem: Mapping[str, Any], mesolve: bool) -> GeneralTables:
+def lower_general(problem: Mapping[str, Any], mesolve: bool, matrix_free: bool = True) -> GeneralTables:
+    if matrix_free:
+        tables = _lower_matrix_free(problem, mesolve)
+        if tables is not None:
+            return tables
+    return _lower_csr(problem, mesolve)
+
+
+def _spline_pp(tknots: np.ndarray, series_knots: list) -> np.ndarray:
+    pp = np.empty((len(series_knots), len(tknots) - 1, 4), dtype=np.complex128)
+    for i, kn in enumerate(series_knots):
+        pp[i] = np.transpose(CubicSpline(tknots, kn, bc_type="not-a-knot").c, (1, 0))
+    return pp
+
+
+def _lower_matrix_free(problem: Mapping[str, Any], mesolve: bool) -> GeneralTables | None:
+    """The term list of :func:`_lower_csr` without materialising any operator: Hamiltonian terms
+    (hamiltonian.py:246-439) as site sums / pair sums / diagonals, the Liouvillian
+    ``-i (H (x) I - I (x) H^T)`` as the same sums on the row and the column digits of row-major
+    vec(rho), the dissipator (hamiltonian.py:97-124) as ONE d^2 x d^2 superoperator on the digit
+    pairs (row_k, col_k)."""
+    n = int(problem["n_qudits"])
+    eigenbasis = list(problem["eigenbasis"])
+    d = len(eigenbasis)
+    D = d**n
+    n_dig = 2 * n if mesolve else n
+    dim = D * D if mesolve else D
+    if dim > (1 << 26):
+        raise NotImplementedError(f"The general (multi-level / XY) path evolves vectors of at most 2^26 "
+                                  f"entries; this system needs {dim}.")
+    ops = _local_ops(eigenbasis)
+    duration = int(problem["duration"])
+    rate = float(problem.get("sampling_rate", 1.0))
+    tknots = sampling_times(duration, rate)
+    bad = np.asarray(problem.get("bad_atoms", np.zeros(n, bool)), dtype=bool)
+    imat = np.asarray(problem["interaction_matrix"], dtype=float)
+    is_xy = problem.get("interaction_type", "ising") == "XY"
+    slm_end = int(problem.get("slm_end", 0))
+    slm_targets = set(problem.get("slm_targets", ()))
+    basis_name = problem["basis_name"]
+    stride = [d ** (n_dig - 1 - p) for p in range(n_dig)]  # digit position -> stride
+
+    def adapt(x: np.ndarray) -> np.ndarray:
+        return adapt_to_sampling_rate(x, rate, duration)
+
+    def digits(pos: int) -> np.ndarray:
+        return (np.arange(dim, dtype=np.int64) // stride[pos]) % d
+
+    # -- Hamiltonian as (object, knots | None); object = _LocalSum or ("diag", real vector over D) --
+    h_terms: list[tuple[Any, np.ndarray | None]] = []
+
+    def interaction(masked: bool = False) -> list:
+        out: list = []
+        if masked:
+            eff = n - int(bad.sum()) - sum(1 for q in slm_targets if not bad[q])
+            if eff < 2:
+                return out
+        pairs = [(i, j) for i, j in itertools.combinations(range(n), 2)
+                 if not (bad[i] or bad[j]) and not (masked and is_xy and (i in slm_targets or j in slm_targets))]
+        if not pairs:
+            return out
+        if is_xy:  # hamiltonian.py:276-294: op = sum_ij imat0 ud_i du_j + 0.5 imat1 uu_i uu_j  (H = op + op^dag)
+            out.append(_LocalSum(np.kron(ops["sigma_ud"], ops["sigma_du"]), [((i, j), imat[0, i, j]) for i, j in pairs]))
+            if np.any([imat[1, i, j] != 0 for i, j in pairs]):
+                out.append(_LocalSum(np.kron(ops["sigma_uu"], ops["sigma_uu"]),
+                                     [((i, j), 0.5 * imat[1, i, j]) for i, j in pairs]))
+        else:  # :260-274: 0.5 U_ij rr_i rr_j, doubled by op + op^dag: a diagonal
+            r = eigenbasis.index("r")
+            nD = [(np.arange(D, dtype=np.int64) // d ** (n - 1 - k)) % d == r for k in range(n)]
+            e = np.zeros(D)
+            for i, j in pairs:
+                e += 0.5 * imat[-1, i, j] * (nD[i] & nD[j])
+            out.append(("diag", e))
+        return out
+
+    if "digital" not in basis_name and (n - int(bad.sum())) > 1:  # :393-424
+        if slm_end > 0 and is_xy:
+            coeff = np.ones(duration - 1)
+            coeff[0:slm_end] = 0
+            h_terms += [(o, adapt(coeff)) for o in interaction()]
+            h_terms += [(o, adapt(np.logical_not(coeff).astype(int))) for o in interaction(masked=True)]
+        else:
+            h_terms += [(o, None) for o in interaction()]
+    samples = problem["samples"]
+    for addr in samples:  # :427-431
+        for basis, s in samples[addr].items():
+            if not s:
+                continue
+            op_ids = _OP_IDS[basis]
+            entries = [(None, s)] if addr == "Global" else [(int(q), sq) for q, sq in s.items()]
+            for q, sq in entries:
+                coeffs = [0.5 * np.asarray(sq["amp"]) * np.exp(-1j * np.asarray(sq["phase"])),
+                          -0.5 * np.asarray(sq["det"])]
+                for op_id, coeff in zip(op_ids, coeffs):
+                    if not np.any(coeff != 0):
+                        continue
+                    sites = range(n) if q is None else [q]
+                    h_terms.append((_LocalSum(ops[op_id], [((k,), 1.0) for k in sites]), adapt(coeff)))
+
+    # -- generator terms: (payload, series index | -1, conj) --
+    terms: list[tuple[tuple, int, int, float]] = []
+    series_knots: list[np.ndarray] = []
+
+    def local_payload(ls: _LocalSum, factor: complex, col_side: bool) -> tuple[tuple, float]:
+        """factor * sum_g w_g embed(M) on the row digits, or factor * embed(M^T) on the column digits."""
+        m = ls.mat.T if col_side else ls.mat
+        p = len(ls.groups[0][0])
+        rr, cc = np.nonzero(m)
+        if len(rr) == 0:
+            return (), 0.0
+        shift = n if col_side else 0
+        st = np.array([[stride[site + shift] for site in sites] for sites, _ in ls.groups], dtype=np.int64)
+        w = np.array([wt for _, wt in ls.groups], dtype=np.float64)
+        vals = (factor * m[rr, cc]).astype(np.complex128)
+        norm = float(np.abs(w).sum() * np.abs(factor * m).sum(axis=1).max())
+        return ("local", d, p, st, w, rr.astype(np.int32), cc.astype(np.int32), vals), norm
+
+    def add_generator(obj: Any, series: int, conj: int, dagger: bool) -> None:
+        """-i obj (kets) or -i [obj, .] (vec rho); `dagger`: of obj^dag."""
+        if isinstance(obj, tuple):  # real diagonal: its own adjoint
+            e = obj[1]
+            if mesolve:
+                v = -1j * (np.repeat(e, D) - np.tile(e, D))
+            else:
+                v = -1j * e
+            terms.append((("diag", np.ascontiguousarray(v, dtype=np.complex128)), series, conj, float(np.abs(v).max())))
+            return
+        ls = obj.dagger() if dagger else obj
+        pay, norm = local_payload(ls, -1j, False)
+        if pay:
+            terms.append((pay, series, conj, norm))
+        if mesolve:
+            pay, norm = local_payload(ls, 1j, True)
+            if pay:
+                terms.append((pay, series, conj, norm))
+
+    for obj, knots in h_terms:
+        if knots is None:
+            si = -1
+        else:
+            series_knots.append(np.asarray(knots, dtype=complex))
+            si = len(series_knots) - 1
+        if isinstance(obj, tuple):
+            # op + op^dag of a real diagonal with a (real) coefficient: 2 * diag, coefficient conj-invariant
+            add_generator(("diag", 2.0 * obj[1]), si, 0, False)
+        else:
+            add_generator(obj, si, 0, False)
+            add_generator(obj, si, 1, True)
+
+    if mesolve:
+        # D[rho] = sum_c  c rho c^dag - 1/2 {c^dag c, rho}: per atom the same d^2 x d^2 superoperator on the
+        # digit pair (row_k, col_k): L (x) conj(L) - 1/2 (L^dag L (x) I) - 1/2 (I (x) (L^dag L)^T)
+        paulis = problem.get("depolarizing_pauli_2ds", {})
+        sup = np.zeros((d * d, d * d), dtype=complex)
+        eye_d = np.eye(d)
+        for coeff, cop in problem.get("collapse_ops", []):
+            if isinstance(cop, str):
+                local = coeff * ops[cop] if cop in ops else sum(coeff * pc * ops[po] for pc, po in paulis[cop])
+            else:
+                local = coeff * np.asarray(cop, dtype=complex)
+            ldl = local.conj().T @ local
+            sup += np.kron(local, local.conj()) - 0.5 * np.kron(ldl, eye_d) - 0.5 * np.kron(eye_d, ldl.T)
+        if np.any(sup != 0):
+            ls = _LocalSum(sup, [((k, n + k), 1.0) for k in range(n)])
+            rr, cc = np.nonzero(sup)
+            st = np.array([[stride[k], stride[n + k]] for k in range(n)], dtype=np.int64)
+            pay = ("local", d, 2, st, np.ones(n), rr.astype(np.int32), cc.astype(np.int32),
+                   sup[rr, cc].astype(np.complex128))
+            terms.append((pay, -1, 0, float(n * np.abs(sup).sum(axis=1).max())))
+            del ls
+    if len(terms) > 96:  # MAX_GEN_TERMS of the library: fall back to merged CSR terms
+        return None
+    if not terms:
+        terms.append((("diag", np.zeros(dim, dtype=np.complex128)), -1, 0, 0.0))
+    if not series_knots:
+        series_knots.append(np.zeros(len(tknots), dtype=complex))
+    nt = len(terms)
+    return GeneralTables(
+        dim=dim, n_qudits=n, local_dim=d, is_density=mesolve,
+        tknots=np.ascontiguousarray(tknots, dtype=np.float64), pp=np.ascontiguousarray(_spline_pp(tknots, series_knots)),
+        row_ptr=[None] * nt, col_idx=[None] * nt, values=[None] * nt,
+        series=np.asarray([t[1] for t in terms], dtype=np.int32), conj=np.asarray([t[2] for t in terms], dtype=np.int32),
+        scale=np.ones(nt, dtype=np.complex128), row_norm=np.asarray([t[3] for t in terms], dtype=np.float64),
+        free=[t[0] for t in terms],
+    )
+
+
+def dense_generator(tables: GeneralTables, coefs: Sequence[complex]) -> np.ndarray:
+    """sum_t coefs[t] A_t as a dense matrix (tests: the matrix-free terms against the CSR ones)."""
+    out = np.zeros((tables.dim, tables.dim), dtype=complex)
+    idx = np.arange(tables.dim, dtype=np.int64)
+    for t in range(len(tables.values)):
+        free = tables.free[t] if tables.free is not None else None
+        if free is None:
+            m = sp.csr_matrix((tables.values[t], tables.col_idx[t], tables.row_ptr[t]), shape=out.shape)
+            out += coefs[t] * m.toarray()
+        elif free[0] == "diag":
+            out[idx, idx] += coefs[t] * free[1]
+        else:
+            _, d, p, st, w, rr, cc, vals = free
+            for g in range(len(w)):
+                a = (idx // st[g, 0]) % d
+                if p == 2:
+                    b = (idx // st[g, 1]) % d
+                    R = a * d + b
+                else:
+                    b = 0
+                    R = a
+                for e in range(len(vals)):
+                    rows = idx[R == rr[e]]
+                    if p == 2:
+                        cols = rows + (cc[e] // d - a[rows]) * st[g, 0] + (cc[e] % d - b[rows]) * st[g, 1]
+                    else:
+                        cols = rows + (cc[e] - a[rows]) * st[g, 0]
+                    np.add.at(out, (rows, cols), coefs[t] * w[g] * vals[e])
+    return out
+
+
+def _lower_csr(problem: Mapping[str, Any], mesolve: bool) -> GeneralTables:
     n = int(problem["n_qudits"])
     eigenbasis = list(problem["eigenbasis"])
     d = len(eigenbasis)
@@ -82,7 +321,7 @@ def lower_general(problem: Mapping[str, Any], mesolve: bool) -> GeneralTables:
     dim = D * D if mesolve else D
     if dim > MAX_DIM:
         raise NotImplementedError(
-            f"The general (multi-level / XY) path materialises sparse operators of size "
+            f"The explicit-CSR lowering materialises sparse operators of size "
             f"{dim}; systems beyond {MAX_DIM} entries are not supported."
         )
     ops = _local_ops(eigenbasis)
@@ -191,9 +430,7 @@ def lower_general(problem: Mapping[str, Any], mesolve: bool) -> GeneralTables:
         mats.append(sp.csr_matrix((dim, dim), dtype=complex)); series_idx.append(-1); conj.append(0)
     if not series_knots:
         series_knots.append(np.zeros(len(tknots), dtype=complex))
-    pp = np.empty((len(series_knots), len(tknots) - 1, 4), dtype=np.complex128)
-    for i, kn in enumerate(series_knots):
-        pp[i] = np.transpose(CubicSpline(tknots, kn, bc_type="not-a-knot").c, (1, 0))
+    pp = _spline_pp(tknots, series_knots)
     row_ptr, col_idx, values, norms = [], [], [], []
     for m in mats:
         m = m.tocsr()
