@@ -124,16 +124,50 @@ extern "C" int ryd_general_add_local_term(ryd_handle* h, int32_t local_dim, int3
   t.dev.n_per = n_per;
   t.dev.n_groups = n_groups;
   t.dev.nnz = nnz;
-  std::vector<int> ent(2 * (size_t)nnz);
-  for (int e = 0; e < nnz; ++e) { ent[2 * e] = rows[e]; ent[2 * e + 1] = cols[e]; }
+  // digits of the vector index: dim = local_dim^n_dig
+  int n_dig = 0;
+  for (size_t v = 1; v < h->dim; v *= (size_t)local_dim) ++n_dig;
+  {
+    size_t v = 1;
+    for (int i = 0; i < n_dig; ++i) v *= (size_t)local_dim;
+    if (v != h->dim) return fail(RYD_ERR_INVALID, "local term: dim is not a power of local_dim=%d", local_dim);
+  }
+  if (h->gen_d && h->gen_d != local_dim)
+    return fail(RYD_ERR_INVALID, "local term: local_dim=%d differs from the earlier terms' %d", local_dim, h->gen_d);
+  const int bits = local_dim <= 4 ? 2 : 4;
+  if (n_dig * bits > 64) return fail(RYD_ERR_UNSUPPORTED, "local term: %d digits do not fit the packed row digits", n_dig);
+  std::vector<int> shifts((size_t)n_groups * n_per);
+  for (int g = 0; g < n_groups * n_per; ++g) {
+    int p = 0;
+    int64_t v = 1;
+    while (v < strides[g]) { v *= local_dim; ++p; }
+    if (v != strides[g]) return fail(RYD_ERR_INVALID, "local term: stride %lld is not a power of local_dim", (long long)strides[g]);
+    shifts[g] = p * bits;
+  }
+  // entries sorted by the row of M, with row starts
+  std::vector<int> order(nnz), rstart(ld + 1, 0), ecol(nnz);
+  for (int e = 0; e < nnz; ++e) { order[e] = e; rstart[rows[e] + 1]++; }
+  for (int r = 0; r < ld; ++r) rstart[r + 1] += rstart[r];
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rows[a] < rows[b]; });
+  std::vector<cplx> sval(nnz);
+  for (int e = 0; e < nnz; ++e) {
+    ecol[e] = cols[order[e]];
+    sval[e] = make_double2(vals[2 * order[e]], vals[2 * order[e] + 1]);
+  }
   HIPCHK(hipMalloc((void**)&t.dev.strides, (size_t)n_groups * n_per * sizeof(long long)));
+  HIPCHK(hipMalloc((void**)&t.dev.shifts, shifts.size() * sizeof(int)));
   HIPCHK(hipMalloc((void**)&t.dev.weights, (size_t)n_groups * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&t.dev.ent, ent.size() * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t.dev.rstart, rstart.size() * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&t.dev.ecol, (size_t)nnz * sizeof(int)));
   HIPCHK(hipMalloc((void**)&t.dev.val, (size_t)nnz * sizeof(cplx)));
   HIPCHK(hipMemcpy((void*)t.dev.strides, strides, (size_t)n_groups * n_per * sizeof(long long), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy((void*)t.dev.shifts, shifts.data(), shifts.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy((void*)t.dev.weights, weights, (size_t)n_groups * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy((void*)t.dev.ent, ent.data(), ent.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy((void*)t.dev.val, vals, (size_t)nnz * sizeof(cplx), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy((void*)t.dev.rstart, rstart.data(), rstart.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy((void*)t.dev.ecol, ecol.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy((void*)t.dev.val, sval.data(), (size_t)nnz * sizeof(cplx), hipMemcpyHostToDevice));
+  h->gen_d = local_dim;
+  h->gen_ndig = n_dig;
   h->gen_host.push_back(t);
   return gen_publish_terms(h);
 }
@@ -194,6 +228,8 @@ static int apply_general(ryd_handle* h, const MixPoint& m, const cplx* in, const
   A.terms = h->gen_terms_dev;
   A.dim = (long long)h->dim;
   A.n_terms = n;
+  A.d = h->gen_d;
+  A.n_dig = h->gen_ndig;
   A.scale = scale;
   dim3 grid((unsigned)((h->dim + 255) / 256), h->B);
   hipLaunchKernelGGL(k_gen_apply, grid, dim3(256), 0, st, A);

@@ -74,6 +74,7 @@ struct ryd_handle {
   // general path (explicit CSR terms)
   bool general = false;
   std::vector<GenTermHost> gen_host;
+  int gen_d = 0, gen_ndig = 0;  // local dimension / digits of the vector index (matrix-free terms)
   cplx* gen_tcoef = nullptr;
   GenTermDev* gen_terms_dev = nullptr;
   int* gen_series_dev = nullptr;
@@ -411,8 +412,10 @@ extern "C" void ryd_destroy(ryd_handle* h) {
     hipFree((void*)t.dev.col);
     hipFree((void*)t.dev.val);
     hipFree((void*)t.dev.strides);
+    hipFree((void*)t.dev.shifts);
     hipFree((void*)t.dev.weights);
-    hipFree((void*)t.dev.ent);
+    hipFree((void*)t.dev.rstart);
+    hipFree((void*)t.dev.ecol);
   }
   for (auto& p : h->ev_used) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }

@@ -348,6 +348,8 @@ static int run_persistent_general(ryd_handle* h, cplx* state, const std::vector<
   A.n_steps = (int)sched.size();
   A.n_terms = (int)h->gen_host.size();
   A.dim = (int)h->dim;
+  A.d = h->gen_d;
+  A.n_dig = h->gen_ndig;
   A.a1 = kA1;
   A.a2 = kA2;
   const size_t lds = 2 * 4096 * sizeof(cplx) + 2 * MAX_GEN_TERMS * sizeof(cplx);

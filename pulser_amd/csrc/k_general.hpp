@@ -11,16 +11,40 @@
 struct GenTermDev {
   const int* row_ptr;   // CSR (kind 0)
   const int* col;
-  const cplx* val;      // CSR values | local: [nnz] values | diagonal: [dim]
+  const cplx* val;      // CSR values | local: [nnz] values sorted by row of M | diagonal: [dim]
   int kind;             // 0 CSR, 1 local, 2 diagonal
   int d, n_per, n_groups, nnz;
   const long long* strides;  // [n_groups][n_per]
+  const int* shifts;         // [n_groups][n_per]: bit position of the digit in the packed digits of a row
   const double* weights;     // [n_groups]
-  const int* ent;            // [nnz][2]: (row, col) of M
+  const int* rstart;         // [d^n_per + 1]: entries of row R of M are rstart[R] .. rstart[R + 1]
+  const int* ecol;           // [nnz]: their columns
 };
 
+// The base-d digits of a row, packed (2 bits per digit for d <= 4, else 4): digit p (0 = most
+// significant of n_dig) sits at bit (n_dig - 1 - p) * bits.  Done once per row - in the one-launch
+// kernel once per kernel.
+__device__ __forceinline__ unsigned long long gen_pack_digits(long long row, int d, int n_dig) {
+  unsigned r = (unsigned)row;  // dim <= 2^26
+  const int bits = d <= 4 ? 2 : 4;
+  unsigned long long packed = 0;
+  for (int p = 0; p < n_dig; ++p) {  // least significant digit first
+    unsigned q, a;
+    switch (d) {
+      case 2: q = r >> 1; a = r & 1u; break;
+      case 3: q = r / 3u; a = r - 3u * q; break;
+      case 4: q = r >> 2; a = r & 3u; break;
+      default: q = r / (unsigned)d; a = r - (unsigned)d * q; break;
+    }
+    packed |= (unsigned long long)a << (p * bits);
+    r = q;
+  }
+  return packed;
+}
+
 // (A_t x)[row]
-__device__ __forceinline__ cplx gen_term_row(const GenTermDev& T, const cplx* __restrict__ x, long long row) {
+__device__ __forceinline__ cplx gen_term_row(const GenTermDev& T, const cplx* __restrict__ x, long long row,
+                                             unsigned long long digits) {
   cplx s = make_double2(0.0, 0.0);
   if (T.kind == 0) {
     const int lo = T.row_ptr[row], hi = T.row_ptr[row + 1];
@@ -28,25 +52,29 @@ __device__ __forceinline__ cplx gen_term_row(const GenTermDev& T, const cplx* __
     return s;
   }
   if (T.kind == 2) return cmul(T.val[row], x[row]);
-  const unsigned r32 = (unsigned)row;  // dim <= 2^26
   const int d = T.d;
+  const unsigned mask = d <= 4 ? 3u : 15u;
   for (int g = 0; g < T.n_groups; ++g) {
-    const long long s0 = T.strides[(size_t)g * T.n_per];
-    const int a = (int)((r32 / (unsigned)s0) % (unsigned)d);
-    long long s1 = 0;
+    const int a = (int)((digits >> T.shifts[g * T.n_per]) & mask);
     int b = 0, R = a;
+    long long s0 = T.strides[(size_t)g * T.n_per], s1 = 0;
     if (T.n_per == 2) {
+      b = (int)((digits >> T.shifts[g * 2 + 1]) & mask);
       s1 = T.strides[(size_t)g * 2 + 1];
-      b = (int)((r32 / (unsigned)s1) % (unsigned)d);
       R = a * d + b;
     }
+    const int lo = T.rstart[R], hi = T.rstart[R + 1];
+    if (lo == hi) continue;
     cplx sg = make_double2(0.0, 0.0);
-    for (int e = 0; e < T.nnz; ++e) {
-      if (T.ent[2 * e] != R) continue;
-      const int Cc = T.ent[2 * e + 1];
+    for (int e = lo; e < hi; ++e) {
+      const int Cc = T.ecol[e];
       long long j;
-      if (T.n_per == 2) j = row + (long long)(Cc / d - a) * s0 + (long long)(Cc % d - b) * s1;
-      else j = row + (long long)(Cc - a) * s0;
+      if (T.n_per == 2) {
+        const int c0 = Cc / d;
+        j = row + (long long)(c0 - a) * s0 + (long long)(Cc - c0 * d - b) * s1;
+      } else {
+        j = row + (long long)(Cc - a) * s0;
+      }
       sg = cfma(T.val[e], x[j], sg);
     }
     const double w = T.weights[g];
@@ -66,6 +94,7 @@ struct GenArgs {
   const GenTermDev* terms;
   long long dim;
   int n_terms;
+  int d, n_dig;  // local dimension and digits of the vector index (0 when every term is CSR)
   double scale;
 };
 
@@ -98,9 +127,10 @@ __global__ __launch_bounds__(256) void k_gen_apply(const GenArgs A) {
   const size_t boff = (size_t)blockIdx.y * A.dim;
   const cplx* __restrict__ x = A.in + boff;
   cplx acc = make_double2(0.0, 0.0);
+  const unsigned long long digits = A.d ? gen_pack_digits(row, A.d, A.n_dig) : 0ull;
   for (int t = 0; t < A.n_terms; ++t) {
     const GenTermDev T = A.terms[t];
-    acc = cfma(A.tcoef[t], gen_term_row(T, x, row), acc);
+    acc = cfma(A.tcoef[t], gen_term_row(T, x, row, digits), acc);
   }
   cplx r = make_double2(A.scale * acc.x, A.scale * acc.y);
   if (A.base) {
@@ -128,6 +158,7 @@ struct GenTrajArgs {
   const GenTermDev* terms;
   const StepDesc* steps;
   int n_int, n_steps, n_terms, dim;
+  int d, n_dig;
   double a1, a2;
 };
 
@@ -142,10 +173,12 @@ __global__ __launch_bounds__(1024) void k_gen_traj(const GenTrajArgs A) {
   const int dim = A.dim;
 
   cplx psi[R];
+  unsigned long long digits[R];  // of this thread's rows: decoded once for the whole schedule
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int row = tid + j * NTT;
     psi[j] = row < dim ? A.state[row] : make_double2(0.0, 0.0);
+    digits[j] = (A.d && row < dim) ? gen_pack_digits(row, A.d, A.n_dig) : 0ull;
   }
   for (int s = 0; s < A.n_steps; ++s) {
     const StepDesc sd = A.steps[s];
@@ -193,7 +226,7 @@ __global__ __launch_bounds__(1024) void k_gen_traj(const GenTrajArgs A) {
           cplx acc = make_double2(0.0, 0.0);
           for (int t = 0; t < A.n_terms; ++t) {
             const GenTermDev T = A.terms[t];
-            acc = cfma(tc[t], gen_term_row(T, rd, row), acc);
+            acc = cfma(tc[t], gen_term_row(T, rd, row, digits[j]), acc);
           }
           w[j] = make_double2(fma(sc, acc.x, psi[j].x), fma(sc, acc.y, psi[j].y));
         }

@@ -7,14 +7,14 @@ mode incl. the SLM-mask switching terms, and arbitrary ``eff_noise`` collapse
 operators - is lowered here and integrated on the GPU by the same CF4/Taylor
 stepper through the ``ryd_general_*`` entry points.
 
-``matrix_free=True`` (default): every operator of the reference's lists is a sum
+``matrix_free=True`` (the default from 2^18 amplitudes on): every operator of the reference's lists is a sum
 of one- and two-site operators or a diagonal, and is handed over AS THAT - a
 d x d or d^2 x d^2 matrix with the digit strides and weights of the sites it acts
 on (``ryd_general_add_local_term``), or a dense diagonal
 (``ryd_general_add_diag_term``); the kernel decodes the digits of a row and
 gathers.  Nothing of size d^N x nnz is built on the host or stored on the device.
-``matrix_free=False``: the same generator as explicit CSR matrices (the round-1
-path, kept as the cross-check).
+``matrix_free=False`` (the default below that): the same generator as explicit CSR
+matrices - faster for the small systems of the reference's tests, and the cross-check.
 
 Term structure restated from
 pulser-simulation/pulser_simulation/hamiltonian.py:246-439 (Hamiltonian) and
@@ -95,7 +95,17 @@ def _embed(n: int, d: int, factors: Mapping[int, np.ndarray]) -> sp.csr_matrix:
     return out
 
 
-def lower_general(problem: Mapping[str, Any], mesolve: bool, matrix_free: bool = True) -> GeneralTables:
+MATRIX_FREE_FROM = 1 << 18  # evolved-vector length from which the matrix-free terms are the default
+
+
+def lower_general(problem: Mapping[str, Any], mesolve: bool, matrix_free: bool | None = None) -> GeneralTables:
+    """``matrix_free=None``: explicit CSR terms for small systems (every case of the reference's tests is
+    <= 4096 entries, where precomputed indices beat the digit decode: measured 16 vs 34 ms at 19 683
+    amplitudes), matrix-free terms from 2^18 entries on, where building and storing the operators
+    (``scipy.sparse.kron``: 40x the lowering time already at 3^9) is what limits the size."""
+    if matrix_free is None:
+        d, n = len(problem["eigenbasis"]), int(problem["n_qudits"])
+        matrix_free = d ** (2 * n if mesolve else n) >= MATRIX_FREE_FROM
     if matrix_free:
         tables = _lower_matrix_free(problem, mesolve)
         if tables is not None:

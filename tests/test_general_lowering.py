@@ -95,6 +95,7 @@ def test_matrix_free_lowering_has_no_size_limit_of_the_operator():
     """3-level register of 9 atoms (19 683 amplitudes): the CSR lowering would build kron products; the
     matrix-free one only produces (d x d) matrices, strides and one diagonal."""
     prob, _ = load_fixture("noises_all_0.npz")
-    free = lower_general(prob, False)
+    free = lower_general(prob, False, matrix_free=True)
+    assert lower_general(prob, False).free is None  # small systems default to explicit CSR terms
     sizes = sum(f[1].nbytes if f[0] == "diag" else f[7].nbytes + f[3].nbytes for f in free.free)
     assert sizes < 64 * free.dim  # a few vectors at most
