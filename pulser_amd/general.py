@@ -25,6 +25,7 @@ pulser-simulation/pulser_simulation/hamiltonian.py:246-439 (Hamiltonian) and
 from __future__ import annotations
 
 import itertools
+import os
 from dataclasses import dataclass
 from typing import Any, Mapping, Sequence
 
@@ -105,7 +106,10 @@ def lower_general(problem: Mapping[str, Any], mesolve: bool, matrix_free: bool |
     (``scipy.sparse.kron``: 40x the lowering time already at 3^9) is what limits the size."""
     if matrix_free is None:
         d, n = len(problem["eigenbasis"]), int(problem["n_qudits"])
-        matrix_free = d ** (2 * n if mesolve else n) >= MATRIX_FREE_FROM
+        # RYD_GENERAL_MATRIX_FREE=1: every general-path solve on the matrix-free terms (how the end-to-end
+        # golden tests are run through them: RYD_GENERAL_MATRIX_FREE=1 pytest tests/test_gpu_emulator.py -m gpu)
+        matrix_free = (d ** (2 * n if mesolve else n) >= MATRIX_FREE_FROM
+                       or os.environ.get("RYD_GENERAL_MATRIX_FREE") == "1")
     if matrix_free:
         tables = _lower_matrix_free(problem, mesolve)
         if tables is not None:
