@@ -196,3 +196,26 @@ def test_split_large_ket_against_the_product_state_solution():
         assert np.max(np.abs(got - ref)) < 1e-10
         import torch
         assert abs(float(torch.linalg.vector_norm(st).item()) - 1.0) < 1e-12
+
+
+def test_split_controller_shrinks_the_step_for_strong_interactions():
+    """Atoms at 4.5 um (nearest-neighbour interaction ~650 rad/us, 50x the drive): one sub-step per knot
+    would be far too long; the controller finds that out from its own measurements (incl. restores of the
+    checkpoint) and still ends on the Taylor solution."""
+    n, T = 10, 201
+    t = np.arange(T) / 1000.0
+    coords = P.register_coords(P.square_rect(2, 5), 4.5)
+    smp = {"amp": 12.0 * np.sin(np.pi * t / t[-1]) ** 2, "det": -20.0 + 200.0 * t, "phase": 1.5 * t}
+    prob = P.make_ising_problem(coords, smp)
+    outs = {}
+    for method in ("taylor", "split"):
+        with _engine([prob]) as eng:
+            st = eng.new_state()
+            kw = {"tol": 1e-13} if method == "taylor" else {}
+            eng.evolve(st, 0.0, 0.2, method=method, **kw)
+            outs[method] = st.cpu().numpy()[0]
+            if method == "split":
+                s = eng.stats()
+    assert np.max(np.abs(outs["taylor"] - outs["split"])) < 2e-8
+    assert s["n_applications"] > 2 * 6 * 200  # sub-steps shorter than a knot interval
+    assert s["reserved"][0] < 5e-8
