@@ -83,13 +83,14 @@ __device__ __forceinline__ double dpp_f64(double v) {
 // others (0); LOGNT: log2 of the workgroup size.  Measured at 14 atoms, 1024 rows (us per stage),
 // final (software-pipelined) form: <14, 4, 9> 9.9, <14, 0, 9> 10.7 (ten b128 reads per pair, twice
 // for the pipeline); before pipelining 10.6 vs 10.4; <14, 4, 10> 13.5 (four waves per SIMD but 128
-// registers per lane: spills in the hot loop).
+// registers per lane: spills in the hot loop); <14, 2, 9> (bits 2, 3 from LDS too: 6 fewer DPP moves and
+// one more b128 read per amplitude pair) 9.80 vs 10.00 at 1024 rows, 11.03 vs 11.18 at 256: a wash.
 #ifndef RYD_KET_F0
 #define RYD_KET_F0 4
 #endif
 template <int N, int F0 = RYD_KET_F0, int LOGNT = 9>
 __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
-  static_assert(F0 == 0 || F0 == 4, "index bits below F0 use the DPP crossbar: 0 or 4");
+  static_assert(F0 == 0 || F0 == 2 || F0 == 4, "index bits below F0 use the DPP crossbar: 0, 2 or 4");
   constexpr int D = 1 << N, NTT = 1 << LOGNT;
   constexpr int R = D / NTT;   // amplitudes per thread (8, 16, 32)
   constexpr int RP = R / 2;    // pairs
@@ -292,11 +293,13 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
           bcc0 = fma(cq[LOGNT + 1 + k], src[2 * jo], bcc0);
           bcc1 = fma(cq[LOGNT + 1 + k], src[2 * jo + 1], bcc1);
         }
-        if constexpr (F0 == 4) {
+        if constexpr (F0 >= 2) {
           bcc0 = fma(cq[0], dpp_f64<0xB1>(s0), bcc0);   // xor 1
           bcc1 = fma(cq[0], dpp_f64<0xB1>(s1), bcc1);
           bcc0 = fma(cq[1], dpp_f64<0x4E>(s0), bcc0);   // xor 2
           bcc1 = fma(cq[1], dpp_f64<0x4E>(s1), bcc1);
+        }
+        if constexpr (F0 == 4) {
           bcc0 = fma(cq[3], dpp_f64<0x128>(s0), bcc0);  // xor 8 (row rotate by 8)
           bcc1 = fma(cq[3], dpp_f64<0x128>(s1), bcc1);
           bcc0 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s0)), bcc0);  // xor 4 = (xor 7) o (xor 3)
