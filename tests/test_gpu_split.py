@@ -219,3 +219,45 @@ def test_split_controller_shrinks_the_step_for_strong_interactions():
     assert np.max(np.abs(outs["taylor"] - outs["split"])) < 2e-8
     assert s["n_applications"] > 2 * 6 * 200  # sub-steps shorter than a knot interval
     assert s["reserved"][0] < 5e-8
+
+
+def test_split_noisy_trajectories_with_hf_detuning_terms_and_per_trajectory_interactions():
+    """pulser-core's noise trajectories (fixture): high-frequency detuning noise = extra detuning terms per
+    (trajectory, atom) on shared series, laser-waist amplitude factors, doppler shifts and register noise
+    (one interaction diagonal per trajectory) - the split-operator passes against the Taylor path."""
+    from pulser_amd import NoiseModel
+    from pulser_amd.engine import Engine
+    from pulser_amd.hamiltonian_data import HamiltonianData, SequenceInputs
+
+    prob, extra = load_fixture("waist_tri6.npz")
+    inputs = SequenceInputs.from_dict(prob["inputs"])
+    kw = dict(extra["noise_model"])
+    for key in ("detuning_hf_psd", "detuning_hf_omegas"):
+        kw[key] = tuple(kw[key])
+    np.random.seed(5)
+    hd = HamiltonianData(inputs.extend_duration(inputs.max_duration + 1), NoiseModel(**kw), 4)
+    tables = hd.device_tables(hd.noise_trajectories, 1.0)
+    t1 = inputs.max_duration * 1e-3
+    outs = {}
+    for method in ("taylor", "split"):
+        with Engine(tables, mode="sesolve") as eng:
+            eng.set_path(True)
+            st = eng.new_state()
+            eng.evolve(st, 0.0, t1, method=method, **({"tol": 1e-13} if method == "taylor" else {}))
+            outs[method] = st.cpu().numpy()
+    assert outs["split"].shape[0] == 4
+    assert np.max(np.abs(outs["taylor"] - outs["split"])) < 5e-9
+    assert np.max(np.abs(outs["split"][0] - outs["split"][1])) > 1e-3  # trajectories really differ
+
+
+@pytest.mark.parametrize("n, batch, seed", [(15, 2, 1), (17, 1, 2), (18, 2, 3)])
+def test_split_random_local_problems_against_taylor(n, batch, seed):
+    """Random geometry, per-atom complex drives and detunings, two tilings with 3 / 5 / 6 high bits."""
+    probs = [local_problem(n, seed=seed + 10 * b, duration=31, spacing=6.0) for b in range(batch)]
+    outs = {}
+    for method in ("taylor", "auto"):
+        with _engine(probs) as eng:
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 0.03, method=method, **({"tol": 1e-13} if method == "taylor" else {}))
+            outs[method] = st.cpu().numpy()
+    assert np.max(np.abs(outs["taylor"] - outs["auto"])) < 5e-9
