@@ -261,3 +261,45 @@ def test_split_random_local_problems_against_taylor(n, batch, seed):
             eng.evolve(st, 0.0, 0.03, method=method, **({"tol": 1e-13} if method == "taylor" else {}))
             outs[method] = st.cpu().numpy()
     assert np.max(np.abs(outs["taylor"] - outs["auto"])) < 5e-9
+
+
+def test_sixteen_atom_sequence_end_to_end_through_the_emulator():
+    """`QutipEmulator(...).run().sample_final_state()` on a 16-atom register (65 536 amplitudes): the
+    noiseless run and a 6-trajectory amplitude + doppler + SPAM run go through the split-operator passes
+    (the default beyond 14 atoms); the final state equals the Taylor path's and the seeded Counter can be
+    replayed from it with the reference's sampling chain (oracle)."""
+    from oracle import sampling as osamp
+    from pulser_amd import NoiseModel, QutipEmulator
+    from pulser_amd.hamiltonian_data import single_global_channel
+
+    n, T = 16, 300
+    coords = P.register_coords(P.square_rect(4, 4), blockade_radius())
+    t = np.arange(T)
+    smp = {"amp": 4 * np.pi * np.sin(np.pi * t / (T - 1)) ** 2, "det": np.linspace(-12.0, 10.0, T), "phase": np.zeros(T)}
+    inputs = single_global_channel(coords, smp, P.C6_LEVEL70, extended=False)
+    np.random.seed(3)
+    sim = QutipEmulator(inputs, evaluation_times="Minimal")
+    with pytest.warns(DeprecationWarning):
+        res = sim.run()
+    assert sim.last_engine_stats["n_applications"] >= 6 * T and sim.last_engine_stats["reserved"][0] > 0
+    psi = np.asarray(res.states[-1]).reshape(-1)
+    # the same sequence on the generator kernels
+    prob = sim._current_problem
+    with _engine([prob]) as eng:
+        st = eng.new_state()
+        eng.evolve(st, 0.0, T * 1e-3, method="taylor", tol=1e-12)
+        ref = st.cpu().numpy()[0]
+    assert np.max(np.abs(psi - ref)) < 5e-9
+    rng_state = np.random.get_state()
+    counts = res.sample_final_state(N_samples=500)
+    np.random.set_state(rng_state)
+    w = osamp.weights(psi, n, ["r", "g"], "ground-rydberg")
+    assert counts == osamp.get_samples(w, 500, n)  # the reference's sampling chain on the device's state
+    assert sum(counts.values()) == 500 and all(len(k) == n for k in counts)
+    # noisy run: 6 trajectories in one batch of 16-atom kets
+    np.random.seed(4)
+    nm = NoiseModel(temperature=50.0, amp_sigma=0.03, p_false_pos=0.01, p_false_neg=0.03, runs=6, samples_per_run=5)
+    sim = QutipEmulator(inputs, noise_model=nm, evaluation_times="Minimal")
+    with pytest.warns(DeprecationWarning):
+        noisy = sim.run()
+    assert sum(noisy[-1].bitstring_counts.values()) == 30
