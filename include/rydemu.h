@@ -280,7 +280,8 @@ int ryd_general_add_diag_term(ryd_handle* h, const double* values, int32_t serie
  * the ket kernel from 10 atoms and any batch size on, 128 = keep the Taylor
  * polynomial where ryd_opts.method 0 would choose the split-operator ket passes,
  * 256 = switch their step-size control off (one sub-step per schedule step),
- * 512 = 12-atom kets pass by pass instead of the one-launch loop over the stages.
+ * 512 = 12-atom kets pass by pass instead of the one-launch loop over the stages,
+ * 1024 = keep every CF4 step inside one knot interval (no multi-knot steps).
  * Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);
 

@@ -37,6 +37,12 @@ struct ryd_handle {
   ryd_dterm* dterms_dev = nullptr;
   std::vector<double> bd_drive, bd_pos, bd_neg;  // per interval, max over batch
   std::vector<double> bd_curv;                   // per interval: non-linearity of H(t)
+  // multi-knot CF4 steps (host_sched.hpp): per-series slope bounds, per-knot "the next piece is the same
+  // polynomial", per-interval per-ATOM maxima of |c|, |dc/dt|, |delta|, |d delta/dt| over the batch
+  std::vector<double> s_der;
+  std::vector<char> join_ok;  // [n_int - 1]: pieces i and i + 1 of EVERY series coincide as polynomials
+  std::vector<double> bd_c1, bd_dc, bd_dl, bd_ddl;
+  double u_rowsum = 0.0;      // max_i sum_j |U_ij|
   bool bounds_valid = false;
   double* e0_dev = nullptr;
   int e0_mats = 0;
@@ -65,6 +71,7 @@ struct ryd_handle {
   double* split_err = nullptr;    // [B] local-error accumulators
   bool no_split = false;          // test hook: keep the Taylor polynomial for 15+ atoms
   bool split_fixed = false;       // test hook: no step-size control (sub-step = schedule step)
+  bool no_merge = false;          // test hook: CF4 steps never span more than one knot interval
   bool split_no_loop = false;     // test hook: 12-atom kets pass by pass instead of the one-launch loop
   bool split_known = false;       // controller state below is valid for the current tables
   double split_tau = 1e300;       // target sub-step (us); 1e300 = whole schedule steps
@@ -442,6 +449,7 @@ extern "C" int ryd_set_series(ryd_handle* h, int32_t n_series, int32_t n_knots,
   h->s_pos.assign((size_t)n_series * n_int, 0.0);
   h->s_neg.assign((size_t)n_series * n_int, 0.0);
   h->s_curv.assign((size_t)n_series * n_int, 0.0);
+  h->s_der.assign((size_t)n_series * n_int, 0.0);
   for (int s = 0; s < n_series; ++s)
     for (int i = 0; i < n_int; ++i) {
       const std::complex<double>* p = &h->pp_host[((size_t)s * n_int + i) * 4];
@@ -452,7 +460,27 @@ extern "C" int ryd_set_series(ryd_handle* h, int32_t n_series, int32_t n_knots,
       h->s_pos[(size_t)s * n_int + i] = std::max(p[3].real() + dev, 0.0);
       h->s_neg[(size_t)s * n_int + i] = std::max(-p[3].real() + dev, 0.0);
       h->s_curv[(size_t)s * n_int + i] = std::abs(p[1]) * dt * dt + std::abs(p[0]) * dt * dt * dt;
+      h->s_der[(size_t)s * n_int + i] = std::abs(p[2]) + 2.0 * std::abs(p[1]) * dt + 3.0 * std::abs(p[0]) * dt * dt;
     }
+  // knot i + 1 is removable when piece i, re-expanded about it, IS piece i + 1 (to rounding) for every
+  // series: linear ramps, plateaus - not the ringing of the not-a-knot spline next to a kink
+  h->join_ok.assign(std::max(n_int - 1, 0), 1);
+  for (int s = 0; s < n_series; ++s) {
+    double smax = 0.0;
+    for (int i = 0; i < n_int; ++i) smax = std::max(smax, h->s_abs[(size_t)s * n_int + i]);
+    const double thr = 1e-13 * std::max(smax, 1e-300);
+    for (int i = 0; i + 1 < n_int; ++i) {
+      const std::complex<double>* p = &h->pp_host[((size_t)s * n_int + i) * 4];
+      const std::complex<double>* q = p + 4;
+      const double dt = tknots[i + 1] - tknots[i], dn = tknots[i + 2] - tknots[i + 1];
+      const std::complex<double> e0 = p[0], e1 = 3.0 * p[0] * dt + p[1],
+                                 e2 = 3.0 * p[0] * dt * dt + 2.0 * p[1] * dt + p[2],
+                                 e3 = ((p[0] * dt + p[1]) * dt + p[2]) * dt + p[3];
+      const double mis = std::abs(e3 - q[3]) + std::abs(e2 - q[2]) * dn + std::abs(e1 - q[1]) * dn * dn +
+                         std::abs(e0 - q[0]) * dn * dn * dn;
+      if (!(mis <= thr)) h->join_ok[i] = 0;
+    }
+  }
   if (h->pp_dev) hipFree(h->pp_dev);
   h->pp_dev = nullptr;
   HIPCHK(hipMalloc((void**)&h->pp_dev, cnt * sizeof(cplx)));
@@ -521,10 +549,14 @@ static void compute_bounds(ryd_handle* h) {
   h->bd_pos.assign(n_int, 0.0);
   h->bd_neg.assign(n_int, 0.0);
   h->bd_curv.assign(n_int, 0.0);
+  h->bd_c1.assign(n_int, 0.0);
+  h->bd_dc.assign(n_int, 0.0);
+  h->bd_dl.assign(n_int, 0.0);
+  h->bd_ddl.assign(n_int, 0.0);
   // batch entries are independent: a few host threads, each with its own
   // accumulators, merged by a maximum at the end
   const int n_thr = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, h->B / 8}));
-  std::vector<std::vector<double>> part(n_thr, std::vector<double>((size_t)n_int * 4, 0.0));
+  std::vector<std::vector<double>> part(n_thr, std::vector<double>((size_t)n_int * 8, 0.0));
   auto work = [&](int tix) {
   std::vector<double> dr(n_int), po(n_int), ne(n_int), cu(n_int), q((size_t)n_int * 4);
   std::unordered_map<int, std::vector<double>> extra_cache;  // combined cubic of an extra-term list
@@ -532,6 +564,10 @@ static void compute_bounds(ryd_handle* h) {
   double* bd_pos = bd_drive + n_int;
   double* bd_neg = bd_pos + n_int;
   double* bd_curv = bd_neg + n_int;
+  double* bd_c1 = bd_curv + n_int;  // per-atom maxima
+  double* bd_dc = bd_c1 + n_int;
+  double* bd_dl = bd_dc + n_int;
+  double* bd_ddl = bd_dl + n_int;
   for (int b = tix; b < h->B; b += n_thr) {
     std::fill(dr.begin(), dr.end(), 0.0);
     std::fill(po.begin(), po.end(), 0.0);
@@ -545,6 +581,11 @@ static void compute_bounds(ryd_handle* h) {
         for (int i = 0; i < n_int; ++i) dr[i] += sc * a[i];
         const double* cv = &h->s_curv[(size_t)d.drive_series * n_int];
         for (int i = 0; i < n_int; ++i) cu[i] += sc * cv[i];
+        const double* dv = &h->s_der[(size_t)d.drive_series * n_int];
+        for (int i = 0; i < n_int; ++i) {
+          bd_c1[i] = std::max(bd_c1[i], sc * a[i]);
+          bd_dc[i] = std::max(bd_dc[i], sc * dv[i]);
+        }
       }
       // The detuning of the atom is ONE real cubic per interval: combine every
       // contribution (samples, doppler / constant offsets, the extra hf-noise
@@ -580,6 +621,8 @@ static void compute_bounds(ryd_handle* h) {
         po[i] += std::max(c[3] + dev, 0.0);
         ne[i] += std::max(-c[3] + dev, 0.0);
         cu[i] += curv;
+        bd_dl[i] = std::max(bd_dl[i], std::fabs(c[3]) + dev);
+        bd_ddl[i] = std::max(bd_ddl[i], std::fabs(c[2]) + 2.0 * std::fabs(c[1]) * dt + 3.0 * std::fabs(c[0]) * dt * dt);
       }
     }
     for (int i = 0; i < n_int; ++i) {
@@ -603,6 +646,10 @@ static void compute_bounds(ryd_handle* h) {
       h->bd_pos[i] = std::max(h->bd_pos[i], part[tix][(size_t)n_int + i]);
       h->bd_neg[i] = std::max(h->bd_neg[i], part[tix][(size_t)2 * n_int + i]);
       h->bd_curv[i] = std::max(h->bd_curv[i], part[tix][(size_t)3 * n_int + i]);
+      h->bd_c1[i] = std::max(h->bd_c1[i], part[tix][(size_t)4 * n_int + i]);
+      h->bd_dc[i] = std::max(h->bd_dc[i], part[tix][(size_t)5 * n_int + i]);
+      h->bd_dl[i] = std::max(h->bd_dl[i], part[tix][(size_t)6 * n_int + i]);
+      h->bd_ddl[i] = std::max(h->bd_ddl[i], part[tix][(size_t)7 * n_int + i]);
     }
   // MODEL 1 of the persistent kernel: inside every trajectory all driven atoms
   // share (series, scale) and that series is real-valued
@@ -654,6 +701,14 @@ extern "C" int ryd_set_interaction(ryd_handle* h, const double* U, int32_t n_mat
   }
   h->e0_min = lo;
   h->e0_max = hi;
+  h->u_rowsum = 0.0;
+  for (int m = 0; m < n_mats; ++m)
+    for (int i = 0; i < N; ++i) {
+      double r = 0.0;
+      for (int j = 0; j < N; ++j)
+        if (j != i) r += std::fabs(U[((size_t)m * N + i) * N + j]);
+      h->u_rowsum = std::max(h->u_rowsum, r);
+    }
   double* Udev = nullptr;
   HIPCHK(hipMalloc((void**)&Udev, (size_t)n_mats * N * N * sizeof(double)));
   hipError_t e = hipMemcpy(Udev, U, (size_t)n_mats * N * N * sizeof(double), hipMemcpyHostToDevice);

@@ -48,10 +48,11 @@ static bool row_path(const ryd_handle* h) {
 
 // spectral bound / shift of  w1 H(t1) + w2 H(t2)  as a KET generator (also for mesolve
 // handles, whose rows are kets)
-static void ket_bound(const ryd_handle* h, int idx, double w1, double w2, double* bound, double* shift) {
+static void ket_bound(const ryd_handle* h, int idx, double w1, double w2, double* bound, double* shift,
+                      int span = 1) {
   const double wmix = w1 + w2;
-  const double drive = wmix * h->bd_drive[idx];
-  const double dpos = wmix * h->bd_pos[idx], dneg = wmix * h->bd_neg[idx];
+  const double drive = wmix * span_max(h->bd_drive, idx, span);
+  const double dpos = wmix * span_max(h->bd_pos, idx, span), dneg = wmix * span_max(h->bd_neg, idx, span);
   const double lo = wmix * h->e0_min - dpos, hi = wmix * h->e0_max + dneg;
   *shift = 0.5 * (lo + hi);
   *bound = 0.5 * (hi - lo) + drive;
@@ -96,8 +97,8 @@ static int to_ket_steps(ryd_handle* h, const std::vector<StepDesc>& sched, const
     std::memset(&k, 0, sizeof k);
     k.h = d.h; k.u1 = d.u1; k.u2 = d.u2; k.idx = d.idx; k.snap = d.snap;
     double ba, bb;
-    ket_bound(h, d.idx, kA1, kA2, &ba, &k.shift_a);
-    ket_bound(h, d.idx, kA2, kA1, &bb, &k.shift_b);
+    ket_bound(h, d.idx, kA1, kA2, &ba, &k.shift_a, d.pad);
+    ket_bound(h, d.idx, kA2, kA1, &bb, &k.shift_b, d.pad);
     if ((rc = pick_scheme(std::fabs(d.h) * ba, tol, &k.sch_a, &k.sub_a))) return rc;
     if ((rc = pick_scheme(std::fabs(d.h) * bb, tol, &k.sch_b, &k.sub_b))) return rc;
     phase += conj_sign * d.h * (k.shift_a + k.shift_b);
@@ -288,6 +289,23 @@ static int row_block_steps(const ryd_handle* h, const ryd_opts& o) {
   return g <= 0.5 ? 2 : 1;
 }
 
+// |change of the dissipator diagonal under one bit flip| is the same for every flip (pure dephasing)
+static bool row_uniform_g(const ryd_handle* h) {
+  const double g01 = h->Sd[1].x - h->Sd[0].x, g10 = h->Sd[2].x - h->Sd[0].x;
+  const double g31 = h->Sd[1].x - h->Sd[3].x, g32 = h->Sd[2].x - h->Sd[3].x;
+  return std::fabs(std::fabs(g01) - std::fabs(g10)) < 1e-14 * (1 + std::fabs(g01)) &&
+         std::fabs(std::fabs(g01) - std::fabs(g31)) < 1e-14 * (1 + std::fabs(g01)) &&
+         std::fabs(std::fabs(g01) - std::fabs(g32)) < 1e-14 * (1 + std::fabs(g01));
+}
+
+// Half a block of the split-operator master equation, in knot intervals (what a multi-knot CF4
+// step must not exceed).
+static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
+  int Kh = row_block_steps(h, o);
+  if ((!row_uniform_g(h) || h->has_dbl) && o.split_steps <= 0) Kh = 1;
+  return Kh;
+}
+
 // mesolve by operator splitting (header of this file).  Blocks of two halves, 4th order
 // (Chin's scheme 4A: all coefficients positive, so the dissipative factor never runs backwards):
 //
@@ -313,12 +331,10 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
   // |change of d under one bit flip|: (0,0)<->(0,1)/(1,0) and (1,1)<->(0,1)/(1,0)
   const double g01 = h->Sd[1].x - h->Sd[0].x, g10 = h->Sd[2].x - h->Sd[0].x;
   const double g31 = h->Sd[1].x - h->Sd[3].x, g32 = h->Sd[2].x - h->Sd[3].x;
-  const bool uniform_g = std::fabs(std::fabs(g01) - std::fabs(g10)) < 1e-14 * (1 + std::fabs(g01)) &&
-                         std::fabs(std::fabs(g01) - std::fabs(g31)) < 1e-14 * (1 + std::fabs(g01)) &&
-                         std::fabs(std::fabs(g01) - std::fabs(g32)) < 1e-14 * (1 + std::fabs(g01));
+  const bool uniform_g = row_uniform_g(h);
   const double gflip = std::fabs(g01);
-  int Kh = row_block_steps(h, o);
-  if ((!uniform_g || h->has_dbl) && o.split_steps <= 0) Kh = 1;
+  (void)g10; (void)g31; (void)g32;
+  const int Kh = row_half_knots(h, o);
   const bool dbl = h->has_dbl;  // the dissipator factor is not elementwise: k_local_exp passes
   double pending = 0.0;         // dissipator time not applied yet (adjacent factors merge)
   const size_t D = (size_t)1 << h->N;
@@ -393,12 +409,14 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
   size_t i = 0;
   while (i < sched.size()) {
     // first half [i, mid), second half [mid, j); a requested evaluation time ends the block
+    // a half lasts Kh knot intervals (steps may be sub-steps next to a kink, or span several knots)
     size_t mid = i, j;
     double t1 = 0.0, t2 = 0.0;
     bool cut = false;
-    while (mid < sched.size() && (int)(mid - i) < Kh && !cut) { t1 += sched[mid].h; cut = sched[mid].snap >= 0; ++mid; }
+    const double half = Kh * (h->tknots[sched[i].idx + 1] - h->tknots[sched[i].idx]) * (1.0 - 1e-9);
+    while (mid < sched.size() && t1 < half && !cut) { t1 += sched[mid].h; cut = sched[mid].snap >= 0; ++mid; }
     j = mid;
-    while (j < sched.size() && (int)(j - mid) < Kh && !cut) { t2 += sched[j].h; cut = sched[j].snap >= 0; ++j; }
+    while (j < sched.size() && t2 < half && !cut) { t2 += sched[j].h; cut = sched[j].snap >= 0; ++j; }
     if (j == mid) {
       // a lone half (end of the schedule / evaluation time): 2nd-order Strang block
       if ((rc = conjugate(i, mid, 0.5 * t1, 0.5 * t1, 0.0, 0.0, 0, 0.0))) return rc;

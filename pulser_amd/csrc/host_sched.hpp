@@ -32,11 +32,18 @@ static int taylor_order_for(double rho, const ryd_opts& o, double dtol) {
 
 // Taylor order and spectral shift of one exponential exp(h (w1 G(t1) + w2 G(t2)))
 // with both Gauss points inside knot interval `idx`.
+// maximum of a per-interval bound over the `span` intervals a (multi-knot) step covers
+static double span_max(const std::vector<double>& v, int idx, int span) {
+  double m = 0.0;
+  for (int i = idx; i < idx + std::max(span, 1) && i < (int)v.size(); ++i) m = std::max(m, v[i]);
+  return m;
+}
+
 static void plan_exp(ryd_handle* h, int idx, double hstep, double w1, double w2,
-                     const ryd_opts& o, int* order_out, double* shift_out) {
+                     const ryd_opts& o, int* order_out, double* shift_out, int span = 1) {
   const double wmix = w1 + w2;
-  const double drive = wmix * h->bd_drive[idx];
-  const double dpos = wmix * h->bd_pos[idx], dneg = wmix * h->bd_neg[idx];
+  const double drive = wmix * span_max(h->bd_drive, idx, span);
+  const double dpos = wmix * span_max(h->bd_pos, idx, span), dneg = wmix * span_max(h->bd_neg, idx, span);
   const double lo = wmix * h->e0_min - dpos, hi = wmix * h->e0_max + dneg;
   double bound, shift = 0.0;
   if (h->general) {
@@ -61,15 +68,51 @@ static void plan_exp(ryd_handle* h, int idx, double hstep, double w1, double w2,
 
 // CF4 steps covering [t0, t1]: never straddling a spline knot (inside a knot
 // interval every coefficient is a single cubic), optionally capped by max_step.
+// Multi-knot steps.  Where the waveforms are the SAME polynomial across knots (join_ok: linear ramps,
+// plateaus - not the ringing next to a kink) a CF4 step may span several knot intervals: the kernels
+// evaluate piece idx at offsets beyond its own interval, which is the same function.  Doubling the
+// step halves the number of exponentials while their polynomial degree grows far less (degree ~ e rho
+// / 2 + log(1 / tol) terms).  The 4th-order Magnus error of a step of length h over linear-in-time
+// H(t) = A + B t is ~ h^5 / 720 ||[B, [B, A]]||; with B = c' X + delta' N the double commutators are
+// delta'^2 |c| and c'^2 (|delta| + sum_j U_ij) per atom (tools/bigstep_probe.py: 8 and 12 atoms, steps of
+// 2 / 3 / 4 / 6 knots end 1e-9 / 5e-9 / 2e-8 / 1e-7 from the converged solution - this estimate is ~3x above).
+static const double kMergeRate = 2e-9;  // allowed Magnus error per us of merged steps (x magnus_tol / 1e-10)
+static const int kMergeMax = 4;
+
+static double merge_error(const ryd_handle* h, int idx, int span, double len) {
+  const double dd = span_max(h->bd_ddl, idx, span), c1 = span_max(h->bd_c1, idx, span);
+  const double dc = span_max(h->bd_dc, idx, span), dl = span_max(h->bd_dl, idx, span);
+  const double h5 = len * len * len * len * len / 720.0;
+  return (h->cfg.mode == RYD_MESOLVE ? 2.0 : 1.0) * h5 * (dd * dd * c1 + dc * dc * (dl + h->u_rowsum));
+}
+
 static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& o,
-                           std::vector<StepDesc>& out, bool in_place_exp = false) {
+                           std::vector<StepDesc>& out, bool in_place_exp = false, int merge_cap = kMergeMax) {
   const double eps = 1e-12;
   double t = t0;
+  const bool merge = merge_cap > 1 && !h->general && !h->mc && !h->no_merge && o.taylor_order <= 0;
   while (t < t1 - eps) {
     const int idx = find_interval(h, t + eps);
     double tend = t1;  // the last interval extends to t1 (extrapolation, as scipy does)
     if (idx < h->n_knots - 2) tend = std::min(t1, h->tknots[idx + 1]);
     if (tend <= t + eps) tend = t1;
+    int span = 1;
+    if (merge && idx < h->n_knots - 2 && std::fabs(t - h->tknots[idx]) < eps &&
+        std::fabs(tend - h->tknots[idx + 1]) < eps) {
+      const double mtol = o.magnus_tol > 0 ? o.magnus_tol : 1e-10;
+      while (span < std::min(merge_cap, kMergeMax) && idx + span < h->n_knots - 2 && h->join_ok[idx + span - 1] &&
+             h->tknots[idx + span + 1] <= t1 + eps) {
+        const double cand = h->tknots[idx + span + 1] - t;
+        if (o.max_step > 0 && cand > o.max_step * (1.0 + 1e-9)) break;
+        if (merge_error(h, idx, span + 1, cand) > kMergeRate * (mtol / 1e-10) * cand) break;
+        // the spline's own non-linearity (same estimate as below, over the longer step)
+        const double dtk = h->tknots[idx + 1] - h->tknots[idx];
+        const double fr = cand / dtk;
+        if (1e-5 * cand * span_max(h->bd_curv, idx, span + 1) * fr * fr > mtol) break;
+        ++span;
+        tend = h->tknots[idx + span];
+      }
+    }
     const double len = tend - t;
     int nsub = 1;
     if (o.max_step > 0) nsub = std::max(1, (int)std::ceil(len / o.max_step - 1e-9));
@@ -80,8 +123,8 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
       // against converged references: err ~ 1e-5 * h * curvature,
       // and it falls as n^-4 with n equal sub-steps.
       const double dtk = h->tknots[idx + 1] - h->tknots[idx];
-      const double frac = dtk > 0 ? std::min(1.0, len / dtk) : 1.0;
-      const double est = 1e-5 * len * h->bd_curv[idx] * frac * frac;
+      const double frac = dtk > 0 ? std::min((double)span, len / dtk) : 1.0;
+      const double est = 1e-5 * len * span_max(h->bd_curv, idx, span) * frac * frac;
       const double mtol = o.magnus_tol > 0 ? o.magnus_tol : 1e-10;
       if (est > mtol) {
         const int nm = (int)std::ceil(std::pow(est / mtol, 0.25));
@@ -95,7 +138,7 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
       // below rho = 6, where the largest term (e^rho) starts to cost digits.
       int ord;
       double sh;
-      plan_exp(h, idx, len / nsub, kA1, kA2, o, &ord, &sh);
+      plan_exp(h, idx, len / nsub, kA1, kA2, o, &ord, &sh, span);
       const double rho = (len / nsub) * h->stats.norm_bound * (kA1 + kA2);
       if (h->general) {
         if (rho > 1.5) nsub *= (int)std::ceil(rho / 1.0);
@@ -132,9 +175,10 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
       d.idx = idx;
       d.u1 = ta + kC1 * hs - h->tknots[idx];
       d.u2 = ta + kC2 * hs - h->tknots[idx];
-      plan_exp(h, idx, hs, kA1, kA2, o, &d.order_a, &d.shift_a);
-      plan_exp(h, idx, hs, kA2, kA1, o, &d.order_b, &d.shift_b);
+      plan_exp(h, idx, hs, kA1, kA2, o, &d.order_a, &d.shift_a, span);
+      plan_exp(h, idx, hs, kA2, kA1, o, &d.order_b, &d.shift_b, span);
       d.snap = -1;
+      d.pad = span;  // knot intervals this step's bounds must cover
       out.push_back(d);
     }
     t = tend;

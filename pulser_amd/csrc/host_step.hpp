@@ -134,10 +134,10 @@ static int run_generic(ryd_handle* h, cplx* state, const std::vector<StepDesc>& 
     m.w1 = kA1; m.w2 = kA2;
     if (kry) {
       double bnd, sh;
-      ket_bound(h, d.idx, kA1, kA2, &bnd, &sh);
+      ket_bound(h, d.idx, kA1, kA2, &bnd, &sh, d.pad);
       if ((rc = exp_step_krylov(h, state, d.h, m, std::fabs(d.h) * bnd, sh, ktol, st))) return rc;
       m.w1 = kA2; m.w2 = kA1;
-      ket_bound(h, d.idx, kA2, kA1, &bnd, &sh);
+      ket_bound(h, d.idx, kA2, kA1, &bnd, &sh, d.pad);
       if ((rc = exp_step_krylov(h, state, d.h, m, std::fabs(d.h) * bnd, sh, ktol, st))) return rc;
     } else {
       if ((rc = exp_step(h, state, d.h, m, d.order_a, d.shift_a, st))) return rc;
@@ -424,11 +424,15 @@ extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const 
   // steps: both skip build_schedule's Taylor sub-stepping
   const bool in_place = ket_path(h) || (row_path(h) && !use_persistent_dm(h)) || krylov_selected(h, o) ||
                         split_selected(h, o);
+  // multi-knot CF4 steps: not under the split-operator ket passes (their sub-steps stay inside a knot
+  // interval); at most half a block of the split-operator master equation
+  const int merge_cap = split_selected(h, o) ? 1
+                        : (row_path(h) && !use_persistent_dm(h)) ? row_half_knots(h, o) : kMergeMax;
   std::vector<StepDesc> sched;
   // snapshot slot i-1 receives the state at times[i]
   for (int i = 1; i < n_times; ++i) {
     const size_t before = sched.size();
-    build_schedule(h, times[i - 1], times[i], o, sched, in_place);
+    build_schedule(h, times[i - 1], times[i], o, sched, in_place, merge_cap);
     if (snaps) {
       if (sched.size() > before) {
         sched.back().snap = i - 1;
@@ -556,6 +560,7 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
     h->no_split = (force_generic & 128) != 0;
     h->split_fixed = (force_generic & 256) != 0;
     h->split_no_loop = (force_generic & 512) != 0;
+    h->no_merge = (force_generic & 1024) != 0;
     if (nt != h->no_tile14 || ft != h->force_tile14 || no != h->no_outer || fo != h->force_outer) {
       h->no_tile14 = nt;
       h->force_tile14 = ft;

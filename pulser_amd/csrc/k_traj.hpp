@@ -20,7 +20,7 @@ struct StepDesc {
   int idx;
   int order_a, order_b;
   int snap;  // snapshot slot written after this step, or -1
-  int pad;
+  int pad;   // host: number of knot intervals the step spans (bounds); unused on the device
 };
 
 struct TrajArgs {

@@ -605,6 +605,11 @@ class QutipEmulator:
             return min(mins)
 
         self._mc_rng = None  # a new run restarts the jump-seed generator (option ``seeds``)
+        # the reference's DEFAULT max_step (shortest waveform variation) keeps QuTiP's adaptive ODE solver
+        # from stepping over pulse features; the CF4 stepper never steps over a spline knot that matters
+        # (it merges knots only where the waveform is the same polynomial on both sides), so only a
+        # max_step the caller asked for is handed to the engine
+        self._default_max_step = "max_step" not in options
         options.setdefault(
             "max_step", min(min_variation(ch) for ch in self.samples_obj.channels) / 1000
         )
@@ -665,7 +670,7 @@ class QutipEmulator:
         for k in ("tol", "taylor_order", "max_order", "magnus_tol"):
             if k in options:
                 kw[k] = options[k]
-        if options.get("max_step"):
+        if options.get("max_step") and not getattr(self, "_default_max_step", False):
             kw["max_step"] = float(options["max_step"])
         return kw
 
