@@ -409,14 +409,19 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
   size_t i = 0;
   while (i < sched.size()) {
     // first half [i, mid), second half [mid, j); a requested evaluation time ends the block
-    // a half lasts Kh knot intervals (steps may be sub-steps next to a kink, or span several knots)
+    // a half holds Kh steps; a multi-knot step counts for the knot intervals it spans (sub-steps next to
+    // a kink count as whole steps: shorter blocks exactly where H(t) changes fastest)
     size_t mid = i, j;
     double t1 = 0.0, t2 = 0.0;
     bool cut = false;
-    const double half = Kh * (h->tknots[sched[i].idx + 1] - h->tknots[sched[i].idx]) * (1.0 - 1e-9);
-    while (mid < sched.size() && t1 < half && !cut) { t1 += sched[mid].h; cut = sched[mid].snap >= 0; ++mid; }
+    int u1 = 0, u2 = 0;
+    while (mid < sched.size() && u1 < Kh && !cut) {
+      t1 += sched[mid].h; u1 += std::max(sched[mid].pad, 1); cut = sched[mid].snap >= 0; ++mid;
+    }
     j = mid;
-    while (j < sched.size() && t2 < half && !cut) { t2 += sched[j].h; cut = sched[j].snap >= 0; ++j; }
+    while (j < sched.size() && u2 < Kh && !cut) {
+      t2 += sched[j].h; u2 += std::max(sched[j].pad, 1); cut = sched[j].snap >= 0; ++j;
+    }
     if (j == mid) {
       // a lone half (end of the schedule / evaluation time): 2nd-order Strang block
       if ((rc = conjugate(i, mid, 0.5 * t1, 0.5 * t1, 0.0, 0.0, 0, 0.0))) return rc;

@@ -76,7 +76,7 @@ static void plan_exp(ryd_handle* h, int idx, double hstep, double w1, double w2,
 // H(t) = A + B t is ~ h^5 / 720 ||[B, [B, A]]||; with B = c' X + delta' N the double commutators are
 // delta'^2 |c| and c'^2 (|delta| + sum_j U_ij) per atom (tools/bigstep_probe.py: 8 and 12 atoms, steps of
 // 2 / 3 / 4 / 6 knots end 1e-9 / 5e-9 / 2e-8 / 1e-7 from the converged solution - this estimate is ~3x above).
-static const double kMergeRate = 2e-9;  // allowed Magnus error per us of merged steps (x magnus_tol / 1e-10)
+static const double kMergeRate = 4e-9;  // allowed Magnus-error ESTIMATE per us of merged steps (x magnus_tol / 1e-10)
 static const int kMergeMax = 4;
 
 static double merge_error(const ryd_handle* h, int idx, int span, double len) {

@@ -665,12 +665,14 @@ class QutipEmulator:
             self._mc_rng = np.random.default_rng(options.get("seeds"))
         return self._mc_rng.integers(0, 2**64, size=n, dtype=np.uint64)
 
-    def _engine_kwargs(self, options: dict[str, Any]) -> dict[str, Any]:
+    def _engine_kwargs(self, options: dict[str, Any], general: bool = False) -> dict[str, Any]:
+        """``general``: the explicit-term engine keeps the reference's default ``max_step`` too (tiny systems;
+        the seeded golden Counters of the multi-level cases were captured with it)."""
         kw = {}
         for k in ("tol", "taylor_order", "max_order", "magnus_tol"):
             if k in options:
                 kw[k] = options[k]
-        if options.get("max_step") and not getattr(self, "_default_max_step", False):
+        if options.get("max_step") and (general or not getattr(self, "_default_max_step", False)):
             kw["max_step"] = float(options["max_step"])
         return kw
 
@@ -867,7 +869,7 @@ class QutipEmulator:
             with GeneralEngine(tables) as eng:
                 state = eng.new_state(np.asarray(self._initial_state).reshape(-1))
                 first = state.cpu().numpy()[0]
-                host = eng.solve(state, times, **self._engine_kwargs(options)).cpu().numpy()
+                host = eng.solve(state, times, **self._engine_kwargs(options, general=True)).cpu().numpy()
                 self.last_engine_stats = eng.stats()
             D = len(prob["eigenbasis"]) ** n
             results = []
