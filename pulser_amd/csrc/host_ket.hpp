@@ -19,7 +19,7 @@
 // times (96 B per element) instead of 72 B per element per generator application
 // (22 applications per ns at 14 atoms): the path is bound by the fp64 vector pipe,
 // not by HBM.  Splitting error measured against the tight oracle (6-atom
-// triangular register, 3.1 us anneal, tools/split_probe.py): K = 1/2/4/8 ns ->
+// triangular register, 3.1 us anneal, tests/probes/split_probe.py): K = 1/2/4/8 ns ->
 // 6e-10 / 5e-10 / 1.2e-9 / 8.7e-9 at gamma = 0.05; it grows with gamma K^2, so K
 // is chosen from the dissipator rate.
 
@@ -280,7 +280,7 @@ static int launch_local_exp(ryd_handle* h, cplx* rho, double f, hipStream_t st) 
 
 // CF4 steps per HALF block of the 4th-order splitting (below): two steps (tau = 4 ns at
 // sampling rate 1) keep the splitting error at the level of the CF4 error (<= 1e-9 after 3.1 us
-// for dephasing rates up to 0.5 / us and drives up to 25 rad/us, tools/split_probe.py); faster
+// for dephasing rates up to 0.5 / us and drives up to 25 rad/us, tests/probes/split_probe.py); faster
 // dephasing halves the block.
 static int row_block_steps(const ryd_handle* h, const ryd_opts& o) {
   if (o.split_steps > 0) return o.split_steps;

@@ -7,7 +7,7 @@ static const double kC1 = 0.5 - kS3 / 6.0, kC2 = 0.5 + kS3 / 6.0;  // Gauss node
 static const double kA1 = 0.25 + kS3 / 6.0, kA2 = 0.25 - kS3 / 6.0;  // CF4 weights
 // Default truncation bound per exponential.  The stated parity bar is 1e-7 on amplitudes after a
 // whole sequence: 1e-10 per exponential ends 5e-9 .. 1.2e-8 from the tight oracle on the
-// 8- and 12-atom anneal sequences (tools/stepper_model.py, tools/order_probe.py); 1e-12 bought 2e-10
+// 8- and 12-atom anneal sequences (tests/probes/stepper_model.py, tools/order_probe.py); 1e-12 bought 2e-10
 // for 14 % more generator applications.
 static const double kDefaultTol = 1e-10;
 // The explicit-term (general) path has no spectral shift and multi-level operators; its systems

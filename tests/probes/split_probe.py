@@ -2,7 +2,7 @@
 error of Strang and of Chin's 4th-order scheme 4A (with / without the exact commutator kick)
 against the tight oracle / the exact single-atom solution, as a function of the block length.
 
-    python tools/split_probe.py            # writes the tables of profiles/r02_split_probe.md to stdout
+    python tests/probes/split_probe.py            # writes the tables of profiles/r02_split_probe.md to stdout
 """
 from __future__ import annotations
 
@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import scipy.linalg as la
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -1,7 +1,7 @@
 """NumPy model of the device stepper (CF4 Magnus; Taylor or in-place symplectic exponential)
 against the tight oracle - used to choose tolerances / schemes without a GPU.
 
-    python tools/stepper_model.py N [tol] [mode]     mode = taylor | symp
+    python tests/probes/stepper_model.py N [tol] [mode]     mode = taylor | symp
 """
 from __future__ import annotations
 
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
