@@ -202,6 +202,7 @@ def run_ensemble(
     from .results import QState, StateResult
 
     qids = tuple(emulator.samples_obj.qubit_ids)
+    matching = emulator._meas_basis in emulator.basis_name  # (a property that walks the channels)
     bit_of = ((np.arange(2**n)[:, None] >> (n - 1 - np.arange(n))[None, :]) & 1).astype(np.float64)
     for start in range(lo, hi, batch):
         block = list(range(start, min(hi, start + batch)))
@@ -219,8 +220,7 @@ def run_ensemble(
         for j, i in enumerate(block):
             for ti in range(n_eval):
                 st = QState(states[j][ti])
-                w = StateResult(qids, emulator._meas_basis, st,
-                                emulator._meas_basis in emulator.basis_name)._weights()
+                w = StateResult(qids, emulator._meas_basis, st, matching)._weights()
                 k = i * n_eval + ti
                 ind = sample_with(rnd_all[offs[k]:offs[k + 1]], w)
                 ind = flips_with(ind, n, mat_all[offs[k]:offs[k + 1]] if meas_err else None,

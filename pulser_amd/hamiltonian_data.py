@@ -447,6 +447,16 @@ class HamiltonianData:
 
     # -- interaction (hamiltonian_data.py:562-652) ------------------------------
     def interaction_matrix(self, coords: np.ndarray, bad_atoms: np.ndarray) -> np.ndarray:
+        # without register noise every trajectory has the same positions: build the pair loop once
+        key = (np.asarray(coords, float).tobytes(), np.asarray(bad_atoms, bool).tobytes())
+        cache = self.__dict__.setdefault("_inter_cache", {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = self._interaction_matrix(coords, bad_atoms)
+        return cache[key].copy()
+
+    def _interaction_matrix(self, coords: np.ndarray, bad_atoms: np.ndarray) -> np.ndarray:
         n = self.n_qudits
         d = distances(coords)
         is_xy = self.interaction_type == "XY"
