@@ -105,7 +105,10 @@ typedef struct ryd_opts {
                            tight oracle after a 3.1 us sequence, the stated bar being 1e-7) */
   double max_step;      /* us; 0 = no cap (steps never straddle a spline knot) */
   double magnus_tol;    /* per-interval Magnus error target driving the automatic
-                           sub-stepping next to waveform kinks (default 1e-10) */
+                           sub-stepping next to waveform kinks (default 1e-10); the allowed
+                           Magnus-error estimate of steps that span several spline knots (taken where
+                           every waveform is the same polynomial across them; 4e-9 per us of such
+                           steps at the default) scales with it */
   int32_t split_steps;  /* mesolve split-operator path: CF4 steps per Strang block (0 = from the
                            dissipator rate: 4 / 2 / 1 for rates <= 0.1 / <= 0.5 / above) */
   int32_t method;       /* propagator of the multi-launch sesolve path: 0 = the library's choice (the
