@@ -33,6 +33,13 @@ def _torch():
 _METHODS = {"auto": 0, "krylov": 1, "split": 2, "taylor": 3}
 
 
+def _method_code(method: str) -> int:
+    try:
+        return _METHODS[method]
+    except KeyError:
+        raise ValueError(f"unknown method {method!r}; one of {sorted(_METHODS)}") from None
+
+
 class Engine:
     """One ``ryd_handle``: a batch of B states of N atoms on one device.
 
@@ -202,7 +209,7 @@ class Engine:
             max_step=float(max_step),
             magnus_tol=float(magnus_tol),
             split_steps=int(split_steps),
-            method=_METHODS[method],
+            method=_method_code(method),
         )
         _lib.check(
             self.lib.ryd_evolve(
@@ -245,7 +252,7 @@ class Engine:
             max_step=float(max_step),
             magnus_tol=float(magnus_tol),
             split_steps=int(split_steps),
-            method=_METHODS[method],
+            method=_method_code(method),
         )
         _lib.check(
             self.lib.ryd_solve(

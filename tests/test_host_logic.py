@@ -1565,3 +1565,18 @@ def test_default_tolerance_oracle_drift_is_a_measured_quantity():
     again = qp.sesolve(ham, qp.all_ground_state(12, prob["eigenbasis"]),
                        np.asarray(extra["eval_times"])[[0, 1]], **opts)[-1]
     assert np.max(np.abs(again - dflt[1])) < 1e-9
+
+
+def test_engine_method_names_match_the_header():
+    """ryd_opts.method codes of include/rydemu.h and the names Engine.evolve / solve accept."""
+    import re
+
+    from pulser_amd import engine
+
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rydemu.h")).read()
+    doc = hdr[hdr.index("int32_t method;"):hdr.index("double reserved[2];")]
+    assert re.search(r"0 = the library's choice", doc) and "1 = Lanczos" in doc
+    assert "2 = split-operator" in doc and "3 = Taylor polynomial" in doc
+    assert engine._METHODS == {"auto": 0, "krylov": 1, "split": 2, "taylor": 3}
+    with pytest.raises(ValueError, match="unknown method"):
+        engine._method_code("rk4")
