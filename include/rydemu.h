@@ -339,6 +339,20 @@ int ryd_ket_to_dm(ryd_handle* h, const void* psi_dev, void* rho_dev,
 int ryd_outer_accumulate(ryd_handle* h, const void* psi_dev,
                          const double* weights, void* acc_dev, void* stream);
 
+/* The same without a handle and for any state dimension `dim` (d^N for the 3- / 4-level bases,
+ * pulser/_hamiltonian_data/hamiltonian_data.py:913-931): what density_matrix_aggregator
+ * (pulser_simulation/aggregators.py:20-37) and the mean over trajectory Results
+ * (pulser_simulation/qutip_backend.py:322-325) need - they hold states, not a solver.
+ * psi_dev complex128[batch][dim], acc_dev complex128[dim][dim], weights host float64[batch] or NULL. */
+int ryd_outer_accumulate_dim(const void* psi_dev, int64_t batch, int64_t dim,
+                             const double* weights, void* acc_dev, int32_t device,
+                             void* stream);
+
+/* Replaces: the running sum of density matrices in density_matrix_aggregator when the trajectory
+ * states are already density matrices (aggregators.py:29-35): acc += weight * x, complex128[count]. */
+int ryd_accumulate(const void* x_dev, double weight, int64_t count, void* acc_dev,
+                   int32_t device, void* stream);
+
 int ryd_get_stats(const ryd_handle* h, ryd_stats* out);
 int ryd_reset_stats(ryd_handle* h);
 

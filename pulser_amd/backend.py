@@ -29,7 +29,7 @@ from typing import Any, Callable, Mapping, Sequence
 import numpy as np
 
 from .noise_model import NoiseModel, has_stochastic_noise
-from .results import QState, multinomial
+from .results import DeviceState, QState, multinomial
 from .simulation import QutipEmulator, Solver
 
 __all__ = [
@@ -71,6 +71,12 @@ class RydState:
     def __init__(self, state: Any, *, eigenstates: Sequence[str]) -> None:
         _validate_eigenstates(eigenstates)
         self.eigenstates = tuple(eigenstates)
+        if isinstance(state, DeviceState):  # a density matrix that lives on the GPU (aggregated results)
+            self._state = state
+            _validate_shape(state.shape, len(self.eigenstates))
+            self._n = int(round(math.log(state.shape[0], len(self.eigenstates))))
+            self._amplitudes = None
+            return
         arr = np.asarray(state)
         if isinstance(state, (str, bytes)) or arr.dtype == object or arr.ndim not in (1, 2):
             raise TypeError(
@@ -1071,14 +1077,45 @@ class Results:
         return out
 
 
+# aggregated density matrices from this size on stay on the GPU (11 two-level atoms: 64 MiB)
+_DEVICE_RESULT_BYTES = 64 << 20
+
+
 def density_matrix_aggregator(values: Sequence[RydState]) -> RydState:
-    """pulser_simulation/aggregators.py:20-37: mean of |psi><psi| (or of rho)."""
-    acc = None
+    """pulser_simulation/aggregators.py:20-37: mean of |psi><psi| (or of rho) over the trajectories.
+
+    Formed on the device: the kets go up as one [n, D] batch and ``ryd_outer_accumulate_dim`` (fp64
+    matrix cores, upper-triangle tiles) adds ``(1/n) sum |psi><psi|``; trajectory density matrices
+    are added elementwise (``ryd_accumulate``).  No D x D array is built on the host; results of
+    64 MiB and more are handed back as a :class:`DeviceState` (copied on explicit request only)."""
+    from .engine import _torch, accumulate, outer_accumulate
+
+    if len(values) == 0:
+        raise ValueError("Cannot average an empty list of states.")
+    torch = _torch()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    D = int(values[0].to_qobj().shape[0])
+    w = 1.0 / len(values)
+    acc = torch.zeros((D, D), dtype=torch.complex128, device=dev)
+    kets = [st.to_qobj() for st in values if st.to_qobj().isket]
+    chunk = max(1, (1 << 30) // (16 * D))  # <= 1 GiB of kets per upload
+    for lo in range(0, len(kets), chunk):
+        part = kets[lo:lo + chunk]
+        host = np.empty((len(part), D), dtype=np.complex128)
+        for i, k in enumerate(part):
+            host[i] = np.asarray(k).reshape(-1)
+        outer_accumulate(torch.from_numpy(host).to(dev), acc, np.full(len(part), w))
     for st in values:
         s = st.to_qobj()
-        rho = np.outer(np.asarray(s)[:, 0], np.asarray(s)[:, 0].conj()) if s.isket else np.asarray(s)
-        acc = rho.copy() if acc is None else acc + rho
-    return RydState(acc / len(values), eigenstates=values[0].eigenstates)
+        if s.isket:
+            continue
+        t = getattr(s, "device_tensor", None)
+        if t is None:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(s), dtype=np.complex128)).to(dev)
+        accumulate(t.contiguous(), acc, w)
+    if 16 * D * D >= _DEVICE_RESULT_BYTES:
+        return RydState(DeviceState(tensor=acc), eigenstates=values[0].eigenstates)
+    return RydState(acc.cpu().numpy(), eigenstates=values[0].eigenstates)
 
 
 # -------------------------------------------------------------------- config

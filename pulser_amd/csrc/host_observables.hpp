@@ -92,32 +92,60 @@ extern "C" int ryd_ket_to_dm(ryd_handle* h, const void* psi_dev, void* rho_dev, 
   return RYD_OK;
 }
 
+// acc[D][D] += sum_b w_b |psi_b><psi_b| for any state dimension: the fp64 matrix cores on 64 x 64
+// upper-triangle tiles when D is a multiple of 64 (every two-level register of 6+ atoms, 4-level
+// registers of 3+), one thread per entry otherwise.
+static int outer_accumulate_impl(const void* psi_dev, int64_t B, int64_t D, const double* weights,
+                                 void* acc_dev, hipStream_t st) {
+  if (B <= 0 || D <= 0 || B > INT32_MAX) return fail(RYD_ERR_INVALID, "batch %lld, dim %lld", (long long)B, (long long)D);
+  double* wdev = nullptr;
+  if (weights) {
+    HIPCHK(hipMalloc((void**)&wdev, B * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(wdev, weights, B * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { hipFree(wdev); return fail(RYD_ERR_HIP, "weights upload: %s", hipGetErrorString(e)); }
+  }
+  if (D % 64 == 0) {
+    constexpr int KT = 16;
+    const unsigned nt = (unsigned)(D / 64);
+    hipLaunchKernelGGL(k_outer_mfma<KT>, dim3(nt, nt), dim3(256), 2 * KT * 128 * sizeof(double), st,
+                       (const cplx*)psi_dev, (size_t)D, (int)B, wdev, (cplx*)acc_dev);
+  } else {
+    const size_t DD = (size_t)D * (size_t)D;
+    hipLaunchKernelGGL(k_outer_acc, dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, st,
+                       (const cplx*)psi_dev, (size_t)D, (int)B, wdev, (cplx*)acc_dev);
+  }
+  hipError_t e = hipGetLastError();
+  if (wdev) { hipStreamSynchronize(st); hipFree(wdev); }
+  if (e != hipSuccess) return fail(RYD_ERR_HIP, "k_outer_acc: %s", hipGetErrorString(e));
+  return RYD_OK;
+}
+
 extern "C" int ryd_outer_accumulate(ryd_handle* h, const void* psi_dev, const double* weights,
                                     void* acc_dev, void* stream) {
   if (!h || !psi_dev || !acc_dev) return fail(RYD_ERR_INVALID, "null argument");
   if (2 * h->N > RYD_MAX_QUBITS) return fail(RYD_ERR_INVALID, "2N exceeds %d", RYD_MAX_QUBITS);
   HIPCHK(hipSetDevice(h->cfg.device));
-  hipStream_t st = (hipStream_t)stream;
-  double* wdev = nullptr;
-  if (weights) {
-    HIPCHK(hipMalloc((void**)&wdev, h->B * sizeof(double)));
-    hipError_t e = hipMemcpyAsync(wdev, weights, h->B * sizeof(double), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) { hipFree(wdev); return fail(RYD_ERR_HIP, "weights upload: %s", hipGetErrorString(e)); }
-  }
-  const size_t DD = (size_t)1 << (2 * h->N);
-  if (h->N >= 6) {
-    // fp64 matrix cores, upper-triangle 64 x 64 tiles (k_outer_mfma)
-    constexpr int KT = 16;
-    const unsigned nt = 1u << (h->N - 6);
-    hipLaunchKernelGGL(k_outer_mfma<KT>, dim3(nt, nt), dim3(256), 2 * KT * 128 * sizeof(double), st,
-                       (const cplx*)psi_dev, h->N, h->B, wdev, (cplx*)acc_dev);
-  } else {
-    hipLaunchKernelGGL(k_outer_acc, dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, st,
-                       (const cplx*)psi_dev, h->N, h->B, wdev, (cplx*)acc_dev);
-  }
+  return outer_accumulate_impl(psi_dev, h->B, (int64_t)1 << h->N, weights, acc_dev, (hipStream_t)stream);
+}
+
+extern "C" int ryd_outer_accumulate_dim(const void* psi_dev, int64_t batch, int64_t dim,
+                                        const double* weights, void* acc_dev, int32_t device,
+                                        void* stream) {
+  if (!psi_dev || !acc_dev) return fail(RYD_ERR_INVALID, "null argument");
+  if (dim > ((int64_t)1 << (RYD_MAX_QUBITS / 2))) return fail(RYD_ERR_INVALID, "dim %lld too large", (long long)dim);
+  HIPCHK(hipSetDevice(device));
+  return outer_accumulate_impl(psi_dev, batch, dim, weights, acc_dev, (hipStream_t)stream);
+}
+
+extern "C" int ryd_accumulate(const void* x_dev, double weight, int64_t count, void* acc_dev,
+                              int32_t device, void* stream) {
+  if (!x_dev || !acc_dev || count <= 0) return fail(RYD_ERR_INVALID, "null argument or empty array");
+  HIPCHK(hipSetDevice(device));
+  const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_axpy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const cplx*)x_dev, weight,
+                     (size_t)count, (cplx*)acc_dev);
   hipError_t e = hipGetLastError();
-  if (wdev) { hipStreamSynchronize(st); hipFree(wdev); }
-  if (e != hipSuccess) return fail(RYD_ERR_HIP, "k_outer_acc: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail(RYD_ERR_HIP, "k_axpy: %s", hipGetErrorString(e));
   return RYD_OK;
 }
 

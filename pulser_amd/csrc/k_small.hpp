@@ -135,15 +135,15 @@ __global__ void k_ket_to_dm(const cplx* __restrict__ psi, int N, cplx* __restric
       make_double2(pa.x * pb.x + pa.y * pb.y, pa.y * pb.x - pa.x * pb.y);
 }
 
-__global__ void k_outer_acc(const cplx* __restrict__ psi, int N, int B,
+// any state dimension D (3^N / 4^N for the multi-level bases): one thread per entry
+__global__ void k_outer_acc(const cplx* __restrict__ psi, size_t D, int B,
                             const double* __restrict__ wts, cplx* __restrict__ acc) {
-  const size_t D = (size_t)1 << N;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= D * D) return;
-  const size_t a = i >> N, b = i & (D - 1);
+  const size_t a = i / D, b = i - a * D;
   double sr = 0, si = 0;
   for (int t = 0; t < B; ++t) {
-    const cplx pa = psi[((size_t)t << N) + a], pb = psi[((size_t)t << N) + b];
+    const cplx pa = psi[(size_t)t * D + a], pb = psi[(size_t)t * D + b];
     const double w = wts ? wts[t] : 1.0;
     sr += w * (pa.x * pb.x + pa.y * pb.y);
     si += w * (pa.y * pb.x - pa.x * pb.y);
@@ -177,7 +177,7 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 // 47 TFLOP/s - the f64 matrix pipe needs >= 4 waves per SIMD to approach its
 // 78.6 TFLOP/s, so the kernel is held to 128 registers (64 of them accumulators).
 template <int KT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_outer_mfma(const cplx* __restrict__ psi, int N, int B,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_outer_mfma(const cplx* __restrict__ psi, size_t D, int B,
                                                     const double* __restrict__ wts,
                                                     cplx* __restrict__ acc) {
   const int ta = blockIdx.y, tb = blockIdx.x;  // row / column tile
@@ -185,7 +185,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* sA = reinterpret_cast<double*>(smem);  // [KT][64][2] = w_t * psi_t[a0 + .]
   double* sB = sA + KT * 128;                    // [KT][64][2] =       psi_t[b0 + .]
-  const size_t D = (size_t)1 << N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;       // 32 x 32 sub-tile of this wave
   const int li = lane & 15, lk = lane >> 4;      // operand row/col, k slot
@@ -212,8 +211,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       pb[it] = pa[it];
       if (t < B) {
         const double w = wts ? wts[t] : 1.0;
-        const cplx va = psi[((size_t)t << N) + a0 + col];
-        pb[it] = psi[((size_t)t << N) + b0 + col];
+        const cplx va = psi[(size_t)t * D + a0 + col];
+        pb[it] = psi[(size_t)t * D + b0 + col];
         pa[it] = make_double2(w * va.x, w * va.y);
       }
     }
@@ -281,4 +280,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           else acc[row * D + col] = make_double2(old[c][g].x + vr, old[c][g].y + vi);
         }
     }
+}
+
+// acc += w * x, elementwise (sum of the trajectories' density matrices, aggregators.py:20-37)
+__global__ void k_axpy(const cplx* __restrict__ x, double w, size_t count, cplx* __restrict__ acc) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const cplx v = x[i];
+    cplx a = acc[i];
+    a.x += w * v.x;
+    a.y += w * v.y;
+    acc[i] = a;
+  }
 }

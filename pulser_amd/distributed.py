@@ -31,6 +31,87 @@ from typing import Any, Callable, Sequence
 import numpy as np
 
 
+# Sharding is an explicit opt-in (a process group may exist for unrelated reasons - a parameter sweep
+# with one sequence per rank, data-parallel training around the emulator - and implicit collectives
+# would deadlock it or sum unrelated histograms): ``enable_sharding()`` or PULSER_AMD_SHARD=1.
+_SHARDING = {"enabled": os.environ.get("PULSER_AMD_SHARD", "0") not in ("", "0")}
+
+
+def enable_sharding(enabled: bool = True) -> None:
+    """Let noisy ``QutipEmulator.run()`` / ``QutipBackendV2.run()`` split their trajectories over the
+    ranks of the initialised ``torch.distributed`` group.  EVERY rank must then make the same call on
+    the same sequence, noise model and evaluation times (checked, see :func:`check_same_problem`)."""
+    _SHARDING["enabled"] = bool(enabled)
+
+
+def sharding_enabled() -> bool:
+    return _SHARDING["enabled"]
+
+
+def problem_digest(emulator: Any) -> str:
+    """SHA-256 over what defines a run: the sampled sequence, register, noise model, evaluation times,
+    trajectory count, sampling rate, solver."""
+    import hashlib
+    import pickle
+
+    h = hashlib.sha256()
+
+    def feed(x: Any) -> None:
+        if isinstance(x, dict):
+            for k in sorted(x):
+                h.update(str(k).encode())
+                feed(x[k])
+        elif isinstance(x, (list, tuple)):
+            h.update(b"[")
+            for v in x:
+                feed(v)
+            h.update(b"]")
+        elif isinstance(x, np.ndarray):
+            h.update(str(x.dtype).encode() + str(x.shape).encode())
+            h.update(np.ascontiguousarray(x).tobytes())
+        else:
+            h.update(repr(x).encode())
+
+    feed(emulator.samples_obj.to_dict())
+    feed(np.asarray(emulator._eval_times_array, dtype=np.float64))
+    feed(repr(emulator.noise_model))
+    feed((emulator.n_trajectories, float(emulator._sampling_rate), str(emulator.solver)))
+    try:
+        feed(np.asarray(emulator._initial_state))
+    except Exception:  # pragma: no cover
+        h.update(pickle.dumps(None))
+    return h.hexdigest()
+
+
+def check_same_problem(dist: Any, emulator: Any) -> None:
+    """Every rank must be running the same emulation before any collective mixes their results."""
+    mine = problem_digest(emulator)
+    digests: list[Any] = [None] * dist.get_world_size()
+    dist.all_gather_object(digests, mine)
+    if any(d != digests[0] for d in digests):
+        bad = [r for r, d in enumerate(digests) if d != digests[0]]
+        raise RuntimeError(
+            "Sharded run refused: ranks " + str(bad) + " hold a different sequence / noise model / "
+            "evaluation times than rank 0. Sharding splits ONE emulation over the ranks; disable it "
+            "(pulser_amd.distributed.enable_sharding(False)) when the ranks run different jobs.")
+
+
+class _DiagonalState:
+    """What the sampling chain needs of a density matrix (qutip_result.py:101-118): its diagonal."""
+
+    isket = False
+
+    def __init__(self, diag: np.ndarray) -> None:
+        self._diag = np.asarray(diag)
+        self.shape = (self._diag.size, self._diag.size)
+
+    def diag(self) -> np.ndarray:
+        return self._diag
+
+    def tr(self) -> complex:
+        return complex(np.sum(self._diag))
+
+
 def env_world() -> tuple[int, int, int]:
     """(rank, local_rank, world_size) from the torchrun environment."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -141,8 +222,11 @@ def run_ensemble(
     contiguous block on its GPU and samples it; ONE all-reduce (sum) per accumulator closes the run:
     bitstring histograms int64[n_eval, 2^N], measured-bit occupation sums float64[n_eval, N + 1]
     and, with ``density_matrix``, the reps-weighted sum of |psi><psi| (aggregators.py:19-37) as
-    float64[n_eval, 2, D, D].  ``solve_fn(problems)`` (tests) returns host states
-    complex[len(problems), n_eval, dim] instead of running the HIP engine.
+    float64[n_eval, D, D, 2].  ``solve_fn(problems)`` (tests) returns host states
+    complex[len(problems), n_eval, dim] instead of running the HIP engine.  On the tuned two-level
+    path the states never leave the device except for the kets the bit-exact sampling replay reads:
+    occupations come from ``ryd_occupations``, the |psi><psi| sum from ``ryd_outer_accumulate_dim``
+    and the result ``density_matrices`` is a CUDA tensor.
     """
     import torch
 
@@ -150,7 +234,11 @@ def run_ensemble(
     if dist is None:
         world, rank = 1, 0
     options = dict(options or {})
-    emulator._validate_options(options)  # max_step / nsteps defaults, the SPAM + initial-state refusal
+    # max_step / nsteps defaults, the SPAM + initial-state refusal; idempotent (a second validation of
+    # options that run() already validated must not turn the DEFAULT max_step into a requested one)
+    emulator._validate_options(options)
+    if dist is not None:
+        check_same_problem(dist, emulator)
     nm = emulator.noise_model
     times = emulator._eval_times_array
     n_eval = len(times)
@@ -188,9 +276,11 @@ def run_ensemble(
         if meas_err:
             mat_all = _broadcast_array(dist, mat_all, (total, n))
     lo, hi = partition(reps, world)[rank]
+    n_traj = int(reps.sum())
     hist = np.zeros((n_eval, 2**n), dtype=np.int64)
     occ_sum = np.zeros((n_eval, n + 1), dtype=np.float64)
-    rho_sum = None
+    rho_sum = None  # host accumulator (``solve_fn`` given / general path): complex128[n_eval, D, D]
+    rho_dev = None  # device accumulator of the tuned path: the MEAN (weights reps / n_traj)
     default_solver = solve_fn is None
     fast = default_solver and emulator._fast_path_ok(emulator._current_problem)
     if default_solver:
@@ -204,41 +294,94 @@ def run_ensemble(
     qids = tuple(emulator.samples_obj.qubit_ids)
     matching = emulator._meas_basis in emulator.basis_name  # (a property that walks the channels)
     bit_of = ((np.arange(2**n)[:, None] >> (n - 1 - np.arange(n))[None, :]) & 1).astype(np.float64)
+
+    def sample(i: int, ti: int, st: Any) -> np.ndarray:
+        """Bit-exact replay of the reference's sampling of trajectory i at evaluation time ti."""
+        w = StateResult(qids, emulator._meas_basis, st, matching)._weights()
+        k = i * n_eval + ti
+        ind = sample_with(rnd_all[offs[k]:offs[k + 1]], w)
+        ind = flips_with(ind, n, mat_all[offs[k]:offs[k + 1]] if meas_err else None,
+                         nm.p_false_pos, nm.p_false_neg)
+        hist[ti] += np.bincount(ind, minlength=2**n)
+        return w
+
     for start in range(lo, hi, batch):
         block = list(range(start, min(hi, start + batch)))
         if mc_seeds is not None:  # a trajectory's jumps depend on its seed only, not on the sharding
             emulator._mc_seed_override = mc_seeds[block]
         try:
-            if fast:  # factored lowering: shared spline tables + per-(trajectory, atom) scales
+            if fast:
+                # factored lowering (shared spline tables + per-(trajectory, atom) scales); the states
+                # stay on the device: occupations / norms are reduced there (ryd_occupations), the
+                # reps-weighted sum of |psi><psi| is formed there (ryd_outer_accumulate_dim, fp64 matrix
+                # cores) and only the kets (or, for density matrices, their diagonals) of the
+                # bit-exact sampling replay cross PCIe - no D x D array exists on the host
+                import torch as _t
+
+                from .engine import accumulate, outer_accumulate
+
                 tables = hd.device_tables([trajs[i] for i in block], emulator._sampling_rate)
-                res = emulator._solve_batch([], False, options, tables=tables)
-                states = np.stack([[np.asarray(s) for s in r.states] for r in res])
-            else:
-                states = solve_fn([hd.problem(trajs[i], emulator._sampling_rate) for i in block])
+                first_dev, snaps_dev, occ = emulator._solve_batch([], False, options, tables=tables, raw=True)
+                is_ket = first_dev.dim() == 2
+                rb = reps[block].astype(np.float64)
+                norm = occ[..., n]  # [n_eval, B]
+                if not matching:  # weights = delta_0 (qutip_result.py:119-122): every measured bit is 0
+                    bits = np.zeros_like(occ[..., :n])
+                elif emulator._meas_basis == "ground-rydberg":  # bit 1 <=> |r> = local index 0
+                    bits = occ[..., :n] / norm[..., None]
+                else:  # digital: bit 1 <=> |h> = local index 1
+                    bits = (norm[..., None] - occ[..., :n]) / norm[..., None]
+                occ_sum[:, :n] += np.einsum("b,tbk->tk", rb, bits)
+                occ_sum[:, n] += norm @ rb
+                if density_matrix:
+                    D = int(first_dev.shape[1])
+                    if rho_dev is None:
+                        rho_dev = _t.zeros((n_eval, D, D), dtype=_t.complex128, device=first_dev.device)
+                    for ti in range(n_eval):
+                        x = first_dev if ti == 0 else snaps_dev[ti - 1]
+                        if is_ket:
+                            outer_accumulate(x, rho_dev[ti], rb / n_traj)
+                        else:
+                            for j in range(len(block)):
+                                accumulate(x[j], rho_dev[ti], float(rb[j]) / n_traj)
+                if is_ket:
+                    host = _t.cat([first_dev[None], snaps_dev]).cpu().numpy()  # [n_eval, B, D]
+                else:
+                    host = _t.cat([_t.diagonal(first_dev, dim1=-2, dim2=-1)[None],
+                                   _t.diagonal(snaps_dev, dim1=-2, dim2=-1)]).cpu().numpy()
+                del first_dev, snaps_dev
+                for j, i in enumerate(block):
+                    for ti in range(n_eval):
+                        sample(i, ti, QState(host[ti, j]) if is_ket else _DiagonalState(host[ti, j]))
+                continue
+            states = solve_fn([hd.problem(trajs[i], emulator._sampling_rate) for i in block])
         finally:
             emulator._mc_seed_override = None
         for j, i in enumerate(block):
             for ti in range(n_eval):
                 st = QState(states[j][ti])
-                w = StateResult(qids, emulator._meas_basis, st, matching)._weights()
-                k = i * n_eval + ti
-                ind = sample_with(rnd_all[offs[k]:offs[k + 1]], w)
-                ind = flips_with(ind, n, mat_all[offs[k]:offs[k + 1]] if meas_err else None,
-                                 nm.p_false_pos, nm.p_false_neg)
-                hist[ti] += np.bincount(ind, minlength=2**n)
+                w = sample(i, ti, st)
                 # measured-bit occupations from the 2^N weights: valid for every basis (2-, 3-, 4-level)
                 occ_sum[ti, :n] += reps[i] * (w @ bit_of)
                 occ_sum[ti, n] += reps[i] * (float(np.vdot(st, st).real) if st.isket else float(st.tr().real))
                 if density_matrix:
+                    # explicit-term general path (multi-level / XY registers of a few atoms) and the
+                    # host ``solve_fn`` of the CPU tests
                     a = np.asarray(st)
                     r1 = (a @ a.conj().T) if st.isket else a
                     if rho_sum is None:
                         rho_sum = np.zeros((n_eval,) + r1.shape, dtype=np.complex128)
                     rho_sum[ti] += reps[i] * r1
     # -- the one collective per accumulator: sum over ranks -----------------
-    if density_matrix and rho_sum is None:  # an empty shard still takes part in the all-reduce
+    on_device = fast and density_matrix
+    if density_matrix and not on_device and rho_sum is None:  # an empty shard still takes part in the all-reduce
         d = len(hd.eigenbasis) ** n
         rho_sum = np.zeros((n_eval, d, d), dtype=np.complex128)
+    if on_device and rho_dev is None:
+        import torch as _t
+
+        d = len(hd.eigenbasis) ** n
+        rho_dev = _t.zeros((n_eval, d, d), dtype=_t.complex128, device=_t.device("cuda", _t.cuda.current_device()))
     if dist is not None:
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         th = torch.from_numpy(hist).to(dev)
@@ -246,11 +389,16 @@ def run_ensemble(
         dist.all_reduce(th)
         dist.all_reduce(to)
         hist, occ_sum = th.cpu().numpy(), to.cpu().numpy()
-        if density_matrix:
+        if on_device:  # the device tensor goes into the all-reduce as it is (RCCL); gloo needs a host hop
+            tr = torch.view_as_real(rho_dev)
+            if dev == "cpu":
+                tr = tr.cpu()
+            dist.all_reduce(tr)
+            rho_dev = torch.view_as_complex(tr.to(rho_dev.device))
+        elif density_matrix:
             tr = torch.view_as_real(torch.from_numpy(rho_sum)).contiguous().to(dev)  # float64[..., 2]
             dist.all_reduce(tr)
             rho_sum = torch.view_as_complex(tr.cpu().contiguous()).numpy()
-    n_traj = int(reps.sum())
     counters = [
         Counter({np.binary_repr(i, n): int(c) for i, c in enumerate(h) if c})
         for h in hist
@@ -264,5 +412,7 @@ def run_ensemble(
         "block": (lo, hi),
     }
     if density_matrix:
-        out["density_matrices"] = rho_sum / n_traj
+        # tuned path: a CUDA tensor complex128[n_eval, D, D] (it never existed on the host; ``.cpu()`` on
+        # request); host solvers: a NumPy array
+        out["density_matrices"] = rho_dev if on_device else rho_sum / n_traj
     return out

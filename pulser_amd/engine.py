@@ -40,6 +40,44 @@ def _method_code(method: str) -> int:
         raise ValueError(f"unknown method {method!r}; one of {sorted(_METHODS)}") from None
 
 
+def outer_accumulate(psi: Any, acc: Any, weights: Any = None) -> None:
+    """``acc[D, D] += sum_b w_b |psi_b><psi_b|`` on the device, without a solver handle and for any
+    state dimension (``ryd_outer_accumulate_dim``): the trajectory mean of
+    pulser_simulation/aggregators.py:20-37.  ``psi`` complex128[B, D] and ``acc`` complex128[D, D]
+    are contiguous CUDA tensors on the same device."""
+    torch = _torch()
+    if not (psi.is_cuda and acc.is_cuda and psi.device == acc.device):
+        raise ValueError("psi and acc must be CUDA tensors on the same device")
+    if psi.dtype != torch.complex128 or acc.dtype != torch.complex128:
+        raise TypeError("complex128 tensors expected")
+    if psi.dim() != 2 or tuple(acc.shape) != (psi.shape[1], psi.shape[1]):
+        raise ValueError(f"shapes {tuple(psi.shape)} / {tuple(acc.shape)} do not match [B, D] / [D, D]")
+    if not (psi.is_contiguous() and acc.is_contiguous()):
+        raise ValueError("contiguous tensors expected")
+    wptr = None
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        if weights.shape != (psi.shape[0],):
+            raise ValueError(f"need one weight per state ({psi.shape[0]}), got {weights.shape}")
+        wptr = weights.ctypes.data
+    _lib.check(_lib.load().ryd_outer_accumulate_dim(
+        psi.data_ptr(), int(psi.shape[0]), int(psi.shape[1]), wptr, acc.data_ptr(), int(psi.device.index or 0),
+        torch.cuda.current_stream(psi.device).cuda_stream))
+
+
+def accumulate(x: Any, acc: Any, weight: float = 1.0) -> None:
+    """``acc += weight * x`` elementwise on the device (``ryd_accumulate``): the running sum of
+    trajectory density matrices of aggregators.py:29-35."""
+    torch = _torch()
+    if not (x.is_cuda and acc.is_cuda and x.device == acc.device) or x.shape != acc.shape:
+        raise ValueError("x and acc must be CUDA tensors of one shape on the same device")
+    if x.dtype != torch.complex128 or acc.dtype != torch.complex128 or not (x.is_contiguous() and acc.is_contiguous()):
+        raise TypeError("contiguous complex128 tensors expected")
+    _lib.check(_lib.load().ryd_accumulate(
+        x.data_ptr(), float(weight), int(x.numel()), acc.data_ptr(), int(x.device.index or 0),
+        torch.cuda.current_stream(x.device).cuda_stream))
+
+
 class Engine:
     """One ``ryd_handle``: a batch of B states of N atoms on one device.
 

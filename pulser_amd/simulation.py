@@ -609,7 +609,10 @@ class QutipEmulator:
         # from stepping over pulse features; the CF4 stepper never steps over a spline knot that matters
         # (it merges knots only where the waveform is the same polynomial on both sides), so only a
         # max_step the caller asked for is handed to the engine
-        self._default_max_step = "max_step" not in options
+        # (recorded in the options themselves, so that validating the same dict twice - run() and then
+        # run_ensemble() - cannot turn the default into a request)
+        options.setdefault("_max_step_is_default", "max_step" not in options)
+        self._default_max_step = bool(options["_max_step_is_default"])
         options.setdefault(
             "max_step", min(min_variation(ch) for ch in self.samples_obj.channels) / 1000
         )
@@ -678,13 +681,17 @@ class QutipEmulator:
 
     def _solve_batch(self, problems: list[dict[str, Any]], progress_bar: Any,
                      options: dict[str, Any], tables: Any = None,
-                     mc_ntraj: int | None = None) -> list[CoherentResults]:
+                     mc_ntraj: int | None = None, raw: bool = False) -> Any:
         """The solver call of ``_run_solver`` (simulation.py:689-766) for a batch
         of trajectories in ONE engine (one GPU launch sequence).  ``tables``:
         pre-lowered device tables for the batch (factored noise) instead of
         ``problems``.  ``mc_ntraj``: the ``ntraj`` of ``qutip.mcsolve`` for the
         deterministic run (simulation.py:843); ``None`` = one quantum-jump
-        trajectory per batch entry (the noisy runs, :726-727 with the default 1)."""
+        trajectory per batch entry (the noisy runs, :726-727 with the default 1).
+        ``raw`` (ensemble runs on pre-lowered ``tables``): nothing is wrapped - returns
+        ``(initial_state_device [B, dim...], snapshots_device [n_eval - 1, B, dim...],
+        occupations float64[n_eval, B, N + 1])`` with the occupations / norms reduced on the device
+        (``ryd_occupations``), so that the caller can keep the state sums there too."""
         if progress_bar not in (True, False, None):
             raise ValueError("`progress_bar` must be a bool.")
         from .engine import Engine
@@ -723,6 +730,7 @@ class QutipEmulator:
                     "give the ket (the density matrix is built on the device).")
             state = eng.new_state(init.reshape(1, -1))
             first = None if on_device else state.cpu().numpy()
+            first_dev = state.clone() if raw else None
             if mode == "mcsolve":
                 snaps = eng.mc_solve(state, times, self._mc_seeds(n_batch, options), store=True,
                                      **self._engine_kwargs(options))
@@ -731,6 +739,11 @@ class QutipEmulator:
                 snaps = eng.solve(state, times, store=True, **self._engine_kwargs(options))
             # large density matrices never cross PCIe as a whole: the results hold the device
             # tensors and reduce the diagonal (sampling weights, qutip_result.py:101-118) there
+            if raw:
+                occ = eng.torch.stack([eng.occupations(first_dev)]
+                                      + [eng.occupations(snaps[i]) for i in range(len(times) - 1)]).cpu().numpy()
+                self.last_engine_stats = eng.stats()
+                return first_dev, snaps, occ
             host = None if on_device else snaps.cpu().numpy()
             del state
             self.last_engine_stats = eng.stats()
@@ -944,7 +957,10 @@ class QutipEmulator:
         td = sys.modules.get("torch.distributed")
         if td is None or not td.is_available() or not td.is_initialized() or td.get_world_size() < 2:
             return None
-        return td
+        from .distributed import sharding_enabled
+
+        # an explicit opt-in: a process group may exist for reasons of the caller's own
+        return td if sharding_enabled() else None
 
     def _refresh_trajectories_if_used(self) -> None:
         """Fresh noise-trajectory draws on every run after the first (simulation.py:892-900)."""

@@ -6,7 +6,8 @@
 
 Names (default: rydberg digital three cfg1 cfg2 cfg3 cfg4): rydberg, digital, xy, all, three, cfg1..cfg4,
 spam_all, results_noisy, final_state_noisy, slm_effective_size, slm_masks, modulation, eom_limit_det,
-multichannel_noise, dmm, results, waist, config.
+multichannel_noise, dmm, results, waist, config, ns14 (14-atom headline, tight), cfg3_8 / cfg3_10
+(interacting 8- / 10-atom Lindblad, tight).
 
 * Inputs are captured by importing the reference's ``pulser-core`` (read-only,
   never shipped; needs the no-op ``jsonschema``/``referencing`` stand-in of
@@ -1058,6 +1059,123 @@ def gen_cfg3_small(rows=2, cols=3):
     )
 
 
+
+def gen_ns_tri14(rows=2, cols=7, name="ns_tri14_anneal"):
+    """The bench headline at FULL size (SURVEY 8c last row): 14-atom triangular register (2 x 7,
+    spacing R_b), the anneal of test_qutip_backend_v2.py:56-88, sesolve; tight oracle only
+    (zvode rtol 1e-13) at six times incl. T.  Minutes of one core."""
+    import time
+    rb = blockade_radius()
+    reg = Register.triangular_lattice(rows, cols, rb, prefix="q")
+    problems, aux, _ = capture(anneal_sequence(reg), None)
+    p = problems[0]
+    n = p["n_qudits"]
+    coords = P.register_coords(P.triangular_rect(rows, cols), rb)
+    assert np.allclose(coords, p["coords"], rtol=0, atol=1e-12)
+    syn = P.anneal_samples()
+    for k in ("amp", "det", "phase"):
+        assert np.array_equal(syn[k], p["samples"]["Global"]["ground-rydberg"][k]), k
+    sel_t = np.array([0.0, 0.5, 1.3, 2.1, 3.099, 3.1])
+    aux_min = dict(aux)
+    aux_min["eval_times"] = sel_t
+    counter = [0]
+    t0 = time.time()
+    opts = dict(aux["options"])
+    opts.update(qp.TIGHT)
+    tight = qp.sesolve(qp.build_hamiltonian(p), qp.all_ground_state(n, p["eigenbasis"]), sel_t, counter=counter, **opts)
+    print(f"{name}: tight zvode {counter[0]} RHS evals in {time.time() - t0:.1f}s; norm drift {np.linalg.norm(tight[-1]) - 1:.2e}", flush=True)
+    small = {k: v for k, v in p.items() if k != "samples"}
+    small["samples"] = {"Global": {}, "Local": {}}
+    P.save_problem(
+        os.path.join(HERE, name + ".npz"), small, aux={k: v for k, v in aux.items() if k not in ("eval_times", "channel_amp_det")},
+        synthetic=f"anneal_samples() on a {rows} x {cols} triangular register at the blockade radius",
+        rows=rows, cols=cols, blockade_radius=float(rb),
+        eval_times=sel_t,
+        oracle_states_tight=np.stack(tight),
+        oracle_rhs_evals_tight=counter[0],
+    )
+
+
+def gen_cfg3_tight(rows=2, cols=4):
+    """cfg3 physics on an INTERACTING triangular register large enough for the split-operator row
+    path (k_ket rows need >= 10 atoms; 8 atoms for the multi-launch kernels): tight oracle only."""
+    import time
+    rb = blockade_radius()
+    reg = Register.triangular_lattice(rows, cols, rb, prefix="q")
+    nm = NoiseModel(dephasing_rate=0.05, p_false_pos=0.01, p_false_neg=0.05)
+    np.random.seed(7)
+    problems, aux, _ = capture(anneal_sequence(reg), nm)
+    p = problems[0]
+    n = p["n_qudits"]
+    coords = P.register_coords(P.triangular_rect(rows, cols), rb)
+    assert np.allclose(coords, p["coords"], rtol=0, atol=1e-12), (coords, p["coords"])
+    sel_t = np.array([0.0, 0.5, 1.3, 2.1, 3.099, 3.1])
+    opts = dict(aux["options"])
+    opts.update(qp.TIGHT)
+    counter = [0]
+    t0 = time.time()
+    ham = qp.build_hamiltonian(p)
+    if n >= 9:
+        from oracle import fast_lindblad as fl  # C restatement of lindblad_rhs, checked against it below
+        rhs = fl.lindblad_rhs_fast(p, ham)
+        y = np.random.default_rng(5).standard_normal(2 * 4**n).view(complex)
+        a, b = rhs(1.234, y), qp.lindblad_rhs(ham)(1.234, y)
+        print(f"fast rhs vs scipy rhs: {np.max(np.abs(a - b)):.2e}", flush=True)
+        assert np.max(np.abs(a - b)) < 1e-11
+        psi0 = qp.all_ground_state(n, p["eigenbasis"])
+        ys = qp._zvode(rhs, np.outer(psi0, psi0.conj()).ravel(), sel_t, opts, counter)
+        tight = [y.reshape(2**n, 2**n) for y in ys]
+    else:
+        tight = qp.mesolve(ham, qp.all_ground_state(n, p["eigenbasis"]), sel_t, counter=counter, **opts)
+    print(f"cfg3_tight N={n}: {counter[0]} RHS evals in {time.time() - t0:.1f}s; trace {np.trace(tight[-1]).real:.12f}", flush=True)
+    small = {k: v for k, v in p.items() if k != "samples"}
+    small["samples"] = {"Global": {}, "Local": {}}
+    P.save_problem(
+        os.path.join(HERE, f"cfg3_tri{n}_dephasing.npz"), small,
+        aux={k: v for k, v in aux.items() if k not in ("eval_times", "channel_amp_det")},
+        rows=rows, cols=cols, blockade_radius=float(rb),
+        eval_times=sel_t, seed=123,
+        meas_errors={"epsilon": 0.01, "epsilon_prime": 0.05},
+        oracle_rhs_evals_tight=counter[0],
+        **sketch_density_matrices(tight, n),
+    )
+
+
+SKETCH_ROWS, SKETCH_PROBES, SKETCH_SEED = 32, 4, 11
+
+
+def sketch_rows(D):
+    """Rows kept in full: first, last (all-ground), and a seeded draw."""
+    rng = np.random.default_rng(SKETCH_SEED)
+    return np.unique(np.concatenate([[0, D - 1], rng.choice(D, min(D, SKETCH_ROWS) - 2, replace=False)]))
+
+
+def sketch_probes(D):
+    rng = np.random.default_rng(SKETCH_SEED + 1)
+    return rng.standard_normal((D, SKETCH_PROBES)) + 1j * rng.standard_normal((D, SKETCH_PROBES))
+
+
+def sketch_density_matrices(tight, n):
+    """A 10-atom rho is 16 MiB per time - too much for a fixture.  Kept instead: 32 full rows, the diagonal,
+    rho @ V for 4 seeded Gaussian probe vectors (an error of size eps ANYWHERE in rho shows up as ~eps in
+    the product of its row), trace and purity; up to 8 atoms the full upper triangle too."""
+    D = 2**n
+    rows, V = sketch_rows(D), sketch_probes(D)
+    out = {
+        "oracle_rows": rows,
+        "oracle_rows_tight": np.stack([t[rows] for t in tight]),
+        "oracle_diag_tight": np.stack([np.diag(t) for t in tight]),
+        "oracle_probe_products_tight": np.stack([t @ V for t in tight]),
+        "oracle_purity_tight": np.array([np.vdot(t, t).real for t in tight]),
+        "oracle_hermiticity_defect": max(float(np.max(np.abs(t - t.conj().T))) for t in tight),
+        "sketch": {"rows": SKETCH_ROWS, "probes": SKETCH_PROBES, "seed": SKETCH_SEED},
+    }
+    if n <= 8:
+        iu = np.triu_indices(D)
+        out["oracle_states_tight_triu"] = np.stack([t[iu] for t in tight])
+    return out
+
+
 def gen_cfg4(n=12, ntraj=1024, keep=3):
     """12-atom chain, doppler + amplitude + SPAM noise, seed 0, 1024 trajectories."""
     rb = blockade_radius()
@@ -1315,6 +1433,12 @@ if __name__ == "__main__":
         gen_cfg3_small(2, 3)
     if "cfg4" in which:
         gen_cfg4()
+    if "ns14" in which:
+        gen_ns_tri14()
+    if "cfg3_8" in which:
+        gen_cfg3_tight(2, 4)
+    if "cfg3_10" in which:
+        gen_cfg3_tight(2, 5)
     if "spam_all" in which:
         gen_noise_spam_all()
     if "results_noisy" in which:

@@ -63,3 +63,44 @@ def rand_state(dim, seed):
     rng = np.random.default_rng(seed)
     v = rng.normal(size=dim) + 1j * rng.normal(size=dim)
     return v / np.linalg.norm(v)
+
+
+def tight_density_matrices(extra, n):
+    """cfg3 fixtures written by ``gen_cfg3_tight`` keep the upper triangle only."""
+    D = 2**n
+    iu = np.triu_indices(D)
+    out = []
+    for vals in np.asarray(extra["oracle_states_tight_triu"]):
+        rho = np.zeros((D, D), complex)
+        rho[iu] = vals
+        low = rho.conj().T.copy()
+        low[np.diag_indices(D)] = 0.0
+        out.append(rho + low)
+    return np.stack(out)
+
+
+def sketch_rows(D, rows=32, seed=11):
+    """The rows / probe vectors of ``make_fixtures.sketch_density_matrices`` (same seeded draws)."""
+    rng = np.random.default_rng(seed)
+    return np.unique(np.concatenate([[0, D - 1], rng.choice(D, min(D, rows) - 2, replace=False)]))
+
+
+def sketch_probes(D, probes=4, seed=11):
+    rng = np.random.default_rng(seed + 1)
+    return rng.standard_normal((D, probes)) + 1j * rng.standard_normal((D, probes))
+
+
+def sketch_errors(rho, extra, k):
+    """Max-abs deviation of ``rho`` from the tight oracle at stored time ``k`` over everything the fixture
+    keeps: 32 full rows, the diagonal, rho @ (4 Gaussian probes) - which sees an error anywhere - and purity."""
+    D = rho.shape[0]
+    sk = extra["sketch"]
+    rows = sketch_rows(D, sk["rows"], sk["seed"])
+    assert np.array_equal(rows, np.asarray(extra["oracle_rows"]))
+    V = sketch_probes(D, sk["probes"], sk["seed"])
+    return {
+        "rows": float(np.max(np.abs(rho[rows] - np.asarray(extra["oracle_rows_tight"])[k]))),
+        "diag": float(np.max(np.abs(np.diag(rho) - np.asarray(extra["oracle_diag_tight"])[k]))),
+        "probes": float(np.max(np.abs(rho @ V - np.asarray(extra["oracle_probe_products_tight"])[k]))),
+        "purity": float(abs(np.vdot(rho, rho).real - np.asarray(extra["oracle_purity_tight"])[k])),
+    }

@@ -152,3 +152,60 @@ def test_sharded_ensemble_equals_serial_reference_world1_and_world2(world):
         assert np.array_equal(hist, out1["histograms"])
         assert np.allclose(occ, out1["mean_occupations"], atol=1e-14)
         assert np.allclose(rho, out1["density_matrices"], atol=1e-14)  # the all-reduced sum of |psi><psi|
+
+
+def test_validating_options_twice_keeps_the_default_max_step_a_default():
+    """QutipEmulator.run() validates its options and hands the same dict to run_ensemble(), which
+    validates again: the reference's DEFAULT max_step must not become a requested one on the way (it
+    would switch the multi-knot CF4 steps off for every sharded run)."""
+    emu = _make_emulator()
+    opts: dict = {}
+    emu._validate_options(opts)
+    assert "max_step" in opts and "max_step" not in emu._engine_kwargs(opts)
+    again = dict(opts)
+    emu._validate_options(again)
+    assert "max_step" not in emu._engine_kwargs(again)
+    asked = {"max_step": 0.002}
+    emu._validate_options(asked)
+    emu._validate_options(asked)
+    assert emu._engine_kwargs(asked)["max_step"] == 0.002
+
+
+def _digest_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from pulser_amd.distributed import check_same_problem, enable_sharding, init_process_group
+
+    d = init_process_group("gloo")
+    emu = _make_emulator()
+    assert emu._distributed() is None  # no opt-in, no sharding
+    enable_sharding()
+    assert emu._distributed() is not None
+    check_same_problem(d, emu)  # identical on every rank: passes
+    other = _make_emulator(n_traj=16 if rank == 0 else 8)  # ranks disagree
+    try:
+        check_same_problem(d, other)
+        q.put((rank, "accepted"))
+    except RuntimeError as exc:
+        q.put((rank, str(exc)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharding_is_an_opt_in_and_refuses_ranks_that_run_different_jobs():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_digest_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, msg in got:
+        assert msg.startswith("Sharded run refused: ranks [1]"), msg

@@ -341,8 +341,9 @@ def test_qutip_config_validation():
         QutipConfig(observables=[BitStrings(evaluation_times=[1.0])], solver="fakesolver")
 
 
+@pytest.mark.gpu
 def test_density_matrix_aggregator():
-    """tests/pulser_simulation/test_aggregators.py:4-47."""
+    """tests/pulser_simulation/test_aggregators.py:4-47 (the mean is formed on the device: a GPU test)."""
     from pulser_amd.backend import density_matrix_aggregator
 
     s1 = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rgr": 1.0})
