@@ -211,6 +211,7 @@ def run_ensemble(
     mc_seed: int | None = None,
     options: dict[str, Any] | None = None,
     density_matrix: bool = False,
+    options_validated: bool = False,
 ) -> dict[str, Any]:
     """Sharded equivalent of the stochastic branch of ``QutipEmulator.run``
     (simulation.py:847-883, 885-915); ``QutipEmulator.run`` calls it when
@@ -234,9 +235,11 @@ def run_ensemble(
     if dist is None:
         world, rank = 1, 0
     options = dict(options or {})
-    # max_step / nsteps defaults, the SPAM + initial-state refusal; idempotent (a second validation of
-    # options that run() already validated must not turn the DEFAULT max_step into a requested one)
-    emulator._validate_options(options)
+    # max_step / nsteps defaults, the SPAM + initial-state refusal - once: validating the dict run() already
+    # validated would take the filled-in DEFAULT max_step for a requested one (and switch the multi-knot
+    # steps off for every sharded run)
+    if not options_validated:
+        emulator._validate_options(options)
     if dist is not None:
         check_same_problem(dist, emulator)
     nm = emulator.noise_model

@@ -553,26 +553,29 @@ class CoherentResults(SimulationResults):
                  sim_times: np.ndarray, meas_basis: str,
                  meas_errors: Optional[Mapping[str, float]] = None) -> None:
         super().__init__(size, basis_name, sim_times)
-        if "all" in self._basis_name:
-            if meas_basis not in {"ground-rydberg", "digital"}:
-                raise ValueError("`meas_basis` must be 'ground-rydberg' or 'digital'.")
-        else:
-            expected = self._basis_name.replace("_with_error", "")
-            if meas_basis != expected:
-                raise ValueError(
-                    f"`meas_basis` associated to basis_name '"
-                    f"{self._basis_name}' must be '{expected}'."
-                )
-        self._meas_basis = meas_basis
+        self._meas_basis = self._checked_meas_basis(meas_basis)
         self._results_seq = tuple(run_output)
-        if meas_errors is not None:
-            if set(meas_errors) != {"epsilon", "epsilon_prime"}:
-                raise ValueError(
-                    "When defining measurement errors, only values of "
-                    "'epsilon' and 'epsilon_prime' must be given."
-                )
+        self._meas_errors = self._checked_meas_errors(meas_errors)
+        if self._meas_errors is not None:  # sampled states become pseudo-densities (simresults.py:192-217)
             self._use_pseudo_dens = True
-        self._meas_errors = meas_errors
+
+    def _checked_meas_basis(self, meas_basis: str) -> str:
+        """Which measurement bases a simulation basis admits (contract of simresults.py:400-412)."""
+        plain = self._basis_name.replace("_with_error", "")
+        if "all" in self._basis_name:
+            if meas_basis in ("ground-rydberg", "digital"):
+                return meas_basis
+            raise ValueError("`meas_basis` must be 'ground-rydberg' or 'digital'.")
+        if meas_basis == plain:
+            return meas_basis
+        raise ValueError(f"`meas_basis` associated to basis_name '{self._basis_name}' must be '{plain}'.")
+
+    @staticmethod
+    def _checked_meas_errors(meas_errors: Optional[Mapping[str, float]]) -> Optional[Mapping[str, float]]:
+        if meas_errors is None or sorted(meas_errors) == ["epsilon", "epsilon_prime"]:
+            return meas_errors
+        raise ValueError("When defining measurement errors, only values of 'epsilon' and 'epsilon_prime' "
+                         "must be given.")
 
     @property
     def states(self) -> list[QState]:

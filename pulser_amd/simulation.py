@@ -488,40 +488,38 @@ class QutipEmulator:
     def evaluation_times(self) -> np.ndarray:
         return np.array(self._eval_times_array)
 
-    def set_evaluation_times(self, value: Any) -> None:
-        """simulation.py:532-599."""
-        st = self.sampling_times
-        if isinstance(value, str):
-            if value == "Full":
-                eval_times = np.copy(st)
-            elif value == "Minimal":
-                eval_times = np.array([])
-            else:
-                raise ValueError(
-                    "Wrong evaluation time label. It should "
-                    "be `Full`, `Minimal`, an array of times or"
-                    + " a float between 0 and 1."
-                )
-        elif isinstance(value, float):
-            if value > 1 or value <= 0:
+    _EVAL_LABEL_ERROR = ("Wrong evaluation time label. It should be `Full`, `Minimal`, an array of times or a "
+                         "float between 0 and 1.")
+
+    def _requested_times(self, spec: Any) -> np.ndarray:
+        """The times (us) a specification asks for, before the end points are added.  A table of
+        the accepted kinds; everything else is a label error (contract of simulation.py:532-599)."""
+        grid = self.sampling_times
+        t_end = self._tot_duration * 1e-3
+        if isinstance(spec, str):
+            named = {"Full": lambda: grid.copy(), "Minimal": lambda: np.empty(0)}
+            if spec not in named:
+                raise ValueError(self._EVAL_LABEL_ERROR)
+            return named[spec]()
+        if isinstance(spec, float):  # a fraction of the sampling grid, evenly thinned
+            if not 0 < spec <= 1:
                 raise ValueError("evaluation_times float must be between 0 and 1.")
-            indices = np.linspace(0, len(st) - 1, int(value * len(st)), dtype=int)
-            eval_times = st[indices]
-        elif isinstance(value, (list, tuple, np.ndarray)):
-            if np.max(value, initial=0) > self._tot_duration * 1e-3:
-                raise ValueError(
-                    "Provided evaluation-time list extends further than sequence duration."
-                )
-            if np.min(value, initial=0) < 0:
-                raise ValueError("Provided evaluation-time list contains negative values.")
-            eval_times = np.array(value)
-        else:
-            raise ValueError(
-                "Wrong evaluation time label. It should "
-                "be `Full`, `Minimal`, an array of times or a "
-                + "float between 0 and 1."
-            )
-        self._eval_times_array = np.union1d(eval_times, [0.0, self._tot_duration * 1e-3])
+            keep = np.linspace(0, grid.size - 1, int(spec * grid.size), dtype=int)
+            return grid[keep]
+        if isinstance(spec, (list, tuple, np.ndarray)):
+            times = np.array(spec)
+            if times.size:
+                if times.max() > t_end and times.max() > 0:
+                    raise ValueError("Provided evaluation-time list extends further than sequence duration.")
+                if times.min() < 0:
+                    raise ValueError("Provided evaluation-time list contains negative values.")
+            return times
+        raise ValueError(self._EVAL_LABEL_ERROR)
+
+    def set_evaluation_times(self, value: Any) -> None:
+        """Evaluation times always contain 0 and the end of the sequence (simulation.py:596-598)."""
+        asked = self._requested_times(value)
+        self._eval_times_array = np.union1d(asked, [0.0, self._tot_duration * 1e-3])
         self._eval_times_instruction = value
 
     # --------------------------------------------------------------- operators
@@ -609,10 +607,9 @@ class QutipEmulator:
         # from stepping over pulse features; the CF4 stepper never steps over a spline knot that matters
         # (it merges knots only where the waveform is the same polynomial on both sides), so only a
         # max_step the caller asked for is handed to the engine
-        # (recorded in the options themselves, so that validating the same dict twice - run() and then
-        # run_ensemble() - cannot turn the default into a request)
-        options.setdefault("_max_step_is_default", "max_step" not in options)
-        self._default_max_step = bool(options["_max_step_is_default"])
+        # (validate a dict ONCE: a second pass would see the filled-in default as a request;
+        # run_ensemble(options_validated=True) when run() hands its options on)
+        self._default_max_step = "max_step" not in options
         options.setdefault(
             "max_step", min(min_variation(ch) for ch in self.samples_obj.channels) / 1000
         )
@@ -921,7 +918,7 @@ class QutipEmulator:
             # histograms; every rank returns the same NoisyResults (pulser_amd/distributed.py)
             from .distributed import run_ensemble
 
-            ens = run_ensemble(self, dist=sharded, options=options)
+            ens = run_ensemble(self, dist=sharded, options=options, options_validated=True)
             qids = tuple(self.samples_obj.qubit_ids)
             results = [
                 SampledResult(qids, self._meas_basis, ens["counters"][ind],

@@ -154,19 +154,23 @@ def test_sharded_ensemble_equals_serial_reference_world1_and_world2(world):
         assert np.allclose(rho, out1["density_matrices"], atol=1e-14)  # the all-reduced sum of |psi><psi|
 
 
-def test_validating_options_twice_keeps_the_default_max_step_a_default():
-    """QutipEmulator.run() validates its options and hands the same dict to run_ensemble(), which
-    validates again: the reference's DEFAULT max_step must not become a requested one on the way (it
-    would switch the multi-knot CF4 steps off for every sharded run)."""
+def test_run_hands_validated_options_to_the_ensemble_without_a_second_validation():
+    """QutipEmulator.run() validates its options and hands the dict to run_ensemble(): a second validation
+    would take the filled-in DEFAULT max_step for a requested one and switch the multi-knot CF4 steps off
+    for every sharded run (serial and sharded runs would then step differently)."""
     emu = _make_emulator()
     opts: dict = {}
     emu._validate_options(opts)
     assert "max_step" in opts and "max_step" not in emu._engine_kwargs(opts)
-    again = dict(opts)
-    emu._validate_options(again)
-    assert "max_step" not in emu._engine_kwargs(again)
+    n_eval = len(emu._eval_times_array)
+    seen = []
+    orig = emu._validate_options
+    emu._validate_options = lambda o: (seen.append(dict(o)), orig(o))[1]
+    run_ensemble(emu, lambda probs: _fake_states(probs, n_eval), dist=None, options=opts, options_validated=True)
+    assert seen == [] and "max_step" not in emu._engine_kwargs(opts)
+    run_ensemble(emu, lambda probs: _fake_states(probs, n_eval), dist=None, options={})  # direct callers: once
+    assert len(seen) == 1 and "max_step" not in emu._engine_kwargs(seen[0] | {"max_step": 1e-3})
     asked = {"max_step": 0.002}
-    emu._validate_options(asked)
     emu._validate_options(asked)
     assert emu._engine_kwargs(asked)["max_step"] == 0.002
 
