@@ -180,6 +180,15 @@ def measured_traffic(key):
     return None
 
 
+def traffic_fields(key):
+    """`traffic` = HBM bytes per launch as a plain number (the bench contract), its provenance beside it."""
+    t = measured_traffic(key) if key else None
+    if t is None:
+        return {"traffic": None}
+    return {"traffic": t["bytes_per_launch"], "traffic_unit": "bytes per launch", "traffic_source": t["source"],
+            "traffic_method": t["method"]}
+
+
 def roofline_hbm(nb, batch, stats, kernel_ms, launches, kernel_name, traffic_key=None):
     """Streaming kernels: algorithmic bytes = 32 B x 2^nb per generator application."""
     apps = stats["n_applications"]
@@ -188,7 +197,7 @@ def roofline_hbm(nb, batch, stats, kernel_ms, launches, kernel_name, traffic_key
     achieved = bytes_total / sec if sec > 0 else 0.0
     return {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": achieved / HBM_PEAK,
-            "traffic": measured_traffic(traffic_key) if traffic_key else None,
+            **traffic_fields(traffic_key),
             "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1), "applications": apps,
             "algorithmic_bytes_per_launch": bytes_total / max(launches, 1)}
 
@@ -202,7 +211,7 @@ def roofline_valu(n_amp, rows, stages, flops_per_amp_stage, kernel_ms, launches,
     tf = flops / sec / 1e12 if sec > 0 else 0.0
     out = {"bound": "valu_f64", "kernel": kernel_name, "achieved": tf, "peak": F64_VALU_PEAK,
            "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK,
-           "traffic": measured_traffic(traffic_key) if traffic_key else None,
+           **traffic_fields(traffic_key),
            "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
            "stages": stages, "flops_per_amplitude_per_stage": flops_per_amp_stage,
            "algorithmic_flops_per_launch": flops / max(launches, 1),
@@ -337,8 +346,10 @@ def main() -> None:
     ap.add_argument("--atoms", type=int, default=20, choices=[20, 22, 24], help="cfg5 workload: register size")
     ap.add_argument("--method", default="auto", choices=["auto", "taylor", "krylov", "split"],
                     help="cfg5 workload: propagator (auto = split-operator passes)")
-    ap.add_argument("--lindblad-ns", type=int, default=100, help="north_star: slice of the cfg3 leg")
-    ap.add_argument("--full-lindblad", action="store_true", help="north_star: full 3.1 us cfg3 leg (~1-2 min)")
+    ap.add_argument("--lindblad-ns", type=int, default=0,
+                    help="north_star: cfg3 leg over a slice of this many ns at t = 1 us (0 = the FULL 3.1 us, the default)")
+    ap.add_argument("--full-lindblad", action="store_true", help="(kept for old recipes: the full leg is the default)")
+    ap.add_argument("--trajectories", type=int, default=1024, help="cfg4 workload: noise trajectories")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="north_star: headline leg only (profiling runs)")
@@ -397,6 +408,8 @@ def main() -> None:
         sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, args.steps, args.warmup, dist, torch)
         value = n_gpus * B * T_SEQ_US / sec
         ket = stats["n_launches"] == 1
+        # every rank runs the same batch of sequences, so this number must not depend on the number of GPUs
+        ens = [float(v) / (n_gpus * B) for v in occ.cpu().numpy()]
         out = {
             "metric": "sim-us/sec, 14-atom Rydberg anneal sequence, sesolve fp64 (aggregate over independent sequences)",
             "value": value, **common, "ms_per_step": sec * 1e3,
@@ -410,6 +423,7 @@ def main() -> None:
                 "stages_per_sequence": stats["n_applications"], "cf4_steps": stats["n_steps"],
                 "parallelism": f"dp{n_gpus} (independent sequences shard over ranks; all-reduce of ensemble sums only)",
             },
+            "ensemble_mean_occupations": ens[:-1], "ensemble_mean_norm": ens[-1],
             "setup": {"lowering_ms": lower_s * 1e3, "handle_and_upload_ms": create_s * 1e3,
                       "note": "spline lowering on the host + ryd_create / ryd_set_* uploads; outside the timed "
                               "step (done once per sequence batch); the step includes the evaluation-time "
@@ -449,6 +463,7 @@ def main() -> None:
             eng = Engine.from_problems([tri_problem(2, 7, ops)], mode="mesolve")
             if args.no_ket:
                 eng.set_path(False, no_ket=True)
+            args.full_lindblad = args.full_lindblad or args.lindblad_ns <= 0
             if args.full_lindblad:
                 t0, t1 = 0.0, T_SEQ_US
             else:
@@ -504,12 +519,12 @@ def main() -> None:
         inputs = single_global_channel(coords, smp, P.C6_LEVEL70, extended=False)
         nm = NoiseModel(temperature=50.0, amp_sigma=0.05, state_prep_error=0.005,
                         p_false_pos=0.01, p_false_neg=0.05)
-        n_traj = 1024
+        n_traj = args.trajectories
 
-        def one_pass(seed):
+        def one_pass(seed, density_matrix=False):
             np.random.seed(seed)
             emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=n_traj, evaluation_times="Minimal")
-            return run_ensemble(emu, dist=dist, batch=256)
+            return run_ensemble(emu, dist=dist, batch=256, density_matrix=density_matrix)
 
         for w in range(args.warmup):
             one_pass(100 + w)
@@ -523,6 +538,16 @@ def main() -> None:
             tmax = torch.tensor([sec], dtype=torch.float64, device="cuda")
             all_reduce(dist, tmax, dist.ReduceOp.MAX)
             sec = float(tmax.item())
+        # the same with the ensemble density matrix (density_matrix_aggregator: the 268-MB mean of |psi><psi|
+        # at both evaluation times, formed on the device and all-reduced there)
+        one_pass(200, True)
+        barrier(torch, dist)
+        tic = time.perf_counter()
+        res_dm = one_pass(0, True)
+        barrier(torch, dist)
+        sec_dm = time.perf_counter() - tic
+        tr_dm = float(torch.diagonal(res_dm["density_matrices"][-1]).real.sum().item())
+        del res_dm
         out = {"metric": "noise trajectories/s, 12-atom anneal sequence, end to end (draws, lowering, sesolve, sampling)",
                "value": n_traj / sec, **common, "unit": "trajectories/s", "scaling": "strong",
                "ms_per_step": sec * 1e3,
@@ -530,6 +555,12 @@ def main() -> None:
                                       "(doppler + amplitude + SPAM), sharded over the ranks, one all-reduce "
                                       "of the bitstring histograms", "n_atoms": 12, "n_trajectories": n_traj,
                           "sim_us_per_s": n_traj * T_SEQ_US / sec, "n_measures": int(res["n_measures"]),
+                          "histogram_total": int(res["histograms"].sum()),
+                          "mean_occupations_final": [float(v) for v in res["mean_occupations"][-1]],
+                          "with_density_matrix": {"ms_per_step": sec_dm * 1e3, "ratio": sec_dm / sec,
+                                                  "trace_final": tr_dm,
+                                                  "note": "A15 on the device: ryd_outer_accumulate_dim per batch and "
+                                                          "evaluation time, all-reduce of the device tensor"},
                           "parallelism": f"dp{n_gpus} over trajectories"},
                "roofline": None}
         extras_ok = False

@@ -47,7 +47,9 @@ typedef enum ryd_status {
   RYD_ERR_INVALID = -1,     /* bad argument */
   RYD_ERR_HIP = -2,         /* HIP runtime error */
   RYD_ERR_UNSUPPORTED = -3, /* valid in the reference, not built yet */
-  RYD_ERR_STATE = -4        /* call order (tables not set) */
+  RYD_ERR_STATE = -4,       /* call order (tables not set) */
+  RYD_ERR_NUMERIC = -5      /* self-check (environment RYD_CHECK=1): non-finite amplitudes, or the norm /
+                               trace of a state moved by more than 1e-6 over a solve that conserves it */
 } ryd_status;
 
 typedef enum ryd_mode {

@@ -89,7 +89,7 @@ static const double kDefaultSympTol = 2e-11;
 
 static int to_ket_steps(ryd_handle* h, const std::vector<StepDesc>& sched, const ryd_opts& o,
                         double conj_sign, std::vector<KetStep>& out) {
-  const double tol = o.tol > 0 ? o.tol : kDefaultSympTol;
+  const double tol = o.tol > 0 ? o.tol : kDefaultSympTol * budget_scale(h);
   int rc;
   double phase = 0.0;  // accumulated spectral shifts: a global phase, applied at snapshots / final stores
   for (const StepDesc& d : sched) {

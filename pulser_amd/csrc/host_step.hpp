@@ -124,7 +124,7 @@ static int run_generic(ryd_handle* h, cplx* state, const std::vector<StepDesc>& 
                        cplx* snaps, hipStream_t st, const ryd_opts& o) {
   int rc;
   const bool kry = krylov_selected(h, o);
-  const double ktol = o.tol > 0 ? o.tol : kDefaultTol;
+  const double ktol = o.tol > 0 ? o.tol : kDefaultTol * budget_scale(h);
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
   for (const StepDesc& d : sched) {
     MixPoint m;
@@ -404,8 +404,62 @@ static int run_steps(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   return run_generic(h, state, sched, snaps, st, o);
 }
 
+// Self-check ("kernel self-checks - norm drift, NaN scan"), enabled by the environment
+// variable RYD_CHECK=1 and off by default (it synchronises the stream): after a solve every state must be
+// finite, and where the dynamics conserve it (no quantum-jump decay) the squared norm / trace must not
+// have moved by more than 1e-6 - a stepper that leaves its stability region or a kernel that reads a
+// stale buffer shows up here long before a parity test looks at amplitudes.
+static bool selfcheck_enabled() {
+  static const int on = [] {
+    const char* e = std::getenv("RYD_CHECK");
+    return (e && e[0] && std::strcmp(e, "0") != 0) ? 1 : 0;
+  }();
+  return on != 0;
+}
+
+static int selfcheck_measure(ryd_handle* h, const cplx* state, hipStream_t st, std::vector<double>& out) {
+  double* dev = nullptr;
+  HIPCHK(hipMalloc((void**)&dev, 2 * h->B * sizeof(double)));
+  hipMemsetAsync(dev, 0, 2 * h->B * sizeof(double), st);
+  const bool dm = h->cfg.mode == RYD_MESOLVE;
+  const size_t D = dm ? (size_t)std::llround(std::sqrt((double)h->dim)) : 0;
+  const unsigned blocks = (unsigned)std::min<size_t>((h->dim + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_selfcheck, dim3(blocks, h->B), dim3(256), 0, st, state, (size_t)h->dim, dm ? D + 1 : (size_t)0, dev);
+  out.assign(2 * h->B, 0.0);
+  hipError_t e = hipMemcpyAsync(out.data(), dev, 2 * h->B * sizeof(double), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFree(dev);
+  if (e != hipSuccess) return fail(RYD_ERR_HIP, "self-check: %s", hipGetErrorString(e));
+  return RYD_OK;
+}
+
+static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
+                      void* out_dev, const ryd_opts* opts, void* stream);
+
 extern "C" int ryd_solve(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
                          void* out_dev, const ryd_opts* opts, void* stream) {
+  if (!selfcheck_enabled() || !h || !state_dev) return solve_impl(h, state_dev, n_times, times, out_dev, opts, stream);
+  int rc = check_ready(h);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  std::vector<double> before, after;
+  if ((rc = selfcheck_measure(h, (const cplx*)state_dev, (hipStream_t)stream, before))) return rc;
+  if ((rc = solve_impl(h, state_dev, n_times, times, out_dev, opts, stream))) return rc;
+  if ((rc = selfcheck_measure(h, (const cplx*)state_dev, (hipStream_t)stream, after))) return rc;
+  for (int b = 0; b < h->B; ++b) {
+    if (after[2 * b + 1] != 0.0)
+      return fail(RYD_ERR_NUMERIC, "self-check: %.0f non-finite entries in state %d after the solve to t = %g us",
+                  after[2 * b + 1], b, times[n_times - 1]);
+    const double n0 = before[2 * b], n1 = after[2 * b];
+    if (!h->mc && before[2 * b + 1] == 0.0 && std::fabs(n1 - n0) > 1e-6 * std::max(std::fabs(n0), 1e-300))
+      return fail(RYD_ERR_NUMERIC, "self-check: %s of state %d moved from %.12g to %.12g over [%g, %g] us",
+                  h->cfg.mode == RYD_MESOLVE ? "trace" : "squared norm", b, n0, n1, times[0], times[n_times - 1]);
+  }
+  return RYD_OK;
+}
+
+static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const double* times,
+                      void* out_dev, const ryd_opts* opts, void* stream) {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!state_dev || !times || n_times < 2) return fail(RYD_ERR_INVALID, "need a state and >= 2 times");

@@ -292,3 +292,27 @@ __global__ void k_axpy(const cplx* __restrict__ x, double w, size_t count, cplx*
     acc[i] = a;
   }
 }
+
+// Self-check of a solve (RYD_CHECK=1): out[b][0] += sum |x|^2 (kets) or Re trace (density matrices),
+// out[b][1] += number of non-finite entries.  `row` = entries per state, `diag_stride` = D + 1 for a
+// density matrix (0 for a ket).
+__global__ __launch_bounds__(256) void k_selfcheck(const cplx* __restrict__ st, size_t row, size_t diag_stride,
+                                                   double* __restrict__ out) {
+  const int b = blockIdx.y;
+  const cplx* x = st + (size_t)b * row;
+  double s = 0.0, bad = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row; i += (size_t)gridDim.x * blockDim.x) {
+    const cplx v = x[i];
+    if (!(isfinite(v.x) && isfinite(v.y))) bad += 1.0;
+    else if (diag_stride == 0) s += v.x * v.x + v.y * v.y;
+    else if (i % diag_stride == 0) s += v.x;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_down(s, o, 64);
+    bad += __shfl_down(bad, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out + 2 * b, s);
+    if (bad != 0.0) atomicAdd(out + 2 * b + 1, bad);
+  }
+}

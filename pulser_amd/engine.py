@@ -254,6 +254,23 @@ class Engine:
                 self._h, state.data_ptr(), float(t0), float(t1), C.byref(opts), self._stream()
             )
         )
+        self._split_budget_check(method, float(tol))
+
+    def _split_budget_check(self, method: str, tol: float) -> None:
+        """The split-operator controller books its local-error estimates in ``ryd_stats.reserved[0]``;
+        when it could not hold the sequence budget (retries used up, nothing to roll back to) say so."""
+        if not (method == "split" or (method == "auto" and self.mode == RYD_SESOLVE and self.n >= 15
+                                      and not self.monte_carlo)):
+            return
+        est = self.stats()["reserved"][0]
+        budget = 500.0 * tol if tol > 0 else 5e-8
+        if est > 2.0 * budget:
+            import warnings
+
+            warnings.warn(
+                f"split-operator step-size controller: accumulated local-error estimate {est:.1e} exceeds "
+                f"the budget {budget:.1e} of this solve; tighten `tol` or use method='taylor'.",
+                RuntimeWarning, stacklevel=3)
 
     def solve(
         self,
@@ -303,6 +320,7 @@ class Engine:
                 self._stream(),
             )
         )
+        self._split_budget_check(method, float(tol))
         return out
 
     def mc_solve(

@@ -79,3 +79,33 @@ def test_multi_knot_steps_in_the_split_operator_master_equation():
     assert out[False][1]["n_steps"] <= 0.55 * out[True][1]["n_steps"]
     assert np.max(np.abs(out[False][0] - out[True][0])) < 2e-8
     assert abs(np.trace(out[False][0]).real - 1.0) < 1e-9
+
+
+def long_anneal_problem(n, cycles=4):
+    """``cycles`` anneals back to back (12.4 us for four): the budgets of the per-exponential defaults grow
+    with the number of exponentials, so they are derived from a whole-sequence budget (host_sched.hpp:
+    budget_scale) - this is the long-sequence case that checks it."""
+    one = P.anneal_samples()
+    s = {k: np.concatenate([v[:-1]] * cycles + [v[-1:]]) for k, v in one.items()}
+    coords = P.register_coords(P.square_rect(1, n), blockade_radius())
+    return P.make_ising_problem(coords, s)
+
+
+def test_long_sequence_stays_inside_the_bar_on_every_ket_path():
+    """10 atoms, 12.4 us, against the tight oracle integrated here (zvode rtol 1e-13)."""
+    from oracle import qutip_path as qp
+
+    n = 10
+    prob = long_anneal_problem(n)
+    T = (prob["duration"] - 1) * 1e-3
+    times = np.array([0.0, 0.5 * T, T])
+    opts = dict(qp.default_options([np.stack([prob["samples"]["Global"]["ground-rydberg"]["amp"],
+                                              prob["samples"]["Global"]["ground-rydberg"]["det"]])], prob["duration"] - 1))
+    opts.update(qp.TIGHT)
+    ref = qp.sesolve(qp.build_hamiltonian(prob), qp.all_ground_state(n, prob["eigenbasis"]), times, **opts)
+    for path in ({}, {"force_ket": True}, {"force_generic": True}):
+        with _engine([prob]) as eng:
+            eng.set_path(path.pop("force_generic", False), **path)
+            snaps = eng.solve(eng.new_state(), times).cpu().numpy()[:, 0]
+        errs = [float(np.max(np.abs(snaps[k - 1] - ref[k]))) for k in (1, 2)]
+        assert max(errs) < 1e-7, (path, errs)
