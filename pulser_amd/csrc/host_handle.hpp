@@ -98,6 +98,11 @@ struct ryd_handle {
   bool no_ket = false;         // test hook: disable the register-resident ket kernel / split-operator rows
   bool force_ket = false;      // test hook: use them from 10 atoms on (instead of 14 / 12)
   bool drive_real = false;     // every drive series is real-valued
+  bool gauge_ok = false;       // complex drives can be gauged away inside k_ket (KET_GAUGE)
+  double gauge_eps2 = 0.0;     // |c|^2 below which a drive has no direction of its own
+  std::vector<double> bd_gpos, bd_gneg;  // per interval: sum over atoms of the bounds of +-theta' (batch maximum)
+  std::vector<double> bd_gvar;           // per interval: largest change of theta' inside it (any series in use)
+  bool gauge_active = false;             // this solve runs KET_GAUGE (set by ryd_solve)
   bool uniform_real_drive = false;  // persistent-kernel MODEL 1 applies
   // Monte-Carlo wavefunction mode (sesolve handles with ryd_set_collapse)
   bool mc = false;         // collapse operators set: H_eff carries -(i/2) sum C^dag C
@@ -677,6 +682,70 @@ static void compute_bounds(ryd_handle* h) {
   for (const ryd_qdesc& d : h->desc_host)
     if (d.drive_series >= 0 && !series_real[d.drive_series]) { dreal = false; break; }
   h->drive_real = dreal;
+  // ---- KET_GAUGE: theta' = Im(c' conj c) / |c|^2 of every complex drive series, sampled per interval ----
+  h->gauge_ok = false;
+  h->bd_gpos.assign(n_int, 0.0);
+  h->bd_gneg.assign(n_int, 0.0);
+  h->bd_gvar.assign(n_int, 0.0);
+  if (!dreal && h->cfg.mode == RYD_SESOLVE) {
+    double smax = 0.0;
+    for (int sidx = 0; sidx < h->n_series; ++sidx)
+      if (!series_real[sidx])
+        for (int i = 0; i < n_int; ++i) smax = std::max(smax, h->s_abs[(size_t)sidx * n_int + i]);
+    const double eps = 1e-9 * smax;
+    h->gauge_eps2 = eps * eps;
+    // per series: the largest theta' of either sign at 9 points of every interval (+25 % margin: the bound
+    // feeds the spectral shift and the choice of the in-place scheme, like the other detuning bounds)
+    std::vector<double> tp((size_t)h->n_series * n_int, 0.0), tn((size_t)h->n_series * n_int, 0.0),
+        tv((size_t)h->n_series * n_int, 0.0);
+    bool ok = true;
+    const double cap = 4000.0;  // rad/us: a phase that turns faster than this inside a step is not gauged
+    for (int sidx = 0; sidx < h->n_series && ok; ++sidx) {
+      if (series_real[sidx]) continue;
+      for (int i = 0; i < n_int && ok; ++i) {
+        const std::complex<double>* pc = &h->pp_host[((size_t)sidx * n_int + i) * 4];
+        const double dt = h->tknots[i + 1] - h->tknots[i];
+        double hi = 0.0, lo = 0.0, vhi = -1e300, vlo = 1e300;
+        for (int g = 0; g <= 8; ++g) {
+          const double u = dt * g / 8.0;
+          const std::complex<double> c = ((pc[0] * u + pc[1]) * u + pc[2]) * u + pc[3];
+          const std::complex<double> dc = (3.0 * pc[0] * u + 2.0 * pc[1]) * u + pc[2];
+          const double m2 = std::norm(c);
+          if (m2 <= h->gauge_eps2) continue;
+          const double thd = (dc * std::conj(c)).imag() / m2;
+          hi = std::max(hi, thd);
+          lo = std::min(lo, thd);
+          vhi = std::max(vhi, thd);
+          vlo = std::min(vlo, thd);
+        }
+        if (hi > cap || -lo > cap) ok = false;
+        tp[(size_t)sidx * n_int + i] = 1.25 * hi;
+        tn[(size_t)sidx * n_int + i] = -1.25 * lo;
+        tv[(size_t)sidx * n_int + i] = vhi > vlo ? vhi - vlo : 0.0;
+      }
+    }
+    if (ok) {
+      // detuning of atom k in the gauge: delta_k + theta_k' enters as -(...) n_k: a positive theta' lowers
+      // the diagonal (bd_gpos), a negative one raises it (bd_gneg)
+      for (int b = 0; b < h->B; ++b) {
+        std::vector<double> gp(n_int, 0.0), gn(n_int, 0.0);
+        for (int k = 0; k < h->N; ++k) {
+          const ryd_qdesc& d = h->desc_host[(size_t)b * h->N + k];
+          if (d.drive_series < 0 || d.drive_scale == 0.0 || series_real[d.drive_series]) continue;
+          for (int i = 0; i < n_int; ++i) {
+            gp[i] += tp[(size_t)d.drive_series * n_int + i];
+            gn[i] += tn[(size_t)d.drive_series * n_int + i];
+            h->bd_gvar[i] = std::max(h->bd_gvar[i], tv[(size_t)d.drive_series * n_int + i]);
+          }
+        }
+        for (int i = 0; i < n_int; ++i) {
+          h->bd_gpos[i] = std::max(h->bd_gpos[i], gp[i]);
+          h->bd_gneg[i] = std::max(h->bd_gneg[i], gn[i]);
+        }
+      }
+    }
+    h->gauge_ok = ok;
+  }
   h->bounds_valid = true;
   h->split_known = false;  // new tables: the split-operator controller starts over
 }

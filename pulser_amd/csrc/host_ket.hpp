@@ -24,7 +24,10 @@
 // is chosen from the dissipator rate.
 
 static bool ket_path(const ryd_handle* h) {
-  if (h->general || h->cfg.mode != RYD_SESOLVE || !h->drive_real || h->mc || h->no_ket) return false;
+  if (h->general || h->cfg.mode != RYD_SESOLVE || h->mc || h->no_ket) return false;
+  // complex drives: gauged away inside the kernel (KET_GAUGE) when no drive passes close to zero while its
+  // phase turns (compute_bounds: gauge_ok)
+  if (!h->drive_real && !h->gauge_ok) return false;
   if (h->force_ket) return h->N >= 10 && h->N <= 14;
   // <= 13 atoms: the LDS-resident kernel k_traj.  One workgroup evolves one sequence on ONE CU
   // (10 us per stage), so a handful of sequences is faster on the multi-launch tiled kernels that
@@ -53,7 +56,13 @@ static void ket_bound(const ryd_handle* h, int idx, double w1, double w2, double
   const double wmix = w1 + w2;
   const double drive = wmix * span_max(h->bd_drive, idx, span);
   const double dpos = wmix * span_max(h->bd_pos, idx, span), dneg = wmix * span_max(h->bd_neg, idx, span);
-  const double lo = wmix * h->e0_min - dpos, hi = wmix * h->e0_max + dneg;
+  double lo = wmix * h->e0_min - dpos, hi = wmix * h->e0_max + dneg;
+  if (!h->drive_real && h->cfg.mode == RYD_SESOLVE) {
+    // KET_GAUGE: the detunings carry theta' = d/dt arg c_k of the complex drives (sum over atoms of the
+    // bounds of either sign, with the margin of compute_bounds)
+    lo -= wmix * span_max(h->bd_gpos, idx, span);
+    hi += wmix * span_max(h->bd_gneg, idx, span);
+  }
   *shift = 0.5 * (lo + hi);
   *bound = 0.5 * (hi - lo) + drive;
 }
@@ -127,34 +136,53 @@ static int upload_ket_steps(ryd_handle* h, const std::vector<KetStep>& ks, hipSt
   return RYD_OK;
 }
 
+template <int MODE>
+static int ket_set_lds_limit() {
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<10, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<11, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<12, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<13, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ket<14, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return RYD_OK;
+}
+
 static int ket_init_device(ryd_handle* h) {
   static bool done[64] = {};
   const int dev = h->cfg.device;
   if (dev >= 0 && dev < 64 && done[dev]) return RYD_OK;
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(kSympDev), kSymp, sizeof(kSymp)));
-  HIPCHK(hipFuncSetAttribute((const void*)k_ket<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_ket<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_ket<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_ket<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)k_ket<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  int rc;
+  if ((rc = ket_set_lds_limit<KET_PLAIN>()) || (rc = ket_set_lds_limit<KET_ROWS>()) ||
+      (rc = ket_set_lds_limit<KET_GAUGE>()))
+    return rc;
   if (dev >= 0 && dev < 64) done[dev] = true;
   return RYD_OK;
 }
 
-static int launch_ket(ryd_handle* h, const KetArgs& A, size_t n_rows, hipStream_t st) {
+template <int MODE>
+static int launch_ket_mode(ryd_handle* h, const KetArgs& A, size_t n_rows, size_t lds, hipStream_t st) {
+  switch (h->N) {
+    case 10: hipLaunchKernelGGL((k_ket<10, MODE>), dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    case 11: hipLaunchKernelGGL((k_ket<11, MODE>), dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    case 12: hipLaunchKernelGGL((k_ket<12, MODE>), dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    case 13: hipLaunchKernelGGL((k_ket<13, MODE>), dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    case 14: hipLaunchKernelGGL((k_ket<14, MODE>), dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
+    default: return fail(RYD_ERR_INVALID, "k_ket needs 10 <= N <= 14");
+  }
+  return RYD_OK;
+}
+
+static int launch_ket(ryd_handle* h, const KetArgs& A, size_t n_rows, hipStream_t st, int mode = KET_PLAIN) {
   const size_t D = (size_t)1 << h->N;
-  const size_t lds = D * sizeof(double) + (64 + 64 + 2 * (D / 512) + 32 + 128 + (D / 512) + 64) * sizeof(double);
+  const size_t R = D / 512;
+  const size_t lds = D * sizeof(double) + (64 + 64 + 2 * R + 32 + 128 + R + 64 + 32 + 2 * R) * sizeof(double);
   std::pair<hipEvent_t, hipEvent_t> ev;
   int rc;
   if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
-  switch (h->N) {
-    case 10: hipLaunchKernelGGL(k_ket<10>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
-    case 11: hipLaunchKernelGGL(k_ket<11>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
-    case 12: hipLaunchKernelGGL(k_ket<12>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
-    case 13: hipLaunchKernelGGL(k_ket<13>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
-    case 14: hipLaunchKernelGGL(k_ket<14>, dim3((unsigned)n_rows), dim3(512), lds, st, A); break;
-    default: return fail(RYD_ERR_INVALID, "k_ket needs 10 <= N <= 14");
-  }
+  rc = mode == KET_ROWS ? launch_ket_mode<KET_ROWS>(h, A, n_rows, lds, st)
+       : mode == KET_GAUGE ? launch_ket_mode<KET_GAUGE>(h, A, n_rows, lds, st)
+                           : launch_ket_mode<KET_PLAIN>(h, A, n_rows, lds, st);
+  if (rc) return rc;
   HIPCHK(hipGetLastError());
   if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
   h->stats.n_launches++;
@@ -200,7 +228,8 @@ static int run_ket(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sche
   A.rows_log2 = 0;
   A.fin_cs = ks.back().cum_cs;
   A.fin_sn = ks.back().cum_sn;
-  if ((rc = launch_ket(h, A, (size_t)h->B, st))) return rc;
+  A.gauge_eps2 = h->gauge_eps2;
+  if ((rc = launch_ket(h, A, (size_t)h->B, st, h->drive_real ? KET_PLAIN : KET_GAUGE))) return rc;
   count_ket_work(h, ks, 0, ks.size(), 1);
   h->stats.n_steps += (int64_t)ks.size();
   return RYD_OK;
@@ -388,7 +417,7 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     A.state = cur;
     A.use_pre = !dbl && f_in != 0.0;
     int rc2;
-    if ((rc2 = launch_ket(h, A, n_rows, st))) return rc2;
+    if ((rc2 = launch_ket(h, A, n_rows, st, KET_ROWS))) return rc2;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->timing) { if ((rc2 = timing_begin(h, st, ev))) return rc2; }
     hipLaunchKernelGGL(k_transpose_conj, dim3(nt, nt, h->B), dim3(256), 0, st, cur, other, h->N);
@@ -399,7 +428,7 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     A.state = cur;
     A.use_pre = 0;
     A.use_post = !dbl && f_out != 0.0;
-    if ((rc2 = launch_ket(h, A, n_rows, st))) return rc2;
+    if ((rc2 = launch_ket(h, A, n_rows, st, KET_ROWS))) return rc2;
     if (dbl) pending += f_out;
     count_ket_work(h, ks, i0, i1, 1);  // one Lindbladian application ~ one two-sided ket stage
     h->stats.n_steps += (int64_t)(i1 - i0);

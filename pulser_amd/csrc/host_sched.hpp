@@ -144,6 +144,16 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
         nsub = std::max(nsub, std::min(nm, 256));
       }
     }
+    if (h->gauge_active) {
+      // KET_GAUGE: the 4th-order Magnus step assumes a Hamiltonian that is smooth inside the step; the gauged
+      // detuning theta'(t) = d/dt arg c(t) is not where the phase of a drive turns quickly (a phase jump
+      // between two pulses is spread over ~2 knot intervals by the complex spline: theta' rises to
+      // ~1500 rad/us and falls again).  Sub-steps keep the change of theta' across a step below 0.02 / h
+      // (tests/probes/gauge_probe.py: a jump of 1.1 rad then ends 2e-8 from the converged solution, the
+      // same drives without it 1e-8); only the few intervals around such a feature are affected.
+      const double var = span_max(h->bd_gvar, idx, span);
+      if (var * len > 0.02) nsub = std::max(nsub, std::min((int)std::ceil(var * len / 0.02), 512));
+    }
     {
       // Sub-steps only where they pay: the Taylor degree grows like e*rho + log(1/tol), so the
       // number of generator applications per unit time FALLS with rho (about 16 / 11 / 8 per unit

@@ -480,6 +480,8 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
                         split_selected(h, o);
   // multi-knot CF4 steps: not under the split-operator ket passes (their sub-steps stay inside a knot
   // interval); at most half a block of the split-operator master equation
+  h->gauge_active = !h->general && !h->drive_real && h->gauge_ok && ket_path(h) && !krylov_selected(h, o) &&
+                    !split_selected(h, o);
   const int merge_cap = split_selected(h, o) ? 1
                         : (row_path(h) && !use_persistent_dm(h)) ? row_half_knots(h, o) : kMergeMax;
   std::vector<StepDesc> sched;

@@ -33,6 +33,7 @@
 #include "symp_coefs.hpp"
 
 __constant__ SympScheme kSympDev[sizeof(kSymp) / sizeof(kSymp[0])];
+#define KET_C1 0.21132486540518713  /* first Gauss node, 1/2 - sqrt(3)/6 */
 
 struct KetStep {
   double h, u1, u2;
@@ -70,7 +71,23 @@ struct KetArgs {
   double kick_u;
   double fin_cs, fin_sn;    // global phase of this launch's steps, applied at the final store
   const double* ftab;       // [2][4][16] = exp(pre[k] n), exp(post[k] n)  (host-computed, device memory)
+  double gauge_eps2;        // KET_GAUGE: |c|^2 below which a drive has no direction of its own
 };
+
+// MODE of k_ket:
+//  KET_PLAIN  real drive coefficients, kets (sesolve batches);
+//  KET_ROWS   the rows of a density matrix (split-operator master equation): elementwise load / store
+//             factors and the drive-only commutator kick;
+//  KET_GAUGE  COMPLEX drives c_k(t) = 0.5 Omega e^{-i phi} (hamiltonian.py:349-351) gauged away: with
+//             psi~ = prod_k exp(i theta_k(t) n_k) psi and e^{i theta_k} = w_k = c_k / r_k (r_k real, signed,
+//             continuous in time) the Hamiltonian is real symmetric again - drive r_k, detuning
+//             delta_k + theta_k', theta_k' = Im(c_k' conj c_k) / |c_k|^2 - so the in-place scheme applies.
+//             |c| and theta' are not polynomials, so the two CF4 exponents are formed from the moments
+//             int f dt and int (t - t_mid) f dt by 4-point Gauss-Legendre quadrature (with the 2 Gauss points of
+//             the polynomial case the quadrature error of |c(t)| dominates: 5e-7 instead of 9e-10 on the
+//             probe tests/probes/gauge_probe.py).  The state is rotated into the gauge at the load and back
+//             at snapshots / the final store (per-atom unit factors w_k, no trigonometric functions).
+enum { KET_PLAIN = 0, KET_ROWS = 1, KET_GAUGE = 2 };
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -88,8 +105,9 @@ __device__ __forceinline__ double dpp_f64(double v) {
 #ifndef RYD_KET_F0
 #define RYD_KET_F0 4
 #endif
-template <int N, int F0 = RYD_KET_F0, int LOGNT = 9>
+template <int N, int MODE = KET_PLAIN, int F0 = RYD_KET_F0, int LOGNT = 9>
 __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
+  constexpr bool ROWS = MODE == KET_ROWS, GAUGE = MODE == KET_GAUGE;
   static_assert(F0 == 0 || F0 == 2 || F0 == 4, "index bits below F0 use the DPP crossbar: 0, 2 or 4");
   constexpr int D = 1 << N, NTT = 1 << LOGNT;
   constexpr int R = D / NTT;   // amplitudes per thread (8, 16, 32)
@@ -103,6 +121,8 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
   double* ftab = hfx + 32;    // [2][4][16] load / store factor tables
   double* ehh = ftab + 128;   // [R] static diagonal of the register-index bits
   double* cfK = ehh + R;      // [16][4] drive coefficients of the splitting kick
+  double* gw = cfK + 64;      // KET_GAUGE: [16][2] unit factors w_k of the atoms at one time
+  double* gj = gw + 32;       // KET_GAUGE: [R][2] products of w over the excited register-index atoms
 
   const int tid = threadIdx.x;
   const size_t row = blockIdx.x;
@@ -111,24 +131,36 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
   cplx* st = A.state + row * D;
   const double* e0g = A.e0 + (size_t)b * A.e0_stride;
 
-  if (A.use_pre || A.use_post) {
-    if (tid < 128) ftab[tid] = A.ftab[tid];
+  if constexpr (ROWS) {
+    if (A.use_pre || A.use_post) {
+      if (tid < 128) ftab[tid] = A.ftab[tid];
+      __syncthreads();
+    }
+  }
+  // exp(sum_k fac[k] n_k(row, col)) for col = tid + 512 j: the (row bit, column bit) pair counts are sums of
+  // a per-thread part (column bits 0-8) and a per-j part (register-index bits), and the tables hold
+  // exp(fac n), so the factor is a product  F_thread x F_j : one double per thread and an LDS table of R
+  // entries per direction (load / store) - one multiplication per element, nothing per element kept alive
+  // (the first version looked four table entries up per element and cost 496 B per lane of scratch)
+  double ft_pre = 1.0, ft_post = 1.0;
+  double* fjt = gj;  // [2][R]: ROWS and GAUGE never coexist, the slot of the gauge tables is free here
+  if constexpr (ROWS) {
+    const unsigned lomask = (unsigned)NTT - 1u, hm = (1u << (N - LOGNT)) - 1u;
+    const int t11 = __popc(rowidx & (unsigned)tid), t10 = __popc(rowidx & ~(unsigned)tid & lomask),
+              t01 = __popc(~rowidx & (unsigned)tid & lomask), t00 = LOGNT - t11 - t10 - t01;
+    if (A.use_pre) ft_pre = ftab[t00] * ftab[16 + t01] * ftab[32 + t10] * ftab[48 + t11];
+    if (A.use_post) ft_post = ftab[64 + t00] * ftab[64 + 16 + t01] * ftab[64 + 32 + t10] * ftab[64 + 48 + t11];
+    if (tid < 2 * R) {
+      const int which = tid / R, j = tid % R;
+      const unsigned rh = rowidx >> LOGNT;
+      const int j11 = __popc(rh & (unsigned)j), j10 = __popc(rh & ~(unsigned)j & hm),
+                j01 = __popc(~rh & (unsigned)j & hm), j00 = (N - LOGNT) - j11 - j10 - j01;
+      const double* tab = ftab + 64 * which;
+      const bool use = which ? A.use_post != 0 : A.use_pre != 0;
+      fjt[tid] = use ? tab[j00] * tab[16 + j01] * tab[32 + j10] * tab[48 + j11] : 1.0;
+    }
     __syncthreads();
   }
-  // exp(sum_k fac[k] n_k(row, col)) for col = tid + 512 j: the (row bit, column bit) pair counts split
-  // into a per-thread part (column bits 0-8; three integers kept) and a per-j part (wave-uniform,
-  // scalar unit), so nothing per element stays alive between the load and the store of the kernel
-  const unsigned lomask = (unsigned)NTT - 1u;
-  const int t11 = __popc(rowidx & (unsigned)tid), t10 = __popc(rowidx & ~(unsigned)tid & lomask),
-            t01 = __popc(~rowidx & (unsigned)tid & lomask);
-  auto factor = [&](const double* tab, int j) -> double {
-    const unsigned rh = __builtin_amdgcn_readfirstlane((int)(rowidx >> LOGNT));
-    const unsigned hm = (1u << (N - LOGNT)) - 1u;
-    const int n11 = t11 + __popc(rh & (unsigned)j), n10 = t10 + __popc(rh & ~(unsigned)j & hm),
-              n01 = t01 + __popc(~rh & (unsigned)j & hm);
-    const int n00 = N - n11 - n10 - n01;
-    return tab[n00] * tab[16 + n01] * tab[32 + n10] * tab[48 + n11];
-  };
 
   // The static interaction diagonal E0 is a quadratic form of the index bits, so with
   // i = (j: register-index bits 9.., t: thread bits 0-8)
@@ -144,18 +176,124 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
   for (int k = 0; k < NH; ++k) vhi[k] = wst * e0g[tid | (HIMASK ^ (1u << (LOGNT + k)))] - ell;
   if (tid < R) ehh[tid] = wst * e0g[((unsigned)tid << LOGNT) | (NTT - 1)];
 
-  double q[R], p[R];
+  // ---- KET_GAUGE: direction w = c / r of a drive at one time, continuous along the lane's own history ----
+  // lanes tid < N own atom tid; (wpx, wpy) = the direction at the previous evaluation (have_w: one exists)
+  double wpx = 1.0, wpy = 0.0;
+  bool have_w = false;
+  ryd_qdesc gd;
+  if constexpr (GAUGE) {
+    if (tid < N) gd = A.desc[(size_t)b * N + tid];
+  }
+  // evaluates atom tid's drive at offset u inside knot interval idx: returns r (signed modulus, times the
+  // scale), theta' and updates the direction
+  auto gauge_eval = [&](int idx, double u, double* r_out, double* thd_out) {
+    double r = 0.0, thd = 0.0;
+    if (gd.drive_series >= 0 && gd.drive_scale != 0.0) {
+      const cplx* pq = A.pp + ((size_t)gd.drive_series * A.n_int + idx) * 4;
+      const cplx p0 = pq[0], p1 = pq[1], p2 = pq[2], p3 = pq[3];
+      const double x = fma(fma(fma(p0.x, u, p1.x), u, p2.x), u, p3.x);
+      const double y = fma(fma(fma(p0.y, u, p1.y), u, p2.y), u, p3.y);
+      const double dx = fma(fma(3.0 * p0.x, u, 2.0 * p1.x), u, p2.x);
+      const double dy = fma(fma(3.0 * p0.y, u, 2.0 * p1.y), u, p2.y);
+      const double m2 = x * x + y * y;
+      double wx = wpx, wy = wpy;
+      bool fresh = false;
+      if (m2 > A.gauge_eps2) {
+        const double inv = 1.0 / sqrt(m2);
+        wx = x * inv;
+        wy = y * inv;
+        thd = (dy * x - dx * y) / m2;
+        fresh = true;
+      } else if (!have_w) {  // a drive that starts from zero points along its derivative
+        const double d2 = dx * dx + dy * dy;
+        if (d2 > 0.0) {
+          const double inv = 1.0 / sqrt(d2);
+          wx = dx * inv;
+          wy = dy * inv;
+          fresh = true;
+        }
+      }
+      if (have_w && fresh && wx * wpx + wy * wpy < 0.0) { wx = -wx; wy = -wy; }  // r changes sign, w does not jump
+      r = gd.drive_scale * (x * wx + y * wy);  // c = r w  =>  r = Re(c conj w)
+      if (fresh) { wpx = wx; wpy = wy; have_w = true; }
+    }
+    *r_out = r;
+    *thd_out = thd;
+  };
+  // unit factors of the current directions -> this thread's product over its excited thread-bit atoms (T) and
+  // the table over the register-index atoms (gj); psi~ = (T J) psi, psi = conj(T J) psi~
+  double Tx = 1.0, Ty = 0.0;
+  auto gauge_publish = [&]() {
+    __syncthreads();
+    if (tid < N) { gw[2 * tid] = wpx; gw[2 * tid + 1] = wpy; }
+    __syncthreads();
+    Tx = 1.0; Ty = 0.0;
 #pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int l = tid + j * NTT;
-    const cplx v = st[l];
-    double f = 1.0;
-    if (A.use_pre) f = factor(ftab, j);
-    q[j] = f * v.x;
-    p[j] = f * v.y;
+    for (int f = 0; f < LOGNT; ++f)
+      if (!((tid >> f) & 1)) {  // atom N-1-f excited
+        const double gx = gw[2 * (N - 1 - f)], gy = gw[2 * (N - 1 - f) + 1];
+        const double nx = Tx * gx - Ty * gy;
+        Ty = Tx * gy + Ty * gx;
+        Tx = nx;
+      }
+    if (tid < R) {
+      double jx = 1.0, jy = 0.0;
+#pragma unroll
+      for (int f = LOGNT; f < N; ++f)
+        if (!((tid >> (f - LOGNT)) & 1)) {
+          const double gx = gw[2 * (N - 1 - f)], gy = gw[2 * (N - 1 - f) + 1];
+          const double nx = jx * gx - jy * gy;
+          jy = jx * gy + jy * gx;
+          jx = nx;
+        }
+      gj[2 * tid] = jx;
+      gj[2 * tid + 1] = jy;
+    }
+    __syncthreads();
+  };
+
+  double q[R], p[R];
+  if constexpr (GAUGE) {
+    if (tid < N && A.n_steps > 0) {
+      const KetStep s0 = A.steps[0];
+      double r0, t0;
+      gauge_eval(s0.idx, s0.u1 - KET_C1 * s0.h, &r0, &t0);  // start of the first step
+    }
+    gauge_publish();
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const cplx v = st[tid + j * NTT];
+      const double fx = Tx * gj[2 * j] - Ty * gj[2 * j + 1], fy = Tx * gj[2 * j + 1] + Ty * gj[2 * j];
+      q[j] = v.x * fx - v.y * fy;
+      p[j] = v.x * fy + v.y * fx;
+    }
+  } else if constexpr (ROWS) {
+    // loads in groups of eight (with the factors applied group by group): hoisting all 32 loads and all 32
+    // factor evaluations together cost 496 B per lane of scratch, written and read back by every row
+    constexpr int G = R < 8 ? R : 8;
+#pragma unroll
+    for (int j0 = 0; j0 < R; j0 += G) {
+      cplx v[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) v[j] = st[tid + (j0 + j) * NTT];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const double f = ft_pre * fjt[j0 + j];
+        q[j0 + j] = f * v[j].x;
+        p[j0 + j] = f * v[j].y;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const cplx v = st[tid + j * NTT];
+      q[j] = v.x;
+      p[j] = v.y;
+    }
   }
 
-  const bool has_kick = A.kick_pre != 0.0 || A.kick_post != 0.0;
+  const bool has_kick = ROWS && (A.kick_pre != 0.0 || A.kick_post != 0.0);
   if (has_kick && tid < N) {
     const ryd_qdesc d = A.desc[(size_t)b * N + tid];
     double c = 0.0;
@@ -197,7 +335,7 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
     }
     if (tid < N) {
       // same arithmetic as k_eval_coefs / k_traj (w1 * val(t1) + w2 * val(t2)); only the real
-      // part of the drive is used (the host routes complex drives elsewhere)
+      // part of the drive is used (complex drives: KET_GAUGE below, or the other kernels)
       const ryd_qdesc d = A.desc[(size_t)b * N + tid];
       auto val = [&](int ser, double u) -> double {
         const cplx* pq = A.pp + ((size_t)ser * A.n_int + sd.idx) * 4;
@@ -208,7 +346,9 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
         return r;
       };
       double c1 = 0, c2 = 0, dlA = 0, dlB = 0;
-      if (d.drive_series >= 0) { c1 = val(d.drive_series, sd.u1); c2 = val(d.drive_series, sd.u2); }
+      if constexpr (!GAUGE) {
+        if (d.drive_series >= 0) { c1 = val(d.drive_series, sd.u1); c2 = val(d.drive_series, sd.u2); }
+      }
       if (d.det_series >= 0) {
         const double d1 = val(d.det_series, sd.u1), d2 = val(d.det_series, sd.u2);
         dlA += d.det_scale * (A.a1 * d1 + A.a2 * d2);
@@ -220,9 +360,31 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
         dlB += d.off_scale * (A.a2 * o1 + A.a1 * o2);
       }
       if (d.extra > 0 && A.dterms) { dlA += hfx[2 * tid]; dlB += hfx[2 * tid + 1]; }
-      cfA[4 * tid + 0] = d.drive_scale * (A.a1 * c1 + A.a2 * c2);
+      double drA, drB;
+      if constexpr (GAUGE) {
+        // exponents 1/2 B0 -+ 2 B1 from the moments B0 = int f, B1 = (1/h) int (t - t_mid) f of the drive
+        // modulus and of theta', 4-point Gauss-Legendre: weights w_i (1/4 -+ x_i / 2) per unit step
+        const double us = sd.u1 - KET_C1 * sd.h, um = us + 0.5 * sd.h, hh = 0.5 * sd.h;
+        drA = 0.0; drB = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          constexpr double X[4] = {-0.8611363115940526, -0.3399810435848563, 0.3399810435848563, 0.8611363115940526};
+          constexpr double W[4] = {0.3478548451374538, 0.6521451548625461, 0.6521451548625461, 0.3478548451374538};
+          double r, thd;
+          gauge_eval(sd.idx, fma(hh, X[g], um), &r, &thd);
+          const double wa = W[g] * (0.25 - 0.5 * X[g]), wb = W[g] * (0.25 + 0.5 * X[g]);
+          drA = fma(wa, r, drA);
+          drB = fma(wb, r, drB);
+          dlA = fma(wa, thd, dlA);
+          dlB = fma(wb, thd, dlB);
+        }
+      } else {
+        drA = d.drive_scale * (A.a1 * c1 + A.a2 * c2);
+        drB = d.drive_scale * (A.a2 * c1 + A.a1 * c2);
+      }
+      cfA[4 * tid + 0] = drA;
       cfA[4 * tid + 2] = dlA;
-      cfB[4 * tid + 0] = d.drive_scale * (A.a2 * c1 + A.a1 * c2);
+      cfB[4 * tid + 0] = drB;
       cfB[4 * tid + 2] = dlB;
     }
     __syncthreads();
@@ -239,11 +401,11 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
 
     // ex = 0, 1: the two exponentials of the CF4 step; ex = -1 / 2: the drive-only kick before
     // the first / after the last step of the launch
-    const int ex_lo = (s == 0 && A.kick_pre != 0.0) ? -1 : 0;
-    const int ex_hi = (s == A.n_steps - 1 && A.kick_post != 0.0) ? 2 : 1;
+    const int ex_lo = (ROWS && s == 0 && A.kick_pre != 0.0) ? -1 : 0;
+    const int ex_hi = (ROWS && s == A.n_steps - 1 && A.kick_post != 0.0) ? 2 : 1;
 #pragma unroll 1
     for (int ex = ex_lo; ex <= ex_hi; ++ex) {
-      const bool kick = ex < 0 || ex > 1;
+      const bool kick = ROWS && (ex < 0 || ex > 1);
       const double* cf = kick ? cfK : (ex ? cfB : cfA);
       const int sch = ex == 1 ? sd.sch_b : sd.sch_a;
       const int nsub = ex == 1 ? sd.sub_b : sd.sub_a;
@@ -386,10 +548,12 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
       // (exact to hk^3) through the same code, whose diagonal term is taken out again afterwards.
       const double hk = ex < 0 ? A.kick_pre : A.kick_post;
       auto undo_diag = [&](double (&dst)[R], const double (&src)[R], double coef) {
+        if constexpr (!ROWS) return;
 #pragma unroll
         for (int jp = 0; jp < RP; ++jp) {
           const double2 eh2 = *reinterpret_cast<const double2*>(ehx + 2 * jp);
           double ec = elo;
+          asm volatile("" : "+v"(ec));  // not hoisted out of the shear loop (the R / 2 partial sums would be parked in scratch)
 #pragma unroll
           for (int k = 1; k < NH; ++k)
             if (!((jp >> (k - 1)) & 1)) ec += vhi[k];
@@ -423,18 +587,64 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
     }
     if (sd.snap >= 0 && A.snaps) {
       cplx* o = A.snaps + ((size_t)sd.snap * gridDim.x + row) * D;
+      int tid_sn = tid;
+      asm volatile("" : "+v"(tid_sn));  // addresses recomputed here, not parked in scratch from the loads on
+      if constexpr (GAUGE) {
+        // back to the laboratory gauge at the END of this step: psi = conj(T J) e^{-i phase} psi~
+        if (tid < N) {
+          double r1, t1;
+          gauge_eval(sd.idx, sd.u1 + (1.0 - KET_C1) * sd.h, &r1, &t1);
+        }
+        gauge_publish();
+        const double ax = Tx * sd.cum_cs - Ty * sd.cum_sn, ay = Tx * sd.cum_sn + Ty * sd.cum_cs;  // T e^{+i phase}
 #pragma unroll
-      for (int j = 0; j < R; ++j)  // psi * e^{-i phase}: the accumulated spectral shifts
-        o[tid + j * NTT] = make_double2(fma(q[j], sd.cum_cs, p[j] * sd.cum_sn), fma(p[j], sd.cum_cs, -q[j] * sd.cum_sn));
+        for (int j = 0; j < R; ++j) {
+          const double fx = ax * gj[2 * j] - ay * gj[2 * j + 1], fy = ax * gj[2 * j + 1] + ay * gj[2 * j];
+          o[tid_sn + j * NTT] = make_double2(q[j] * fx + p[j] * fy, p[j] * fx - q[j] * fy);  // (q + i p) conj(f)
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j)  // psi * e^{-i phase}: the accumulated spectral shifts
+          o[tid_sn + j * NTT] = make_double2(fma(q[j], sd.cum_cs, p[j] * sd.cum_sn), fma(p[j], sd.cum_cs, -q[j] * sd.cum_sn));
+      }
     }
     __syncthreads();  // cf / ehi are rewritten by the next step
   }
+  // the store addresses are recomputed from an opaque copy of the thread index: kept alive from the loads
+  // they would be parked in scratch for the whole kernel (46 doubles per lane at 14 atoms)
+  int tid_st = tid;
+  asm volatile("" : "+v"(tid_st));
+  if constexpr (GAUGE) {
+    if (tid < N && A.n_steps > 0) {
+      const KetStep sl = A.steps[A.n_steps - 1];
+      double r1, t1;
+      gauge_eval(sl.idx, sl.u1 + (1.0 - KET_C1) * sl.h, &r1, &t1);
+    }
+    gauge_publish();
+    const double ax = Tx * A.fin_cs - Ty * A.fin_sn, ay = Tx * A.fin_sn + Ty * A.fin_cs;
 #pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int l = tid + j * NTT;
-    double f = 1.0;
-    if (A.use_post) f = factor(ftab + 64, j);
-    st[l] = make_double2(f * fma(q[j], A.fin_cs, p[j] * A.fin_sn), f * fma(p[j], A.fin_cs, -q[j] * A.fin_sn));
+    for (int j = 0; j < R; ++j) {
+      const double fx = ax * gj[2 * j] - ay * gj[2 * j + 1], fy = ax * gj[2 * j + 1] + ay * gj[2 * j];
+      st[tid_st + j * NTT] = make_double2(q[j] * fx + p[j] * fy, p[j] * fx - q[j] * fy);
+    }
+  } else if constexpr (ROWS) {
+    constexpr int G = R < 8 ? R : 8;
+    const double* fj_st = fjt + R;
+    asm volatile("" : "+v"(fj_st));  // read now, not hoisted to the top of the kernel and parked
+#pragma unroll
+    for (int j0 = 0; j0 < R; j0 += G) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const double f = ft_post * fj_st[j0 + j];
+        st[tid_st + (j0 + j) * NTT] = make_double2(f * fma(q[j0 + j], A.fin_cs, p[j0 + j] * A.fin_sn),
+                                               f * fma(p[j0 + j], A.fin_cs, -q[j0 + j] * A.fin_sn));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      st[tid_st + j * NTT] = make_double2(fma(q[j], A.fin_cs, p[j] * A.fin_sn), fma(p[j], A.fin_cs, -q[j] * A.fin_sn));
   }
 }
 

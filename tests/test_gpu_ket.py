@@ -309,3 +309,86 @@ def test_split_operator_rows_relaxation_product_state_12_atoms():
                         for a, b in pairs])
         assert abs(float(torch.diagonal(st[0]).real.sum().item()) - 1.0) < 1e-11
         assert np.max(np.abs(got - ref)) < 5e-8
+
+
+# ---------------------------------------------------------------------------------------------------------
+# complex drives on the register-resident kernel (KET_GAUGE): c_k(t) = 0.5 Omega e^{-i phi}
+# (hamiltonian.py:349-351) is gauged away inside the kernel, the state rotated back at snapshots / the end
+# ---------------------------------------------------------------------------------------------------------
+def _with_phases(prob, phase_fn):
+    prob = dict(prob)
+    loc = {q: dict(v) for q, v in prob["samples"]["Local"]["ground-rydberg"].items()}
+    T = len(next(iter(loc.values()))["amp"])
+    t = np.arange(T) / 1000.0
+    for q in loc:
+        loc[q]["phase"] = phase_fn(q, t)
+    prob["samples"] = {"Global": {}, "Local": {"ground-rydberg": loc}}
+    return prob
+
+
+PHASES = {
+    "time-dependent": lambda q, t: 0.3 * q + 0.8 * np.sin(5 * t),          # helpers.local_problem's phases
+    "constant-per-atom": lambda q, t: 0.7 * q - 1.0 + 0 * t,
+    "chirp": lambda q, t: 40.0 * t + 300.0 * t * t * (1 + q % 3),          # theta' up to ~76 rad/us
+    "jump": lambda q, t: np.where(t < 0.03, 0.2 * q, 0.2 * q + 1.1),       # phase jump at constant amplitude
+}
+
+
+@pytest.mark.parametrize("kind", sorted(PHASES))
+@pytest.mark.parametrize("n", [10, 13, 14])
+def test_complex_drives_run_on_the_ket_kernel_in_one_launch(n, kind):
+    probs = [_with_phases(real_local_problem(n, seed=s), PHASES[kind]) for s in range(2)]
+    times = np.array([0.0, 0.017, 0.041, 0.06])
+    outs = {}
+    for force in (True, False):
+        with _engine(probs, "sesolve") as eng:
+            eng.set_path(not force, force_ket=force, no_ket=not force)
+            outs[force] = eng.solve(eng.new_state(), times, tol=0.0 if force else 1e-12).cpu().numpy()
+            if force:
+                assert eng.stats()["n_launches"] == 1, "complex drives must stay on k_ket"
+    assert np.max(np.abs(outs[True] - outs[False])) < 2e-8, np.max(np.abs(outs[True] - outs[False]), axis=(1, 2))
+    assert abs(np.linalg.norm(outs[True][-1, 1]) - 1.0) < 1e-9
+
+
+def test_complex_global_drive_starting_from_zero_amplitude_against_the_oracle():
+    """A global pulse with a phase (the commonest complex drive): amplitude ramps from 0, so the gauge direction at
+    t = 0 comes from the derivative; checked against the tight oracle integrated here."""
+    from oracle import qutip_path as qp
+
+    n = 10
+    prob = tri_problem(2, 5)
+    g = dict(prob["samples"]["Global"]["ground-rydberg"])
+    T = 301
+    g = {k: np.asarray(v)[:T].copy() for k, v in g.items()}
+    g["amp"][-1] = 0.0
+    g["phase"] = np.full(T, 0.9)
+    prob = dict(prob, duration=T, samples={"Global": {"ground-rydberg": g}, "Local": {}})
+    times = np.array([0.0, 0.12, 0.3])
+    opts = dict(qp.default_options([np.stack([g["amp"], g["det"]])], T - 1))
+    opts.update(qp.TIGHT)
+    ref = qp.sesolve(qp.build_hamiltonian(prob), qp.all_ground_state(n, prob["eigenbasis"]), times, **opts)
+    with _engine([prob], "sesolve") as eng:
+        eng.set_path(False, force_ket=True)
+        snaps = eng.solve(eng.new_state(), times).cpu().numpy()[:, 0]
+        assert eng.stats()["n_launches"] == 1
+    for k in (1, 2):
+        assert np.max(np.abs(snaps[k - 1] - ref[k])) < AMP_TOL, k
+
+
+def test_a_drive_through_zero_with_a_turning_phase_is_not_gauged():
+    """theta' = Im(c' conj c) / |c|^2 is unbounded where a drive passes by zero while its phase turns - e.g. a
+    phase jump of almost pi at constant amplitude: the complex spline takes c from A e^{-i phi_1} to A e^{-i phi_2}
+    along a chord that passes within 0.02 A of the origin.  The host refuses the gauge there (cap 4000 rad/us)
+    and the multi-launch kernels (complex coefficients) take the problem."""
+    n = 13
+    prob = _with_phases(real_local_problem(n, seed=4), lambda q, tt: np.where(tt < 0.03, 0.0, 3.1))
+    outs = {}
+    for no_ket in (False, True):
+        with _engine([prob] * 8, "sesolve") as eng:
+            eng.set_path(False, no_ket=no_ket)
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 0.06)
+            assert eng.stats()["n_launches"] > 1  # not the one-launch ket kernel, with or without the switch
+            outs[no_ket] = st.cpu().numpy()[0]
+    assert np.array_equal(outs[False], outs[True])
+    assert abs(np.linalg.norm(outs[False]) - 1.0) < 1e-9
