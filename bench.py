@@ -628,6 +628,18 @@ def main() -> None:
                      "applications_per_sequence": stats["n_applications"],
                      "kernel": "k_traj<12,1024,0> (persistent, per-atom complex coefficients)"})
         eng.close()
+        # 14 atoms with per-atom complex drives: gauged away inside the register-resident kernel (KET_GAUGE);
+        # round 2 sent these to the multi-launch kernels (250 sim-us/s on a round-1 figure)
+        eng = Engine.from_problems([local_problem(14, seed=s, duration=401) for s in range(8)] * 32, mode="sesolve")
+        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, 0.4, 2, 1, None, torch)
+        also.append({"workload": "256 x 14-atom sequences with per-atom complex, time-dependent drives, 400 ns",
+                     "value": 256 * 0.4 / sec, "unit": "sim-us/s", "ms_per_batch": sec * 1e3,
+                     "stages_per_sequence": stats["n_applications"], "launches": stats["n_launches"],
+                     "kernel": "k_ket<14, KET_GAUGE> (complex drives gauged away: 4-point Gauss moments of |c| and "
+                               "d/dt arg c per step and atom)",
+                     "roofline": roofline_valu(2.0**14, 256, stats["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kms, kl,
+                                               "k_ket<14, KET_GAUGE>")})
+        eng.close()
         # quantum-jump trajectories (what Solver.DEFAULT runs for dissipation + stochastic noise)
         mc_prob = chain_problem(12)
         mc_prob["collapse_ops"] = [(float(np.sqrt(2 * 0.05)), "sigma_rr"), (float(np.sqrt(0.02)), "sigma_gr")]

@@ -137,6 +137,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # dev probes (tools/): an alternative build of the same library, e.g. with another RYD_KET_F0
+    global LIB_PATH
+    LIB_PATH = os.environ.get("RYD_LIB") or LIB_PATH
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP library first "

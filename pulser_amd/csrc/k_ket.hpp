@@ -96,19 +96,24 @@ __device__ __forceinline__ double dpp_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// F0: index bits below F0 take their partners over the DPP crossbar (4) or from LDS like the
-// others (0); LOGNT: log2 of the workgroup size.  Measured at 14 atoms, 1024 rows (us per stage),
-// final (software-pipelined) form: <14, 4, 9> 9.9, <14, 0, 9> 10.7 (ten b128 reads per pair, twice
-// for the pipeline); before pipelining 10.6 vs 10.4; <14, 4, 10> 13.5 (four waves per SIMD but 128
-// registers per lane: spills in the hot loop); <14, 2, 9> (bits 2, 3 from LDS too: 6 fewer DPP moves and
-// one more b128 read per amplitude pair) 9.80 vs 10.00 at 1024 rows, 11.03 vs 11.18 at 256: a wash.
-#ifndef RYD_KET_F0
-#define RYD_KET_F0 4
+// DPPM: mask of the index bits 0-3 whose partners come over the DPP crossbar (quad permutes for bits 0 and
+// 1, row rotate by 8 for bit 3: one v_mov_dpp per 32-bit half; bit 2 needs two); every other thread bit is a
+// ds_read_b128 from the published copy.  The two resources trade against each other: a DPP-served bit costs
+// 4 (bit 2: 8) vector instructions per amplitude pair, an LDS-served one 64 LDS cycles per pair and CU.
+// Measured at 14 atoms, us per stage (256 / 1024 rows; round 3, after the partner addresses moved into the
+// read's immediate offset): 0b1111: 10.49 / 9.42, 0b0011: 10.15 / 8.95, 0b0000: 10.93 / 9.83,
+// 0b1011 (the cheap three): see profiles/r03_kket_variants.md.  Round 2 (address arithmetic per read still
+// in the loop): 0b1111 9.9, 0b0000 10.7.  LOGNT: log2 of the workgroup size (1024 threads x 16 amplitudes
+// spill in the hot loop: 13.5).
+#ifndef RYD_KET_DPPM
+#define RYD_KET_DPPM 0xB
 #endif
-template <int N, int MODE = KET_PLAIN, int F0 = RYD_KET_F0, int LOGNT = 9>
+template <int N, int MODE = KET_PLAIN, unsigned DPPM = RYD_KET_DPPM, int LOGNT = 9>
 __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
   constexpr bool ROWS = MODE == KET_ROWS, GAUGE = MODE == KET_GAUGE;
-  static_assert(F0 == 0 || F0 == 2 || F0 == 4, "index bits below F0 use the DPP crossbar: 0, 2 or 4");
+  static_assert(DPPM < 16u, "only index bits 0-3 can use the DPP crossbar");
+  constexpr int NDPP = __builtin_popcount(DPPM);
+  constexpr int NLDS = LOGNT - NDPP;  // thread bits read from the published copy
   constexpr int D = 1 << N, NTT = 1 << LOGNT;
   constexpr int R = D / NTT;   // amplitudes per thread (8, 16, 32)
   constexpr int RP = R / 2;    // pairs
@@ -427,10 +432,23 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
       // from the published copy (two amplitudes per read), bits 9.. register to register.
       // One pair (2jp, 2jp+1) of  dst += coef * (H~ - shift) src ; `ra` = byte address of this
       // thread's slot of pair jp inside the published copy.
-      constexpr int NLD = LOGNT - F0 + 1;  // partner reads + the diagonal table entry of a pair
-      auto load_pair = [&](double2 (&pv)[NLD], int jp, unsigned ra) {
+      constexpr int NLD = NLDS + 1;  // partner reads + the diagonal table entry of a pair
+      // k-th LDS-served bit (ascending)
+      auto lds_bit = [](int k) constexpr -> int {
+        int seen = 0;
+        for (int f = 0; f < LOGNT; ++f)
+          if (!((DPPM >> f) & 1u)) { if (seen == k) return f; ++seen; }
+        return -1;
+      };
+      // Partner addresses = a per-thread base per index bit (own slot with bit f flipped: +-(16 << f) bytes,
+      // the sign is the thread's own bit) + a compile-time offset per pair, which rides in the 16-bit
+      // immediate of ds_read_b128: no address arithmetic per read (it was one v_xor + adds per read: 100
+      // of the 586 vector instructions per 16 amplitudes)
+      constexpr unsigned STRIDE = NTT * 16u;  // bytes per pair plane of the published copy
+      auto load_pair = [&](double2 (&pv)[NLD], int jp, const unsigned (&base)[NLDS + 1], int jp0) {
 #pragma unroll
-        for (int f = F0; f < LOGNT; ++f) pv[f - F0] = *reinterpret_cast<const double2*>(smem + (ra ^ (16u << f)));
+        for (int k = 0; k < NLDS; ++k)
+          pv[k] = *reinterpret_cast<const double2*>(smem + base[k] + (unsigned)(jp - jp0) * STRIDE);
         pv[NLD - 1] = *reinterpret_cast<const double2*>(ehx + 2 * jp);
       };
       auto do_pair = [&](double (&dst)[R], const double (&src)[R], double coef, int jp, const double2 (&pv)[NLD]) {
@@ -455,22 +473,26 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
           bcc0 = fma(cq[LOGNT + 1 + k], src[2 * jo], bcc0);
           bcc1 = fma(cq[LOGNT + 1 + k], src[2 * jo + 1], bcc1);
         }
-        if constexpr (F0 >= 2) {
+        if constexpr (DPPM & 1u) {
           bcc0 = fma(cq[0], dpp_f64<0xB1>(s0), bcc0);   // xor 1
           bcc1 = fma(cq[0], dpp_f64<0xB1>(s1), bcc1);
+        }
+        if constexpr (DPPM & 2u) {
           bcc0 = fma(cq[1], dpp_f64<0x4E>(s0), bcc0);   // xor 2
           bcc1 = fma(cq[1], dpp_f64<0x4E>(s1), bcc1);
         }
-        if constexpr (F0 == 4) {
+        if constexpr (DPPM & 8u) {
           bcc0 = fma(cq[3], dpp_f64<0x128>(s0), bcc0);  // xor 8 (row rotate by 8)
           bcc1 = fma(cq[3], dpp_f64<0x128>(s1), bcc1);
+        }
+        if constexpr (DPPM & 4u) {
           bcc0 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s0)), bcc0);  // xor 4 = (xor 7) o (xor 3)
           bcc1 = fma(cq[2], dpp_f64<0x1B>(dpp_f64<0x141>(s1)), bcc1);
         }
 #pragma unroll
-        for (int f = F0; f < LOGNT; ++f) {
-          acc0 = fma(cq[f], pv[f - F0].x, acc0);
-          acc1 = fma(cq[f], pv[f - F0].y, acc1);
+        for (int k = 0; k < NLDS; ++k) {
+          acc0 = fma(cq[lds_bit(k)], pv[k].x, acc0);
+          acc1 = fma(cq[lds_bit(k)], pv[k].y, acc1);
         }
         dst[2 * jp] = fma(coef, acc0 + bcc0, dst[2 * jp]);
         dst[2 * jp + 1] = fma(coef, acc1 + bcc1, dst[2 * jp + 1]);
@@ -489,34 +511,42 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
       // phase (17 % of a stage before), and there are still two barriers per half-stage.
       auto half_stage = [&](double (&dst)[R], const double (&src)[R], double coef) {
         constexpr int H = RP / 2;
+        unsigned base[NLDS + 1];  // [0, NLDS): partner bases; last: the thread's own slot
+#pragma unroll
+        for (int k = 0; k < NLDS; ++k) base[k] = ((unsigned)tid * 16u) ^ (16u << lds_bit(k));
+        base[NLDS] = (unsigned)tid * 16u;
+#pragma unroll
+        for (int f = 0; f <= NLDS; ++f) asm volatile("" : "+v"(base[f]));
         if constexpr (RP >= 2) {
           // software pipeline: the LDS reads of pair jp + 1 are in flight while pair jp is computed
           // (two register sets; with two waves per SIMD the read latency was not covered otherwise)
           double2 pvs[2][NLD];
-          unsigned ra = (unsigned)tid * 16u;
-          load_pair(pvs[0], 0, ra);
+          load_pair(pvs[0], 0, base, 0);
 #pragma unroll
           for (int jp = 0; jp < H; ++jp) {
-            asm volatile("" : "+v"(ra));
-            *reinterpret_cast<double2*>(smem + ra + (unsigned)H * NTT * 16u) =
+            *reinterpret_cast<double2*>(smem + base[NLDS] + (unsigned)(jp + H) * STRIDE) =
                 make_double2(src[2 * (jp + H)], src[2 * (jp + H) + 1]);
-            if (jp + 1 < H) load_pair(pvs[(jp + 1) & 1], jp + 1, ra + NTT * 16u);
+            if (jp + 1 < H) load_pair(pvs[(jp + 1) & 1], jp + 1, base, 0);
             __builtin_amdgcn_sched_barrier(0);  // issue order: next pair's reads, then this pair's arithmetic
             do_pair(dst, src, coef, jp, pvs[jp & 1]);
-            ra += NTT * 16u;
             __builtin_amdgcn_sched_barrier(0);
           }
           __syncthreads();  // B complete; every read of A done
-          load_pair(pvs[H & 1], H, ra);
+          // second half: the bases move up by H planes (64 KiB at 14 atoms: beyond the immediate's reach)
+#pragma unroll
+          for (int f = 0; f <= NLDS; ++f) {
+            base[f] += (unsigned)H * STRIDE;
+            asm volatile("" : "+v"(base[f]));
+          }
+          load_pair(pvs[H & 1], H, base, H);
 #pragma unroll
           for (int jp = H; jp < RP; ++jp) {
-            asm volatile("" : "+v"(ra));
-            *reinterpret_cast<double2*>(smem + ra - (unsigned)H * NTT * 16u) =
+            // finished dst[0, H) goes into A = H planes below this half's bases
+            *reinterpret_cast<double2*>(smem + (base[NLDS] - (unsigned)H * STRIDE) + (unsigned)(jp - H) * STRIDE) =
                 make_double2(dst[2 * (jp - H)], dst[2 * (jp - H) + 1]);
-            if (jp + 1 < RP) load_pair(pvs[(jp + 1) & 1], jp + 1, ra + NTT * 16u);
+            if (jp + 1 < RP) load_pair(pvs[(jp + 1) & 1], jp + 1, base, H);
             __builtin_amdgcn_sched_barrier(0);
             do_pair(dst, src, coef, jp, pvs[jp & 1]);
-            ra += NTT * 16u;
             __builtin_amdgcn_sched_barrier(0);
           }
           __syncthreads();  // A complete (next source); every read of B done
@@ -525,7 +555,7 @@ __global__ __launch_bounds__(1 << LOGNT) void k_ket(const KetArgs A) {
           *reinterpret_cast<double2*>(smem + (unsigned)tid * 16u) = make_double2(src[0], src[1]);
           __syncthreads();
           double2 pv1[NLD];
-          load_pair(pv1, 0, (unsigned)tid * 16u);
+          load_pair(pv1, 0, base, 0);
           do_pair(dst, src, coef, 0, pv1);
         }
       };

@@ -379,8 +379,8 @@ def test_a_drive_through_zero_with_a_turning_phase_is_not_gauged():
     """theta' = Im(c' conj c) / |c|^2 is unbounded where a drive passes by zero while its phase turns - e.g. a
     phase jump of almost pi at constant amplitude: the complex spline takes c from A e^{-i phi_1} to A e^{-i phi_2}
     along a chord that passes within 0.02 A of the origin.  The host refuses the gauge there (cap 4000 rad/us)
-    and the multi-launch kernels (complex coefficients) take the problem."""
-    n = 13
+    and the multi-launch kernels (complex coefficients) take the problem (14 atoms: k_traj stops at 13)."""
+    n = 14
     prob = _with_phases(real_local_problem(n, seed=4), lambda q, tt: np.where(tt < 0.03, 0.0, 3.1))
     outs = {}
     for no_ket in (False, True):

@@ -1,5 +1,5 @@
 """Count the fp64 instructions of one half-stage of k_ket<14> in the compiled ISA (the flop
-accounting behind bench.py's roofline): python tools/count_isa.py > profiles/r02_kket_isa.md"""
+accounting behind bench.py's roofline): python tools/count_isa.py [mode] > profiles/r03_kket_isa.md"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,14 +9,15 @@ with tempfile.TemporaryDirectory() as d:
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                     "-Wno-unused-value", src, "-o", asm], check=True, stderr=subprocess.DEVNULL)
     text = open(asm).read()
-m = re.search(r"^_Z5k_ketILi14E\w*EEv7KetArgs:(.*?)s_endpgm", text, re.S | re.M)
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # 0 plain, 1 rows, 2 gauge
+m = re.search(r"^_Z5k_ketILi14ELi%dE\w*EEv7KetArgs:(.*?)s_endpgm" % mode, text, re.S | re.M)
 body = m.group(1).split("\n")
 bars = [i for i, l in enumerate(body) if "s_barrier" in l]
 # half-stages = the longest barrier-to-barrier regions that contain ds_read_b128 partner reads
 regions = sorted(((b - a, a, b) for a, b in zip(bars, bars[1:])), reverse=True)
 # since the LDS publishes ride along, a half-stage is two barrier-to-barrier regions of 8 pairs each
 hs = sorted([r for r in regions if sum("ds_read_b128" in l for l in body[r[1]:r[2]]) >= 40][:4], key=lambda r: r[1])
-print("# r02: fp64 instruction count of one half-stage of `k_ket<14>` (hipcc 7.2, gfx950, -O3)\n")
+print(f"# r03: fp64 instruction count of one half-stage of `k_ket<14, MODE {mode}>` (hipcc 7.2, gfx950, -O3)\n")
 print("One half-stage = `dst += coef (H~ - shift) src` for the 32 amplitudes of a lane (16 pairs), in two")
 print("barrier-to-barrier halves of 8 pairs (16 amplitudes) each; the two hot copies are q <- p and p <- q.\n")
 print("| region (ISA lines) | v_fma/v_fmac_f64 | v_mul_f64 | v_add_f64 | ds_read_b128 | v_mov_dpp | other VALU | scratch ops | flops / amplitude |")
