@@ -19,6 +19,7 @@ static const int kSplitMaxSub = SPLIT_MAX_SUB;
 static const double kSplitTolTotal = 5e-8;
 
 static int snapshot_copy(ryd_handle* h, const cplx* state, cplx* dst, hipStream_t st);
+static int mc_after_step(ryd_handle* h, cplx* state, hipStream_t st);
 
 struct SubStep {
   int idx;     // knot interval
@@ -26,8 +27,10 @@ struct SubStep {
   double tau;
 };
 
+// (quantum-jump trajectories included: H_eff only adds a real decay factor to the D stages, the jump
+// bookkeeping runs between schedule steps as on the Taylor path)
 static bool split_capable(const ryd_handle* h) {
-  return !h->general && h->cfg.mode == RYD_SESOLVE && !h->mc && h->N >= 4;
+  return !h->general && h->cfg.mode == RYD_SESOLVE && h->N >= 4;
 }
 
 // ryd_opts.method: 0 = library default (split-operator for two-level kets of 15+ atoms, else the
@@ -113,7 +116,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
 
   const std::vector<Pass>& til = h->split_tilings;
   const int m = (int)til.size();
-  if (m == 1 && N == 12 && !h->split_no_loop) {
+  if (m == 1 && N == 12 && !h->split_no_loop && !h->mc) {
     // the whole ket is one tile: every stage of the run in one launch, the ket stays in registers
     SplitArgs A;
     std::memset(&A, 0, sizeof A);
@@ -164,6 +167,10 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
       A.do_diag = 1;
       A.ccur = h->split_coefs + (size_t)si * stride;
       A.wE = wE[si];
+      if (h->mc) {  // H_eff: the decay diagonal a + b popc(index) over the D time of this stage
+        A.use_decay = 1;
+        for (int ne = 0; ne <= N; ++ne) A.dec[ne] = std::exp(wE[si] * (h->mc_a + h->mc_b * (N - ne)));
+      }
       if (si < n_stages - 1) {  // a rotation follows (the last stage only closes)
         A.cur_mask = (1u << p.T) - 1u;
         done = bits;
@@ -172,7 +179,8 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
       ++si;
     }
     if (A.fin_mask || A.do_diag) {
-      const size_t lds = ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TMAX * 4 * 8 + 128 * 8 + 2 * SPLIT_NMAX * 4 * 8;
+      const size_t lds = ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TMAX * 4 * 8 + 128 * 8 + 2 * SPLIT_NMAX * 4 * 8 +
+                         (SPLIT_NMAX + 1) * 8;
       if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
       const dim3 grid(1u << (N - p.T), B);
       if (p.T == 12 && !(A.fin_mask & 0xFu)) {
@@ -249,6 +257,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   if (control && h->split_known && std::fabs(t_start - h->split_t_end) > 1e-9) since = kSplitCheckEvery;
   size_t i = 0;
   double off = 0.0;
+  const bool jumps = h->mc_active;  // quantum-jump solve: norm check / jump after EVERY schedule step
   bool have_ck = false;
   size_t ck_i = 0;
   double ck_off = 0.0;
@@ -266,6 +275,8 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     have_ck = true;
   }
   auto finish_step = [&](size_t k) -> int {
+    int rcf;
+    if (jumps && (rcf = mc_after_step(h, state, st))) return rcf;
     if (snaps && sched[k].snap >= 0)
       return snapshot_copy(h, state, snaps + (size_t)sched[k].snap * h->dim * h->B, st);
     return RYD_OK;
@@ -296,7 +307,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       const double tau_new = s0.tau * fac;
       h->stats.reserved[1] = e;
       h->stats.reserved[2] = s0.tau;
-      if (e > 4.0 * allowed && have_ck && retries < 4) {
+      if (e > 4.0 * allowed && have_ck && retries < 4 && !jumps) {  // (a roll-back would replay jumps)
         // the stretch since the last checkpoint ran with a sub-step that has become too long
         HIPCHK(hipMemcpyAsync(state, h->wB, bytes, hipMemcpyDeviceToDevice, st));
         i = ck_i;
@@ -354,7 +365,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       h->stats.n_steps++;
       ++since;
       const bool snap = snaps && d.snap >= 0;
-      if (snap || i + 1 == stop) {
+      if (snap || jumps || i + 1 == stop) {
         if ((rc = split_advance(h, state, subs, st))) return rc;
         subs.clear();
         if ((rc = finish_step(i))) return rc;

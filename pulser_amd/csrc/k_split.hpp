@@ -33,6 +33,10 @@ struct SplitArgs {
   int N, T;
   unsigned fin_mask, cur_mask;  // tile-local bits to rotate before / after D
   int do_diag;
+  // quantum-jump trajectories (H_eff = H - i/2 sum C^dag C, diagonal for every built-in channel): D also
+  // carries the real factor dec[number of excited atoms] = exp(wE (a + b popc(index))), host-computed
+  int use_decay;
+  double dec[SPLIT_NMAX + 1];
 };
 
 // One closed run of the composition: consecutive sub-steps (knot interval, start offset, length),
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
   double* dlo = rot + 2 * SPLIT_TMAX * 4;                         // [64]
   double* dhi = dlo + 64;                                         // [64]
   double* cfs = dhi + 64;                                         // [2][SPLIT_NMAX][4] staged coefficients
+  double* dlut = cfs + 2 * SPLIT_NMAX * 4;                        // [SPLIT_NMAX + 1] decay factors (quantum jumps)
 
   const int tid = threadIdx.x;
   const int N = A.N;
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
     cfs[4 * SPLIT_NMAX + tid] = ccur[tid];
   }
   if (tid >= 128 && tid < 192) trig[tid - 128] = make_double2(kSplitTrig[tid - 128][0], kSplitTrig[tid - 128][1]);
+  if (A.use_decay && tid >= 192 && tid < 192 + SPLIT_NMAX + 1) dlut[tid - 192] = A.dec[tid - 192];
   __syncthreads();
   if (tid < 2 * T) {
     const int set = tid / T, q = tid % T;
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
     o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
   }
   double d_outer = 0.0;
+  int nexc_outer = 0;  // excited atoms among the bits outside the tile (fixed per workgroup)
   if (A.do_diag) {
     const double* cc = cfs + 4 * SPLIT_NMAX;
     // detuning integral part of the phase: sum_k Delta_k n_k, n_k = 1 - bit
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
       bool in_tile = false;
 #pragma unroll
       for (int i = 0; i < 3; ++i) in_tile |= (p >= A.tile.lo[i] && p < A.tile.lo[i] + A.tile.len[i]);
-      if (!in_tile && !((base >> p) & 1ull)) d_outer += cc[4 * (N - 1 - p) + 3];
+      if (!in_tile && !((base >> p) & 1ull)) { d_outer += cc[4 * (N - 1 - p) + 3]; ++nexc_outer; }
     }
   }
   __syncthreads();
@@ -342,6 +349,11 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
       const double phi = fma(A.wE, ev[r], -(d_outer + dlo[i & 63u] + dhi[i >> 6]));
       double c, s;
       split_sincos(phi, trig, c, s);
+      if (A.use_decay) {
+        const double f = dlut[nexc_outer + T - __popc(i)];
+        c *= f;
+        s *= f;
+      }
       const cplx a = x[r];
       x[r] = make_double2(fma(a.x, c, a.y * s), fma(a.y, c, -a.x * s));  // a * (c - i s)
     }
@@ -382,6 +394,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   double* dlo = rot + 2 * SPLIT_TMAX * 4;
   double* dhi = dlo + 64;
   double* cfs = dhi + 64;
+  double* dlut = cfs + 2 * SPLIT_NMAX * 4;
 
   const unsigned tid = threadIdx.x;
   const int N = A.N;
@@ -409,6 +422,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
     cfs[4 * SPLIT_NMAX + tid] = ccur[tid];
   }
   if (tid >= 128 && tid < 192) trig[tid - 128] = make_double2(kSplitTrig[tid - 128][0], kSplitTrig[tid - 128][1]);
+  if (A.use_decay && tid >= 192 && tid < 192 + SPLIT_NMAX + 1) dlut[tid - 192] = A.dec[tid - 192];
   __syncthreads();
   if (tid < 2 * T) {
     const int set = tid / T, q = tid % T;
@@ -418,6 +432,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
     o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
   }
   double d_outer = 0.0;
+  int nexc_outer = 0;
   if (A.do_diag) {
     const double* cc = cfs + 4 * SPLIT_NMAX;
     if (tid >= 128) {
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
       bool in_tile = false;
 #pragma unroll
       for (int i = 0; i < 3; ++i) in_tile |= (p >= A.tile.lo[i] && p < A.tile.lo[i] + A.tile.len[i]);
-      if (!in_tile && !((base >> p) & 1ull)) d_outer += cc[4 * (N - 1 - p) + 3];
+      if (!in_tile && !((base >> p) & 1ull)) { d_outer += cc[4 * (N - 1 - p) + 3]; ++nexc_outer; }
     }
   }
   __syncthreads();
@@ -480,6 +495,11 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
       const double phi = fma(A.wE, ev[r], -(d_outer + dlo[i & 63u] + dhi[i >> 6]));
       double c, s;
       split_sincos(phi, trig, c, s);
+      if (A.use_decay) {
+        const double f = dlut[nexc_outer + 12 - __popc(i)];
+        c *= f;
+        s *= f;
+      }
       const cplx a = x[r];
       x[r] = make_double2(fma(a.x, c, a.y * s), fma(a.y, c, -a.x * s));
     }

@@ -334,6 +334,7 @@ class Engine:
         max_step: float = 0.0,
         max_order: int = 0,
         magnus_tol: float = 0.0,
+        method: str = "auto",
     ) -> Any:
         """One quantum-jump trajectory per batch entry (``qutip.mcsolve`` with
         ``ntraj=1``, simulation.py:705-735): ``seeds`` holds one uint64 per batch
@@ -352,7 +353,7 @@ class Engine:
             out = self.torch.empty((len(t) - 1,) + self.state_shape, dtype=self.torch.complex128,
                                    device=self.device)
         opts = RydOpts(taylor_order=int(taylor_order), max_order=int(max_order), tol=float(tol),
-                       max_step=float(max_step), magnus_tol=float(magnus_tol))
+                       max_step=float(max_step), magnus_tol=float(magnus_tol), method=_method_code(method))
         _lib.check(
             self.lib.ryd_mc_solve(
                 self._h, state.data_ptr(), len(t), t.ctypes.data,

@@ -235,10 +235,50 @@ def test_quantum_jumps_on_register_tile_and_tiled_kernels_agree():
         with Engine(tables, mode="mcsolve") as eng:
             eng.set_path(False, no_tile14=no14, no_single_pass=no_single)
             state = eng.new_state()
-            eng.mc_solve(state, np.array([0.0, 0.03]), seeds, store=False)
+            # (the default for quantum jumps at 14+ atoms is the split-operator path, tested below)
+            eng.mc_solve(state, np.array([0.0, 0.03]), seeds, store=False, method="taylor")
             out.append((state.cpu().numpy(), eng.mc_jumps(), eng.stats()["passes"]))
     assert [o[2] for o in out] == [1, 1, 2]
     for other in out[1:]:
         assert np.array_equal(out[0][1], other[1]) and out[0][1].sum() > 10
         assert np.max(np.abs(out[0][0] - other[0])) < 1e-10
     assert np.allclose(np.linalg.norm(out[0][0], axis=-1), 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,batch", [(14, 16), (16, 6), (20, 2)])
+def test_quantum_jumps_on_the_split_operator_passes_match_the_taylor_path(n, batch):
+    """Collapse operators on the split-operator ket passes (the default from 14 atoms on): H_eff's decay
+    diagonal is a real factor of the D stages, the jump bookkeeping runs between schedule steps exactly as
+    on the CF4 + Taylor path - same seeds, same jumps, kets within the parity bar."""
+    strong = [(np.sqrt(6.0), "sigma_gr"), (np.sqrt(2 * 1.5), "sigma_rr")] + [(np.sqrt(2.0 / 4), p) for p in "xyz"]
+    prob = local_problem(n, seed=40 + n, duration=61, collapse_ops=strong, paulis=DEPOL_PAULIS)
+    seeds = np.arange(batch, dtype=np.uint64) * np.uint64(7919) + np.uint64(11)
+    times = np.array([0.0, 0.02, 0.06])
+    out = {}
+    for method in ("auto", "taylor"):
+        with Engine(lower([prob] * batch), mode="mcsolve") as eng:
+            state = eng.new_state()
+            snaps = eng.mc_solve(state, times, seeds, method=method, tol=0.0 if method == "auto" else 1e-12).cpu().numpy()
+            out[method] = (snaps, eng.mc_jumps(), eng.stats())
+    assert out["auto"][2]["passes"] in (1, 2) and out["auto"][2]["n_applications"] < out["taylor"][2]["n_applications"]
+    assert np.array_equal(out["auto"][1], out["taylor"][1]) and out["auto"][1].sum() >= batch // 2
+    assert np.max(np.abs(out["auto"][0] - out["taylor"][0])) < 1e-7
+    assert np.allclose(np.linalg.norm(out["auto"][0], axis=-1), 1.0, atol=1e-12)
+
+
+def test_split_operator_no_jump_decay_against_the_tight_oracle():
+    """No-jump evolution under H_eff on the split-operator passes (forced at 8 atoms, where zvode is cheap)."""
+    from oracle import mcwf, qutip_path as qp
+
+    n = 8
+    prob = local_problem(n, seed=3, duration=61, collapse_ops=OPS, paulis=DEPOL_PAULIS)
+    ham = qp.build_hamiltonian(prob)
+    psi0 = qp.all_ground_state(n, prob["eigenbasis"])
+    times = np.array([0.0, 0.03, 0.06])
+    ref = qp._zvode(mcwf.effective_rhs(ham), psi0, times, qp.TIGHT)
+    with Engine(lower([prob]), mode="mcsolve") as eng:
+        state = eng.new_state()
+        got = eng.solve(state, times, method="split").cpu().numpy()
+    for i in (1, 2):
+        assert np.max(np.abs(got[i - 1][0] - ref[i])) < 1e-8
+    assert np.vdot(ref[-1], ref[-1]).real < 0.95
