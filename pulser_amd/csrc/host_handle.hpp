@@ -73,6 +73,7 @@ struct ryd_handle {
   bool split_fixed = false;       // test hook: no step-size control (sub-step = schedule step)
   bool no_merge = false;          // test hook: CF4 steps never span more than one knot interval
   bool split_no_loop = false;     // test hook: 12-atom kets pass by pass instead of the one-launch loop
+  bool split_small_tiles = false; // test / bench hook: keep 2^12 tiles for every register size
   bool split_known = false;       // controller state below is valid for the current tables
   double split_tau = 1e300;       // target sub-step (us); 1e300 = whole schedule steps
   double split_rate = 0.0;        // last measured local error per us at that sub-step

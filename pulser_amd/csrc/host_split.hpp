@@ -45,13 +45,24 @@ static bool split_selected(const ryd_handle* h, const ryd_opts& o) {
 
 // Tilings: the low T bits, then tilings of the remaining high bits (at most 8 each) that keep
 // the low T - n_high bits for coalescing (runs of >= 16 amplitudes = 256 B).
+// Tile size: 2^12 (the static kernel k_split12) covers N <= 20 in two tilings, i.e. one pass per stage (a
+// 21st atom needs 9 > 8 high bits: three tilings = two passes); 2^13 tiles (k_split_t<512>) cover 21 - 23
+// atoms in two tilings (23 atoms: 10 high bits + 3 low ones, 128-B runs).
+static int split_tile_bits(const ryd_handle* h) {
+  const int N = h->N;
+  static const bool env_small = [] { const char* e = std::getenv("RYD_SPLIT_SMALL_TILES"); return e && e[0] == '1'; }();
+  if (h->split_small_tiles || env_small) return std::min(N, SPLIT_TMAX);  // (environment: A/B runs of bench.py)
+  if (N >= 21 && N <= 23) return 13;
+  return std::min(N, SPLIT_TMAX);
+}
+
 static void split_plan(ryd_handle* h) {
   if (!h->split_tilings.empty()) return;
-  const int N = h->N, T = std::min(N, SPLIT_TMAX);
+  const int N = h->N, T = split_tile_bits(h);
   h->split_tilings.push_back(make_pass(N, {{0, T}}));
   int rem = N - T, at = T;
   if (rem > 0) {
-    const int cap = T - 4;
+    const int cap = (T == 13 && N == 23) ? T - 3 : T - 4;
     const int extra = (rem + cap - 1) / cap;
     for (int e = 0; e < extra; ++e) {
       const int nh = rem / (extra - e);  // spread evenly
@@ -179,15 +190,33 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
       ++si;
     }
     if (A.fin_mask || A.do_diag) {
-      const size_t lds = ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TMAX * 4 * 8 + 128 * 8 + 2 * SPLIT_NMAX * 4 * 8 +
-                         (SPLIT_NMAX + 1) * 8;
+      const bool big = p.T > SPLIT_TMAX;
+      const size_t lds = p.T == 12 && !(A.fin_mask & 0xFu)
+                             ? ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TMAX * 4 * 8 + 128 * 8 + 2 * SPLIT_NMAX * 4 * 8 +
+                                   (SPLIT_NMAX + 1) * 8
+                             : ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TBIG * 4 * 8 + 256 * 8 +
+                                   2 * SPLIT_NMAX * 4 * 8 + (SPLIT_NMAX + 1) * 8;
       if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
       const dim3 grid(1u << (N - p.T), B);
       if (p.T == 12 && !(A.fin_mask & 0xFu)) {
         if (h->drive_real) hipLaunchKernelGGL(k_split12<true>, grid, dim3(SPLIT_NT), lds, st, A);
         else hipLaunchKernelGGL(k_split12<false>, grid, dim3(SPLIT_NT), lds, st, A);
+      } else if (big) {
+        static bool attr13[64] = {};
+        const int dev = h->cfg.device;
+        if (dev < 0 || dev >= 64 || !attr13[dev]) {
+          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          if (dev >= 0 && dev < 64) attr13[dev] = true;
+        }
+        hipLaunchKernelGGL((k_split_t<512>), grid, dim3(512), lds, st, A);
       } else {
-        hipLaunchKernelGGL(k_split, grid, dim3(SPLIT_NT), lds, st, A);
+        static bool attr12[64] = {};
+        const int dev = h->cfg.device;
+        if (dev < 0 || dev >= 64 || !attr12[dev]) {
+          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<SPLIT_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          if (dev >= 0 && dev < 64) attr12[dev] = true;
+        }
+        hipLaunchKernelGGL((k_split_t<SPLIT_NT>), grid, dim3(SPLIT_NT), lds, st, A);
       }
       HIPCHK(hipGetLastError());
       if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }

@@ -617,6 +617,10 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
     h->split_fixed = (force_generic & 256) != 0;
     h->split_no_loop = (force_generic & 512) != 0;
     h->no_merge = (force_generic & 1024) != 0;
+    {
+      const bool small = (force_generic & 2048) != 0;
+      if (small != h->split_small_tiles) { h->split_small_tiles = small; h->split_tilings.clear(); }
+    }
     if (nt != h->no_tile14 || ft != h->force_tile14 || no != h->no_outer || fo != h->force_outer) {
       h->no_tile14 = nt;
       h->force_tile14 = ft;

@@ -19,6 +19,7 @@
 // Roofline: HBM / Infinity-Cache streaming, 40 B per amplitude and stage.
 
 #define SPLIT_TMAX 12
+#define SPLIT_TBIG 14  /* table sizing of the generic pass kernel k_split_t (tiles of up to 2^14 amplitudes) */
 #define SPLIT_NT 256
 #define SPLIT_NMAX 32
 
@@ -192,16 +193,24 @@ __device__ __forceinline__ void split_sincos(double phi, const cplx* __restrict_
   s = fma(t.y, cr, t.x * sr);
 }
 
-__global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
+// NT: workgroup size (>= 2^(T - 4): 16 amplitudes per active lane).  Tiles of 2^13 amplitudes (512 lanes,
+// 128 KiB of LDS) give registers of 21 - 23 atoms ONE pass per stage (two tilings) where 2^12 tiles need three
+// tilings = two passes: measured 0.62 -> 1.43 sim-us/s at 22 atoms although this runtime-indexed kernel
+// takes 83 us per pass against 2 x 40 us of k_split12 (the wall clock also loses the second pass of every
+// controller check).  A 2^14 tile (1024 lanes x 16 amplitudes, real and imaginary parts turned separately
+// through 128 KiB) was built and measured too: at 128 registers per lane it spills (500 us per pass at 24
+// atoms against 2 x 128 us) - 24+ atoms stay on 2^12 tiles.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_split_t(const SplitArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = A.T;
   const int G = (T + 3) >> 2;  // register-bit groups
   cplx* xs = reinterpret_cast<cplx*>(smem);                       // [2^T] swizzled slots
   cplx* trig = xs + ((size_t)1 << T);                             // [64] exp(i k pi/32)
-  double* rot = reinterpret_cast<double*>(trig + 64);             // [2][SPLIT_TMAX][4]
-  double* dlo = rot + 2 * SPLIT_TMAX * 4;                         // [64]
-  double* dhi = dlo + 64;                                         // [64]
-  double* cfs = dhi + 64;                                         // [2][SPLIT_NMAX][4] staged coefficients
+  double* rot = reinterpret_cast<double*>(trig + 64);             // [2][SPLIT_TBIG][4]
+  double* dlo = rot + 2 * SPLIT_TBIG * 4;                         // [128] detuning integrals of tile bits 0-6
+  double* dhi = dlo + 128;                                        // [128] of tile bits 7-13
+  double* cfs = dhi + 128;                                        // [2][SPLIT_NMAX][4] staged coefficients
   double* dlut = cfs + 2 * SPLIT_NMAX * 4;                        // [SPLIT_NMAX + 1] decay factors (quantum jumps)
 
   const int tid = threadIdx.x;
@@ -243,6 +252,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
   int gD = G - 1;
   for (int gg = G - 1; gg >= 0; --gg)
     if (group_mask(gg, A.fin_mask)) gD = gg;
+  // E0 is prefetched with the tile (its latency hides behind the finishing rotations)
   double ev[16];
   if (A.do_diag && active) {
     const int pos = pos_of(gD);
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
     const int set = tid / T, q = tid % T;
     const int k = N - 1 - tile_bit_pos(A.tile, q);
     const double* c = cfs + set * 4 * SPLIT_NMAX + 4 * k;
-    double* o = rot + (set * SPLIT_TMAX + q) * 4;
+    double* o = rot + (set * SPLIT_TBIG + q) * 4;
     o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
   }
   double d_outer = 0.0;
@@ -271,12 +281,12 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
   if (A.do_diag) {
     const double* cc = cfs + 4 * SPLIT_NMAX;
     // detuning integral part of the phase: sum_k Delta_k n_k, n_k = 1 - bit
-    if (tid >= 128 && tid < 256) {
-      const int e = tid - 128;
-      const bool hiHalf = e >= 64;
-      const int v = e & 63;
-      const int q0 = hiHalf ? 6 : 0;
-      const int nq = hiHalf ? max(T - 6, 0) : min(T, 6);
+    if (tid < 256) {
+      const int e = tid;
+      const bool hiHalf = e >= 128;
+      const int v = e & 127;
+      const int q0 = hiHalf ? 7 : 0;
+      const int nq = hiHalf ? max(T - 7, 0) : min(T, 7);
       double s = 0.0;
       for (int q = 0; q < nq; ++q)
         if (!((v >> q) & 1)) s += cc[4 * (N - 1 - tile_bit_pos(A.tile, q0 + q)) + 3];
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
       // bit q belongs to group q/4 below the top group, else to the top group
       const int owner = (q >> 2) < G - 1 ? (q >> 2) : G - 1;
       if (!((mask >> q) & 1u) || owner != gg) continue;
-      const double* c = rot + (set * SPLIT_TMAX + q) * 4;
+      const double* c = rot + (set * SPLIT_TBIG + q) * 4;
       const double C = c[0], gr = c[1], gi = c[2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split(const SplitArgs A) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned i = idx_of(r, pos);
-      const double phi = fma(A.wE, ev[r], -(d_outer + dlo[i & 63u] + dhi[i >> 6]));
+      const double phi = fma(A.wE, ev[r], -(d_outer + dlo[i & 127u] + dhi[i >> 7]));
       double c, s;
       split_sincos(phi, trig, c, s);
       if (A.use_decay) {

@@ -118,7 +118,7 @@ def test_split_is_the_default_from_15_atoms_and_matches_taylor(n, rows, cols, ns
             s = eng.stats()
             if method == "auto":
                 assert s["n_applications"] >= 6 * ns and s["reserved"][0] > 0  # stages; error estimate kept
-                assert s["passes"] == (2 if n > 20 else 1)
+                assert s["passes"] == 1  # 21 - 23 atoms: 2^13 tiles keep one pass per stage
     assert np.max(np.abs(outs["taylor"] - outs["auto"])) < 2e-9
     assert abs(np.linalg.norm(outs["auto"]) - 1.0) < 1e-9
 
@@ -303,3 +303,31 @@ def test_sixteen_atom_sequence_end_to_end_through_the_emulator():
     with pytest.warns(DeprecationWarning):
         noisy = sim.run()
     assert sum(noisy[-1].bitstring_counts.values()) == 30
+
+
+@pytest.mark.parametrize("n", [21, 22, 23])
+def test_large_tiles_give_21_to_23_atoms_one_pass_per_stage(n):
+    """2^13-amplitude tiles (k_split_t<512>): two tilings instead of three, so a stage is ONE pass over the
+    ket; identical amplitudes to the 2^12 tiles (the same arithmetic in another order of the tile bits), and
+    the exact product-state solution of far-apart atoms."""
+    T = 6
+    coords = P.register_coords(P.square_rect(1, n), 40.0)
+    rng = np.random.default_rng(n)
+    samples = {"amp": np.full(T + 1, 6.0), "det": np.full(T + 1, -2.0), "phase": np.zeros(T + 1)}
+    prob = P.make_ising_problem(coords, samples)
+    idx = [0, 1, (1 << n) - 1, (1 << (n - 1)) + 5, 0x155AAA & ((1 << n) - 1)] + [int(v) for v in rng.integers(0, 1 << n, 40)]
+    outs = {}
+    for small in (False, True):
+        with _engine([prob]) as eng:
+            eng.set_path(False, split_fixed=True, split_small_tiles=small)
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 0.003)
+            s = eng.stats()
+            assert s["passes"] == (2 if small else 1)
+            outs[small] = st[0, idx].cpu().numpy()
+    assert np.max(np.abs(outs[False] - outs[True])) < 1e-14
+    h1 = np.array([[2.0, 3.0], [3.0, 0.0]])
+    w, v = np.linalg.eigh(h1)
+    a1 = (v @ np.diag(np.exp(-1j * w * 0.003)) @ v.conj().T) @ np.array([0.0, 1.0])
+    ref = np.array([np.prod([a1[(i >> (n - 1 - k)) & 1] for k in range(n)]) for i in idx])
+    assert np.max(np.abs(outs[False] - ref)) < 1e-10
