@@ -594,7 +594,8 @@ def main() -> None:
             roof = roofline_valu(2.0**14, 2.0**15, stats["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kms, kl, kname, "cfg3:k_ket")
         else:
             key = "cfg3:k_apply" if args.workload == "cfg3" else (
-                "cfg5_24atoms:k_split" if (args.atoms == 24 and kname == KSPLIT_NAME) else None if args.atoms != 20
+                "cfg5_24atoms:k_split" if (args.atoms == 24 and kname == KSPLIT_NAME) else
+                "cfg5_22atoms:k_split" if (args.atoms == 22 and kname == KSPLIT_NAME) else None if args.atoms != 20
                 else "cfg5:k_split" if kname == KSPLIT_NAME else "cfg5:k_apply")
             roof = roofline_hbm(nb, 1, stats, kms, kl, kname, key)
         out = {"metric": "sim-us/sec", "value": n_gpus * (t1 - t0) / sec, **common, "ms_per_step": sec * 1e3,

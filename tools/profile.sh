@@ -14,6 +14,7 @@ run cfg3_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg3_stats -o cfg3 --out
 run cfg5_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5_stats -o cfg5 --output-format csv -- python bench.py --workload cfg5 --steps 2 --warmup 1 --slice-ns 50
 run cfg5t_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5t_stats -o cfg5t --output-format csv -- python bench.py --workload cfg5 --method taylor --steps 2 --warmup 1 --slice-ns 20
 run cfg5b_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5b_stats -o cfg5b --output-format csv -- python bench.py --workload cfg5 --atoms 24 --steps 2 --warmup 1 --slice-ns 10
+run cfg5c_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5c_stats -o cfg5c --output-format csv -- python bench.py --workload cfg5 --atoms 22 --steps 2 --warmup 1 --slice-ns 10
 run cfg2_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg2_stats -o cfg2 --output-format csv -- python bench.py --workload cfg2 --steps 2 --warmup 1
 run ns_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/ns_fetch -o ns --output-format csv -- $NS --steps 1 --warmup 0
 run ns_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/ns_write -o ns --output-format csv -- $NS --steps 1 --warmup 0
@@ -25,6 +26,10 @@ run cfg5t_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg5t_fetch -o
 run cfg5t_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg5t_write -o cfg5t --output-format csv -- python bench.py --workload cfg5 --method taylor --steps 1 --warmup 0 --slice-ns 4
 run cfg5b_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg5b_fetch -o cfg5b --output-format csv -- python bench.py --workload cfg5 --atoms 24 --steps 1 --warmup 0 --slice-ns 4
 run cfg5b_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg5b_write -o cfg5b --output-format csv -- python bench.py --workload cfg5 --atoms 24 --steps 1 --warmup 0 --slice-ns 4
+run cfg5c_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg5c_fetch -o cfg5c --output-format csv -- python bench.py --workload cfg5 --atoms 22 --steps 1 --warmup 0 --slice-ns 4
+run cfg5c_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg5c_write -o cfg5c --output-format csv -- python bench.py --workload cfg5 --atoms 22 --steps 1 --warmup 0 --slice-ns 4
+run cfg2_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg2_fetch -o cfg2 --output-format csv -- python bench.py --workload cfg2 --steps 1 --warmup 0
+run cfg2_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg2_write -o cfg2 --output-format csv -- python bench.py --workload cfg2 --steps 1 --warmup 0
 find $OUT -type f | head -60
 # keep only small files for the merge back
 find $OUT -type f -size +4M -delete
