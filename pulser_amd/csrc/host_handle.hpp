@@ -80,7 +80,6 @@ struct ryd_handle {
   double split_eps = 0.0;         // tolerance the state was measured for
   int split_since = 0;            // schedule steps since the last check
   double split_since_len = 0.0;   // simulated time (us) covered since the last check
-  double split_t_end = 0.0;       // where the previous call stopped (us)
   // general path (explicit CSR terms)
   bool general = false;
   std::vector<GenTermHost> gen_host;

@@ -178,10 +178,8 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
       A.do_diag = 1;
       A.ccur = h->split_coefs + (size_t)si * stride;
       A.wE = wE[si];
-      if (h->mc) {  // H_eff: the decay diagonal a + b popc(index) over the D time of this stage
-        A.use_decay = 1;
-        for (int ne = 0; ne <= N; ++ne) A.dec[ne] = std::exp(wE[si] * (h->mc_a + h->mc_b * (N - ne)));
-      }
+      A.dec_a = h->mc_a;  // H_eff: the decay diagonal a + b popc(index) over the D time of this stage
+      A.dec_b = h->mc_b;
       if (si < n_stages - 1) {  // a rotation follows (the last stage only closes)
         A.cur_mask = (1u << p.T) - 1u;
         done = bits;
@@ -199,24 +197,30 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
       if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
       const dim3 grid(1u << (N - p.T), B);
       if (p.T == 12 && !(A.fin_mask & 0xFu)) {
-        if (h->drive_real) hipLaunchKernelGGL(k_split12<true>, grid, dim3(SPLIT_NT), lds, st, A);
-        else hipLaunchKernelGGL(k_split12<false>, grid, dim3(SPLIT_NT), lds, st, A);
-      } else if (big) {
-        static bool attr13[64] = {};
-        const int dev = h->cfg.device;
-        if (dev < 0 || dev >= 64 || !attr13[dev]) {
-          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          if (dev >= 0 && dev < 64) attr13[dev] = true;
+        if (h->mc) {
+          if (h->drive_real) hipLaunchKernelGGL((k_split12<true, true>), grid, dim3(SPLIT_NT), lds, st, A);
+          else hipLaunchKernelGGL((k_split12<false, true>), grid, dim3(SPLIT_NT), lds, st, A);
+        } else {
+          if (h->drive_real) hipLaunchKernelGGL((k_split12<true, false>), grid, dim3(SPLIT_NT), lds, st, A);
+          else hipLaunchKernelGGL((k_split12<false, false>), grid, dim3(SPLIT_NT), lds, st, A);
         }
-        hipLaunchKernelGGL((k_split_t<512>), grid, dim3(512), lds, st, A);
       } else {
-        static bool attr12[64] = {};
+        static bool attr[64] = {};
         const int dev = h->cfg.device;
-        if (dev < 0 || dev >= 64 || !attr12[dev]) {
-          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<SPLIT_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          if (dev >= 0 && dev < 64) attr12[dev] = true;
+        if (dev < 0 || dev >= 64 || !attr[dev]) {
+          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<SPLIT_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<SPLIT_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          if (dev >= 0 && dev < 64) attr[dev] = true;
         }
-        hipLaunchKernelGGL((k_split_t<SPLIT_NT>), grid, dim3(SPLIT_NT), lds, st, A);
+        if (big) {
+          if (h->mc) hipLaunchKernelGGL((k_split_t<512, true>), grid, dim3(512), lds, st, A);
+          else hipLaunchKernelGGL((k_split_t<512, false>), grid, dim3(512), lds, st, A);
+        } else {
+          if (h->mc) hipLaunchKernelGGL((k_split_t<SPLIT_NT, true>), grid, dim3(SPLIT_NT), lds, st, A);
+          else hipLaunchKernelGGL((k_split_t<SPLIT_NT, false>), grid, dim3(SPLIT_NT), lds, st, A);
+        }
       }
       HIPCHK(hipGetLastError());
       if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }
@@ -265,8 +269,6 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
   double t_total = 0.0;
   for (const StepDesc& d : sched) t_total += d.h;
-  const double t_start = h->tknots[sched[0].idx] + sched[0].u1 - kC1 * sched[0].h;
-  const double t_stop = t_start + t_total;
   // the budget is per pulse sequence: a solve over a slice gets its share
   t_total = std::max(t_total, h->tknots.back() - h->tknots.front());
   const double eps = o.tol > 0 ? 500.0 * o.tol : kSplitTolTotal;
@@ -281,9 +283,8 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   }
   double tau_t = control ? h->split_tau : 1e300;  // target sub-step (us); 1e300 = whole steps
   int since = h->split_since;                     // schedule steps since the last check
-  // a sub-step measured on another time region (or another state) says nothing here: a call that does
-  // not continue where the previous one stopped starts with a check
-  if (control && h->split_known && std::fabs(t_start - h->split_t_end) > 1e-9) since = kSplitCheckEvery;
+  // (a sub-step measured on another time region or state is caught by the next periodic check, which can
+  // roll back to the checkpoint taken at the start of this call)
   size_t i = 0;
   double off = 0.0;
   const bool jumps = h->mc_active;  // quantum-jump solve: norm check / jump after EVERY schedule step
@@ -406,7 +407,6 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     h->split_tau = tau_t;
     h->split_rate = err_rate;
     h->split_since = since;
-    h->split_t_end = t_stop;
   }
   return RYD_OK;
 }

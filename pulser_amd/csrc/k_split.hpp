@@ -35,9 +35,9 @@ struct SplitArgs {
   unsigned fin_mask, cur_mask;  // tile-local bits to rotate before / after D
   int do_diag;
   // quantum-jump trajectories (H_eff = H - i/2 sum C^dag C, diagonal for every built-in channel): D also
-  // carries the real factor dec[number of excited atoms] = exp(wE (a + b popc(index))), host-computed
-  int use_decay;
-  double dec[SPLIT_NMAX + 1];
+  // carries the real factor exp(wE (dec_a + dec_b popc(index))) (template parameter DECAY of the pass kernels:
+  // the plain passes carry neither the table nor the test)
+  double dec_a, dec_b;
 };
 
 // One closed run of the composition: consecutive sub-steps (knot interval, start offset, length),
@@ -200,7 +200,7 @@ __device__ __forceinline__ void split_sincos(double phi, const cplx* __restrict_
 // controller check).  A 2^14 tile (1024 lanes x 16 amplitudes, real and imaginary parts turned separately
 // through 128 KiB) was built and measured too: at 128 registers per lane it spills (500 us per pass at 24
 // atoms against 2 x 128 us) - 24+ atoms stay on 2^12 tiles.
-template <int NT>
+template <int NT, bool DECAY>
 __global__ __launch_bounds__(NT) void k_split_t(const SplitArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = A.T;
@@ -267,7 +267,9 @@ __global__ __launch_bounds__(NT) void k_split_t(const SplitArgs A) {
     cfs[4 * SPLIT_NMAX + tid] = ccur[tid];
   }
   if (tid >= 128 && tid < 192) trig[tid - 128] = make_double2(kSplitTrig[tid - 128][0], kSplitTrig[tid - 128][1]);
-  if (A.use_decay && tid >= 192 && tid < 192 + SPLIT_NMAX + 1) dlut[tid - 192] = A.dec[tid - 192];
+  if constexpr (DECAY) {  // factor by number of excited atoms ne: popc(index) = N - ne
+    if (tid >= 192 && tid < 192 + SPLIT_NMAX + 1) dlut[tid - 192] = exp(A.wE * (A.dec_a + A.dec_b * (double)(N - ((int)tid - 192))));
+  }
   __syncthreads();
   if (tid < 2 * T) {
     const int set = tid / T, q = tid % T;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(NT) void k_split_t(const SplitArgs A) {
       const double phi = fma(A.wE, ev[r], -(d_outer + dlo[i & 127u] + dhi[i >> 7]));
       double c, s;
       split_sincos(phi, trig, c, s);
-      if (A.use_decay) {
+      if constexpr (DECAY) {
         const double f = dlut[nexc_outer + T - __popc(i)];
         c *= f;
         s *= f;
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(NT) void k_split_t(const SplitArgs A) {
 //   L2: finish bits 8-11 | L1: finish bits 4-7, D, start bits 4-7 | L0: start bits 0-3 | L2: start bits 8-11
 // (the tilings keep >= 4 low bits, so a finishing rotation never touches bits 0-3).  LDS slots and
 // global offsets fold into immediates; REAL: every drive coefficient is real (g = -i S c is imaginary).
-template <bool REAL>
+template <bool REAL, bool DECAY>
 __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = 12;
@@ -432,7 +434,9 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
     cfs[4 * SPLIT_NMAX + tid] = ccur[tid];
   }
   if (tid >= 128 && tid < 192) trig[tid - 128] = make_double2(kSplitTrig[tid - 128][0], kSplitTrig[tid - 128][1]);
-  if (A.use_decay && tid >= 192 && tid < 192 + SPLIT_NMAX + 1) dlut[tid - 192] = A.dec[tid - 192];
+  if constexpr (DECAY) {  // factor by number of excited atoms ne: popc(index) = N - ne
+    if (tid >= 192 && tid < 192 + SPLIT_NMAX + 1) dlut[tid - 192] = exp(A.wE * (A.dec_a + A.dec_b * (double)(N - ((int)tid - 192))));
+  }
   __syncthreads();
   if (tid < 2 * T) {
     const int set = tid / T, q = tid % T;
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
       const double phi = fma(A.wE, ev[r], -(d_outer + dlo[i & 63u] + dhi[i >> 6]));
       double c, s;
       split_sincos(phi, trig, c, s);
-      if (A.use_decay) {
+      if constexpr (DECAY) {
         const double f = dlut[nexc_outer + 12 - __popc(i)];
         c *= f;
         s *= f;

@@ -83,7 +83,7 @@ def test_split_operator_rows_interacting_10_atoms_against_tight_oracle(no_merge)
     for k in range(1, len(times)):
         errs = sketch_errors(snaps[k - 1], extra, k)
         assert max(errs.values()) < AMP_TOL, (no_merge, k, errs)
-    assert abs(np.trace(snaps[-1]).real - 1.0) < 5e-9  # the in-place exponentials are unitary to ~1e-12 each
+    assert abs(np.trace(snaps[-1]).real - 1.0) < 2e-8  # in-place exponentials: unitary to ~1e-12 each, 12 000 of them
 
 
 @pytest.mark.parametrize("fixture,n", [("cfg3_tri8_dephasing.npz", 8), ("cfg3_tri10_dephasing.npz", 10)])
