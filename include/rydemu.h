@@ -274,6 +274,16 @@ int ryd_general_add_local_term(ryd_handle* h, int32_t local_dim, int32_t n_per, 
 int ryd_general_add_diag_term(ryd_handle* h, const double* values, int32_t series, int32_t conj,
                               double scale_re, double scale_im, double row_norm);
 
+/* Replaces: the serial loop of QutipEmulator._noisy_runs (pulser_simulation/simulation.py:903-915) over the
+ * noise trajectories of a MULTI-LEVEL / XY run (bases of pulser/_hamiltonian_data/hamiltonian_data.py:913-931):
+ * every trajectory is its own general handle (bad atoms, detuning offsets and amplitude factors change the term
+ * list), all of them advance through `times` in ONE launch - one workgroup per problem.  Handles: general,
+ * batch 1, at most 4096 entries, same device, tables set; times strictly increasing.  states_dev[b]
+ * complex128[dim_b] in place; outs_dev (or NULL) [b] -> complex128[n_times - 1][dim_b] or NULL. */
+int ryd_general_solve_many(ryd_handle** hs, int32_t n, void* const* states_dev, int32_t n_times,
+                           const double* times, void* const* outs_dev, const ryd_opts* opts,
+                           void* stream);
+
 /* Test/bench hook (bit mask): 1 = disable the persistent small-N kernel, 2 =
  * disable the single-launch plan of small states (partner tiles read through
  * L2; the multi-pass tiling is used instead), 4 = disable the 2^14

@@ -74,6 +74,8 @@ struct ryd_handle {
   bool no_merge = false;          // test hook: CF4 steps never span more than one knot interval
   bool split_no_loop = false;     // test hook: 12-atom kets pass by pass instead of the one-launch loop
   bool split_small_tiles = false; // test / bench hook: keep 2^12 tiles for every register size
+  void* many_args_dev = nullptr;  // ryd_general_solve_many: argument table of the batched launch (first handle)
+  size_t many_cap = 0;
   bool split_known = false;       // controller state below is valid for the current tables
   double split_tau = 1e300;       // target sub-step (us); 1e300 = whole schedule steps
   double split_rate = 0.0;        // last measured local error per us at that sub-step
@@ -411,6 +413,7 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->desc_dev);
   hipFree(h->dterms_dev);
   hipFree(h->sched_dev);
+  hipFree(h->many_args_dev);
   hipFree(h->ksched_dev);
   hipFree(h->kry_V);
   hipFree(h->ftab_dev);

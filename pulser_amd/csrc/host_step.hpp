@@ -377,6 +377,38 @@ static int run_persistent_general(ryd_handle* h, cplx* state, const std::vector<
   return RYD_OK;
 }
 
+// GenTrajArgs of the persistent general kernel for `sched` (uploaded into the handle's schedule buffer)
+static int fill_gen_traj_args(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
+                              hipStream_t st, GenTrajArgs& A) {
+  const size_t bytes = sched.size() * sizeof(StepDesc);
+  if (h->sched_cap < sched.size()) {
+    if (h->sched_dev) hipFree(h->sched_dev);
+    h->sched_dev = nullptr;
+    h->sched_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->sched_dev, bytes * 2));
+    h->sched_cap = sched.size() * 2;
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMemcpyAsync(h->sched_dev, sched.data(), bytes, hipMemcpyHostToDevice, st));
+  A.state = state;
+  A.snaps = snaps;
+  A.pp = h->pp_dev;
+  A.series = h->gen_series_dev;
+  A.conjf = h->gen_conj_dev;
+  A.scale = h->gen_scale_dev;
+  A.terms = h->gen_terms_dev;
+  A.steps = h->sched_dev;
+  A.n_int = h->n_knots - 1;
+  A.n_steps = (int)sched.size();
+  A.n_terms = (int)h->gen_host.size();
+  A.dim = (int)h->dim;
+  A.d = h->gen_d;
+  A.n_dig = h->gen_ndig;
+  A.a1 = kA1;
+  A.a2 = kA2;
+  return RYD_OK;
+}
+
 static bool use_persistent_general(const ryd_handle* h) {
   return h->general && h->B == 1 && h->dim <= 4096 && !h->force_generic && !h->gen_host.empty();
 }
@@ -629,5 +661,69 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
       plan_passes(h);
     }
   }
+  return RYD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// ryd_general_solve_many: n independent small general-path problems, ONE launch
+// ---------------------------------------------------------------------------
+extern "C" int ryd_general_solve_many(ryd_handle** hs, int32_t n, void* const* states_dev, int32_t n_times,
+                                      const double* times, void* const* outs_dev, const ryd_opts* opts,
+                                      void* stream) {
+  if (!hs || n < 1 || !states_dev || !times || n_times < 2) return fail(RYD_ERR_INVALID, "null argument / no problems");
+  for (int i = 1; i < n_times; ++i)
+    if (!(times[i] > times[i - 1])) return fail(RYD_ERR_INVALID, "times must be strictly increasing");
+  ryd_opts o;
+  std::memset(&o, 0, sizeof o);
+  if (opts) o = *opts;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  for (int b = 0; b < n; ++b) {
+    ryd_handle* h = hs[b];
+    if ((rc = check_ready(h))) return rc;
+    if (!h->general || h->B != 1 || h->dim > 4096 || h->gen_host.empty())
+      return fail(RYD_ERR_UNSUPPORTED, "problem %d: ryd_general_solve_many takes general handles of one state "
+                  "with at most 4096 entries", b);
+    if (h->cfg.device != hs[0]->cfg.device) return fail(RYD_ERR_INVALID, "problem %d lives on another device", b);
+    if (!states_dev[b]) return fail(RYD_ERR_INVALID, "problem %d: null state", b);
+  }
+  HIPCHK(hipSetDevice(hs[0]->cfg.device));
+  std::vector<GenTrajArgs> args(n);
+  for (int b = 0; b < n; ++b) {
+    ryd_handle* h = hs[b];
+    if (!h->bounds_valid) compute_bounds_general(h);
+    std::vector<StepDesc> sched;
+    for (int i = 1; i < n_times; ++i) {
+      build_schedule(h, times[i - 1], times[i], o, sched, false, kMergeMax);
+      if (outs_dev && outs_dev[b]) sched.back().snap = i - 1;
+    }
+    std::memset(&args[b], 0, sizeof(GenTrajArgs));
+    if ((rc = fill_gen_traj_args(h, (cplx*)states_dev[b], sched, outs_dev ? (cplx*)outs_dev[b] : nullptr, st, args[b])))
+      return rc;
+    for (const StepDesc& d : sched) {
+      h->stats.n_applications += d.order_a + d.order_b;
+      h->stats.n_steps++;
+    }
+  }
+  ryd_handle* h0 = hs[0];
+  if (h0->many_cap < (size_t)n) {
+    if (h0->many_args_dev) hipFree(h0->many_args_dev);
+    h0->many_args_dev = nullptr;
+    h0->many_cap = 0;
+    HIPCHK(hipMalloc((void**)&h0->many_args_dev, (size_t)n * sizeof(GenTrajArgs)));
+    h0->many_cap = (size_t)n;
+  }
+  HIPCHK(hipStreamSynchronize(st));  // an earlier launch may still read the argument table
+  HIPCHK(hipMemcpyAsync(h0->many_args_dev, args.data(), (size_t)n * sizeof(GenTrajArgs), hipMemcpyHostToDevice, st));
+  const size_t lds = 2 * 4096 * sizeof(cplx) + 2 * MAX_GEN_TERMS * sizeof(cplx);
+  static bool attr_set[64] = {};
+  const int dev = h0->cfg.device;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_gen_traj_many, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(k_gen_traj_many, dim3((unsigned)n), dim3(1024), lds, st, (const GenTrajArgs*)h0->many_args_dev);
+  HIPCHK(hipGetLastError());
+  h0->stats.n_launches++;
   return RYD_OK;
 }

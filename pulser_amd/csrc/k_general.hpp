@@ -162,7 +162,7 @@ struct GenTrajArgs {
   double a1, a2;
 };
 
-__global__ __launch_bounds__(1024) void k_gen_traj(const GenTrajArgs A) {
+__device__ __forceinline__ void gen_traj_body(const GenTrajArgs& A) {
   constexpr int NTT = 1024, R = 4;  // dim <= 4096
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx* ws0 = reinterpret_cast<cplx*>(smem);
@@ -259,4 +259,15 @@ __global__ __launch_bounds__(1024) void k_gen_traj(const GenTrajArgs A) {
     const int row = tid + j * NTT;
     if (row < dim) A.state[row] = psi[j];
   }
+}
+
+__global__ __launch_bounds__(1024) void k_gen_traj(const GenTrajArgs A) { gen_traj_body(A); }
+
+// A batch of INDEPENDENT small general-path problems in one launch: workgroup b runs the whole schedule of
+// problem b from its own tables (the noise trajectories of a multi-level run, hamiltonian_data.py:913-931
+// bases under simulation.py:903-915: bad atoms and detuning offsets change the term list per trajectory, so
+// every trajectory brings its own terms - the systems are <= 4096 entries and their tables a few KB).
+__global__ __launch_bounds__(1024) void k_gen_traj_many(const GenTrajArgs* __restrict__ args) {
+  const GenTrajArgs A = args[blockIdx.x];
+  gen_traj_body(A);
 }

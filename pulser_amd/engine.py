@@ -583,6 +583,28 @@ class GeneralEngine:
                                       out.data_ptr(), C.byref(o), self._stream()))
         return out
 
+    @staticmethod
+    def solve_many(engines: Sequence["GeneralEngine"], states: Sequence[Any], times: Sequence[float],
+                   **opts: Any) -> list[Any]:
+        """Advance ``states[b]`` (in place) of every engine through ``times`` in ONE launch
+        (``ryd_general_solve_many``: one workgroup per problem, vectors of at most 4096 entries) and return
+        the snapshots complex128[len(times) - 1, 1, dim_b] per engine - the noise trajectories of a
+        multi-level run (simulation.py:903-915)."""
+        if not engines:
+            return []
+        e0 = engines[0]
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        outs = [e.torch.empty((len(t) - 1, 1, e.dim), dtype=e.torch.complex128, device=e.device) for e in engines]
+        n = len(engines)
+        hs = (C.c_void_p * n)(*[e._h for e in engines])
+        sp = (C.c_void_p * n)(*[s.data_ptr() for s in states])
+        op = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        o = RydOpts(taylor_order=int(opts.get("taylor_order", 0)), max_order=int(opts.get("max_order", 0)),
+                    tol=float(opts.get("tol", 0.0)), max_step=float(opts.get("max_step", 0.0)),
+                    magnus_tol=float(opts.get("magnus_tol", 0.0)))
+        _lib.check(e0.lib.ryd_general_solve_many(hs, n, sp, len(t), t.ctypes.data, op, C.byref(o), e0._stream()))
+        return outs
+
     def apply_generator(self, x: Any, t: float) -> Any:
         # the C side trusts the pointer: a mis-sized vector would read / write out of bounds
         if (tuple(x.shape) != (1, self.dim) or x.dtype != self.torch.complex128

@@ -874,13 +874,25 @@ class QutipEmulator:
         qids = tuple(self.samples_obj.qubit_ids)
         n = self._hamiltonian_data.n_qudits
         out = []
-        for prob in problems:
-            tables = lower_general(prob, mesolve=(mode == "mesolve"))
-            with GeneralEngine(tables) as eng:
-                state = eng.new_state(np.asarray(self._initial_state).reshape(-1))
-                first = state.cpu().numpy()[0]
-                host = eng.solve(state, times, **self._engine_kwargs(options, general=True)).cpu().numpy()
-                self.last_engine_stats = eng.stats()
+        kw = self._engine_kwargs(options, general=True)
+        solved: list[tuple[np.ndarray, np.ndarray]] = []
+        engines = [GeneralEngine(lower_general(prob, mesolve=(mode == "mesolve"))) for prob in problems]
+        try:
+            states = [eng.new_state(np.asarray(self._initial_state).reshape(-1)) for eng in engines]
+            firsts = [st.cpu().numpy()[0] for st in states]
+            if len(engines) > 1 and all(eng.dim <= 4096 for eng in engines) and np.all(np.diff(times) > 0):
+                # the trajectories of a multi-level / XY run: one launch, one workgroup per trajectory
+                snaps = GeneralEngine.solve_many(engines, states, times, **kw)
+                solved = [(f, s.cpu().numpy()) for f, s in zip(firsts, snaps)]
+                self.last_engine_stats = engines[0].stats()
+            else:
+                for eng, st, f in zip(engines, states, firsts):
+                    solved.append((f, eng.solve(st, times, **kw).cpu().numpy()))
+                    self.last_engine_stats = eng.stats()
+        finally:
+            for eng in engines:
+                eng.close()
+        for prob, (first, host) in zip(problems, solved):
             D = len(prob["eigenbasis"]) ** n
             results = []
             for i, t in enumerate(times):

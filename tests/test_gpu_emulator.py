@@ -349,6 +349,37 @@ def test_reference_golden_counter_test_noise_end_to_end(capsys):
         "Emulating Trajectories [1 - 13]/15", "Emulating Trajectory 14/15",
         "Emulating Trajectory 15/15"]
     assert r.sample_final_state() == Counter(extra["reference_golden_counter"])
+    # the three distinct SPAM trajectories (3-level register, each with its own term list) ran in ONE launch
+    assert emu.last_engine_stats["n_launches"] == 1
+
+
+def test_multi_level_trajectories_in_one_launch_equal_the_one_by_one_solves():
+    """ryd_general_solve_many: the noise trajectories of a multi-level run (one general handle each) through
+    one launch against the same handles solved one after the other."""
+    from test_host_logic import _spam_all_emulator
+
+    from pulser_amd.engine import GeneralEngine
+    from pulser_amd.general import lower_general
+
+    emu, _ = _spam_all_emulator()
+    hd = emu._hamiltonian_data
+    probs = [hd.problem(t, emu._sampling_rate) for t in hd.noise_trajectories]
+    assert len(probs) >= 3
+    times = np.asarray(emu._eval_times_array)
+    psi0 = np.asarray(emu._initial_state).reshape(-1)
+    engines = [GeneralEngine(lower_general(p, mesolve=False)) for p in probs]
+    try:
+        st_a = [e.new_state(psi0) for e in engines]
+        many = [s.cpu().numpy() for s in GeneralEngine.solve_many(engines, st_a, times)]
+        assert engines[0].stats()["n_launches"] == 1 and all(e.stats()["n_launches"] == 0 for e in engines[1:])
+        for e, got, sa in zip(engines, many, st_a):
+            sb = e.new_state(psi0)
+            one = e.solve(sb, times).cpu().numpy()
+            assert np.array_equal(got, one)  # same kernel body, same schedule: bit-identical
+            assert np.array_equal(sa.cpu().numpy(), sb.cpu().numpy())
+    finally:
+        for e in engines:
+            e.close()
 
 
 def test_reference_results_noisy_goldens_end_to_end():
