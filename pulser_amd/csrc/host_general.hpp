@@ -54,6 +54,7 @@ static int gen_publish_terms(ryd_handle* h) {
   HIPCHK(hipMemcpy(h->gen_conj_dev, cj.data(), n * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->gen_scale_dev, sc.data(), n * sizeof(cplx), hipMemcpyHostToDevice));
   h->bounds_valid = false;
+  h->gen_sites_valid = false;
   return RYD_OK;
 }
 
@@ -168,6 +169,13 @@ extern "C" int ryd_general_add_local_term(ryd_handle* h, int32_t local_dim, int3
   HIPCHK(hipMemcpy((void*)t.dev.val, sval.data(), (size_t)nnz * sizeof(cplx), hipMemcpyHostToDevice));
   h->gen_d = local_dim;
   h->gen_ndig = n_dig;
+  t.h_strides.assign(strides, strides + (size_t)n_groups * n_per);
+  t.h_weights.assign(weights, weights + n_groups);
+  t.h_rows.assign(rows, rows + nnz);
+  t.h_cols.assign(cols, cols + nnz);
+  t.h_shifts = shifts;
+  t.h_vals.resize(nnz);
+  for (int e = 0; e < nnz; ++e) t.h_vals[e] = std::complex<double>(vals[2 * e], vals[2 * e + 1]);
   h->gen_host.push_back(t);
   return gen_publish_terms(h);
 }
@@ -216,10 +224,129 @@ static void compute_bounds_general(ryd_handle* h) {
   h->bounds_valid = true;
 }
 
+// Site table of a matrix-free handle (every term local or diagonal): which terms / groups act on which
+// site, the union of their sparsity patterns per site and, per pattern entry, the list of (term, weight x
+// entry) contributions that k_gen_sitevals adds up per exponential.
+static int gen_build_sites(ryd_handle* h) {
+  h->gen_sites_valid = true;
+  h->gen_sites_ok = false;
+  if (h->gen_no_sites || h->gen_d == 0) return RYD_OK;
+  for (const GenTermHost& t : h->gen_host)
+    if (t.dev.kind == 0) return RYD_OK;  // explicit CSR terms: the term-by-term kernel
+  struct SiteBuild {
+    GenSite g;
+    std::map<std::pair<int, int>, std::vector<std::pair<int, std::complex<double>>>> ent;  // (R, C) -> contributions
+  };
+  std::vector<SiteBuild> sb;
+  std::map<std::tuple<int, long long, long long>, int> index;
+  std::vector<int> diag_terms;
+  for (int ti = 0; ti < (int)h->gen_host.size(); ++ti) {
+    const GenTermHost& t = h->gen_host[ti];
+    if (t.dev.kind == 2) { diag_terms.push_back(ti); continue; }
+    const int np = t.dev.n_per, ld = np == 2 ? t.dev.d * t.dev.d : t.dev.d;
+    for (int g = 0; g < t.dev.n_groups; ++g) {
+      const long long s0 = t.h_strides[(size_t)g * np], s1 = np == 2 ? t.h_strides[(size_t)g * np + 1] : 0;
+      auto key = std::make_tuple(np, s0, s1);
+      auto it = index.find(key);
+      if (it == index.end()) {
+        SiteBuild b;
+        b.g.s0 = s0; b.g.s1 = s1;
+        b.g.shift0 = t.h_shifts[(size_t)g * np];
+        b.g.shift1 = np == 2 ? t.h_shifts[(size_t)g * np + 1] : 0;
+        b.g.n_per = np; b.g.ld = ld; b.g.rs_off = 0;
+        it = index.emplace(key, (int)sb.size()).first;
+        sb.push_back(std::move(b));
+      }
+      SiteBuild& b = sb[it->second];
+      for (size_t e = 0; e < t.h_vals.size(); ++e)
+        b.ent[{t.h_rows[e], t.h_cols[e]}].push_back({ti, t.h_weights[g] * t.h_vals[e]});
+    }
+  }
+  std::vector<GenSite> sites;
+  std::vector<int> prs, pcol, cstart(1, 0), cterm;
+  std::vector<cplx> cval;
+  for (SiteBuild& b : sb) {
+    b.g.rs_off = (int)prs.size();
+    int R = 0;
+    prs.push_back((int)pcol.size());
+    for (auto& kv : b.ent) {  // sorted by (R, C)
+      while (R < kv.first.first) { prs.push_back((int)pcol.size()); ++R; }
+      pcol.push_back(kv.first.second);
+      for (auto& c : kv.second) {
+        cterm.push_back(c.first);
+        cval.push_back(make_double2(c.second.real(), c.second.imag()));
+      }
+      cstart.push_back((int)cterm.size());
+    }
+    while (R < b.g.ld) { prs.push_back((int)pcol.size()); ++R; }
+    sites.push_back(b.g);
+  }
+  const int P = (int)pcol.size();
+  if (P == 0 || P > GEN_SITES_LDS_MAX || sites.size() > 512) return RYD_OK;  // (huge pattern: keep the generic kernel)
+  // one device pool: 16-byte objects first
+  const size_t b_cval = cval.size() * sizeof(cplx), b_mv = (size_t)P * sizeof(cplx), b_sites = sites.size() * sizeof(GenSite),
+               b_prs = prs.size() * sizeof(int), b_pcol = (size_t)P * sizeof(int), b_cs = cstart.size() * sizeof(int),
+               b_ct = cterm.size() * sizeof(int);
+  auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t total = up16(b_cval) + up16(b_mv) + up16(b_sites) + up16(b_prs) + up16(b_pcol) + up16(b_cs) + up16(b_ct);
+  if (h->gen_sites_pool) hipFree(h->gen_sites_pool);
+  h->gen_sites_pool = nullptr;
+  HIPCHK(hipMalloc(&h->gen_sites_pool, total));
+  char* p = (char*)h->gen_sites_pool;
+  auto put = [&](const void* src, size_t bytes) -> void* {
+    void* dst = p;
+    if (src && bytes) hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    p += up16(bytes);
+    return dst;
+  };
+  GenSitesDev& S = h->gen_sites;
+  S.contrib_val = (const cplx*)put(cval.data(), b_cval);
+  S.mvals = (cplx*)put(nullptr, b_mv);
+  S.sites = (const GenSite*)put(sites.data(), b_sites);
+  S.pat_rstart = (const int*)put(prs.data(), b_prs);
+  S.pat_col = (const int*)put(pcol.data(), b_pcol);
+  S.contrib_start = (const int*)put(cstart.data(), b_cs);
+  S.contrib_term = (const int*)put(cterm.data(), b_ct);
+  S.n_sites = (int)sites.size();
+  S.P = P;
+  S.n_rs = (int)prs.size();
+  if (h->gen_diag_terms_dev) hipFree(h->gen_diag_terms_dev);
+  h->gen_diag_terms_dev = nullptr;
+  h->gen_n_diag = (int)diag_terms.size();
+  HIPCHK(hipMalloc((void**)&h->gen_diag_terms_dev, std::max<size_t>(diag_terms.size(), 1) * sizeof(int)));
+  if (!diag_terms.empty())
+    HIPCHK(hipMemcpy(h->gen_diag_terms_dev, diag_terms.data(), diag_terms.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->gen_sites_ok = true;
+  return RYD_OK;
+}
+
 static int apply_general(ryd_handle* h, const MixPoint& m, const cplx* in, const cplx* base,
                          cplx* out, double scale, hipStream_t st) {
   const int n = (int)h->gen_host.size();
   if (n == 0) return fail(RYD_ERR_STATE, "no terms: call ryd_general_add_term first");
+  if (h->gen_sites_ok) {
+    GenSiteArgs A;
+    A.in = in;
+    A.base = base;
+    A.out = out;
+    A.tcoef = h->gen_tcoef;
+    A.terms = h->gen_terms_dev;
+    A.diag_terms = h->gen_diag_terms_dev;
+    A.S = h->gen_sites;
+    A.dim = (long long)h->dim;
+    A.n_diag = h->gen_n_diag;
+    A.d = h->gen_d;
+    A.n_dig = h->gen_ndig;
+    A.scale = scale;
+    const size_t lds = (size_t)A.S.P * (sizeof(cplx) + sizeof(int)) + (size_t)((A.S.n_rs + 3) & ~3) * sizeof(int) +
+                       (size_t)A.S.n_sites * sizeof(GenSite) + 16;
+    dim3 grid((unsigned)((h->dim + 255) / 256), h->B);
+    hipLaunchKernelGGL(k_gen_apply_sites, grid, dim3(256), lds, st, A);
+    HIPCHK(hipGetLastError());
+    h->stats.n_launches++;
+    h->stats.n_applications++;
+    return RYD_OK;
+  }
   GenArgs A;
   A.in = in;
   A.base = base;
@@ -246,5 +373,13 @@ static int launch_eval_general(ryd_handle* h, const MixPoint& m, hipStream_t st)
                      h->gen_series_dev, h->gen_conj_dev, h->gen_scale_dev, n, m.idx1, m.u1, m.w1,
                      m.u2, m.w2, h->gen_tcoef);
   HIPCHK(hipGetLastError());
+  if (!h->gen_sites_valid) {
+    int rc = gen_build_sites(h);
+    if (rc) return rc;
+  }
+  if (h->gen_sites_ok) {  // the site matrices of this exponential
+    hipLaunchKernelGGL(k_gen_sitevals, dim3((h->gen_sites.P + 127) / 128), dim3(128), 0, st, h->gen_sites, h->gen_tcoef);
+    HIPCHK(hipGetLastError());
+  }
   return RYD_OK;
 }

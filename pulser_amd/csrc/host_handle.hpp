@@ -18,6 +18,11 @@ struct GenTermHost {
   int series = -1, conj = 0;
   std::complex<double> scale{1.0, 0.0};
   double row_norm = 0.0;
+  // host copy of a matrix-free local term (the site-fused application is assembled from these)
+  std::vector<long long> h_strides;
+  std::vector<double> h_weights;
+  std::vector<int> h_rows, h_cols, h_shifts;
+  std::vector<std::complex<double>> h_vals;
 };
 
 struct ryd_handle {
@@ -87,6 +92,13 @@ struct ryd_handle {
   std::vector<GenTermHost> gen_host;
   int gen_d = 0, gen_ndig = 0;  // local dimension / digits of the vector index (matrix-free terms)
   cplx* gen_tcoef = nullptr;
+  // site-fused application of matrix-free handles (k_gen_apply_sites)
+  bool gen_sites_valid = false, gen_sites_ok = false;
+  GenSitesDev gen_sites{};
+  void* gen_sites_pool = nullptr;
+  int* gen_diag_terms_dev = nullptr;
+  int gen_n_diag = 0;
+  bool gen_no_sites = false;  // test hook: keep the term-by-term kernel
   GenTermDev* gen_terms_dev = nullptr;
   int* gen_series_dev = nullptr;
   int* gen_conj_dev = nullptr;
@@ -419,6 +431,8 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->ftab_dev);
   hipFree(h->kry_pool);
   hipFree(h->gen_tcoef);
+  hipFree(h->gen_sites_pool);
+  hipFree(h->gen_diag_terms_dev);
   hipFree(h->gen_terms_dev);
   hipFree(h->gen_series_dev);
   hipFree(h->gen_conj_dev);

@@ -650,6 +650,10 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
     h->split_no_loop = (force_generic & 512) != 0;
     h->no_merge = (force_generic & 1024) != 0;
     {
+      const bool ns = (force_generic & 4096) != 0;  // general path: term-by-term kernel instead of the site-fused one
+      if (ns != h->gen_no_sites) { h->gen_no_sites = ns; h->gen_sites_valid = false; }
+    }
+    {
       const bool small = (force_generic & 2048) != 0;
       if (small != h->split_small_tiles) { h->split_small_tiles = small; h->split_tilings.clear(); }
     }

@@ -84,6 +84,107 @@ __device__ __forceinline__ cplx gen_term_row(const GenTermDev& T, const cplx* __
   return s;
 }
 
+// ---------------------------------------------------------------------------
+// Site-fused application (round 3): every matrix-free term is a sum over SITES (one digit, or a digit pair
+// such as (row_k, col_k) of a Liouvillian or the two atoms of an exchange term) of a small matrix, so all terms
+// that act on a site are added up ONCE per exponential into one matrix per site,
+//     M_s = sum_{t, g on s} coef_t(t) w_g M_t      (k_gen_sitevals, a few hundred entries),
+// and a row then costs  sum_s nnz(M_s row)  independent gathers instead of a loop over terms x groups with
+// a descriptor load each (3-level register of 9 atoms, 19 683 amplitudes: 38 -> ~9 us per application).
+// ---------------------------------------------------------------------------
+struct GenSite {
+  long long s0, s1;    // strides of the digit(s)
+  int shift0, shift1;  // bit positions in the packed digits of a row
+  int n_per, ld;       // digits, local dimension (d or d^2)
+  int rs_off;          // this site's row starts: pat_rstart[rs_off .. rs_off + ld]
+};
+
+struct GenSitesDev {
+  const GenSite* sites;
+  const int* pat_rstart;      // per site: ld + 1 entries (offsets into pat_col / mvals)
+  const int* pat_col;         // [P] local column of every pattern entry
+  const int* contrib_start;   // [P + 1]
+  const int* contrib_term;    // [K]
+  const cplx* contrib_val;    // [K] weight x matrix entry
+  cplx* mvals;                // [P] site-matrix entries of the current exponential
+  int n_sites, P, n_rs;
+};
+
+__global__ void k_gen_sitevals(const GenSitesDev S, const cplx* __restrict__ tcoef) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= S.P) return;
+  cplx m = make_double2(0.0, 0.0);
+  for (int k = S.contrib_start[p]; k < S.contrib_start[p + 1]; ++k) m = cfma(tcoef[S.contrib_term[k]], S.contrib_val[k], m);
+  S.mvals[p] = m;
+}
+
+#define GEN_SITES_LDS_MAX 1536  /* pattern entries staged in LDS (24 KiB of values) */
+struct GenSiteArgs {
+  const cplx* in;
+  const cplx* base;
+  cplx* out;
+  const cplx* tcoef;
+  const GenTermDev* terms;   // only the diagonal (kind 2) terms are read here
+  const int* diag_terms;     // [n_diag] indices into terms / tcoef
+  GenSitesDev S;
+  long long dim;
+  int n_diag, d, n_dig;
+  double scale;
+};
+
+__global__ __launch_bounds__(256) void k_gen_apply_sites(const GenSiteArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx* mv = reinterpret_cast<cplx*>(smem);                                   // [P]
+  int* pcol = reinterpret_cast<int*>(mv + A.S.P);                             // [P]
+  int* prs = pcol + A.S.P;                                                    // [n_rs]
+  GenSite* sites = reinterpret_cast<GenSite*>(prs + ((A.S.n_rs + 3) & ~3));   // [n_sites]
+  for (int i = threadIdx.x; i < A.S.P; i += blockDim.x) { mv[i] = A.S.mvals[i]; pcol[i] = A.S.pat_col[i]; }
+  for (int i = threadIdx.x; i < A.S.n_rs; i += blockDim.x) prs[i] = A.S.pat_rstart[i];
+  for (int i = threadIdx.x; i < A.S.n_sites; i += blockDim.x) sites[i] = A.S.sites[i];
+  __syncthreads();
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= A.dim) return;
+  const size_t boff = (size_t)blockIdx.y * A.dim;
+  const cplx* __restrict__ x = A.in + boff;
+  const unsigned long long digits = gen_pack_digits(row, A.d, A.n_dig);
+  const unsigned mask = A.d <= 4 ? 3u : 15u;
+  const cplx xr = x[row];
+  cplx dsum = make_double2(0.0, 0.0);
+  for (int k = 0; k < A.n_diag; ++k) {
+    const int t = A.diag_terms[k];
+    dsum = cfma(A.tcoef[t], A.terms[t].val[row], dsum);
+  }
+  cplx acc = cmul(dsum, xr);
+  for (int s = 0; s < A.S.n_sites; ++s) {
+    const GenSite si = sites[s];
+    const int a = (int)((digits >> si.shift0) & mask);
+    int b = 0, R = a;
+    if (si.n_per == 2) {
+      b = (int)((digits >> si.shift1) & mask);
+      R = a * A.d + b;
+    }
+    const int lo = prs[si.rs_off + R], hi = prs[si.rs_off + R + 1];
+    for (int e = lo; e < hi; ++e) {
+      const int Cc = pcol[e];
+      long long j;
+      if (si.n_per == 2) {
+        const int c0 = Cc / A.d;
+        j = row + (long long)(c0 - a) * si.s0 + (long long)(Cc - c0 * A.d - b) * si.s1;
+      } else {
+        j = row + (long long)(Cc - a) * si.s0;
+      }
+      acc = cfma(mv[e], x[j], acc);
+    }
+  }
+  cplx r = make_double2(A.scale * acc.x, A.scale * acc.y);
+  if (A.base) {
+    const cplx bb = A.base[boff + row];
+    r.x += bb.x;
+    r.y += bb.y;
+  }
+  A.out[boff + row] = r;
+}
+
 #define MAX_GEN_TERMS 96
 
 struct GenArgs {

@@ -37,7 +37,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <tuple>
 #include <thread>
 #include <unordered_map>
 #include <vector>

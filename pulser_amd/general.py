@@ -7,12 +7,13 @@ mode incl. the SLM-mask switching terms, and arbitrary ``eff_noise`` collapse
 operators - is lowered here and integrated on the GPU by the same CF4/Taylor
 stepper through the ``ryd_general_*`` entry points.
 
-``matrix_free=True`` (the default from 2^18 amplitudes on): every operator of the reference's lists is a sum
+``matrix_free=True`` (the default above 4096 amplitudes, i.e. beyond the one-launch kernel): every operator of the reference's lists is a sum
 of one- and two-site operators or a diagonal, and is handed over AS THAT - a
 d x d or d^2 x d^2 matrix with the digit strides and weights of the sites it acts
 on (``ryd_general_add_local_term``), or a dense diagonal
 (``ryd_general_add_diag_term``); the kernel decodes the digits of a row and
-gathers.  Nothing of size d^N x nnz is built on the host or stored on the device.
+gathers - site by site since round 3: all terms acting on a site are added into one small matrix per
+exponential (``k_gen_apply_sites``).  Nothing of size d^N x nnz is built on the host or stored on the device.
 ``matrix_free=False`` (the default below that): the same generator as explicit CSR
 matrices - faster for the small systems of the reference's tests, and the cross-check.
 
@@ -96,14 +97,15 @@ def _embed(n: int, d: int, factors: Mapping[int, np.ndarray]) -> sp.csr_matrix:
     return out
 
 
-MATRIX_FREE_FROM = 1 << 18  # evolved-vector length from which the matrix-free terms are the default
+MATRIX_FREE_FROM = 4097  # evolved-vector length from which the matrix-free terms are the default
 
 
 def lower_general(problem: Mapping[str, Any], mesolve: bool, matrix_free: bool | None = None) -> GeneralTables:
-    """``matrix_free=None``: explicit CSR terms for small systems (every case of the reference's tests is
-    <= 4096 entries, where precomputed indices beat the digit decode: measured 16 vs 34 ms at 19 683
-    amplitudes), matrix-free terms from 2^18 entries on, where building and storing the operators
-    (``scipy.sparse.kron``: 40x the lowering time already at 3^9) is what limits the size."""
+    """``matrix_free=None``: explicit CSR terms for the systems the one-launch kernel holds (<= 4096 entries:
+    every case of the reference's tests; precomputed indices beat the digit decode there), matrix-free terms
+    above: the site-fused application measures 11 ms against 16 ms (CSR) and 34 ms (term by term, round 2)
+    on a 40-ns solve at 19 683 amplitudes, and nothing of the operators' size is built or stored
+    (``scipy.sparse.kron``: 40x the lowering time already at 3^9)."""
     if matrix_free is None:
         d, n = len(problem["eigenbasis"]), int(problem["n_qudits"])
         # RYD_GENERAL_MATRIX_FREE=1: every general-path solve on the matrix-free terms (how the end-to-end

@@ -100,3 +100,21 @@ def test_matrix_free_three_level_register_of_nine_atoms():
     assert np.max(np.abs(outs[0][0] - init)) > 1e-2
     print(f"3-level 9 atoms: lowering {secs[0][0]:.2f} s (matrix-free) vs {secs[1][0]:.2f} s (CSR); "
           f"solve {secs[0][1] * 1e3:.0f} ms vs {secs[1][1] * 1e3:.0f} ms")
+    # the site-fused application (all terms of a site added into one small matrix per exponential) against the
+    # term-by-term kernel: same generator, several times faster (round 2: 34 ms for this solve)
+    tables = lower_general(prob, mesolve=False, matrix_free=True)
+    res = {}
+    xh = rng.normal(size=(1, tables.dim)) + 1j * rng.normal(size=(1, tables.dim))
+    for no_sites in (False, True):
+        with GeneralEngine(tables) as eng:
+            eng.set_path(False, no_sites=no_sites)
+            g = eng.apply_generator(eng.torch.from_numpy(xh).to(eng.device), 0.0123).cpu().numpy()
+            eng.solve(eng.new_state(init), [0.0, 0.002])
+            eng.torch.cuda.synchronize()
+            t0 = time.time()
+            out = eng.solve(eng.new_state(init), [0.0, (T - 1) * 1e-3]).cpu().numpy()[-1]
+            res[no_sites] = (g, out, time.time() - t0)
+    assert np.max(np.abs(res[False][0] - res[True][0])) < 1e-12 * np.max(np.abs(res[True][0]))
+    assert np.max(np.abs(res[False][1] - res[True][1])) < 1e-12
+    print(f"3-level 9 atoms: site-fused {res[False][2] * 1e3:.1f} ms vs term-by-term {res[True][2] * 1e3:.1f} ms")
+    assert res[False][2] < 0.6 * res[True][2]
