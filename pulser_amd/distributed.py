@@ -96,6 +96,21 @@ def check_same_problem(dist: Any, emulator: Any) -> None:
             "(pulser_amd.distributed.enable_sharding(False)) when the ranks run different jobs.")
 
 
+def cumulative_weights(states: np.ndarray, is_ket: bool, meas_basis: str, matching: bool) -> np.ndarray:
+    """``np.cumsum(QutipResult._weights())`` of TWO-LEVEL states for a whole array [..., 2^N] of kets (or of
+    density-matrix diagonals) at once.  Bit-identical to the per-state path: ``np.abs(psi) ** 2`` /
+    ``np.abs(diag)`` are elementwise, the reversal is a view, and ``cumsum`` along the last axis is the same
+    sequential left-to-right sum as the 1-D call (qutip_result.py:101-118, 158; multinomial.py:32-36)."""
+    probs = np.abs(states) ** 2 if is_ket else np.abs(states)
+    if matching:
+        weights = probs[..., ::-1] if meas_basis == "ground-rydberg" else probs
+    else:  # qutip_result.py:119-122
+        weights = np.zeros(probs.shape)
+        weights[..., 0] = 1.0
+    w = weights / np.cumsum(weights, axis=-1)[..., -1:]
+    return np.cumsum(w, axis=-1)
+
+
 class _DiagonalState:
     """What the sampling chain needs of a density matrix (qutip_result.py:101-118): its diagonal."""
 
@@ -165,9 +180,10 @@ def flips_with(indices: np.ndarray, n_qudits: int, rnd_matrix: np.ndarray | None
     repeats each group; the random matrix rows are consumed in that order."""
     if rnd_matrix is None or (eps == 0.0 and eps_p == 0):
         return indices
-    counter = Counter(int(i) for i in indices)  # insertion order = first occurrence
-    shots = np.array(list(counter.keys()), dtype=np.int64)
-    counts = np.array(list(counter.values()), dtype=np.int64)
+    # the reference's Counter: distinct outcomes in order of first occurrence, with their multiplicities
+    uniq, first, cnt = np.unique(np.asarray(indices, dtype=np.int64), return_index=True, return_counts=True)
+    order = np.argsort(first, kind="stable")
+    shots, counts = uniq[order], cnt[order]
     bits = (shots[:, None] >> (n_qudits - 1 - np.arange(n_qudits))[None, :]) & 1
     flip_probs = np.where(bits == 1, eps_p, eps)
     flips = rnd_matrix < np.repeat(flip_probs, counts, axis=0)
@@ -308,6 +324,8 @@ def run_ensemble(
         hist[ti] += np.bincount(ind, minlength=2**n)
         return w
 
+    pool = None
+    pending: list[Any] = []
     for start in range(lo, hi, batch):
         block = list(range(start, min(hi, start + batch)))
         if mc_seeds is not None:  # a trajectory's jumps depend on its seed only, not on the sharding
@@ -353,9 +371,25 @@ def run_ensemble(
                     host = _t.cat([_t.diagonal(first_dev, dim1=-2, dim2=-1)[None],
                                    _t.diagonal(snaps_dev, dim1=-2, dim2=-1)]).cpu().numpy()
                 del first_dev, snaps_dev
-                for j, i in enumerate(block):
-                    for ti in range(n_eval):
-                        sample(i, ti, QState(host[ti, j]) if is_ket else _DiagonalState(host[ti, j]))
+                # the reference's weights and cumulative sums (qutip_result.py:101-158, multinomial.py:32-36) for
+                # the whole block at once: the same elementwise operations and the same sequential row sums
+                # ... on a worker thread, so that the replay of this block overlaps the solve of the next one
+                # (the GPU work is asynchronous C calls; the histogram is only read after the last block)
+                def replay(host: np.ndarray = host, block: list[int] = block, is_ket: bool = is_ket) -> None:
+                    cum = cumulative_weights(host, is_ket, emulator._meas_basis, matching)
+                    for j, i in enumerate(block):
+                        for ti in range(n_eval):
+                            k = i * n_eval + ti
+                            ind = np.searchsorted(cum[ti, j], rnd_all[offs[k]:offs[k + 1]])
+                            ind = flips_with(ind, n, mat_all[offs[k]:offs[k + 1]] if meas_err else None,
+                                             nm.p_false_pos, nm.p_false_neg)
+                            hist[ti] += np.bincount(ind, minlength=2**n)
+
+                if pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+
+                    pool = ThreadPoolExecutor(max_workers=1)  # one worker: the replays run in block order
+                pending.append(pool.submit(replay))
                 continue
             states = solve_fn([hd.problem(trajs[i], emulator._sampling_rate) for i in block])
         finally:
@@ -375,6 +409,10 @@ def run_ensemble(
                     if rho_sum is None:
                         rho_sum = np.zeros((n_eval,) + r1.shape, dtype=np.complex128)
                     rho_sum[ti] += reps[i] * r1
+    for fut in pending:
+        fut.result()  # (re-raises what a replay raised)
+    if pool is not None:
+        pool.shutdown()
     # -- the one collective per accumulator: sum over ranks -----------------
     on_device = fast and density_matrix
     if density_matrix and not on_device and rho_sum is None:  # an empty shard still takes part in the all-reduce

@@ -213,3 +213,27 @@ def test_sharding_is_an_opt_in_and_refuses_ranks_that_run_different_jobs():
         assert p.exitcode == 0
     for _, msg in got:
         assert msg.startswith("Sharded run refused: ranks [1]"), msg
+
+
+def test_batched_cumulative_weights_are_bit_identical_to_the_per_state_path():
+    """The block-wise weights / cumulative sums of the sharded fast path against ``StateResult._weights`` +
+    ``np.cumsum`` state by state: the sampled indices must not depend on the batching."""
+    from pulser_amd.distributed import cumulative_weights
+    from pulser_amd.results import QState, StateResult
+
+    rng = np.random.default_rng(0)
+    n, D = 6, 64
+    kets = rng.normal(size=(3, 5, D)) + 1j * rng.normal(size=(3, 5, D))
+    kets /= np.linalg.norm(kets, axis=-1, keepdims=True) * (1 + 1e-7 * rng.normal(size=(3, 5, 1)))  # norms 1 +- 1e-7
+    kets[0, :, :] = 0.0
+    kets[0, :, -1] = 1.0  # the all-ground initial state
+    diags = np.abs(rng.normal(size=(2, 4, D))) + 0j
+    qids = tuple(f"q{i}" for i in range(n))
+    for basis, matching in (("ground-rydberg", True), ("digital", True), ("ground-rydberg", False)):
+        for arr, is_ket in ((kets, True), (diags, False)):
+            cum = cumulative_weights(arr, is_ket, basis, matching)
+            for a in range(arr.shape[0]):
+                for b in range(arr.shape[1]):
+                    st = QState(arr[a, b]) if is_ket else QState(np.diag(arr[a, b]))
+                    ref = np.cumsum(StateResult(qids, basis, st, matching)._weights())
+                    assert np.array_equal(cum[a, b], ref), (basis, matching, is_ket, a, b)
