@@ -325,6 +325,8 @@ def run_ensemble(
         return w
 
     pool = None
+    lower_pool = None
+    lowered: dict[int, Any] = {}
     pending: list[Any] = []
     for start in range(lo, hi, batch):
         block = list(range(start, min(hi, start + batch)))
@@ -341,7 +343,18 @@ def run_ensemble(
 
                 from .engine import accumulate, outer_accumulate
 
-                tables = hd.device_tables([trajs[i] for i in block], emulator._sampling_rate)
+                # the factored lowering of the NEXT block runs on a worker thread while this block is solved
+                if lower_pool is None:
+                    from concurrent.futures import ThreadPoolExecutor as _TPE
+
+                    lower_pool = _TPE(max_workers=1)
+                if start not in lowered:
+                    lowered[start] = lower_pool.submit(hd.device_tables, [trajs[i] for i in block], emulator._sampling_rate)
+                nxt = start + batch
+                if nxt < hi and nxt not in lowered:
+                    lowered[nxt] = lower_pool.submit(
+                        hd.device_tables, [trajs[i] for i in range(nxt, min(hi, nxt + batch))], emulator._sampling_rate)
+                tables = lowered.pop(start).result()
                 first_dev, snaps_dev, occ = emulator._solve_batch([], False, options, tables=tables, raw=True)
                 is_ket = first_dev.dim() == 2
                 rb = reps[block].astype(np.float64)
@@ -413,6 +426,8 @@ def run_ensemble(
         fut.result()  # (re-raises what a replay raised)
     if pool is not None:
         pool.shutdown()
+    if lower_pool is not None:
+        lower_pool.shutdown()
     # -- the one collective per accumulator: sum over ranks -----------------
     on_device = fast and density_matrix
     if density_matrix and not on_device and rho_sum is None:  # an empty shard still takes part in the all-reduce
