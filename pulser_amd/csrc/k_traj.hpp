@@ -47,6 +47,21 @@ struct TrajArgs {
 // MC: the generator is G_eff (adds the real decay diagonal); with A.mc_jumps the
 //     norm threshold is tested after every step and collapses are applied in
 //     place (same arithmetic and random stream as the k_mc_* kernels).
+// partner amplitude of lane bit 0 / 1 / 3 over the DPP crossbar (quad permutes, row rotate by 8): the LDS read
+// bandwidth is what binds this kernel at 12 atoms (40 ds_read_b128 per lane and stage x 16 waves = 5 120 LDS
+// clocks against 3 200 vector-issue cycles), so three of the ten LDS-served bits move to the vector pipe
+template <int CTRL>
+__device__ __forceinline__ cplx traj_dpp(cplx v) {
+  const int a = __builtin_amdgcn_mov_dpp(__double2loint(v.x), CTRL, 0xF, 0xF, true);
+  const int b = __builtin_amdgcn_mov_dpp(__double2hiint(v.x), CTRL, 0xF, 0xF, true);
+  const int c = __builtin_amdgcn_mov_dpp(__double2loint(v.y), CTRL, 0xF, 0xF, true);
+  const int d = __builtin_amdgcn_mov_dpp(__double2hiint(v.y), CTRL, 0xF, 0xF, true);
+  return make_double2(__hiloint2double(b, a), __hiloint2double(d, c));
+}
+#ifndef RYD_TRAJ_DPPM
+#define RYD_TRAJ_DPPM 0xB
+#endif
+
 template <int N, int NTT, int MODEL, bool MC>
 __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
   constexpr int D = 1 << N;
@@ -252,8 +267,14 @@ __global__ __launch_bounds__(NTT) void k_traj(const TrajArgs A) {
             __builtin_amdgcn_sched_barrier(0);
             continue;
           }
+          // index bits 0, 1, 3 (lane bits; only the two-buffer layouts, where w[j] is the published iterate)
+          constexpr unsigned DPPM = (!SINGLE && NTT >= 64) ? (unsigned)RYD_TRAJ_DPPM & ((1u << (N < 4 ? N : 4)) - 1u) : 0u;
 #pragma unroll
-          for (int q = 0; q < NLDS; ++q) xv[q] = rd[(l ^ (1 << q)) & (D - 1)];
+          for (int q = 0; q < NLDS; ++q)
+            if (!((DPPM >> q) & 1u)) xv[q] = rd[(l ^ (1 << q)) & (D - 1)];
+          if constexpr (DPPM & 1u) xv[0] = traj_dpp<0xB1>(w[j]);
+          if constexpr ((DPPM & 2u) != 0) xv[1 < NLDS ? 1 : 0] = traj_dpp<0x4E>(w[j]);
+          if constexpr ((DPPM & 8u) != 0) xv[3 < NLDS ? 3 : 0] = traj_dpp<0x128>(w[j]);
           if (MODEL == 0) {
             cplx a = make_double2(eg[j] * w[j].y, -eg[j] * w[j].x);  // -i e x
 #pragma unroll
