@@ -392,3 +392,34 @@ def test_a_drive_through_zero_with_a_turning_phase_is_not_gauged():
             outs[no_ket] = st.cpu().numpy()[0]
     assert np.array_equal(outs[False], outs[True])
     assert abs(np.linalg.norm(outs[False]) - 1.0) < 1e-9
+
+
+def test_emulator_noise_trajectories_with_a_pulse_phase_run_on_the_ket_kernel():
+    """End to end: a 13-atom sequence whose global pulse carries a phase (complex drive coefficients,
+    hamiltonian.py:349-351), amplitude + doppler noise, 16 trajectories: `QutipEmulator` lowers the batch once and
+    the whole batch advances in ONE launch of k_ket<13, KET_GAUGE>; states equal the complex-coefficient kernels."""
+    from pulser_amd import NoiseModel, QutipEmulator
+    from pulser_amd.hamiltonian_data import single_global_channel
+
+    n = 13
+    coords = P.register_coords(P.square_rect(1, n), 8.0)
+    s = {k: np.asarray(v)[:300].copy() for k, v in P.anneal_samples().items()}
+    s["phase"] = np.full(300, 0.7)
+    inputs = single_global_channel(coords, s, P.C6_LEVEL70, extended=False)
+    nm = NoiseModel(temperature=50.0, amp_sigma=0.05)
+    outs = {}
+    for env in ("", "no_ket"):
+        np.random.seed(4)
+        emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=16, evaluation_times="Minimal")
+        hd = emu._hamiltonian_data
+        tables = hd.device_tables(hd.noise_trajectories, emu._sampling_rate)
+        from pulser_amd.engine import Engine
+
+        with Engine(tables, mode="sesolve") as eng:
+            eng.set_path(False, no_ket=bool(env))
+            st = eng.new_state()
+            snaps = eng.solve(st, np.asarray(emu._eval_times_array)).cpu().numpy()
+            outs[env] = (snaps, eng.stats()["n_launches"])
+    assert outs[""][1] == 1 and outs["no_ket"][1] >= 1
+    assert np.max(np.abs(outs[""][0] - outs["no_ket"][0])) < 2e-8
+    assert np.max(np.abs(outs[""][0][-1, 0] - outs[""][0][-1, 5])) > 1e-3  # the trajectories differ (noise)
