@@ -79,6 +79,8 @@ struct ryd_handle {
   bool no_merge = false;          // test hook: CF4 steps never span more than one knot interval
   bool split_no_loop = false;     // test hook: 12-atom kets pass by pass instead of the one-launch loop
   bool split_small_tiles = false; // test / bench hook: keep 2^12 tiles for every register size
+  bool split_s10 = false;         // scheme of the current split-operator solve (host_step.hpp decides per call)
+  bool split_s6_only = false;     // test / bench hook: the 4th-order scheme with one-knot sub-steps (round 2)
   void* many_args_dev = nullptr;  // ryd_general_solve_many: argument table of the batched launch (first handle)
   size_t many_cap = 0;
   bool split_known = false;       // controller state below is valid for the current tables

@@ -100,7 +100,8 @@ static double merge_error(const ryd_handle* h, int idx, int span, double len) {
 }
 
 static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& o,
-                           std::vector<StepDesc>& out, bool in_place_exp = false, int merge_cap = kMergeMax) {
+                           std::vector<StepDesc>& out, bool in_place_exp = false, int merge_cap = kMergeMax,
+                           bool no_estimate = false) {
   const double eps = 1e-12;
   double t = t0;
   const bool merge = merge_cap > 1 && !h->general && !h->mc && !h->no_merge && o.taylor_order <= 0;
@@ -113,15 +114,17 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
     if (merge && idx < h->n_knots - 2 && std::fabs(t - h->tknots[idx]) < eps &&
         std::fabs(tend - h->tknots[idx + 1]) < eps) {
       const double mtol = o.magnus_tol > 0 ? o.magnus_tol : 1e-10;
-      while (span < std::min(merge_cap, kMergeMax) && idx + span < h->n_knots - 2 && h->join_ok[idx + span - 1] &&
-             h->tknots[idx + span + 1] <= t1 + eps) {
+      while (span < (no_estimate ? merge_cap : std::min(merge_cap, kMergeMax)) && idx + span < h->n_knots - 2 &&
+             h->join_ok[idx + span - 1] && h->tknots[idx + span + 1] <= t1 + eps) {
         const double cand = h->tknots[idx + span + 1] - t;
         if (o.max_step > 0 && cand > o.max_step * (1.0 + 1e-9)) break;
-        if (merge_error(h, idx, span + 1, cand) > kMergeRate * budget_scale(h) * (mtol / 1e-10) * cand) break;
-        // the spline's own non-linearity (same estimate as below, over the longer step)
-        const double dtk = h->tknots[idx + 1] - h->tknots[idx];
-        const double fr = cand / dtk;
-        if (1e-5 * cand * span_max(h->bd_curv, idx, span + 1) * fr * fr > mtol) break;
+        if (!no_estimate) {
+          if (merge_error(h, idx, span + 1, cand) > kMergeRate * budget_scale(h) * (mtol / 1e-10) * cand) break;
+          // the spline's own non-linearity (same estimate as below, over the longer step)
+          const double dtk = h->tknots[idx + 1] - h->tknots[idx];
+          const double fr = cand / dtk;
+          if (1e-5 * cand * span_max(h->bd_curv, idx, span + 1) * fr * fr > mtol) break;
+        }
         ++span;
         tend = h->tknots[idx + span];
       }

@@ -2,17 +2,58 @@
 // ---------------------------------------------------------------------------
 // Split-operator ket path (k_split.hpp): tilings, pass pipeline, step-size controller (host)
 // ---------------------------------------------------------------------------
-// Symmetric 4th-order composition with 6 stages (Blanes & Moan, J. Comput. Appl. Math. 142 (2002),
-// scheme S6 of table 2):  D(a1) R(b1) D(a2) R(b2) D(a3) R(b3) D(a4) R(b3) D(a3) R(b2) D(a2) R(b1) D(a1).
-static const double kSplitA[7] = {0.0792036964311957, 0.353172906049774, -0.0420650803577195,
-                                  1.0 - 2.0 * (0.0792036964311957 + 0.353172906049774 - 0.0420650803577195),
-                                  -0.0420650803577195, 0.353172906049774, 0.0792036964311957};
-static const double kSplitB[6] = {0.209515106613362, -0.143851773179818,
-                                  0.5 - (0.209515106613362 - 0.143851773179818),
-                                  0.5 - (0.209515106613362 - 0.143851773179818),
-                                  -0.143851773179818, 0.209515106613362};
-static const int kSplitStages = 6;
+// Symmetric compositions D(a_1) R(b_1) D(a_2) ... R(b_1) D(a_1) of Blanes & Moan, J. Comput. Appl. Math. 142 (2002),
+// tables 2 - 3: S6 (4th order, 6 stages) and S10 (6th order, 10 stages).
+//
+// Which one (round 3).  Sub-steps used to end at every spline knot, so a stage count of 6 per knot interval was the
+// floor whatever the accuracy: on the 20-atom anneal the controller sat at whole knot intervals with an error estimate
+// of a quarter of the budget.  Where the waveforms are ONE polynomial across knots (join_ok: ramps, plateaus - the same
+// criterion as the multi-knot CF4 steps) a sub-step may now span several knot intervals; there the 6th-order scheme
+// wins: NumPy model (tools/ket_split_probe.py, 10-atom triangular register, 1.44 us of the detuning sweep) S6 at
+// 1 / 2 / 3 knots: 1.9e-10 / 3.0e-9 / 1.5e-8;  S10 at 2 / 3 / 4 / 6 knots: 3.6e-12 / 3.2e-11 / 1.8e-10 / 2.0e-9 - i.e.
+// 1.7 - 3.3 stages per ns inside the budget instead of 6.  Where no knot can be removed (noise series, kinks) S10
+// at <= 1 knot would cost 10 stages instead of 6, so the scheme is chosen per handle from the share of removable knots.
+struct SplitScheme {
+  int S, order;
+  double a[SPLIT_MAX_STAGES + 1], b[SPLIT_MAX_STAGES];
+};
+static const SplitScheme kSplitS6 = {
+    6, 4,
+    {0.0792036964311957, 0.353172906049774, -0.0420650803577195,
+     1.0 - 2.0 * (0.0792036964311957 + 0.353172906049774 - 0.0420650803577195), -0.0420650803577195, 0.353172906049774,
+     0.0792036964311957},
+    {0.209515106613362, -0.143851773179818, 0.5 - (0.209515106613362 - 0.143851773179818),
+     0.5 - (0.209515106613362 - 0.143851773179818), -0.143851773179818, 0.209515106613362}};
+static const double kS10a[5] = {0.0502627644003922, 0.413514300428344, 0.0450798897943977, -0.188054853819569,
+                                0.541960678450780};
+static const double kS10b[4] = {0.148816447901042, -0.132385865767784, 0.067307604692185, 0.432666402578175};
+static SplitScheme make_s10() {
+  SplitScheme c;
+  c.S = 10;
+  c.order = 6;
+  double sa = 0.0, sb = 0.0;
+  for (int i = 0; i < 5; ++i) { c.a[i] = kS10a[i]; c.a[10 - i] = kS10a[i]; sa += kS10a[i]; }
+  c.a[5] = 1.0 - 2.0 * sa;
+  for (int i = 0; i < 4; ++i) { c.b[i] = kS10b[i]; c.b[9 - i] = kS10b[i]; sb += kS10b[i]; }
+  c.b[4] = c.b[5] = 0.5 - sb;
+  return c;
+}
+static const SplitScheme kSplitS10 = make_s10();
 static const int kSplitMaxSub = SPLIT_MAX_SUB;
+static const int kSplitMergeMax = 8;  // knot intervals a sub-step of the 6th-order scheme may span
+
+// May this handle use the 6th-order scheme at all?  (At least half of the knots removable, not switched off.)
+static bool split_s10_allowed(const ryd_handle* h) {
+  // quantum-jump solves keep one-knot steps (the jump time is quantised to the step), as do the A/B switches and
+  // the fixed-step mode (one sub-step per knot, no controller to measure a longer one)
+  if (h->split_s6_only || h->split_fixed || h->no_merge || h->mc || h->join_ok.empty()) return false;
+  size_t ok = 0;
+  for (char j : h->join_ok) ok += j ? 1 : 0;
+  return 2 * ok >= h->join_ok.size();
+}
+// The scheme of the current solve (ryd_solve decides per call, from the schedule it has to run: evaluation
+// times at every knot leave nothing to merge, and one-knot sub-steps are cheaper with the 6 stages of S6).
+static const SplitScheme& split_scheme(const ryd_handle* h) { return h->split_s10 ? kSplitS10 : kSplitS6; }
 // Target of the accumulated local-error estimate (sum over the steps of the largest amplitude of the
 // local error) over a whole pulse sequence when ryd_opts.tol is 0 (else 500 tol).  The stated parity bar
 // is 1e-7 on amplitudes.
@@ -94,7 +135,7 @@ static int split_ensure_tables(ryd_handle* h, int n_stages) {
 
 // Largest number of sub-steps whose coefficient tables stay under 32 MiB.
 static int split_max_sub(const ryd_handle* h) {
-  const size_t per_sub = (size_t)kSplitStages * h->B * h->N * 4 * sizeof(double);
+  const size_t per_sub = (size_t)split_scheme(h).S * h->B * h->N * 4 * sizeof(double);
   return (int)std::min<size_t>(kSplitMaxSub, std::max<size_t>(1, ((size_t)32 << 20) / per_sub));
 }
 
@@ -104,11 +145,15 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   int rc;
   split_plan(h);
   const int N = h->N, B = h->B;
-  const int n_stages = kSplitStages * nsub + 1;
+  const SplitScheme& sc = split_scheme(h);
+  const int n_stages = sc.S * nsub + 1;
   if ((rc = split_ensure_tables(h, n_stages))) return rc;
   SplitRun R;
   std::memset(&R, 0, sizeof R);
   R.nsub = nsub;
+  R.S = sc.S;
+  for (int i = 0; i <= sc.S; ++i) R.a[i] = sc.a[i];
+  for (int i = 0; i < sc.S; ++i) R.b[i] = sc.b[i];
   for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[s].idx; R.u0[s] = subs[s].u0; R.tau[s] = subs[s].tau; }
   const int total = B * N;
   hipLaunchKernelGGL(k_split_coefs, dim3((total + 3) / 4, n_stages), dim3(256), 0, st, h->pp_dev,
@@ -118,10 +163,10 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   // weight of E0 in the D of every stage
   std::vector<double> wE(n_stages);
   for (int j = 0; j < n_stages; ++j) {
-    const int s = j / kSplitStages, i = j % kSplitStages;
+    const int s = j / sc.S, i = j % sc.S;
     double w = 0.0;
-    if (j < n_stages - 1) w += kSplitA[i] * subs[s].tau;
-    if (i == 0 && s > 0) w += kSplitA[6] * subs[s - 1].tau;  // carried over from the previous sub-step
+    if (j < n_stages - 1) w += sc.a[i] * subs[s].tau;
+    if (i == 0 && s > 0) w += sc.a[sc.S] * subs[s - 1].tau;  // carried over from the previous sub-step
     wE[j] = w;
   }
 
@@ -280,12 +325,14 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     h->split_tau = 1e300;
     h->split_rate = 0.0;
     h->split_since = 0;
+    h->split_since_len = 0.0;
   }
   double tau_t = control ? h->split_tau : 1e300;  // target sub-step (us); 1e300 = whole steps
   int since = h->split_since;                     // schedule steps since the last check
   // (a sub-step measured on another time region or state is caught by the next periodic check, which can
   // roll back to the checkpoint taken at the start of this call)
   size_t i = 0;
+  size_t last_regime_check = (size_t)-1;
   double off = 0.0;
   const bool jumps = h->mc_active;  // quantum-jump solve: norm check / jump after EVERY schedule step
   bool have_ck = false;
@@ -312,12 +359,31 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     return RYD_OK;
   };
   while (i < sched.size()) {
-    if (control && (!h->split_known || since >= kSplitCheckEvery)) {
+    // A run of multi-knot steps that starts after knots which could not be removed (a waveform kink, the start of
+    // the sequence) is a new regime: the local error measured before it says nothing about 8-knot sub-steps of the
+    // 6th-order scheme here (measured: 1.75e-7 on a 20-atom slice across the kink at 0.5 us with periodic checks
+    // only).  The first multi-knot step of such a run is checked, the periodic checks follow.
+    const bool new_regime = control && off == 0.0 && sched[i].pad > 1 && (i == 0 || sched[i - 1].pad <= 1) &&
+                            i != last_regime_check;
+    if (new_regime) last_regime_check = i;
+    if (control && (!h->split_known || since >= kSplitCheckEvery || new_regime)) {
       // ---- check: one sub-step whole (wA) against two halves (state) ----
       const StepDesc& d = sched[i];
       subs.clear();
       split_substeps(h, d, off, tau_t, subs);
       const SubStep s0 = subs[0];
+      if (!have_ck && !jumps) {
+        // the first check of a call: its own start is the checkpoint (a sub-step never measured here - 8 knots of the
+        // 6th-order scheme, say - may be far over its allowance, and the two halves kept below would carry 2^-p
+        // of it: 3.8e-9 on a 14-atom slice before this)
+        HIPCHK(hipMemcpyAsync(h->wB, state, bytes, hipMemcpyDeviceToDevice, st));
+        ck_i = i;
+        ck_off = off;
+        ck_steps = h->stats.n_steps;
+        ck_est = h->stats.reserved[0];
+        have_ck = true;
+      }
+      const bool ck_here = ck_i == i && ck_off == off;
       HIPCHK(hipMemcpyAsync(h->wA, state, bytes, hipMemcpyDeviceToDevice, st));
       if ((rc = split_run(h, h->wA, &s0, 1, st))) return rc;
       const SubStep halves[2] = {{s0.idx, s0.u0, 0.5 * s0.tau}, {s0.idx, s0.u0 + 0.5 * s0.tau, 0.5 * s0.tau}};
@@ -330,15 +396,25 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       HIPCHK(hipStreamSynchronize(st));
       double e = 0.0;
       for (double v : errs) e = std::max(e, std::sqrt(std::max(v, 0.0)));
-      e *= 16.0 / 15.0;
+      // whole step against two halves: the difference is (1 - 2^-p) of the local error of the whole step
+      const int p_ord = split_scheme(h).order;
+      const double two_p = std::ldexp(1.0, p_ord);
+      e *= two_p / (two_p - 1.0);
       const double allowed = eps * s0.tau / t_total;
-      double fac = std::pow(0.5 * allowed / std::max(e, 1e-300), 0.25);
-      fac = std::min(std::max(fac, 0.2), 4.0);
+      double fac = std::pow(0.5 * allowed / std::max(e, 1e-300), 1.0 / p_ord);
+      fac = std::min(std::max(fac, 0.2), p_ord == 6 ? 2.0 : 4.0);  // (x 2 in tau is x 64 in the 6th-order error)
       const double tau_new = s0.tau * fac;
       h->stats.reserved[1] = e;
       h->stats.reserved[2] = s0.tau;
       if (e > 4.0 * allowed && have_ck && retries < 4 && !jumps) {  // (a roll-back would replay jumps)
         // the stretch since the last checkpoint ran with a sub-step that has become too long
+        if (ck_here && h->split_since_len > 0.0) {
+          // ... and when that stretch belongs to earlier calls (nothing to roll back to but this call's start) it ran
+          // at about this error rate: booked in full, so that ryd_stats.reserved[0] (which callers compare with
+          // their tolerance; the Python engine warns) tells the truth
+          ck_est += std::max(0.0, e / s0.tau - err_rate) * h->split_since_len;
+          h->split_since_len = 0.0;
+        }
         HIPCHK(hipMemcpyAsync(state, h->wB, bytes, hipMemcpyDeviceToDevice, st));
         i = ck_i;
         off = ck_off;
@@ -350,16 +426,14 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
         continue;
       }
       if (e > 4.0 * allowed) {
-        // nothing to roll back to (first check of a call that continues a stretch of earlier calls) or
-        // the retries are used up: the stretch behind us ran at about this error rate - it is booked in
-        // full, so that ryd_stats.reserved[0] (which callers compare with their tolerance; the Python
-        // engine warns) tells the truth
+        // the retries are used up (or a quantum-jump solve, which cannot roll back): the stretch behind us ran
+        // at about this error rate - booked in full
         h->stats.reserved[0] += std::max(0.0, e / s0.tau - err_rate) * h->split_since_len;
       }
       retries = 0;
       if (fac < 0.9 || fac > 1.6) tau_t = tau_new;
       if (tau_t > 0.99 * d.h && fac >= 1.0) tau_t = 1e300;
-      h->stats.reserved[0] += e / 16.0;  // the two halves are what was kept
+      h->stats.reserved[0] += e / two_p;  // the two halves are what was kept
       off += s0.tau;
       if (off >= d.h * (1.0 - 1e-12)) {
         h->stats.n_steps++;
@@ -374,14 +448,17 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       ck_est = h->stats.reserved[0];
       h->split_since_len = 0.0;
       have_ck = true;
-      err_rate = (e / s0.tau) * std::pow(std::min(tau_t, s0.tau) / s0.tau, 4.0);
+      err_rate = (e / s0.tau) * std::pow(std::min(tau_t, s0.tau) / s0.tau, (double)p_ord);
       since = 0;
       h->split_known = true;
       h->split_eps = eps;
     }
     // ---- the stretch up to the next check ----
-    const size_t stop = control ? std::min(sched.size(), i + (size_t)std::max(kSplitCheckEvery - since, 1))
-                                : sched.size();
+    size_t stop = control ? std::min(sched.size(), i + (size_t)std::max(kSplitCheckEvery - since, 1))
+                          : sched.size();
+    if (control)  // the stretch ends where a run of multi-knot steps begins: that step is checked (above)
+      for (size_t q = i + 1; q < stop; ++q)
+        if (sched[q].pad > 1 && sched[q - 1].pad <= 1) { stop = q; break; }
     subs.clear();
     while (i < stop) {
       const StepDesc& d = sched[i];

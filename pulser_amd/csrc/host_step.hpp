@@ -514,13 +514,28 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
   // interval); at most half a block of the split-operator master equation
   h->gauge_active = !h->general && !h->drive_real && h->gauge_ok && ket_path(h) && !krylov_selected(h, o) &&
                     !split_selected(h, o);
-  const int merge_cap = split_selected(h, o) ? 1
+  // split-operator ket passes: sub-steps may span knots only with the 6th-order scheme (host_split.hpp); how far is
+  // the controller's business (it measures the error), so the a-priori Magnus estimate is skipped there
+  bool split_merge = split_selected(h, o) && split_s10_allowed(h);
+  if (split_merge) {
+    // ... and only where this call's schedule has something to merge: multi-knot steps over half of its time
+    std::vector<StepDesc> trial;
+    for (int i = 1; i < n_times; ++i) build_schedule(h, times[i - 1], times[i], o, trial, true, kSplitMergeMax, true);
+    double all = 0.0, merged = 0.0;
+    for (const StepDesc& d : trial) { all += d.h; if (d.pad > 1) merged += d.h; }
+    split_merge = 2.0 * merged >= all && all > 0.0;
+  }
+  if (split_selected(h, o) && split_merge != h->split_s10) {
+    h->split_s10 = split_merge;
+    h->split_known = false;  // the controller's sub-step belongs to the other scheme
+  }
+  const int merge_cap = split_selected(h, o) ? (split_merge ? kSplitMergeMax : 1)
                         : (row_path(h) && !use_persistent_dm(h)) ? row_half_knots(h, o) : kMergeMax;
   std::vector<StepDesc> sched;
   // snapshot slot i-1 receives the state at times[i]
   for (int i = 1; i < n_times; ++i) {
     const size_t before = sched.size();
-    build_schedule(h, times[i - 1], times[i], o, sched, in_place, merge_cap);
+    build_schedule(h, times[i - 1], times[i], o, sched, in_place, merge_cap, split_merge);
     if (snaps) {
       if (sched.size() > before) {
         sched.back().snap = i - 1;
@@ -649,6 +664,10 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
     h->split_fixed = (force_generic & 256) != 0;
     h->split_no_loop = (force_generic & 512) != 0;
     h->no_merge = (force_generic & 1024) != 0;
+    {
+      const bool s6 = (force_generic & 8192) != 0;  // split-operator passes: S6, sub-steps end at every knot
+      if (s6 != h->split_s6_only) { h->split_s6_only = s6; h->split_known = false; }
+    }
     {
       const bool ns = (force_generic & 4096) != 0;  // general path: term-by-term kernel instead of the site-fused one
       if (ns != h->gen_no_sites) { h->gen_no_sites = ns; h->gen_sites_valid = false; }

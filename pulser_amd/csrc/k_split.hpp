@@ -44,20 +44,16 @@ struct SplitArgs {
 // by value in the kernel arguments.  Stage j = 6 s + i is D(a_i) R(b_i) of sub-step s (its D also
 // carries the last D(a_7) of sub-step s - 1); stage 6 nsub only closes with D(a_7).
 #define SPLIT_MAX_SUB 64
+#define SPLIT_MAX_STAGES 10
 struct SplitRun {
   int nsub;
+  int S;  // stages of the composition: 6 (4th order, Blanes & Moan S6) or 10 (6th order, S10)
   int idx[SPLIT_MAX_SUB];
   double u0[SPLIT_MAX_SUB];
   double tau[SPLIT_MAX_SUB];
+  double a[SPLIT_MAX_STAGES + 1];  // D(a_1) R(b_1) ... R(b_S) D(a_{S+1})
+  double b[SPLIT_MAX_STAGES];
 };
-
-__device__ static const double kSplitADev[7] = {
-    0.0792036964311957, 0.353172906049774, -0.0420650803577195,
-    1.0 - 2.0 * (0.0792036964311957 + 0.353172906049774 - 0.0420650803577195),
-    -0.0420650803577195, 0.353172906049774, 0.0792036964311957};
-__device__ static const double kSplitBDev[6] = {
-    0.209515106613362, -0.143851773179818, 0.5 - (0.209515106613362 - 0.143851773179818),
-    0.5 - (0.209515106613362 - 0.143851773179818), -0.143851773179818, 0.209515106613362};
 
 // out[stage][b][k] = (C, Re g, Im g, Delta): the rotation exp(-i beta (c |1><0| + conj(c) |0><1|)) =
 // C + g |1><0| + g' |0><1| with the drive frozen at the stage's time, and the integral of the
@@ -71,24 +67,25 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
   if (i >= total) return;
   const int j = blockIdx.y;
   const int ns = R.nsub;
-  const bool closing = j == 6 * ns;
-  const int s = closing ? ns - 1 : j / 6, st = closing ? 6 : j % 6;
+  const int S = R.S;
+  const bool closing = j == S * ns;
+  const int s = closing ? ns - 1 : j / S, st = closing ? S : j % S;
   // D intervals: (knot interval, start offset, length)
   int idx_d[2] = {R.idx[s], 0};
   double us_d[2], len_d[2] = {0.0, 0.0};
   double cum = 0.0;
-  for (int l = 0; l < st; ++l) cum += kSplitADev[l];
+  for (int l = 0; l < st; ++l) cum += R.a[l];
   us_d[0] = R.u0[s] + cum * R.tau[s];
-  len_d[0] = kSplitADev[st] * R.tau[s];
+  len_d[0] = R.a[st] * R.tau[s];
   us_d[1] = 0.0;
   if (!closing && st == 0 && s > 0) {
     idx_d[1] = R.idx[s - 1];
-    us_d[1] = R.u0[s - 1] + (1.0 - kSplitADev[6]) * R.tau[s - 1];
-    len_d[1] = kSplitADev[6] * R.tau[s - 1];
+    us_d[1] = R.u0[s - 1] + (1.0 - R.a[S]) * R.tau[s - 1];
+    len_d[1] = R.a[S] * R.tau[s - 1];
   }
   const int idx_c = R.idx[s];
   const double u_c = us_d[0] + len_d[0];
-  const double beta = closing ? 0.0 : kSplitBDev[st] * R.tau[s];
+  const double beta = closing ? 0.0 : R.b[st] * R.tau[s];
 
   const ryd_qdesc d = desc[i];
   auto val = [&](int sr, int idx, double u) -> cplx {
@@ -559,7 +556,7 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12_loop(const SplitArgs A, co
   const unsigned tid = threadIdx.x;
   const int N = A.N;  // == 12
   const int b = blockIdx.y;
-  const int n_stages = 6 * R.nsub + 1;
+  const int n_stages = R.S * R.nsub + 1;
   cplx* __restrict__ st = A.state + ((size_t)b << N);
   const double* __restrict__ coefs = A.ccur + (size_t)b * N * 4;
   const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride;
@@ -636,9 +633,9 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12_loop(const SplitArgs A, co
     // weight of E0 in this stage's D: a_i tau (+ the a_7 tau carried over from the previous sub-step)
     double w;
     {
-      const int sub = last ? R.nsub - 1 : sgi / 6, i = last ? 6 : sgi % 6;
-      w = kSplitADev[i] * R.tau[sub];
-      if (!last && i == 0 && sub > 0) w += kSplitADev[6] * R.tau[sub - 1];
+      const int sub = last ? R.nsub - 1 : sgi / R.S, i = last ? R.S : sgi % R.S;
+      w = R.a[i] * R.tau[sub];
+      if (!last && i == 0 && sub > 0) w += R.a[R.S] * R.tau[sub - 1];
     }
     if (!(sgi & 1)) {
       phase(w, ev2, tid, 8);
