@@ -692,7 +692,7 @@ def main() -> None:
         del psi, rho
         # cfg5: 20-atom sesolve slice: split-operator passes (default) and CF4 + Taylor on the generator
         # kernels (Lanczos comparison: profiles/r02_krylov_vs_taylor.md); 24 atoms = the HBM-bound regime
-        for n_at, shape, ns in ((20, (4, 5), 100), (24, (4, 6), 10)):
+        for n_at, shape, ns in ((20, (4, 5), 100), (24, (4, 6), 40)):
             eng = Engine.from_problems([rect_problem(*shape)], mode="sesolve")
             psi1 = eng.new_state()
             eng.evolve(psi1, 0.0, 1.0)  # the slice starts from the state the sequence has reached at 1 us

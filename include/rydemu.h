@@ -118,7 +118,9 @@ typedef struct ryd_opts {
                            atoms on - and for fewer than 8 sequences of 14 atoms - else the Taylor
                            polynomial), 1 = Lanczos / Krylov subspace (batched inner products V^H w and
                            V c), 2 = split-operator (exact diagonal phases x exact single-atom rotations,
-                           4th-order 6-stage composition; `tol` x 500 = target of the accumulated
+                           symmetric composition: 6th order / 10 stages over sub-steps of up to 8 knot
+                           intervals where the call's schedule has such steps, else 4th order / 6 stages
+                           inside one knot interval; `tol` x 500 = target of the accumulated
                            local-error estimate of a whole pulse sequence, default 5e-8),
                            3 = Taylor polynomial (Horner) */
   double reserved[2];

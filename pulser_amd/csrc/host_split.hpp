@@ -12,7 +12,8 @@
 // wins: NumPy model (tools/ket_split_probe.py, 10-atom triangular register, 1.44 us of the detuning sweep) S6 at
 // 1 / 2 / 3 knots: 1.9e-10 / 3.0e-9 / 1.5e-8;  S10 at 2 / 3 / 4 / 6 knots: 3.6e-12 / 3.2e-11 / 1.8e-10 / 2.0e-9 - i.e.
 // 1.7 - 3.3 stages per ns inside the budget instead of 6.  Where no knot can be removed (noise series, kinks) S10
-// at <= 1 knot would cost 10 stages instead of 6, so the scheme is chosen per handle from the share of removable knots.
+// at <= 1 knot would cost 10 stages instead of 6, so the scheme is chosen per solve call (host_step.hpp) from the share
+// of the call's schedule that multi-knot steps cover (evaluation times at every knot leave nothing to merge either).
 struct SplitScheme {
   int S, order;
   double a[SPLIT_MAX_STAGES + 1], b[SPLIT_MAX_STAGES];
