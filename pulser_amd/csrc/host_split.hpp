@@ -140,6 +140,12 @@ static int split_max_sub(const ryd_handle* h) {
   return (int)std::min<size_t>(kSplitMaxSub, std::max<size_t>(1, ((size_t)32 << 20) / per_sub));
 }
 
+// 14-atom kets in one launch per closed run (k_split14_loop: register-resident, one workgroup per sequence)?  From 8
+// sequences on (below, the passes spread each ket over 4 CUs); not for quantum-jump solves (no decay table there).
+static bool split_loop14(const ryd_handle* h) {
+  return h->N == 14 && !h->mc && !h->split_no_loop && (h->B >= 8 || h->force_ket);
+}
+
 // Advance `buf` over `subs` (consecutive sub-steps, at most split_max_sub) from a closed state to
 // a closed state: one k_split_coefs launch, then one k_split launch per pass.
 static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hipStream_t st) {
@@ -149,6 +155,16 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   const SplitScheme& sc = split_scheme(h);
   const int n_stages = sc.S * nsub + 1;
   if ((rc = split_ensure_tables(h, n_stages))) return rc;
+  bool loop14 = N == 14 && split_loop14(h);
+  if (loop14 && h->drive_real) {
+    // tan-form rotations need cos(beta |c|) away from zero: |beta c| <= 1 for every atom over every sub-step
+    double bmax = 0.0;
+    for (int i = 0; i < sc.S; ++i) bmax = std::max(bmax, std::fabs(sc.b[i]));
+    for (int s = 0; s < nsub && loop14; ++s) {
+      const int span = std::max(1, (int)std::ceil((subs[s].u0 + subs[s].tau) / (h->tknots[subs[s].idx + 1] - h->tknots[subs[s].idx]) - 1e-9));
+      if (span_max(h->bd_c1, subs[s].idx, std::min(span, (int)h->bd_c1.size() - subs[s].idx)) * bmax * subs[s].tau > 1.0) loop14 = false;
+    }
+  }
   SplitRun R;
   std::memset(&R, 0, sizeof R);
   R.nsub = nsub;
@@ -156,6 +172,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   for (int i = 0; i <= sc.S; ++i) R.a[i] = sc.a[i];
   for (int i = 0; i < sc.S; ++i) R.b[i] = sc.b[i];
   for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[s].idx; R.u0[s] = subs[s].u0; R.tau[s] = subs[s].tau; }
+  R.tan_form = loop14 && h->drive_real ? 1 : 0;
   const int total = B * N;
   hipLaunchKernelGGL(k_split_coefs, dim3((total + 3) / 4, n_stages), dim3(256), 0, st, h->pp_dev,
                      h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);
@@ -190,6 +207,37 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
       hipLaunchKernelGGL(k_split12_loop<true>, dim3(1, B), dim3(SPLIT_NT), lds, st, A, R, (long long)B * N * 4);
     else
       hipLaunchKernelGGL(k_split12_loop<false>, dim3(1, B), dim3(SPLIT_NT), lds, st, A, R, (long long)B * N * 4);
+    HIPCHK(hipGetLastError());
+    if (h->timing) { HIPCHK(hipEventRecord(ev1.second, st)); h->ev_used.push_back(ev1); }
+    h->stats.n_launches++;
+    h->stats.n_applications += n_stages - 1;
+    h->stats.passes = 1;
+    return RYD_OK;
+  }
+  if (loop14) {
+    // 14 atoms, a batch: one workgroup per sequence, every stage of the run in one launch (k_split14_loop)
+    SplitArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.state = buf;
+    A.e0 = h->e0_dev;
+    A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << N);
+    A.ccur = h->split_coefs;
+    A.N = N;
+    A.T = 14;
+    const size_t lds = ((size_t)8 << 14) + SPLIT14_TRIG * 16 + 64 * 8;
+    static bool attr14[64] = {};
+    const int dev = h->cfg.device;
+    if (dev < 0 || dev >= 64 || !attr14[dev]) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_split14_loop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_split14_loop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      if (dev >= 0 && dev < 64) attr14[dev] = true;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev1;
+    if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
+    if (h->drive_real)
+      hipLaunchKernelGGL(k_split14_loop<true>, dim3(1, B), dim3(SPLIT14_NT), lds, st, A, R, (long long)B * N * 4);
+    else
+      hipLaunchKernelGGL(k_split14_loop<false>, dim3(1, B), dim3(SPLIT14_NT), lds, st, A, R, (long long)B * N * 4);
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(ev1.second, st)); h->ev_used.push_back(ev1); }
     h->stats.n_launches++;

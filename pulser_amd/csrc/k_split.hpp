@@ -53,6 +53,7 @@ struct SplitRun {
   double tau[SPLIT_MAX_SUB];
   double a[SPLIT_MAX_STAGES + 1];  // D(a_1) R(b_1) ... R(b_S) D(a_{S+1})
   double b[SPLIT_MAX_STAGES];
+  int tan_form;  // real drives on k_split14_loop: the Re g slot (zero there) carries Im g / C
 };
 
 // out[stage][b][k] = (C, Re g, Im g, Delta): the rotation exp(-i beta (c |1><0| + conj(c) |0><1|)) =
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
       gr = S * ci;  // g = -i S c
       gi = -S * cr;
     }
+    if (R.tan_form) gr = gi / C;  // (real drives: gr was 0; the host keeps |beta c| <= 1, so C >= 0.54)
     double* o = out + ((size_t)j * total + i) * 4;
     o[0] = C;
     o[1] = gr;
@@ -682,6 +684,227 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12_loop(const SplitArgs A, co
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[tid | (r << 8)] = x[r];
+  }
+}
+
+// Whole kets of exactly 14 atoms, one workgroup (512 lanes x 32 amplitudes = 5 register bits) per sequence: every stage
+// of a closed run in ONE launch, the ket stays in registers (the headline batch: 256 sequences = one per CU).  A stage
+// is D + the 14 rotations; three layouts
+//   LA: i = t | r << 9 (register bits 9-13, the coalesced load / store layout)     LB: i = (t & 15) | r << 4 | (t >> 4) << 9
+//   LC: i = r | t << 5 (register bits 0-4)                                         (register bits 4-8; rotates 5-8)
+// alternate LA -> LB -> LC on even stages and LC -> LB -> LA on odd ones: two turns per stage.  A turn moves the real
+// parts and then the imaginary parts through 128 KiB of LDS (8-B slots, XOR-swizzled per turn: T1 between LA and LB
+// folds index bits 9-10 into slot bits 4-5, T2 between LB and LC folds bits 5-9 into bits 0-4 - both sides of both
+// turns are conflict-free per half-wave).  The coefficients of a stage are uniform: scalar loads, SGPR operands.
+// E0 is never read inside the stage loop (pairwise additivity: 12 doubles per lane + two 32-entry tables, see below).
+// Arithmetic per amplitude and stage (real drives): a rotation is  x' = x - T y_p,  y' = y + T x_p  with T = gi / C
+// (SplitRun.tan_form: k_split_coefs stores it in the unused Re g slot; host_split.hpp keeps |beta c| <= 1) - 2 FMAs per
+// amplitude and bit instead of 2 + 2 - and the product of the 14 cosines of a stage, one number, rides on the next
+// stage's phase factor; exp(-i phi) from a 512-entry table of exp(2 pi i k / 512) (built once per launch) and a
+// degree-5 series on |r| <= pi / 512.
+#define SPLIT14_NT 512
+#define SPLIT14_TRIG 512
+template <bool REAL>
+__global__ __launch_bounds__(SPLIT14_NT) void k_split14_loop(const SplitArgs A, const SplitRun R, long long stage_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int N = 14;
+  double* xs = reinterpret_cast<double*>(smem);          // 2^14 x 8 B
+  cplx* trig = reinterpret_cast<cplx*>(xs + (1 << N));   // 512 x 16 B
+
+  const unsigned t = threadIdx.x;
+  const int b = blockIdx.y;
+  const int n_stages = R.S * R.nsub + 1;
+  cplx* __restrict__ st = A.state + ((size_t)b << N);
+  const double* __restrict__ coefs = A.ccur + (size_t)b * N * 4;
+  const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride;
+
+  double* eregA = reinterpret_cast<double*>(trig + SPLIT14_TRIG);  // 32: E0 of the register atoms alone, layout LA
+  double* eregC = eregA + 32;                                      // ... layout LC
+  {  // (before the state is loaded: the library routine wants registers)
+    double sn, cs;
+    sincospi((double)t * (2.0 / SPLIT14_TRIG), &sn, &cs);
+    trig[t] = make_double2(cs, sn);
+  }
+  // E0 is pairwise additive, so for an amplitude (lane t, register r) it is
+  //   E0 = Et(t) + Ereg(r) + sum over the excited register atoms j of V_j(t)
+  // with Et = E0 of the lane's atoms alone, Ereg = E0 of the register atoms alone (uniform: an LDS table of 32), and
+  // V_j = the interaction of register atom j with the lane's excited atoms - all read off the E0 table once per
+  // launch (12 doubles per lane for the two layouts D meets), so no stage reads E0 from memory.
+  double etA, vA[5], etC, vC[5];
+  etA = e0[t | (31u << 9)];
+  etC = e0[31u | (t << 5)];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    vA[j] = e0[t | ((31u ^ (1u << j)) << 9)] - etA;
+    vC[j] = e0[(31u ^ (1u << j)) | (t << 5)] - etC;
+  }
+  if (t < 32) {
+    eregA[t] = e0[(t << 9) | 511u];
+    eregC[t] = e0[t | (511u << 5)];
+  }
+  __syncthreads();
+  double xr[32], xi[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const cplx v = st[t | (unsigned)(r << 9)];
+    xr[r] = v.x;
+    xi[r] = v.y;
+  }
+
+  // tile-local index of register r in the three layouts
+  auto iA = [](unsigned tt, int r) -> unsigned { return tt | (unsigned)(r << 9); };
+  auto iB = [](unsigned tt, int r) -> unsigned { return (tt & 15u) | (unsigned)(r << 4) | ((tt >> 4) << 9); };
+  auto iC = [](unsigned tt, int r) -> unsigned { return (unsigned)r | (tt << 5); };
+  auto slot1 = [](unsigned i) -> unsigned { return i ^ (((i >> 9) & 3u) << 4); };
+  auto slot2 = [](unsigned i) -> unsigned { return i ^ ((i >> 5) & 31u); };
+
+  // the coefficients of the current stage, by index bit p (atom N - 1 - p): uniform values, moved to scalar registers
+  // (v_readfirstlane) so that they are free operands of the vector arithmetic and hold no vector registers
+  // (read through the constant address space: uniform addresses there are scalar loads - all of a stage's issued
+  // back to back, one wait; as vector loads + v_readfirstlane the compiler waited per atom: 14 L2 round trips = 10 us)
+  typedef const __attribute__((address_space(4))) double* cptr_t;
+  double cC[N], cT[N], cGi[N], cDl[N];
+  double cprod = 1.0;  // product of the cosines of the previous stage's rotations (tan form): rides on this stage's phase
+  double cnext = 1.0;
+  auto load_coefs = [&](const double* cs) {
+    cptr_t c4 = (cptr_t)(unsigned long long)cs;
+    double prod = 1.0;
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      cptr_t c = c4 + 4 * (N - 1 - p);
+      if (REAL) {
+        prod *= c[0];
+        cC[p] = 1.0;
+        cGi[p] = 0.0;
+      } else {
+        cC[p] = c[0];
+        cGi[p] = c[2];
+      }
+      cT[p] = c[1];  // REAL: gi / C;  else Re g
+      cDl[p] = c[3];
+    }
+    cprod = cnext;
+    cnext = REAL ? prod : 1.0;
+  };
+  // rotations of the register bits [lo, hi) at index bits pos + j
+  auto rotate = [&](int pos, int lo, int hi) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j < lo || j >= hi) continue;
+      const double C = cC[pos + j], T = cT[pos + j], gi = cGi[pos + j];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        if (r & (1 << j)) continue;
+        const int q = r | (1 << j);
+        const double a0x = xr[r], a0y = xi[r], a1x = xr[q], a1y = xi[q];
+        if (REAL) {
+          xr[r] = fma(-T, a1y, a0x);
+          xi[r] = fma(T, a1x, a0y);
+          xr[q] = fma(-T, a0y, a1x);
+          xi[q] = fma(T, a0x, a1y);
+        } else {
+          xr[r] = fma(-T, a1x, fma(-gi, a1y, C * a0x));
+          xi[r] = fma(-T, a1y, fma(gi, a1x, C * a0y));
+          xr[q] = fma(T, a0x, fma(-gi, a0y, C * a1x));
+          xi[q] = fma(T, a0y, fma(gi, a0x, C * a1y));
+        }
+      }
+    }
+  };
+  // D in layout LA (register bits 9-13, lane bits 0-8) or LC (register bits 0-4, lane bits 5-13):
+  //   phi(r) = wE E0 - sum over excited atoms of Delta = [wE Et - Delta(lane atoms)] + wE Ereg(r) + sum_{j excited in r} Q_j,
+  //   Q_j = wE V_j - Delta_j  (a tree over r: one addition per amplitude)
+  auto phase = [&](double wE, auto inA) {
+    constexpr bool kA = decltype(inA)::value;
+    constexpr int rpos = kA ? 9 : 0, tpos = kA ? 0 : 5;
+    double dthr = 0.0;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) dthr += ((t >> p) & 1u) ? 0.0 : cDl[tpos + p];
+    const double base0 = fma(wE, kA ? etA : etC, -dthr);
+    double Q[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) Q[j] = fma(wE, kA ? vA[j] : vC[j], -cDl[rpos + j]);
+    const double* ereg = kA ? eregA : eregC;
+    const double scale = cprod;
+    double P[32];
+#pragma unroll
+    for (int r = 31; r >= 0; --r) {
+      if (r == 31) {
+        P[r] = base0;
+      } else {
+        int j = 0;
+        while (r & (1 << j)) ++j;  // lowest clear bit: the parent has it set
+        P[r] = P[r | (1 << j)] + Q[j];
+      }
+      const double phi = fma(wE, ereg[r], P[r]);
+      // exp(-i phi) = (c, -s): table of exp(2 pi i k / 512), series on |rr| <= pi / 512
+      const double kk = rint(phi * (SPLIT14_TRIG / 6.283185307179586));
+      double rr = fma(-kk, 6.283185307179586 / SPLIT14_TRIG, phi);
+      rr = fma(-kk, 2.4492935982947064e-16 / SPLIT14_TRIG, rr);  // 2 pi - double(2 pi)
+      const cplx tb = trig[((int)kk) & (SPLIT14_TRIG - 1)];
+      const double r2 = rr * rr;
+      const double cr = fma(r2, fma(r2, 4.1666666666666664e-02, -0.5), 1.0) * scale;
+      const double sr = rr * fma(r2, fma(r2, 8.333333333333333e-03, -1.6666666666666666e-01), 1.0) * scale;
+      const double c = fma(tb.x, cr, -tb.y * sr), sn = fma(tb.y, cr, tb.x * sr);
+      const double ax = xr[r], ay = xi[r];
+      xr[r] = fma(ax, c, ay * sn);
+      xi[r] = fma(ay, c, -ax * sn);
+    }
+  };
+  // (the lane index is made opaque per turn: slot addresses are a few integer operations each and must not be hoisted
+  // out of the stage loop - 4 turns x 64 addresses would live in registers the state needs, i.e. in scratch)
+  auto turn = [&](auto from, auto to, auto slot) {
+    unsigned tt = t;
+    asm volatile("" : "+v"(tt));
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) xs[slot(from(tt, r))] = xr[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) xr[r] = xs[slot(to(tt, r))];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) xs[slot(from(tt, r))] = xi[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) xi[r] = xs[slot(to(tt, r))];
+  };
+
+  for (int sgi = 0; sgi < n_stages; ++sgi) {
+    load_coefs(coefs + (size_t)sgi * stage_stride);
+    const bool last = sgi == n_stages - 1, even = !(sgi & 1);
+    double w;
+    {
+      const int sub = last ? R.nsub - 1 : sgi / R.S, i = last ? R.S : sgi % R.S;
+      w = R.a[i] * R.tau[sub];
+      if (!last && i == 0 && sub > 0) w += R.a[R.S] * R.tau[sub - 1];
+    }
+    if (even) {
+      phase(w, std::true_type{});
+      if (!last) {
+        rotate(9, 0, 5);
+        turn(iA, iB, slot1);
+        rotate(4, 1, 5);
+        turn(iB, iC, slot2);
+        rotate(0, 0, 5);
+      }
+    } else {
+      phase(w, std::false_type{});
+      if (!last) {
+        rotate(0, 0, 5);
+        turn(iC, iB, slot2);
+        rotate(4, 1, 5);
+        turn(iB, iA, slot1);
+        rotate(9, 0, 5);
+      }
+    }
+  }
+  if ((n_stages - 1) & 1) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) st[(unsigned)r | (t << 5)] = make_double2(xr[r], xi[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) st[t | (unsigned)(r << 9)] = make_double2(xr[r], xi[r]);
   }
 }
 
