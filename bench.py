@@ -54,6 +54,12 @@ T_SEQ_US = 3.1
 # profiles/r02_kket_isa.md): per 16 amplitudes of a lane 224 v_fma_f64 + 32 v_mul_f64 + 52..60 v_add_f64
 # = 33.25 / 33.75 flops per amplitude per half-stage (second / first half), two half-stages per stage
 KKET_FLOPS_PER_AMP_STAGE = 2 * 0.5 * (33.25 + 33.75)
+# k_split14_loop<true>: per 32 amplitudes of a lane and stage 1254.5 v_fma/v_fmac_f64 + 295 v_mul_f64 + 40 v_add_f64
+# + 32 v_rndne_f64 in the stage loop of the compiled kernel (tools/count_isa.py split14 -> profiles/r03_ksplit14_isa.md)
+KSPLIT14_FLOPS_PER_AMP_STAGE = (2 * 1254.5 + 295 + 40 + 32) / 32.0
+KSPLIT14_NAME = ("k_split14_loop (register-resident split-operator kernel: one workgroup per sequence, exact phases x "
+                 "single-atom rotations, 6th-order composition over multi-knot sub-steps; one launch per closed run "
+                 "of <= 64 sub-steps)")
 # k_traj<12,1024,1>: 120 fp64 instructions per wave and stage for 4 amplitudes per lane
 # (profiles/r01_ktraj_counters.md), ~85 % of them FMAs
 KTRAJ_FLOPS_PER_AMP_STAGE = 120 * 1.85 / 4.0
@@ -354,6 +360,8 @@ def main() -> None:
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="north_star: headline leg only (profiling runs)")
     ap.add_argument("--no-ket", action="store_true", help="disable k_ket / the split-operator rows (A/B runs)")
+    ap.add_argument("--no-split14", action="store_true",
+                    help="north star: keep the batch on k_ket instead of k_split14_loop (A/B runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -403,11 +411,12 @@ def main() -> None:
         eng = Engine(tables, mode="sesolve")
         torch.cuda.synchronize()
         create_s = time.perf_counter() - tic
-        if args.no_ket:
-            eng.set_path(False, no_ket=True)
+        if args.no_ket or args.no_split14:
+            eng.set_path(False, no_ket=args.no_ket, no_split14=args.no_split14)
         sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, args.steps, args.warmup, dist, torch)
         value = n_gpus * B * T_SEQ_US / sec
         ket = stats["n_launches"] == 1
+        split14 = not ket and not args.no_ket and stats["reserved"][0] > 0.0
         # every rank runs the same batch of sequences, so this number must not depend on the number of GPUs
         ens = [float(v) / (n_gpus * B) for v in occ.cpu().numpy()]
         out = {
@@ -419,7 +428,11 @@ def main() -> None:
                             "batch of independent sequences per GPU (amplitude / detuning scale factors spread +-1 %)",
                 "n_atoms": n, "sequences_per_gpu": B, "sim_us_per_sequence": T_SEQ_US,
                 "integrator": "CF4 Magnus; exponentials by the in-place symplectic scheme (k_ket), "
-                              "2e-11 per exponential" if ket else "CF4 Magnus + Taylor(Horner), 1e-10 per exponential",
+                              "2e-11 per exponential" if ket else
+                              "split-operator: exact diagonal phases x exact single-atom rotations, 6th-order 10-stage "
+                              "composition over sub-steps of <= 8 knot intervals, measured step-size control "
+                              "(accumulated local-error estimate %.1e; k_split14_loop)" % stats["reserved"][0] if split14
+                              else "CF4 Magnus + Taylor(Horner), 1e-10 per exponential",
                 "stages_per_sequence": stats["n_applications"], "cf4_steps": stats["n_steps"],
                 "parallelism": f"dp{n_gpus} (independent sequences shard over ranks; all-reduce of ensemble sums only)",
             },
@@ -437,6 +450,15 @@ def main() -> None:
                 note="the state lives in registers / LDS for the whole sequence; HBM sees the initial load, "
                      "the final store and the tables only ('traffic'). hbm_equivalent_GBps = what a "
                      "streaming kernel would have to sustain for the same applications")
+        elif split14:
+            out["roofline"] = roofline_valu(
+                2.0**n, B, stats["n_applications"], KSPLIT14_FLOPS_PER_AMP_STAGE, kms, kl, KSPLIT14_NAME,
+                "north_star:k_split14",
+                note="the kets live in registers for a closed run of sub-steps (a turn through LDS re-sorts them "
+                     "twice per stage); HBM sees the states once per launch in and out plus the per-stage "
+                     "coefficients ('traffic'). Stages include the step-size controller's check sub-steps. "
+                     "k_ket (the round-2 / early round-3 kernel of this line: 26 253 stages, frac 0.43) remains "
+                     "behind set_path(no_split14=True)")
         else:
             out["roofline"] = roofline_hbm(n, B, stats, kms, kl, "k_apply14<sesolve> (2^14 register tiles, 1 pass)")
         eng.close()

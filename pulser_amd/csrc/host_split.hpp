@@ -82,7 +82,7 @@ static bool split_selected(const ryd_handle* h, const ryd_opts& o) {
   if (o.method == 2) return true;
   if (o.method != 0 || o.taylor_order > 0 || h->force_generic || h->no_split) return false;
   // 14 atoms: batches of >= 8 real-drive sequences stay on the register-resident k_ket
-  return h->N >= 15 || (h->N == 14 && !ket_path(h));
+  return h->N >= 15 || (h->N == 14 && (!ket_path(h) || h->split14_auto));
 }
 
 // Tilings: the low T bits, then tilings of the remaining high bits (at most 8 each) that keep

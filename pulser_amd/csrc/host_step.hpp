@@ -506,6 +506,24 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
   cplx* state = (cplx*)state_dev;
   cplx* snaps = (cplx*)out_dev;
   const size_t bytes = h->dim * (size_t)h->B * sizeof(cplx);
+  // 14-atom batches of real-drive sequences (the headline): the register-resident split-operator kernel
+  // (k_split14_loop) instead of the register-resident polynomial one (k_ket) when this call's schedule is mostly
+  // multi-knot steps - 6th order over 8-knot sub-steps needs a third of k_ket's stages there, at 2.2x the work per
+  // stage; with evaluation times at every knot k_ket keeps the job
+  auto merged_share = [&]() {
+    std::vector<StepDesc> trial;
+    for (int i = 1; i < n_times; ++i) build_schedule(h, times[i - 1], times[i], o, trial, true, kSplitMergeMax, true);
+    double all = 0.0, merged = 0.0;
+    for (const StepDesc& d : trial) { all += d.h; if (d.pad > 1) merged += d.h; }
+    return all > 0.0 ? merged / all : 0.0;
+  };
+  h->split14_auto = false;
+  double share = -1.0;
+  if (h->N == 14 && o.method == 0 && o.taylor_order <= 0 && !h->force_generic && !h->no_split && !h->force_ket &&
+      !h->no_split14 && split_capable(h) && ket_path(h) && h->drive_real && split_loop14(h) && split_s10_allowed(h)) {
+    share = merged_share();
+    h->split14_auto = share >= 0.5;
+  }
   // the in-place schemes split an exponential themselves and a Lanczos process takes whole
   // steps: both skip build_schedule's Taylor sub-stepping
   const bool in_place = ket_path(h) || (row_path(h) && !use_persistent_dm(h)) || krylov_selected(h, o) ||
@@ -519,11 +537,8 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
   bool split_merge = split_selected(h, o) && split_s10_allowed(h);
   if (split_merge) {
     // ... and only where this call's schedule has something to merge: multi-knot steps over half of its time
-    std::vector<StepDesc> trial;
-    for (int i = 1; i < n_times; ++i) build_schedule(h, times[i - 1], times[i], o, trial, true, kSplitMergeMax, true);
-    double all = 0.0, merged = 0.0;
-    for (const StepDesc& d : trial) { all += d.h; if (d.pad > 1) merged += d.h; }
-    split_merge = 2.0 * merged >= all && all > 0.0;
+    if (share < 0.0) share = merged_share();
+    split_merge = share >= 0.5;
   }
   if (split_selected(h, o) && split_merge != h->split_s10) {
     h->split_s10 = split_merge;
@@ -664,6 +679,7 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
     h->split_fixed = (force_generic & 256) != 0;
     h->split_no_loop = (force_generic & 512) != 0;
     h->no_merge = (force_generic & 1024) != 0;
+    h->no_split14 = (force_generic & 16384) != 0;  // 14-atom batches stay on k_ket
     {
       const bool s6 = (force_generic & 8192) != 0;  // split-operator passes: S6, sub-steps end at every knot
       if (s6 != h->split_s6_only) { h->split_s6_only = s6; h->split_known = false; }

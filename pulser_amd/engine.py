@@ -263,7 +263,7 @@ class Engine:
     def _split_budget_check(self, method: str, tol: float) -> None:
         """The split-operator controller books its local-error estimates in ``ryd_stats.reserved[0]``;
         when it could not hold the sequence budget (retries used up, nothing to roll back to) say so."""
-        if not (method == "split" or (method == "auto" and self.mode == RYD_SESOLVE and self.n >= 15
+        if not (method == "split" or (method == "auto" and self.mode == RYD_SESOLVE and self.n >= 14
                                       and not self.monte_carlo)):
             return
         est = self.stats()["reserved"][0]
@@ -378,7 +378,8 @@ class Engine:
                  force_single_pass: bool = False, no_ket: bool = False,
                  force_ket: bool = False, no_split: bool = False,
                  split_fixed: bool = False, split_no_loop: bool = False,
-                 no_merge: bool = False, split_small_tiles: bool = False, split_s6: bool = False) -> None:
+                 no_merge: bool = False, split_small_tiles: bool = False, split_s6: bool = False,
+                 no_split14: bool = False) -> None:
         """Test/bench hook: disable the persistent small-N kernel and/or the 2^14
         register-tile kernel with the Hermitian mesolve path (the tiled
         multi-pass kernels are used instead), or force the register tiles;
@@ -389,7 +390,9 @@ class Engine:
         switches the step-size control of the split-operator path off; ``no_merge`` keeps
         every CF4 step inside one knot interval (no multi-knot steps on smooth stretches);
         ``split_small_tiles`` keeps the 2^12 tiles of the split-operator passes where 2^14 tiles are the default
-        (21 - 23 atoms); ``split_s6`` keeps the 4th-order composition with sub-steps that end at every knot
+        (21 - 23 atoms); ``no_split14`` keeps batches of 14-atom sequences on the polynomial
+        register-resident kernel (k_ket) instead of the split-operator one (k_split14_loop);
+        ``split_s6`` keeps the 4th-order composition with sub-steps that end at every knot
         (round 2) where the 6th-order one with multi-knot sub-steps is the default."""
         _lib.check(self.lib.ryd_set_path(
             self._h, int(bool(force_generic)) | (2 if no_single_pass else 0)
@@ -397,7 +400,8 @@ class Engine:
             | (16 if force_single_pass else 0) | (32 if no_ket else 0)
             | (64 if force_ket else 0) | (128 if no_split else 0)
             | (256 if split_fixed else 0) | (512 if split_no_loop else 0)
-            | (1024 if no_merge else 0) | (2048 if split_small_tiles else 0) | (8192 if split_s6 else 0)))
+            | (1024 if no_merge else 0) | (2048 if split_small_tiles else 0) | (8192 if split_s6 else 0)
+            | (16384 if no_split14 else 0)))
 
     def apply_generator(self, x: Any, t: float) -> Any:
         """``G(t) x`` with ``G = -iH`` (sesolve) or the Lindbladian (mesolve)."""

@@ -40,10 +40,11 @@ def _worst(snaps, ref):
 
 @pytest.mark.parametrize("no_merge", [False, True])
 def test_headline_kernel_k_ket14_full_anneal_against_tight_oracle(ns14, no_merge):
-    """The bench's own configuration: a batch (>= 8 sequences -> k_ket by default), whole schedule = 1 launch."""
+    """A batch (>= 8 sequences) on k_ket (the bench's kernel until the register-resident split-operator one took the
+    line; still the kernel of calls with evaluation times at every knot): whole schedule = 1 launch."""
     prob, times, ref = ns14
     with _engine([prob] * 8) as eng:
-        eng.set_path(False, no_merge=no_merge)
+        eng.set_path(False, no_merge=no_merge, no_split14=True)
         snaps = eng.solve(eng.new_state(), times).cpu().numpy()
         st = eng.stats()
     assert st["n_launches"] == 1
@@ -55,6 +56,22 @@ def test_headline_kernel_k_ket14_full_anneal_against_tight_oracle(ns14, no_merge
         assert st["n_applications"] > 40_000
     else:
         assert st["n_applications"] < 30_000
+
+
+def test_headline_batch_default_kernel_full_anneal_against_tight_oracle(ns14):
+    """The bench's own configuration: a batch of 14-atom sequences, default path = k_split14_loop (6th-order
+    split-operator composition over multi-knot sub-steps, the kets register-resident for a closed run per launch),
+    every stored time of the tight oracle."""
+    prob, times, ref = ns14
+    with _engine([prob] * 8) as eng:
+        snaps = eng.solve(eng.new_state(), times).cpu().numpy()
+        st = eng.stats()
+    assert 1 < st["n_launches"] < 200 and st["n_applications"] < 12_000  # (k_ket: 26 253 stages in one launch)
+    for b in (0, 7):
+        errs = _worst(snaps[:, b], ref)
+        assert max(errs) < AMP_TOL / 10, errs
+        assert max(errs) < max(4 * st["reserved"][0], 2e-9), (errs, st["reserved"])  # the estimate covers the error
+    assert np.array_equal(snaps[:, 0], snaps[:, 7])  # identical sequences, identical arithmetic
 
 
 @pytest.mark.parametrize("method,path", [("split", {}), ("taylor", {"no_ket": True}), ("krylov", {"no_ket": True}),

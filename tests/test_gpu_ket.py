@@ -84,7 +84,7 @@ def test_ket_kernel_14_atom_triangular_anneal_against_multi_launch():
     outs = {}
     for no_ket in (False, True):
         with _engine([prob] * 8, "sesolve") as eng:  # from 8 sequences on the ket kernel is the default
-            eng.set_path(False, no_ket=no_ket)
+            eng.set_path(False, no_ket=no_ket, no_split14=True)  # (k_ket itself: not the split-operator kernel)
             st = eng.new_state()
             eng.evolve(st, 0.0, 0.25)  # first part of the rise: Omega and |delta| both large
             outs[no_ket] = st.cpu().numpy()[0]

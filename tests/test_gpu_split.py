@@ -403,3 +403,80 @@ def test_scheme_follows_the_schedule_of_the_call():
     assert s_every["n_applications"] % 6 == 0 and s_end["n_applications"] % 10 == 0
     assert s_end["n_applications"] < 0.5 * s_every["n_applications"]
     assert float((snaps[-1] - end[-1]).abs().max()) < 2e-9
+
+
+# ---- k_split14_loop: 14-atom batches, one workgroup per sequence, a closed run per launch ----
+
+def _scaled_anneals(n_seq):
+    coords = P.register_coords(P.triangular_rect(2, 7), blockade_radius())
+    base = P.anneal_samples()
+    probs = []
+    for b in range(n_seq):
+        f = 1.0 - 0.3 * b / max(n_seq - 1, 1)
+        probs.append(P.make_ising_problem(coords, {"amp": base["amp"] * f, "det": base["det"] * (2.0 - f),
+                                                   "phase": base["phase"]}))
+    return probs
+
+
+@pytest.mark.parametrize("t0, t1", [(0.0, 0.62), (2.4, 3.1)])
+def test_register_resident_14_atom_kernel_equals_the_pass_by_pass_launches(t0, t1):
+    """8 different sequences across the kinks of the anneal: the same stages in the same order, so the one-launch kernel
+    (tan-form rotations, E0 from its pairwise-additive pieces, a 512-entry phase table) has to agree with the tile
+    passes to rounding."""
+    probs = _scaled_anneals(8)
+    outs, stats = {}, {}
+    for no_loop in (False, True):
+        with _engine(probs) as eng:
+            eng.set_path(False, split_no_loop=no_loop)
+            st = eng.new_state()
+            if t0 > 0:
+                eng.evolve(st, 0.0, t0, method="taylor")
+            eng.reset_stats()
+            eng.evolve(st, t0, t1, method="split")
+            outs[no_loop], stats[no_loop] = st.cpu().numpy(), eng.stats()
+    assert np.max(np.abs(outs[False] - outs[True])) < 1e-12
+    assert stats[False]["n_applications"] == stats[True]["n_applications"]
+    assert stats[False]["n_launches"] < stats[True]["n_launches"] / 20
+    if t0 == 0.0:  # (a start state from the Taylor path carries that path's norm drift)
+        assert np.max(np.abs(np.linalg.norm(outs[False], axis=1) - 1.0)) < 1e-11
+
+
+def test_register_resident_14_atom_kernel_complex_drives_and_per_sequence_interactions():
+    """Per-atom complex, time-dependent drives and a different geometry (interaction diagonal) per sequence: the
+    general rotation branch and the per-sequence E0 pieces, against the tile passes and against CF4 + Taylor."""
+    probs = [local_problem(14, seed=3 + 10 * b, duration=41, spacing=6.5) for b in range(8)]
+    outs = {}
+    for name, kw, method, opts in (("loop", {}, "split", {}), ("passes", {"split_no_loop": True}, "split", {}),
+                                   ("taylor", {"no_ket": True}, "taylor", {"tol": 1e-13})):
+        with _engine(probs) as eng:
+            eng.set_path(False, **kw)
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 0.04, method=method, **opts)
+            outs[name] = st.cpu().numpy()
+    assert np.max(np.abs(outs["loop"] - outs["passes"])) < 1e-12
+    assert np.max(np.abs(outs["loop"] - outs["taylor"])) < 5e-9
+    assert np.max(np.abs(outs["loop"][0] - outs["loop"][1])) > 1e-3  # the sequences really differ
+
+
+def test_14_atom_batches_choose_their_kernel_from_the_schedule_of_the_call():
+    """End state of the anneal: multi-knot steps -> k_split14_loop (a launch per closed run, a third of k_ket's
+    stages).  Evaluation times at every knot: nothing to merge -> k_ket, the whole schedule in one launch.
+    `no_split14` keeps k_ket in either case.  Same kets (both inside the bar by the full-size tests)."""
+    probs = _scaled_anneals(8)
+    res = {}
+    with _engine(probs) as eng:
+        for name, kw in (("auto", {}), ("k_ket", {"no_split14": True})):
+            eng.set_path(False, **kw)
+            st = eng.new_state()
+            eng.reset_stats()
+            eng.evolve(st, 0.0, 0.9)
+            res[name] = (st.cpu().numpy(), eng.stats())
+        eng.set_path(False)
+        eng.reset_stats()
+        every = np.arange(0, 61) * 1e-3
+        eng.solve(eng.new_state(), every)
+        s_every = eng.stats()
+    assert res["k_ket"][1]["n_launches"] == 1 and s_every["n_launches"] == 1
+    assert res["auto"][1]["n_launches"] > 1 and res["auto"][1]["reserved"][0] > 0
+    assert res["auto"][1]["n_applications"] < 0.5 * res["k_ket"][1]["n_applications"]
+    assert np.max(np.abs(res["auto"][0] - res["k_ket"][0])) < 2e-8

@@ -9,6 +9,26 @@ with tempfile.TemporaryDirectory() as d:
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                     "-Wno-unused-value", src, "-o", asm], check=True, stderr=subprocess.DEVNULL)
     text = open(asm).read()
+if len(sys.argv) > 1 and sys.argv[1] == "split14":
+    # k_split14_loop<true>: fp64 work of the stage loop (two unrolled stage bodies, 32 amplitudes per lane)
+    m = re.search(r"^(_Z\d+k_split14_loopILb1E\w*):(.*?)s_endpgm", text, re.S | re.M)
+    body = m.group(2).split("\n")
+    hdr = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l][0]
+    lab = body[hdr].split(":")[0]
+    back = [i for i, l in enumerate(body) if re.search(r"s_c?branch\w*\s+%s\b" % re.escape(lab), l)][-1]
+    reg = body[hdr:back + 1]
+    c = lambda pat: sum(1 for l in reg if re.search(pat, l))
+    fma, mul, add, rnd = c(r"\sv_fmac?_f64"), c(r"\sv_mul_f64"), c(r"\sv_add_f64"), c(r"v_rndne_f64")
+    valu = c(r"^\s+v_")
+    print("# r03: fp64 instruction count of the stage loop of `k_split14_loop<true>` (hipcc 7.2, gfx950, -O3)\n")
+    print("The loop body holds TWO stages (even: layouts LA -> LB -> LC, odd: back), 32 amplitudes per lane.\n")
+    print("| v_fma/v_fmac_f64 | v_mul_f64 | v_add_f64 | v_rndne_f64 | other VALU | ds ops | scratch ops | barriers | flops / amplitude / stage |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    n_ds = c(r"^\s+ds_")
+    print(f"| {fma} | {mul} | {add} | {rnd} | {valu - fma - mul - add - rnd} | {n_ds} | {c('scratch_')} | {c('s_barrier')} | {(2 * fma + mul + add + rnd) / 64:.2f} |")
+    print("\nPer stage and amplitude: 14 rotations x 2 FMAs (tan form) + the phase factor (range reduction, table entry, degree-5 series,")
+    print("two complex multiplications).  bench.py uses KSPLIT14_FLOPS_PER_AMP_STAGE = the last column; re-run after changing the kernel.")
+    sys.exit(0)
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # 0 plain, 1 rows, 2 gauge
 m = re.search(r"^_Z5k_ketILi14ELi%dE\w*EEv7KetArgs:(.*?)s_endpgm" % mode, text, re.S | re.M)
 body = m.group(1).split("\n")
