@@ -41,7 +41,8 @@ static SplitScheme make_s10() {
 }
 static const SplitScheme kSplitS10 = make_s10();
 static const int kSplitMaxSub = SPLIT_MAX_SUB;
-static const int kSplitMergeMax = 8;  // knot intervals a sub-step of the 6th-order scheme may span
+static const int kSplitMergeMax = 8;  // knot intervals a sub-step of the 6th-order scheme may span (16: measured worse -
+                                      // the controller overshoots and rolls back: 8 760 -> 16 050 stages at 14 atoms)
 
 // May this handle use the 6th-order scheme at all?  (At least half of the knots removable, not switched off.)
 static bool split_s10_allowed(const ryd_handle* h) {
@@ -224,7 +225,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
     A.ccur = h->split_coefs;
     A.N = N;
     A.T = 14;
-    const size_t lds = ((size_t)8 << 14) + SPLIT14_TRIG * 16 + 64 * 8;
+    const size_t lds = (size_t)SPLIT14_SLOTS * 8 + SPLIT14_TRIG * 16 + 64 * 8;
     static bool attr14[64] = {};
     const int dev = h->cfg.device;
     if (dev < 0 || dev >= 64 || !attr14[dev]) {

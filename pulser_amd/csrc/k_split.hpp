@@ -693,9 +693,8 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12_loop(const SplitArgs A, co
 //   LA: i = t | r << 9 (register bits 9-13, the coalesced load / store layout)     LB: i = (t & 15) | r << 4 | (t >> 4) << 9
 //   LC: i = r | t << 5 (register bits 0-4)                                         (register bits 4-8; rotates 5-8)
 // alternate LA -> LB -> LC on even stages and LC -> LB -> LA on odd ones: two turns per stage.  A turn moves the real
-// parts and then the imaginary parts through 128 KiB of LDS (8-B slots, XOR-swizzled per turn: T1 between LA and LB
-// folds index bits 9-10 into slot bits 4-5, T2 between LB and LC folds bits 5-9 into bits 0-4 - both sides of both
-// turns are conflict-free per half-wave).  The coefficients of a stage are uniform: scalar loads, SGPR operands.
+// parts and then the imaginary parts through 132 KiB of LDS (8-B slots, padded per turn so that both sides of both
+// turns are conflict-free per half-wave and every address is a lane base + an immediate).  The coefficients of a stage are uniform: scalar loads, SGPR operands.
 // E0 is never read inside the stage loop (pairwise additivity: 12 doubles per lane + two 32-entry tables, see below).
 // Arithmetic per amplitude and stage (real drives): a rotation is  x' = x - T y_p,  y' = y + T x_p  with T = gi / C
 // (SplitRun.tan_form: k_split_coefs stores it in the unused Re g slot; host_split.hpp keeps |beta c| <= 1) - 2 FMAs per
@@ -704,12 +703,13 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12_loop(const SplitArgs A, co
 // degree-5 series on |r| <= pi / 512.
 #define SPLIT14_NT 512
 #define SPLIT14_TRIG 512
+#define SPLIT14_SLOTS (16384 + 512)
 template <bool REAL>
 __global__ __launch_bounds__(SPLIT14_NT) void k_split14_loop(const SplitArgs A, const SplitRun R, long long stage_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int N = 14;
-  double* xs = reinterpret_cast<double*>(smem);          // 2^14 x 8 B
-  cplx* trig = reinterpret_cast<cplx*>(xs + (1 << N));   // 512 x 16 B
+  double* xs = reinterpret_cast<double*>(smem);             // (2^14 + 512 pads) x 8 B
+  cplx* trig = reinterpret_cast<cplx*>(xs + SPLIT14_SLOTS);  // 512 x 16 B
 
   const unsigned t = threadIdx.x;
   const int b = blockIdx.y;
@@ -755,8 +755,14 @@ __global__ __launch_bounds__(SPLIT14_NT) void k_split14_loop(const SplitArgs A, 
   auto iA = [](unsigned tt, int r) -> unsigned { return tt | (unsigned)(r << 9); };
   auto iB = [](unsigned tt, int r) -> unsigned { return (tt & 15u) | (unsigned)(r << 4) | ((tt >> 4) << 9); };
   auto iC = [](unsigned tt, int r) -> unsigned { return (unsigned)r | (tt << 5); };
-  auto slot1 = [](unsigned i) -> unsigned { return i ^ (((i >> 9) & 3u) << 4); };
-  auto slot2 = [](unsigned i) -> unsigned { return i ^ ((i >> 5) & 31u); };
+  // LDS slots (8 B) of index i: padded, not XOR-swizzled, so that every address is (a per-lane base) + (a
+  // compile-time offset of the register): T1 (LA <-> LB) pads 16 slots per 512, T2 (LB <-> LC) one slot per 32.
+  //   LA side of T1: t + 528 r            LB side of T1: [a + 528 T] + 16 r'           (a = t & 15, T = t >> 4)
+  //   LB side of T2: [a + 528 T] + 16 r + (r >> 1)                LC side of T2: 33 t + r
+  // Banks (4 B, 64 of them; a ds_*_b64 serves 32 lanes per pass): LA: consecutive lanes; LB (either turn): 2a (+ 32
+  // for odd T); LC: 2 (t + r) mod 64 - all conflict-free.
+  auto slot1 = [](unsigned i) -> unsigned { return i + ((i >> 9) << 4); };
+  auto slot2 = [](unsigned i) -> unsigned { return i + (i >> 5); };
 
   // the coefficients of the current stage, by index bit p (atom N - 1 - p): uniform values, moved to scalar registers
   // (v_readfirstlane) so that they are free operands of the vector arithmetic and hold no vector registers
@@ -851,11 +857,9 @@ __global__ __launch_bounds__(SPLIT14_NT) void k_split14_loop(const SplitArgs A, 
       xi[r] = fma(ay, c, -ax * sn);
     }
   };
-  // (the lane index is made opaque per turn: slot addresses are a few integer operations each and must not be hoisted
-  // out of the stage loop - 4 turns x 64 addresses would live in registers the state needs, i.e. in scratch)
   auto turn = [&](auto from, auto to, auto slot) {
     unsigned tt = t;
-    asm volatile("" : "+v"(tt));
+    asm volatile("" : "+v"(tt));  // (lane bases recomputed per turn: a few integer operations, no registers held)
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 32; ++r) xs[slot(from(tt, r))] = xr[r];
