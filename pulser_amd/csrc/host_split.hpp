@@ -175,8 +175,8 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[s].idx; R.u0[s] = subs[s].u0; R.tau[s] = subs[s].tau; }
   R.tan_form = loop14 && h->drive_real ? 1 : 0;
   const int total = B * N;
-  hipLaunchKernelGGL(k_split_coefs, dim3((total + 3) / 4, n_stages), dim3(256), 0, st, h->pp_dev,
-                     h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);
+  hipLaunchKernelGGL(k_split_coefs, dim3(h->dterms_dev ? (total + 3) / 4 : (total + 255) / 256, n_stages), dim3(256), 0, st,
+                     h->pp_dev, h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);
   HIPCHK(hipGetLastError());
 
   // weight of E0 in the D of every stage

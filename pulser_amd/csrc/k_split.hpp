@@ -63,8 +63,12 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
                                                      const ryd_qdesc* __restrict__ desc,
                                                      const ryd_dterm* __restrict__ dterms, int total,
                                                      const SplitRun R, double* __restrict__ out) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  // one wave per (trajectory, atom) when extra detuning terms have to be summed (high-frequency noise); one LANE per
+  // (trajectory, atom) otherwise (dterms == nullptr: 256 items per workgroup - the wave-per-item launch of the 256 x
+  // 14-atom batch took 205 us per closed run, 8 % of the bench step)
+  const bool per_lane = dterms == nullptr;
+  const int i = per_lane ? (int)(blockIdx.x * 256 + threadIdx.x) : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int lane = per_lane ? 0 : (int)(threadIdx.x & 63);
   if (i >= total) return;
   const int j = blockIdx.y;
   const int ns = R.nsub;
