@@ -115,8 +115,10 @@ typedef struct ryd_opts {
                            dissipator rate: 4 / 2 / 1 for rates <= 0.1 / <= 0.5 / above) */
   int32_t method;       /* propagator of the multi-launch sesolve path: 0 = the library's choice (the
                            split-operator passes for two-level kets without collapse operators from 15
-                           atoms on - and for fewer than 8 sequences of 14 atoms - else the Taylor
-                           polynomial), 1 = Lanczos / Krylov subspace (batched inner products V^H w and
+                           atoms on and for fewer than 8 sequences of 14 atoms; for batches of >= 8 real-drive
+                           14-atom sequences the register-resident split-operator kernel when multi-knot
+                           steps cover half of the call's schedule, else the register-resident polynomial
+                           kernel; else the Taylor polynomial), 1 = Lanczos / Krylov subspace (batched inner products V^H w and
                            V c), 2 = split-operator (exact diagonal phases x exact single-atom rotations,
                            symmetric composition: 6th order / 10 stages over sub-steps of up to 8 knot
                            intervals where the call's schedule has such steps, else 4th order / 6 stages
@@ -297,8 +299,13 @@ int ryd_general_solve_many(ryd_handle** hs, int32_t n, void* const* states_dev, 
  * the ket kernel from 10 atoms and any batch size on, 128 = keep the Taylor
  * polynomial where ryd_opts.method 0 would choose the split-operator ket passes,
  * 256 = switch their step-size control off (one sub-step per schedule step),
- * 512 = 12-atom kets pass by pass instead of the one-launch loop over the stages,
- * 1024 = keep every CF4 step inside one knot interval (no multi-knot steps).
+ * 512 = 12- and 14-atom kets pass by pass instead of the one-launch loops over the stages
+ * (k_split12_loop, k_split14_loop),
+ * 1024 = keep every CF4 step inside one knot interval (no multi-knot steps),
+ * 2048 = 2^12-amplitude tiles of the split-operator passes where 2^13 ones are the default (21 - 23 atoms),
+ * 4096 = general path: term-by-term kernel instead of the site-fused one,
+ * 8192 = split-operator passes: the 4th-order 6-stage scheme with sub-steps that end at every knot,
+ * 16384 = batches of 14-atom sequences stay on the register-resident polynomial kernel (k_ket).
  * Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);
 
