@@ -54,9 +54,9 @@ T_SEQ_US = 3.1
 # profiles/r02_kket_isa.md): per 16 amplitudes of a lane 224 v_fma_f64 + 32 v_mul_f64 + 52..60 v_add_f64
 # = 33.25 / 33.75 flops per amplitude per half-stage (second / first half), two half-stages per stage
 KKET_FLOPS_PER_AMP_STAGE = 2 * 0.5 * (33.25 + 33.75)
-# k_split14_loop<true>: per 32 amplitudes of a lane and stage 1254.5 v_fma/v_fmac_f64 + 295 v_mul_f64 + 40 v_add_f64
+# k_split14_loop<true>: per 32 amplitudes of a lane and stage 1255 v_fma/v_fmac_f64 + 302 v_mul_f64 + 40 v_add_f64
 # + 32 v_rndne_f64 in the stage loop of the compiled kernel (tools/count_isa.py split14 -> profiles/r03_ksplit14_isa.md)
-KSPLIT14_FLOPS_PER_AMP_STAGE = (2 * 1254.5 + 295 + 40 + 32) / 32.0
+KSPLIT14_FLOPS_PER_AMP_STAGE = (2 * 1255 + 302 + 40 + 32) / 32.0
 KSPLIT14_NAME = ("k_split14_loop (register-resident split-operator kernel: one workgroup per sequence, exact phases x "
                  "single-atom rotations, 6th-order composition over multi-knot sub-steps; one launch per closed run "
                  "of <= 64 sub-steps)")

@@ -156,7 +156,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   const SplitScheme& sc = split_scheme(h);
   const int n_stages = sc.S * nsub + 1;
   if ((rc = split_ensure_tables(h, n_stages))) return rc;
-  bool loop14 = N == 14 && split_loop14(h);
+  bool loop14 = N == 14 && split_loop14(h) && (n_stages & 1);  // (the kernel runs its stages in pairs + the closing one)
   if (loop14 && h->drive_real) {
     // tan-form rotations need cos(beta |c|) away from zero: |beta c| <= 1 for every atom over every sub-step
     double bmax = 0.0;

@@ -878,42 +878,37 @@ __global__ __launch_bounds__(SPLIT14_NT) void k_split14_loop(const SplitArgs A, 
     for (int r = 0; r < 32; ++r) xi[r] = xs[slot(to(tt, r))];
   };
 
-  for (int sgi = 0; sgi < n_stages; ++sgi) {
+  // weight of E0 in the D of stage j: a_i tau (+ the last a tau carried over from the previous sub-step)
+  auto stage_w = [&](int j) -> double {
+    const bool last = j == n_stages - 1;
+    const int sub = last ? R.nsub - 1 : j / R.S, i = last ? R.S : j % R.S;
+    double w = R.a[i] * R.tau[sub];
+    if (!last && i == 0 && sub > 0) w += R.a[R.S] * R.tau[sub - 1];
+    return w;
+  };
+  // Two stages per iteration, straight-line (n_stages is odd - S is even - so the closing stage is an even one after
+  // the loop).  An if / else over the stage parity inside the loop made the two bodies use different registers for
+  // the state: 64 v_mov_b64 at every merge and, with both copies live, the spills that put 5 GB per launch on HBM.
+  for (int sgi = 0; sgi + 1 < n_stages; sgi += 2) {
     load_coefs(coefs + (size_t)sgi * stage_stride);
-    const bool last = sgi == n_stages - 1, even = !(sgi & 1);
-    double w;
-    {
-      const int sub = last ? R.nsub - 1 : sgi / R.S, i = last ? R.S : sgi % R.S;
-      w = R.a[i] * R.tau[sub];
-      if (!last && i == 0 && sub > 0) w += R.a[R.S] * R.tau[sub - 1];
-    }
-    if (even) {
-      phase(w, std::true_type{});
-      if (!last) {
-        rotate(9, 0, 5);
-        turn(iA, iB, slot1);
-        rotate(4, 1, 5);
-        turn(iB, iC, slot2);
-        rotate(0, 0, 5);
-      }
-    } else {
-      phase(w, std::false_type{});
-      if (!last) {
-        rotate(0, 0, 5);
-        turn(iC, iB, slot2);
-        rotate(4, 1, 5);
-        turn(iB, iA, slot1);
-        rotate(9, 0, 5);
-      }
-    }
+    phase(stage_w(sgi), std::true_type{});
+    rotate(9, 0, 5);
+    turn(iA, iB, slot1);
+    rotate(4, 1, 5);
+    turn(iB, iC, slot2);
+    rotate(0, 0, 5);
+    load_coefs(coefs + (size_t)(sgi + 1) * stage_stride);
+    phase(stage_w(sgi + 1), std::false_type{});
+    rotate(0, 0, 5);
+    turn(iC, iB, slot2);
+    rotate(4, 1, 5);
+    turn(iB, iA, slot1);
+    rotate(9, 0, 5);
   }
-  if ((n_stages - 1) & 1) {
+  load_coefs(coefs + (size_t)(n_stages - 1) * stage_stride);
+  phase(stage_w(n_stages - 1), std::true_type{});  // the closing D
 #pragma unroll
-    for (int r = 0; r < 32; ++r) st[(unsigned)r | (t << 5)] = make_double2(xr[r], xi[r]);
-  } else {
-#pragma unroll
-    for (int r = 0; r < 32; ++r) st[t | (unsigned)(r << 9)] = make_double2(xr[r], xi[r]);
-  }
+  for (int r = 0; r < 32; ++r) st[t | (unsigned)(r << 9)] = make_double2(xr[r], xi[r]);
 }
 
 // err[b] = max |x - y|^2 over the amplitudes (local-error estimate of the step-size controller);
