@@ -862,8 +862,8 @@ __global__ __launch_bounds__(SPLIT14_NT) void k_split14_loop(const SplitArgs A, 
     }
   };
   auto turn = [&](auto from, auto to, auto slot) {
-    unsigned tt = t;
-    asm volatile("" : "+v"(tt));  // (lane bases recomputed per turn: a few integer operations, no registers held)
+    const unsigned tt = t;  // (lane bases: 4 registers held across the loop; the 14 scratch instructions left in the
+                            // loop are reloads of the 12 E0 pieces - no stores, no HBM traffic)
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 32; ++r) xs[slot(from(tt, r))] = xr[r];
