@@ -1580,3 +1580,30 @@ def test_engine_method_names_match_the_header():
     assert engine._METHODS == {"auto": 0, "krylov": 1, "split": 2, "taylor": 3}
     with pytest.raises(ValueError, match="unknown method"):
         engine._method_code("rk4")
+
+
+def test_engine_set_path_bits_match_the_header():
+    """Every bit Engine.set_path can set is documented in the ryd_set_path comment of include/rydemu.h and is handled
+    by ryd_set_path (host_step.hpp); no two keywords share a bit."""
+    import inspect
+    import re
+
+    from pulser_amd import engine
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "rydemu.h")).read()
+    doc = hdr[hdr.index("/* Test/bench hook (bit mask)"):hdr.index("int ryd_set_path(")]
+    documented = {int(v) for v in re.findall(r"\b(\d+) =", doc)}
+    src = inspect.getsource(engine.Engine.set_path)
+    used = {int(v): kw for v, kw in re.findall(r"\((\d+) if (\w+) else 0\)", src)}
+    used[1] = "force_generic"
+    assert len(used) == len(set(used.values()))
+    assert set(used) <= documented, sorted(set(used) - documented)
+    host = open(os.path.join(root, "pulser_amd", "csrc", "host_step.hpp")).read()
+    body = host[host.index('extern "C" int ryd_set_path('):]
+    body = body[:body.index("\n}\n")]
+    handled = {int(v) for v in re.findall(r"force_generic & (\d+)\)", body)}
+    assert set(used) <= handled, sorted(set(used) - handled)
+    assert all(b & (b - 1) == 0 for b in used)  # single bits
+    params = set(inspect.signature(engine.Engine.set_path).parameters) - {"self"}
+    assert params == set(used.values()), params ^ set(used.values())
