@@ -518,6 +518,7 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
     return all > 0.0 ? merged / all : 0.0;
   };
   h->split14_auto = false;
+  h->stats.reserved[0] = 0.0;  // accumulated local-error estimate of THIS solve (the split-operator paths book it)
   double share = -1.0;
   if (h->N == 14 && o.method == 0 && o.taylor_order <= 0 && !h->force_generic && !h->no_split && !h->force_ket &&
       !h->no_split14 && split_capable(h) && ket_path(h) && h->drive_real && split_loop14(h) && split_s10_allowed(h)) {
