@@ -1607,3 +1607,31 @@ def test_engine_set_path_bits_match_the_header():
     assert all(b & (b - 1) == 0 for b in used)  # single bits
     params = set(inspect.signature(engine.Engine.set_path).parameters) - {"self"}
     assert params == set(used.values()), params ^ set(used.values())
+
+
+def test_bench_flop_constants_match_the_compiled_kernels():
+    """bench.py's roofline divides ISA-counted fp64 flops by kernel time: the constants it uses must be what
+    tools/count_isa.py counts in the kernels as compiled now (hipcc cross-compiles without a GPU)."""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    ns = {}
+    for name in ("KKET_FLOPS_PER_AMP_STAGE", "KSPLIT14_FLOPS_PER_AMP_STAGE"):
+        exec(re.search(r"^%s = .*$" % name, src, re.M).group(0), ns)
+    import tempfile
+
+    tmp = tempfile.mkdtemp()
+    asm = os.path.join(tmp, "rydemu.s")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "count_isa.py"), "split14"], check=True,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, RYD_ISA_KEEP=asm)).stdout
+    row = [l for l in out.splitlines() if re.match(r"^\| \d+ \|", l)][0]
+    cells = [c.strip() for c in row.strip("|").split("|")]
+    assert abs(float(cells[-1]) - ns["KSPLIT14_FLOPS_PER_AMP_STAGE"]) < 0.01 * ns["KSPLIT14_FLOPS_PER_AMP_STAGE"], row
+    assert int(cells[6]) <= 16, row  # scratch instructions in the stage loop: reloads of loop invariants at most
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "count_isa.py"), "0"], check=True,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, RYD_ISA_TEXT=asm)).stdout
+    per_half = [float(l.strip("|").split("|")[-1]) for l in out.splitlines() if re.match(r"^\| \d+\.\.\d+ \|", l)]
+    assert per_half and abs(2 * sum(per_half) / len(per_half) - ns["KKET_FLOPS_PER_AMP_STAGE"]) < 0.02 * ns["KKET_FLOPS_PER_AMP_STAGE"]

@@ -4,11 +4,16 @@ import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "pulser_amd", "csrc", "rydemu.hip")
-with tempfile.TemporaryDirectory() as d:
-    asm = os.path.join(d, "r.s")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                    "-Wno-unused-value", src, "-o", asm], check=True, stderr=subprocess.DEVNULL)
-    text = open(asm).read()
+if os.environ.get("RYD_ISA_TEXT"):  # (an assembly listing made earlier: the tests compile once for several counts)
+    text = open(os.environ["RYD_ISA_TEXT"]).read()
+else:
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, "r.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        "-Wno-unused-value", src, "-o", asm], check=True, stderr=subprocess.DEVNULL)
+        text = open(asm).read()
+    if os.environ.get("RYD_ISA_KEEP"):
+        open(os.environ["RYD_ISA_KEEP"], "w").write(text)
 if len(sys.argv) > 1 and sys.argv[1] == "split14":
     # k_split14_loop<true>: fp64 work of the stage loop (two unrolled stage bodies, 32 amplitudes per lane)
     m = re.search(r"^(_Z\d+k_split14_loopILb1E\w*):(.*?)s_endpgm", text, re.S | re.M)
