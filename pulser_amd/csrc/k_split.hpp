@@ -698,8 +698,8 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12_loop(const SplitArgs A, co
 //   LC: i = r | t << 5 (register bits 0-4)                                         (register bits 4-8; rotates 5-8)
 // alternate LA -> LB -> LC on even stages and LC -> LB -> LA on odd ones: two turns per stage.  A turn moves the real
 // parts and then the imaginary parts through 132 KiB of LDS (8-B slots, padded per turn so that both sides of both
-// turns are conflict-free per half-wave and every address is a lane base + an immediate).  The coefficients of a stage are uniform: scalar loads, SGPR operands.
-// E0 is never read inside the stage loop (pairwise additivity: 12 doubles per lane + two 32-entry tables, see below).
+// turns are conflict-free per half-wave and every address is a lane base + an immediate).  The coefficients of a
+// stage are uniform: scalar loads, SGPR operands.  E0 is never read inside the stage loop (pairwise additivity: 12 doubles per lane + two 32-entry tables, see below).
 // Arithmetic per amplitude and stage (real drives): a rotation is  x' = x - T y_p,  y' = y + T x_p  with T = gi / C
 // (SplitRun.tan_form: k_split_coefs stores it in the unused Re g slot; host_split.hpp keeps |beta c| <= 1) - 2 FMAs per
 // amplitude and bit instead of 2 + 2 - and the product of the 14 cosines of a stage, one number, rides on the next
@@ -768,10 +768,10 @@ __global__ __launch_bounds__(SPLIT14_NT) void k_split14_loop(const SplitArgs A, 
   auto slot1 = [](unsigned i) -> unsigned { return i + ((i >> 9) << 4); };
   auto slot2 = [](unsigned i) -> unsigned { return i + (i >> 5); };
 
-  // the coefficients of the current stage, by index bit p (atom N - 1 - p): uniform values, moved to scalar registers
-  // (v_readfirstlane) so that they are free operands of the vector arithmetic and hold no vector registers
-  // (read through the constant address space: uniform addresses there are scalar loads - all of a stage's issued
-  // back to back, one wait; as vector loads + v_readfirstlane the compiler waited per atom: 14 L2 round trips = 10 us)
+  // the coefficients of the current stage, by index bit p (atom N - 1 - p): uniform values, read through the constant
+  // address space so that they are scalar loads (all of a stage's issued back to back, one wait) into scalar
+  // registers - free operands of the vector arithmetic, no vector registers held.  (As vector loads +
+  // v_readfirstlane the compiler waited per atom; fetched a stage ahead through lanes + v_readlane: slower)
   typedef const __attribute__((address_space(4))) double* cptr_t;
   double cC[N], cT[N], cGi[N], cDl[N];
   double cprod = 1.0;  // product of the cosines of the previous stage's rotations (tan form): rides on this stage's phase
