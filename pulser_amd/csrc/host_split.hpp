@@ -235,7 +235,16 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
     }
     std::pair<hipEvent_t, hipEvent_t> ev1;
     if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
-    if (h->drive_real)
+    if (h->drive_real && !h->split_turns) {
+      // round 4: lane bits over the DPP crossbar / permlane swaps, one LDS pass per stage (k_split_lane.hpp)
+      const size_t lds_lane = (size_t)2 * 512 * 8 * 16 + SPLITL_TRIG * 16 + 8 * 32 * 16;
+      static bool attr_lane[64] = {};
+      if (dev < 0 || dev >= 64 || !attr_lane[dev]) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_split_lane<14, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev >= 0 && dev < 64) attr_lane[dev] = true;
+      }
+      hipLaunchKernelGGL((k_split_lane<14, false>), dim3(1, B), dim3(512), lds_lane, st, A, R, (long long)B * N * 4);
+    } else if (h->drive_real)
       hipLaunchKernelGGL(k_split14_loop<true>, dim3(1, B), dim3(SPLIT14_NT), lds, st, A, R, (long long)B * N * 4);
     else
       hipLaunchKernelGGL(k_split14_loop<false>, dim3(1, B), dim3(SPLIT14_NT), lds, st, A, R, (long long)B * N * 4);
