@@ -82,7 +82,7 @@ struct ryd_handle {
   bool split14_auto = false;      // this solve: a 14-atom batch goes to k_split14_loop instead of k_ket (host_step.hpp)
   bool no_split14 = false;        // test / bench hook: keep 14-atom batches on k_ket
   bool split_turns = false;       // test / bench hook: 14-atom one-launch runs on k_split14_loop (two LDS turns per stage,
-                                  // round 3) instead of k_split_lane
+                                  // round 3) instead of k_split_reg
   bool split_s10 = false;         // scheme of the current split-operator solve (host_step.hpp decides per call)
   bool split_s6_only = false;     // test / bench hook: the 4th-order scheme with one-knot sub-steps (round 2)
   void* many_args_dev = nullptr;  // ryd_general_solve_many: argument table of the batched launch (first handle)

@@ -141,10 +141,11 @@ static int split_max_sub(const ryd_handle* h) {
   return (int)std::min<size_t>(kSplitMaxSub, std::max<size_t>(1, ((size_t)32 << 20) / per_sub));
 }
 
-// 14-atom kets in one launch per closed run (k_split14_loop: register-resident, one workgroup per sequence)?  From 8
-// sequences on (below, the passes spread each ket over 4 CUs); not for quantum-jump solves (no decay table there).
+// 14-atom kets in one launch per closed run (k_split_reg: register-resident, one workgroup per sequence)?  Any batch
+// size since round 4 (a stage of the one-launch kernel takes less than a 4-tile pass + its launch; the round-3 kernel
+// keeps its threshold of 8 sequences); not for quantum-jump solves yet.
 static bool split_loop14(const ryd_handle* h) {
-  return h->N == 14 && !h->mc && !h->split_no_loop && (h->B >= 8 || h->force_ket);
+  return h->N == 14 && !h->mc && !h->split_no_loop && (h->B >= 8 || h->force_ket || (h->drive_real && !h->split_turns));
 }
 
 // Advance `buf` over `subs` (consecutive sub-steps, at most split_max_sub) from a closed state to
@@ -236,14 +237,20 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
     std::pair<hipEvent_t, hipEvent_t> ev1;
     if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
     if (h->drive_real && !h->split_turns) {
-      // round 4: lane bits over the DPP crossbar / permlane swaps, one LDS pass per stage (k_split_lane.hpp)
-      const size_t lds_lane = (size_t)2 * 512 * 8 * 16 + SPLITL_TRIG * 16 + 8 * 32 * 16;
-      static bool attr_lane[64] = {};
-      if (dev < 0 || dev >= 64 || !attr_lane[dev]) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_split_lane<14, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (dev >= 0 && dev < 64) attr_lane[dev] = true;
+      // round 4 (k_split_reg.hpp): lane bits over the DPP crossbar / permlane swaps, one chunked LDS pass per stage.
+      // RYD_SPLIT_NR=6 (dev A/B): 64 amplitudes per lane on 256 lanes instead of 32 on 512 (measured slower)
+      static const int nr_env = [] { const char* e = std::getenv("RYD_SPLIT_NR"); return e ? std::atoi(e) : 5; }();
+      const size_t lds_reg = (size_t)2 * 512 * 8 * 16 + SPLITR_TRIG * 16 + 8 * 32 * 16 + (SPLIT_MAX_SUB * SPLIT_MAX_STAGES + 2) * 8 + 4 * 512 * 8;
+      static bool attr_reg[64] = {};
+      if (dev < 0 || dev >= 64 || !attr_reg[dev]) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<14, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<14, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev >= 0 && dev < 64) attr_reg[dev] = true;
       }
-      hipLaunchKernelGGL((k_split_lane<14, false>), dim3(1, B), dim3(512), lds_lane, st, A, R, (long long)B * N * 4);
+      if (nr_env == 6)
+        hipLaunchKernelGGL((k_split_reg<14, 6, false>), dim3(1, B), dim3(256), lds_reg, st, A, R, (long long)B * N * 4);
+      else
+        hipLaunchKernelGGL((k_split_reg<14, 5, false>), dim3(1, B), dim3(512), lds_reg, st, A, R, (long long)B * N * 4);
     } else if (h->drive_real)
       hipLaunchKernelGGL(k_split14_loop<true>, dim3(1, B), dim3(SPLIT14_NT), lds, st, A, R, (long long)B * N * 4);
     else

@@ -58,7 +58,7 @@ typedef double2 cplx;
 #include "k_ket.hpp"
 #include "k_krylov.hpp"
 #include "k_split.hpp"
-#include "k_split_lane.hpp"
+#include "k_split_reg.hpp"
 #include "k_observe.hpp"
 #include "k_general.hpp"
 #include "host_handle.hpp"

@@ -392,7 +392,7 @@ class Engine:
         ``split_small_tiles`` keeps the 2^12 tiles of the split-operator passes where 2^14 tiles are the default
         (21 - 23 atoms); ``no_split14`` keeps batches of 14-atom sequences on the polynomial
         register-resident kernel (k_ket) instead of the split-operator one (k_split14_loop);
-        ``split_turns`` runs them on the round-3 kernel (two LDS turns per stage) instead of k_split_lane;
+        ``split_turns`` runs them on the round-3 kernel (two LDS turns per stage) instead of k_split_reg;
         ``split_s6`` keeps the 4th-order composition with sub-steps that end at every knot
         (round 2) where the 6th-order one with multi-knot sub-steps is the default."""
         _lib.check(self.lib.ryd_set_path(

@@ -1,4 +1,4 @@
-"""Dev probe (round 4): 14-atom batches on k_split_lane (lane bits over the DPP crossbar / permlane swaps, one LDS
+"""Dev probe (round 4): 14-atom batches on k_split_reg (lane bits over the DPP crossbar / permlane swaps, one LDS
 pass per stage) against k_split14_loop (round 3: two LDS turns per stage) and the pass-by-pass launches.
   python tools/lane_bench.py [B] [t1]"""
 import os, sys, time
@@ -42,7 +42,7 @@ for t0, te in ((0.0, 0.62), (2.4, 3.1)):
 # 2. the headline batch
 probs = problems(B)
 res = {}
-for name, kw in (("k_split_lane", {}), ("k_split14_loop", {"split_turns": True})):
+for name, kw in (("k_split_reg", {}), ("k_split14_loop", {"split_turns": True})):
     with Engine.from_problems(probs, mode="sesolve") as eng:
         eng.set_path(False, **kw)
         st = eng.new_state(); eng.evolve(st, 0.0, min(t1, 0.2))
@@ -56,4 +56,4 @@ for name, kw in (("k_split_lane", {}), ("k_split14_loop", {"split_turns": True})
         print(f"B={B} {name:15s}: {B * t1 / best:8.1f} sim-us/s ({best * 1e3:.1f} ms), stages {s['n_applications']}, launches {s['n_launches']}, "
               f"{best * 1e6 / max(s['n_applications'], 1):.2f} us per stage (wall), estimate {s['reserved'][0]:.2e}, "
               f"norm-1 {np.max(np.abs(np.linalg.norm(res[name], axis=1) - 1)):.1e}", flush=True)
-print(f"max |lane - turns| = {np.max(np.abs(res['k_split_lane'] - res['k_split14_loop'])):.2e}")
+print(f"max |lane - turns| = {np.max(np.abs(res['k_split_reg'] - res['k_split14_loop'])):.2e}")
