@@ -82,8 +82,9 @@ static bool split_selected(const ryd_handle* h, const ryd_opts& o) {
   if (!split_capable(h)) return false;
   if (o.method == 2) return true;
   if (o.method != 0 || o.taylor_order > 0 || h->force_generic || h->no_split) return false;
-  // 14 atoms: batches of >= 8 real-drive sequences stay on the register-resident k_ket
-  return h->N >= 15 || (h->N == 14 && (!ket_path(h) || h->split14_auto));
+  // 12 - 14 atoms: ryd_solve decides per call (split14_auto: the register-resident split-operator kernel when the
+  // call's schedule is mostly multi-knot steps); 14 atoms without a register-resident alternative: the passes
+  return h->N >= 15 || (h->N == 14 && (!ket_path(h) || h->split14_auto)) || (h->N >= 12 && h->N <= 13 && h->split14_auto);
 }
 
 // Tilings: the low T bits, then tilings of the remaining high bits (at most 8 each) that keep
@@ -141,11 +142,48 @@ static int split_max_sub(const ryd_handle* h) {
   return (int)std::min<size_t>(kSplitMaxSub, std::max<size_t>(1, ((size_t)32 << 20) / per_sub));
 }
 
+// Whole kets of 12 - 14 atoms with real drives run on k_split_reg (below)
+static bool split_reg_shape(const ryd_handle* h) {
+  return h->N >= 12 && h->N <= 14 && h->drive_real && !h->split_turns && !h->split_no_loop;
+}
+
 // 14-atom kets in one launch per closed run (k_split_reg: register-resident, one workgroup per sequence)?  Any batch
 // size since round 4 (a stage of the one-launch kernel takes less than a 4-tile pass + its launch; the round-3 kernel
 // keeps its threshold of 8 sequences); not for quantum-jump solves yet.
 static bool split_loop14(const ryd_handle* h) {
-  return h->N == 14 && !h->mc && !h->split_no_loop && (h->B >= 8 || h->force_ket || (h->drive_real && !h->split_turns));
+  if (split_reg_shape(h)) return h->N == 14;
+  return h->N == 14 && !h->mc && !h->split_no_loop && (h->B >= 8 || h->force_ket);
+}
+
+// Whole kets of 12 - 14 atoms with real drives: every stage of a closed run in ONE launch of k_split_reg (k_split_reg.hpp,
+// round 4), the ket register-resident, one workgroup per sequence (14 atoms: one per CU; 13: two; 12: three).
+// Quantum-jump solves included (the decay factor of H_eff rides on the phase factors: template parameter DECAY).
+template <int N>
+static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R, hipStream_t st) {
+  constexpr int NT = 64 << (N - 11);
+  // RYD_SPLIT_NR=6 (dev A/B, 14 atoms only): 64 amplitudes per lane on 256 lanes instead of 32 on 512 (measured slower)
+  static const int nr_env = [] { const char* e = std::getenv("RYD_SPLIT_NR"); return e ? std::atoi(e) : 5; }();
+  const size_t lds = (size_t)2 * NT * 8 * 16 + SPLITR_TRIG * 16 + (size_t)(NT / 64) * 32 * 16 +
+                     (SPLIT_MAX_SUB * SPLIT_MAX_STAGES + 2) * 8 + (SPLITR_EMODE ? 4 * NT * 8 : 0);
+  const int dev = h->cfg.device;
+  static bool attr[64] = {};
+  if (dev < 0 || dev >= 64 || !attr[dev]) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if constexpr (N == 14)
+      HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<14, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (dev >= 0 && dev < 64) attr[dev] = true;
+  }
+  const long long stride = (long long)h->B * N * 4;
+  if (h->mc)
+    hipLaunchKernelGGL((k_split_reg<N, 5, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
+  else if (N == 14 && nr_env == 6) {
+    if constexpr (N == 14)
+      hipLaunchKernelGGL((k_split_reg<14, 6, false>), dim3(1, h->B), dim3(256), lds, st, A, R, stride);
+  } else
+    hipLaunchKernelGGL((k_split_reg<N, 5, false>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
+  HIPCHK(hipGetLastError());
+  return RYD_OK;
 }
 
 // Advance `buf` over `subs` (consecutive sub-steps, at most split_max_sub) from a closed state to
@@ -157,16 +195,18 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   const SplitScheme& sc = split_scheme(h);
   const int n_stages = sc.S * nsub + 1;
   if ((rc = split_ensure_tables(h, n_stages))) return rc;
-  bool loop14 = N == 14 && split_loop14(h) && (n_stages & 1);  // (the kernel runs its stages in pairs + the closing one)
-  if (loop14 && h->drive_real) {
+  bool reg_loop = split_reg_shape(h);
+  bool loop14 = N == 14 && split_loop14(h) && ((n_stages & 1) || reg_loop);  // (k_split14_loop runs its stages in pairs + the closing one)
+  if ((loop14 || reg_loop) && h->drive_real) {
     // tan-form rotations need cos(beta |c|) away from zero: |beta c| <= 1 for every atom over every sub-step
     double bmax = 0.0;
     for (int i = 0; i < sc.S; ++i) bmax = std::max(bmax, std::fabs(sc.b[i]));
-    for (int s = 0; s < nsub && loop14; ++s) {
+    for (int s = 0; s < nsub && (loop14 || reg_loop); ++s) {
       const int span = std::max(1, (int)std::ceil((subs[s].u0 + subs[s].tau) / (h->tknots[subs[s].idx + 1] - h->tknots[subs[s].idx]) - 1e-9));
-      if (span_max(h->bd_c1, subs[s].idx, std::min(span, (int)h->bd_c1.size() - subs[s].idx)) * bmax * subs[s].tau > 1.0) loop14 = false;
+      if (span_max(h->bd_c1, subs[s].idx, std::min(span, (int)h->bd_c1.size() - subs[s].idx)) * bmax * subs[s].tau > 1.0) loop14 = reg_loop = false;
     }
   }
+  if (reg_loop && N == 14 && !loop14) reg_loop = false;
   SplitRun R;
   std::memset(&R, 0, sizeof R);
   R.nsub = nsub;
@@ -174,7 +214,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   for (int i = 0; i <= sc.S; ++i) R.a[i] = sc.a[i];
   for (int i = 0; i < sc.S; ++i) R.b[i] = sc.b[i];
   for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[s].idx; R.u0[s] = subs[s].u0; R.tau[s] = subs[s].tau; }
-  R.tan_form = loop14 && h->drive_real ? 1 : 0;
+  R.tan_form = (loop14 || reg_loop) && h->drive_real ? 1 : 0;
   const int total = B * N;
   hipLaunchKernelGGL(k_split_coefs, dim3(h->dterms_dev ? (total + 3) / 4 : (total + 255) / 256, n_stages), dim3(256), 0, st,
                      h->pp_dev, h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);
@@ -192,6 +232,27 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
 
   const std::vector<Pass>& til = h->split_tilings;
   const int m = (int)til.size();
+  if (reg_loop) {
+    SplitArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.state = buf;
+    A.e0 = h->e0_dev;
+    A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << N);
+    A.ccur = h->split_coefs;
+    A.N = N;
+    A.T = N;
+    A.dec_a = h->mc_a;  // H_eff: the decay diagonal a + b popc(index) over the D time of every stage
+    A.dec_b = h->mc_b;
+    std::pair<hipEvent_t, hipEvent_t> ev1;
+    if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
+    rc = N == 14 ? launch_split_reg<14>(h, A, R, st) : N == 13 ? launch_split_reg<13>(h, A, R, st) : launch_split_reg<12>(h, A, R, st);
+    if (rc) return rc;
+    if (h->timing) { HIPCHK(hipEventRecord(ev1.second, st)); h->ev_used.push_back(ev1); }
+    h->stats.n_launches++;
+    h->stats.n_applications += n_stages - 1;
+    h->stats.passes = 1;
+    return RYD_OK;
+  }
   if (m == 1 && N == 12 && !h->split_no_loop && !h->mc) {
     // the whole ket is one tile: every stage of the run in one launch, the ket stays in registers
     SplitArgs A;
@@ -236,22 +297,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
     }
     std::pair<hipEvent_t, hipEvent_t> ev1;
     if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
-    if (h->drive_real && !h->split_turns) {
-      // round 4 (k_split_reg.hpp): lane bits over the DPP crossbar / permlane swaps, one chunked LDS pass per stage.
-      // RYD_SPLIT_NR=6 (dev A/B): 64 amplitudes per lane on 256 lanes instead of 32 on 512 (measured slower)
-      static const int nr_env = [] { const char* e = std::getenv("RYD_SPLIT_NR"); return e ? std::atoi(e) : 5; }();
-      const size_t lds_reg = (size_t)2 * 512 * 8 * 16 + SPLITR_TRIG * 16 + 8 * 32 * 16 + (SPLIT_MAX_SUB * SPLIT_MAX_STAGES + 2) * 8 + 4 * 512 * 8;
-      static bool attr_reg[64] = {};
-      if (dev < 0 || dev >= 64 || !attr_reg[dev]) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<14, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<14, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (dev >= 0 && dev < 64) attr_reg[dev] = true;
-      }
-      if (nr_env == 6)
-        hipLaunchKernelGGL((k_split_reg<14, 6, false>), dim3(1, B), dim3(256), lds_reg, st, A, R, (long long)B * N * 4);
-      else
-        hipLaunchKernelGGL((k_split_reg<14, 5, false>), dim3(1, B), dim3(512), lds_reg, st, A, R, (long long)B * N * 4);
-    } else if (h->drive_real)
+    if (h->drive_real)
       hipLaunchKernelGGL(k_split14_loop<true>, dim3(1, B), dim3(SPLIT14_NT), lds, st, A, R, (long long)B * N * 4);
     else
       hipLaunchKernelGGL(k_split14_loop<false>, dim3(1, B), dim3(SPLIT14_NT), lds, st, A, R, (long long)B * N * 4);

@@ -6,8 +6,8 @@
 
 Names (default: rydberg digital three cfg1 cfg2 cfg3 cfg4): rydberg, digital, xy, all, three, cfg1..cfg4,
 spam_all, results_noisy, final_state_noisy, slm_effective_size, slm_masks, modulation, eom_limit_det,
-multichannel_noise, dmm, results, waist, config, ns14 (14-atom headline, tight), cfg3_8 / cfg3_10
-(interacting 8- / 10-atom Lindblad, tight).
+multichannel_noise, dmm, results, waist, config, ns14 (14-atom headline, tight), cfg3_8 / cfg3_10 / cfg3_12
+(interacting 8- / 10- / 12-atom Lindblad, tight), rect16 (16-atom square register, tight).
 
 * Inputs are captured by importing the reference's ``pulser-core`` (read-only,
   never shipped; needs the no-op ``jsonschema``/``referencing`` stand-in of
@@ -1096,6 +1096,40 @@ def gen_ns_tri14(rows=2, cols=7, name="ns_tri14_anneal"):
     )
 
 
+def gen_ns_rect16(rows=4, cols=4, name="ns_rect16_anneal"):
+    """SURVEY 8(d) cfg5 row, "oracle at N <= 16": 16-atom 4 x 4 square register at the blockade radius, the same anneal,
+    sesolve, tight oracle (zvode rtol 1e-13) at four times incl. T - the register size from which the split-operator
+    passes (and the Lanczos alternative) are the product's default.  Tens of minutes of one core; 4 MiB of kets."""
+    import time
+    rb = blockade_radius()
+    reg = Register.rectangle(rows, cols, rb, prefix="q")
+    problems, aux, _ = capture(anneal_sequence(reg), None)
+    p = problems[0]
+    n = p["n_qudits"]
+    coords = P.register_coords(P.square_rect(rows, cols), rb)
+    assert np.allclose(coords, p["coords"], rtol=0, atol=1e-12), (coords, p["coords"])
+    syn = P.anneal_samples()
+    for k in ("amp", "det", "phase"):
+        assert np.array_equal(syn[k], p["samples"]["Global"]["ground-rydberg"][k]), k
+    sel_t = np.array([0.0, 0.5, 1.3, 2.1, 3.1])
+    counter = [0]
+    t0 = time.time()
+    opts = dict(aux["options"])
+    opts.update(qp.TIGHT)
+    tight = qp.sesolve(qp.build_hamiltonian(p), qp.all_ground_state(n, p["eigenbasis"]), sel_t, counter=counter, **opts)
+    print(f"{name}: tight zvode {counter[0]} RHS evals in {time.time() - t0:.1f}s; norm drift {np.linalg.norm(tight[-1]) - 1:.2e}", flush=True)
+    small = {k: v for k, v in p.items() if k != "samples"}
+    small["samples"] = {"Global": {}, "Local": {}}
+    P.save_problem(
+        os.path.join(HERE, name + ".npz"), small, aux={k: v for k, v in aux.items() if k not in ("eval_times", "channel_amp_det")},
+        synthetic=f"anneal_samples() on a {rows} x {cols} square register at the blockade radius",
+        rows=rows, cols=cols, blockade_radius=float(rb),
+        eval_times=sel_t,
+        oracle_states_tight=np.stack(tight[1:]),  # (t = 0 is the all-ground ket)
+        oracle_rhs_evals_tight=counter[0],
+    )
+
+
 def gen_cfg3_tight(rows=2, cols=4):
     """cfg3 physics on an INTERACTING triangular register large enough for the split-operator row
     path (k_ket rows need >= 10 atoms; 8 atoms for the multi-launch kernels): tight oracle only."""
@@ -1439,6 +1473,10 @@ if __name__ == "__main__":
         gen_cfg3_tight(2, 4)
     if "cfg3_10" in which:
         gen_cfg3_tight(2, 5)
+    if "cfg3_12" in which:
+        gen_cfg3_tight(2, 6)
+    if "rect16" in which:
+        gen_ns_rect16()
     if "spam_all" in which:
         gen_noise_spam_all()
     if "results_noisy" in which:

@@ -116,3 +116,27 @@ def test_multi_launch_lindbladian_interacting_against_tight_oracle(fixture, n):
         assert max(errs.values()) < AMP_TOL, (k, errs)
     if n <= 8:  # small enough to keep every entry
         assert max(_worst(snaps, tight_density_matrices(extra, n))) < AMP_TOL
+
+
+# ---- 16 atoms: the sizes where the split-operator passes are the default ("oracle at N <= 16") ----
+
+@pytest.fixture(scope="module")
+def ns16():
+    prob, extra = load_fixture("ns_rect16_anneal.npz")
+    return with_anneal_samples(prob), np.asarray(extra["eval_times"]), np.asarray(extra["oracle_states_tight"])
+
+
+@pytest.mark.parametrize("method", ["auto", "krylov", "taylor"])
+def test_16_atom_square_register_full_anneal_against_tight_oracle(ns16, method):
+    """4 x 4 square register at R_b, full anneal, zvode rtol 1e-13 (25 673 right-hand sides) at 0.5, 1.3, 2.1 and 3.1
+    us: the default path of 15+ atoms (split-operator passes, 6th-order composition over multi-knot sub-steps, its
+    own step-size controller), the Lanczos exponential (cfg5's named solver) and CF4 + Taylor, every stored time."""
+    prob, times, ref = ns16
+    with _engine([prob]) as eng:
+        snaps = eng.solve(eng.new_state(), times, method=method).cpu().numpy()[:, 0]
+        st = eng.stats()
+    errs = [float(np.max(np.abs(snaps[k] - ref[k])) ) for k in range(len(ref))]
+    assert max(errs) < AMP_TOL, (method, errs)
+    if method == "auto":  # the split-operator passes: many launches, an error estimate that covers the truth
+        assert st["reserved"][0] > 0 and st["n_launches"] >= st["n_applications"]
+        assert st["reserved"][0] < AMP_TOL and max(errs) < max(4 * st["reserved"][0], 2e-9), (errs, st["reserved"])
