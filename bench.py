@@ -14,7 +14,7 @@ Default workload = the north-star target (BASELINE.json): the 14-atom triangular
                    value = GPUs x batch x 3.1 us / seconds-per-step.  Multi-GPU: sequences shard
                    over the ranks, no data-path collective; one all-reduce (RCCL) of the ensemble
                    occupation sums per step.
-  single_sequence  ONE 14-atom sequence, full 3.1 us (latency; split-operator passes, 4 tiles).
+  single_sequence  ONE 14-atom sequence, full 3.1 us (latency; the one-launch split-operator kernel on one CU).
   lindblad         cfg3: 14-atom dephasing master equation (rho = 4.29 GB), `--lindblad-ns` ns slice
                    (default 100) through the split-operator row path; `--full-lindblad` runs all 3.1 us.
   setup            handle creation + table upload, timed separately (not inside a step).
@@ -25,7 +25,12 @@ Default workload = the north-star target (BASELINE.json): the 14-atom triangular
                    N = 1 only: primary = one 14-atom sequence on one core; `legs` = the other
                    baselines SURVEY 8(d) lists.
   also             secondary workloads (12-atom batch = the round-1 headline, quantum jumps, small
-                   density matrices, ensemble density matrix, cfg5 slice).
+                   density matrices, ensemble density matrix, cfg4 end to end - 1024 noise trajectories through
+                   run_ensemble with and without the density-matrix sum -, cfg5: 20 atoms over the full 3.1 us with
+                   the Lanczos figure beside it, 24-atom slice).
+  parity_max_abs   sequence 0 of the timed batch against the tight-oracle fixture of the same register (the line is
+                   not printed beyond 1e-7).
+  collective       N > 1: backend, world size, PCI bus ids of the ranks' devices (all-gathered), an all-reduce of ones.
 """
 from __future__ import annotations
 
@@ -57,9 +62,17 @@ KKET_FLOPS_PER_AMP_STAGE = 2 * 0.5 * (33.25 + 33.75)
 # k_split14_loop<true>: per 32 amplitudes of a lane and stage 1255 v_fma/v_fmac_f64 + 302 v_mul_f64 + 40 v_add_f64
 # + 32 v_rndne_f64 in the stage loop of the compiled kernel (tools/count_isa.py split14 -> profiles/r03_ksplit14_isa.md)
 KSPLIT14_FLOPS_PER_AMP_STAGE = (2 * 1255 + 302 + 40 + 32) / 32.0
-KSPLIT14_NAME = ("k_split14_loop (register-resident split-operator kernel: one workgroup per sequence, exact phases x "
-                 "single-atom rotations, 6th-order composition over multi-knot sub-steps; one launch per closed run "
-                 "of <= 64 sub-steps)")
+KSPLIT14_NAME = ("k_split14_loop (round-3 register-resident split-operator kernel: two LDS turns per stage; "
+                 "set_path(split_turns=True))")
+# k_split_reg<14, 5>: per 32 amplitudes of a lane and stage (ONE stage body in the loop) 687 v_fma_f64 + 475 v_fmac_f64
+# + 241 v_mul_f64 + 9 v_add_f64 + 7 v_rndne_f64 (tools/count_isa.py splitreg -> profiles/r04_ksplitreg_isa.md)
+KSPLITREG_FLOPS_PER_AMP_STAGE = (2 * (687 + 475) + 241 + 9 + 7) / 32.0
+# the same stage counted on paper: 14 tan-form rotations (2 FMAs each) + one complex multiplication by the phase
+# factor; everything else the kernel spends (building the phase factors, range reduction) is overhead, not work
+SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE = 14 * 2 * 2 + 6.0
+KSPLITREG_NAME = ("k_split_reg<14, 5> (register-resident split-operator kernel: one workgroup per sequence, exact phases x "
+                  "single-atom rotations, 6th-order composition over multi-knot sub-steps; lane bits over the DPP crossbar / "
+                  "permlane swaps, one chunked LDS pass per stage; one launch per closed run of <= 64 sub-steps)")
 # k_traj<12,1024,1>: 120 fp64 instructions per wave and stage for 4 amplitudes per lane
 # (profiles/r01_ktraj_counters.md), ~85 % of them FMAs
 KTRAJ_FLOPS_PER_AMP_STAGE = 120 * 1.85 / 4.0
@@ -134,10 +147,14 @@ def all_reduce(dist, t, op=None):
 def timed_run(eng, state_fn, t0, t1, steps, warmup, dist=None, torch=None, **opts):
     """W warm-up + K timed passes over [t0, t1] (no per-launch events inside the timed region),
     then ONE more pass with the library's HIP-event pairs around every launch for the roofline.
-    Returns (sec/step, stats of one step, kernel ms of one step, launches of one step, last occ)."""
+    Returns (sec/step, stats of one step, kernel ms of one step, launches of one step, last occ); the state the
+    event-timed pass ended in is kept in `timed_run.last_state` (the in-process parity check reads it)."""
     for _ in range(warmup):
         st = state_fn()
         eng.evolve(st, t0, t1, **opts)
+        occ = eng.occupations(st).sum(dim=0)  # (the first call of a torch reduction loads its code object: ~10 ms)
+        if dist is not None:
+            all_reduce(dist, occ)
     barrier(torch, dist)
     eng.reset_stats()
     states = [state_fn() for _ in range(steps)]
@@ -166,6 +183,7 @@ def timed_run(eng, state_fn, t0, t1, steps, warmup, dist=None, torch=None, **opt
     torch.cuda.synchronize()
     kms, kl = eng.kernel_timing()
     eng.set_kernel_timing(False)
+    timed_run.last_state = st
     return dt / steps, stats, kms, kl, occ
 
 
@@ -205,13 +223,16 @@ def roofline_hbm(nb, batch, stats, kernel_ms, launches, kernel_name, traffic_key
             "unit": "GB/s", "frac": achieved / HBM_PEAK,
             **traffic_fields(traffic_key),
             "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1), "applications": apps,
+            "us_per_stage": kernel_ms * 1e3 / max(apps, 1),
             "algorithmic_bytes_per_launch": bytes_total / max(launches, 1)}
 
 
 def roofline_valu(n_amp, rows, stages, flops_per_amp_stage, kernel_ms, launches, kernel_name,
-                  traffic_key=None, note=None):
+                  traffic_key=None, note=None, algorithmic_flops_per_amp_stage=None):
     """Register / LDS-resident kernels: the state never streams through HBM, the fp64 vector pipe
-    binds.  achieved = algorithmic fp64 flops (ISA count per amplitude per stage) / kernel time."""
+    binds.  achieved = fp64 flops the kernel ISSUES (ISA count per amplitude per stage) / kernel time; the bare
+    algorithmic count (what the stage needs on paper) and the time per stage stand beside it, because a cheaper
+    evaluation lowers `frac` while making the kernel faster."""
     flops = flops_per_amp_stage * n_amp * rows * stages
     sec = kernel_ms * 1e-3
     tf = flops / sec / 1e12 if sec > 0 else 0.0
@@ -219,9 +240,15 @@ def roofline_valu(n_amp, rows, stages, flops_per_amp_stage, kernel_ms, launches,
            "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK,
            **traffic_fields(traffic_key),
            "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
-           "stages": stages, "flops_per_amplitude_per_stage": flops_per_amp_stage,
-           "algorithmic_flops_per_launch": flops / max(launches, 1),
+           "stages": stages, "us_per_stage": kernel_ms * 1e3 / max(stages, 1),
+           "flops_per_amplitude_per_stage": flops_per_amp_stage,
+           "isa_flops_per_launch": flops / max(launches, 1),
            "hbm_equivalent_GBps": 32.0 * n_amp * rows * stages / sec / 1e9 if sec > 0 else 0.0}
+    if algorithmic_flops_per_amp_stage:
+        alg = algorithmic_flops_per_amp_stage * n_amp * rows * stages
+        out["algorithmic_flops_per_amplitude_per_stage"] = algorithmic_flops_per_amp_stage
+        out["algorithmic_flops_per_launch"] = alg / max(launches, 1)
+        out["frac_algorithmic"] = alg / sec / 1e12 / F64_VALU_PEAK if sec > 0 else 0.0
     if note:
         out["note"] = note
     return out
@@ -324,6 +351,64 @@ def cpu_baselines(full: bool):
     return out
 
 
+def cfg4_line(n_traj, steps, warmup, dist, torch, n_gpus, common):
+    """BASELINE configs[3]: noise trajectories of the 12-atom sequence, END TO END through the emulator front-end (noise
+    draws on rank 0, factored lowering, solve, reference-order sampling), sharded over the ranks with one all-reduce of
+    the histograms (strong scaling); the same again with the ensemble density matrix (A15 on the device)."""
+    from pulser_amd import NoiseModel, QutipEmulator, problem as P
+    from pulser_amd.distributed import run_ensemble
+    from pulser_amd.hamiltonian_data import single_global_channel
+
+    coords = P.register_coords(P.square_rect(1, 12), blockade_radius())
+    smp = {k: v[:-1] for k, v in P.anneal_samples().items()}
+    inputs = single_global_channel(coords, smp, P.C6_LEVEL70, extended=False)
+    nm = NoiseModel(temperature=50.0, amp_sigma=0.05, state_prep_error=0.005,
+                    p_false_pos=0.01, p_false_neg=0.05)
+
+    def one_pass(seed, density_matrix=False):
+        np.random.seed(seed)
+        emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=n_traj, evaluation_times="Minimal")
+        return run_ensemble(emu, dist=dist, batch=256, density_matrix=density_matrix)
+
+    for w in range(warmup):
+        one_pass(100 + w)
+    barrier(torch, dist)
+    tic = time.perf_counter()
+    for k in range(steps):
+        res = one_pass(k)
+    barrier(torch, dist)
+    sec = (time.perf_counter() - tic) / steps
+    if dist is not None:
+        tmax = torch.tensor([sec], dtype=torch.float64, device="cuda")
+        all_reduce(dist, tmax, dist.ReduceOp.MAX)
+        sec = float(tmax.item())
+    # the same with the ensemble density matrix (density_matrix_aggregator: the 268-MB mean of |psi><psi|
+    # at both evaluation times, formed on the device and all-reduced there)
+    one_pass(200, True)
+    barrier(torch, dist)
+    tic = time.perf_counter()
+    res_dm = one_pass(0, True)
+    barrier(torch, dist)
+    sec_dm = time.perf_counter() - tic
+    tr_dm = float(torch.diagonal(res_dm["density_matrices"][-1]).real.sum().item())
+    del res_dm
+    return {"metric": "noise trajectories/s, 12-atom anneal sequence, end to end (draws, lowering, sesolve, sampling)",
+            "value": n_traj / sec, **common, "unit": "trajectories/s", "scaling": "strong",
+            "ms_per_step": sec * 1e3,
+            "config": {"workload": "BASELINE configs[3]: 12-atom register, 1024 noise trajectories "
+                                   "(doppler + amplitude + SPAM), sharded over the ranks, one all-reduce "
+                                   "of the bitstring histograms", "n_atoms": 12, "n_trajectories": n_traj,
+                       "sim_us_per_s": n_traj * T_SEQ_US / sec, "n_measures": int(res["n_measures"]),
+                       "histogram_total": int(res["histograms"].sum()),
+                       "mean_occupations_final": [float(v) for v in res["mean_occupations"][-1]],
+                       "with_density_matrix": {"ms_per_step": sec_dm * 1e3, "ratio": sec_dm / sec,
+                                               "trace_final": tr_dm,
+                                               "note": "A15 on the device: ryd_outer_accumulate_dim per batch and "
+                                                       "evaluation time, all-reduce of the device tensor"},
+                       "parallelism": f"dp{n_gpus} over trajectories"},
+            "roofline": None}
+
+
 def device_copy_bandwidth(torch):
     """Measured device-to-device copy bandwidth (read + write bytes / time), 2 GiB buffer."""
     n = 1 << 28
@@ -361,7 +446,9 @@ def main() -> None:
     ap.add_argument("--no-legs", action="store_true", help="north_star: headline leg only (profiling runs)")
     ap.add_argument("--no-ket", action="store_true", help="disable k_ket / the split-operator rows (A/B runs)")
     ap.add_argument("--no-split14", action="store_true",
-                    help="north star: keep the batch on k_ket instead of k_split14_loop (A/B runs)")
+                    help="north star: keep the batch on k_ket instead of the split-operator kernel (A/B runs)")
+    ap.add_argument("--split-turns", action="store_true",
+                    help="north star: the round-3 kernel k_split14_loop instead of k_split_reg (A/B runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -390,6 +477,22 @@ def main() -> None:
         dist = dist_mod
     else:
         torch.cuda.set_device(0)
+    collective = None
+    if dist is not None:
+        # what the ranks really ran on: backend, world size, the PCI bus id of every rank's device (all-gathered), and
+        # one all-reduce of ones through the backend (its result must be the world size)
+        prop = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident = {"rank": rank, "device": torch.cuda.current_device(), "name": prop.name,
+                 "pci": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0),
+                                            getattr(prop, "pci_device_id", 0)),
+                 "uuid": str(getattr(prop, "uuid", ""))}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ident)
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        all_reduce(dist, ones)
+        collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": gathered,
+                      "distinct_devices": len({(g["pci"], g["uuid"]) for g in gathered}),
+                      "allreduce_of_ones": float(ones.item())}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
 
@@ -411,12 +514,22 @@ def main() -> None:
         eng = Engine(tables, mode="sesolve")
         torch.cuda.synchronize()
         create_s = time.perf_counter() - tic
-        if args.no_ket or args.no_split14:
-            eng.set_path(False, no_ket=args.no_ket, no_split14=args.no_split14)
+        if args.no_ket or args.no_split14 or args.split_turns:
+            eng.set_path(False, no_ket=args.no_ket, no_split14=args.no_split14, split_turns=args.split_turns)
         sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, args.steps, args.warmup, dist, torch)
         value = n_gpus * B * T_SEQ_US / sec
         ket = stats["n_launches"] == 1
         split14 = not ket and not args.no_ket and stats["reserved"][0] > 0.0
+        # in-process parity: sequence 0 of the batch is the nominal sequence = the tight-oracle fixture of the headline
+        # register (tests/golden/ns_tri14_anneal.npz: zvode rtol 1e-13, final time); the line is not printed when the
+        # state the timed kernels produced is further than the stated bar (1e-7) from it
+        from pulser_amd import problem as P_
+
+        _, fx = P_.load_problem(os.path.join(ROOT, "tests", "golden", "ns_tri14_anneal.npz"))
+        ref_final = np.asarray(fx["oracle_states_tight"])[-1]
+        parity = float(np.max(np.abs(timed_run.last_state[0].cpu().numpy() - ref_final)))
+        if not parity < 1e-7:
+            raise SystemExit(f"bench.py: sequence 0 of the timed batch is {parity:.3e} from the tight oracle (bar 1e-7)")
         # every rank runs the same batch of sequences, so this number must not depend on the number of GPUs
         ens = [float(v) / (n_gpus * B) for v in occ.cpu().numpy()]
         out = {
@@ -431,12 +544,15 @@ def main() -> None:
                               "2e-11 per exponential" if ket else
                               "split-operator: exact diagonal phases x exact single-atom rotations, 6th-order 10-stage "
                               "composition over sub-steps of <= 8 knot intervals, measured step-size control "
-                              "(accumulated local-error estimate %.1e; k_split14_loop)" % stats["reserved"][0] if split14
+                              "(accumulated local-error estimate %.1e; %s)" % (stats["reserved"][0], "k_split14_loop" if args.split_turns else "k_split_reg") if split14
                               else "CF4 Magnus + Taylor(Horner), 1e-10 per exponential",
                 "stages_per_sequence": stats["n_applications"], "cf4_steps": stats["n_steps"],
                 "parallelism": f"dp{n_gpus} (independent sequences shard over ranks; all-reduce of ensemble sums only)",
             },
             "ensemble_mean_occupations": ens[:-1], "ensemble_mean_norm": ens[-1],
+            "parity_max_abs": parity,
+            "parity_reference": "tests/golden/ns_tri14_anneal.npz (tight oracle: zvode rtol 1e-13), final state, sequence 0 "
+                                "of the timed batch (event-timed pass); bar 1e-7",
             "setup": {"lowering_ms": lower_s * 1e3, "handle_and_upload_ms": create_s * 1e3,
                       "note": "spline lowering on the host + ryd_create / ryd_set_* uploads; outside the timed "
                               "step (done once per sequence batch); the step includes the evaluation-time "
@@ -452,13 +568,17 @@ def main() -> None:
                      "streaming kernel would have to sustain for the same applications")
         elif split14:
             out["roofline"] = roofline_valu(
-                2.0**n, B, stats["n_applications"], KSPLIT14_FLOPS_PER_AMP_STAGE, kms, kl, KSPLIT14_NAME,
-                "north_star:k_split14",
-                note="the kets live in registers for a closed run of sub-steps (a turn through LDS re-sorts them "
-                     "twice per stage); HBM sees the states once per launch in and out plus the per-stage "
-                     "coefficients ('traffic'). Stages include the step-size controller's check sub-steps. "
-                     "k_ket (the round-2 / early round-3 kernel of this line: 26 253 stages, frac 0.43) remains "
-                     "behind set_path(no_split14=True)")
+                2.0**n, B, stats["n_applications"],
+                KSPLIT14_FLOPS_PER_AMP_STAGE if args.split_turns else KSPLITREG_FLOPS_PER_AMP_STAGE, kms, kl,
+                KSPLIT14_NAME if args.split_turns else KSPLITREG_NAME,
+                "north_star:k_split14" if args.split_turns else "north_star:k_split_reg",
+                note="the kets live in registers for a closed run of sub-steps; HBM sees the states once per launch in "
+                     "and out plus the per-stage coefficients ('traffic'). Stages include the step-size controller's "
+                     "check sub-steps. `frac` counts the fp64 instructions the kernel issues (ISA), `frac_algorithmic` "
+                     "the rotations + one complex multiplication per amplitude a stage needs on paper. Earlier kernels "
+                     "of this line: k_split14_loop (round 3: 12.2 us per stage, set_path(split_turns=True)), k_ket "
+                     "(26 253 stages, set_path(no_split14=True))",
+                algorithmic_flops_per_amp_stage=SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE)
         else:
             out["roofline"] = roofline_hbm(n, B, stats, kms, kl, "k_apply14<sesolve> (2^14 register tiles, 1 pass)")
         eng.close()
@@ -477,6 +597,12 @@ def main() -> None:
                                           "k_ket<14> (one workgroup = one CU of 256)",
                                           note="a single sequence occupies one CU; frac is against the whole chip")
                 if st1["n_launches"] == 1 else
+                roofline_valu(2.0**n, 1, st1["n_applications"], KSPLITREG_FLOPS_PER_AMP_STAGE, k1, l1,
+                              KSPLITREG_NAME + "; one workgroup = one CU of 256",
+                              note="a single sequence occupies one CU; frac is against the whole chip (x 256 = the "
+                                   "fraction of that CU's fp64 pipe)",
+                              algorithmic_flops_per_amp_stage=SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE)
+                if st1["n_launches"] * 20 < st1["n_applications"] else
                 roofline_hbm(n, 1, st1, k1, l1, KSPLIT_NAME + "; 4 tiles: launch-latency-bound"),
                 "local_error_estimate": st1["reserved"][0]}
             eng.close()
@@ -529,62 +655,7 @@ def main() -> None:
         }
         eng.close()
     elif args.workload == "cfg4":
-        # BASELINE configs[3]: 1024 noise trajectories of the 12-atom sequence, END TO END through
-        # the emulator front-end (noise draws on rank 0, factored lowering, solve, reference-order
-        # sampling), sharded over the ranks with one all-reduce of the histograms (strong scaling)
-        from pulser_amd import NoiseModel, QutipEmulator, problem as P
-        from pulser_amd.distributed import run_ensemble
-        from pulser_amd.hamiltonian_data import single_global_channel
-
-        coords = P.register_coords(P.square_rect(1, 12), blockade_radius())
-        smp = {k: v[:-1] for k, v in P.anneal_samples().items()}
-        inputs = single_global_channel(coords, smp, P.C6_LEVEL70, extended=False)
-        nm = NoiseModel(temperature=50.0, amp_sigma=0.05, state_prep_error=0.005,
-                        p_false_pos=0.01, p_false_neg=0.05)
-        n_traj = args.trajectories
-
-        def one_pass(seed, density_matrix=False):
-            np.random.seed(seed)
-            emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=n_traj, evaluation_times="Minimal")
-            return run_ensemble(emu, dist=dist, batch=256, density_matrix=density_matrix)
-
-        for w in range(args.warmup):
-            one_pass(100 + w)
-        barrier(torch, dist)
-        tic = time.perf_counter()
-        for k in range(args.steps):
-            res = one_pass(k)
-        barrier(torch, dist)
-        sec = (time.perf_counter() - tic) / args.steps
-        if dist is not None:
-            tmax = torch.tensor([sec], dtype=torch.float64, device="cuda")
-            all_reduce(dist, tmax, dist.ReduceOp.MAX)
-            sec = float(tmax.item())
-        # the same with the ensemble density matrix (density_matrix_aggregator: the 268-MB mean of |psi><psi|
-        # at both evaluation times, formed on the device and all-reduced there)
-        one_pass(200, True)
-        barrier(torch, dist)
-        tic = time.perf_counter()
-        res_dm = one_pass(0, True)
-        barrier(torch, dist)
-        sec_dm = time.perf_counter() - tic
-        tr_dm = float(torch.diagonal(res_dm["density_matrices"][-1]).real.sum().item())
-        del res_dm
-        out = {"metric": "noise trajectories/s, 12-atom anneal sequence, end to end (draws, lowering, sesolve, sampling)",
-               "value": n_traj / sec, **common, "unit": "trajectories/s", "scaling": "strong",
-               "ms_per_step": sec * 1e3,
-               "config": {"workload": "BASELINE configs[3]: 12-atom register, 1024 noise trajectories "
-                                      "(doppler + amplitude + SPAM), sharded over the ranks, one all-reduce "
-                                      "of the bitstring histograms", "n_atoms": 12, "n_trajectories": n_traj,
-                          "sim_us_per_s": n_traj * T_SEQ_US / sec, "n_measures": int(res["n_measures"]),
-                          "histogram_total": int(res["histograms"].sum()),
-                          "mean_occupations_final": [float(v) for v in res["mean_occupations"][-1]],
-                          "with_density_matrix": {"ms_per_step": sec_dm * 1e3, "ratio": sec_dm / sec,
-                                                  "trace_final": tr_dm,
-                                                  "note": "A15 on the device: ryd_outer_accumulate_dim per batch and "
-                                                          "evaluation time, all-reduce of the device tensor"},
-                          "parallelism": f"dp{n_gpus} over trajectories"},
-               "roofline": None}
+        out = cfg4_line(args.trajectories, args.steps, args.warmup, dist, torch, n_gpus, common)
         extras_ok = False
         args.no_cpu = True
     elif args.workload in ("cfg3", "cfg5"):
@@ -712,24 +783,51 @@ def main() -> None:
                                           "(tools/ubench/mfma_f64.hip); a full ZGEMM would need 2x the flops"}})
         eng.close()
         del psi, rho
-        # cfg5: 20-atom sesolve slice: split-operator passes (default) and CF4 + Taylor on the generator
-        # kernels (Lanczos comparison: profiles/r02_krylov_vs_taylor.md); 24 atoms = the HBM-bound regime
-        for n_at, shape, ns in ((20, (4, 5), 100), (24, (4, 6), 40)):
-            eng = Engine.from_problems([rect_problem(*shape)], mode="sesolve")
-            psi1 = eng.new_state()
-            eng.evolve(psi1, 0.0, 1.0)  # the slice starts from the state the sequence has reached at 1 us
-            sec, stats, kms, kl, occ = timed_run(eng, psi1.clone, 1.0, 1.0 + ns * 1e-3, 2, 1, None, torch)
-            leg = {"workload": f"cfg5: {n_at}-atom {shape[0]}x{shape[1]} register, sesolve, {ns} ns slice at t = 1 us",
-                   "value": ns * 1e-3 / sec, "unit": "sim-us/s", "stages": stats["n_applications"],
-                   "passes_per_stage": stats["passes"], "local_error_estimate": stats["reserved"][0],
-                   "roofline": roofline_hbm(n_at, 1, stats, kms, kl, KSPLIT_NAME, "cfg5:k_split" if n_at == 20 else "cfg5_24atoms:k_split")}
-            if n_at == 20:
-                sec, stats, kms, kl, occ = timed_run(eng, psi1.clone, 1.0, 1.02, 2, 1, None, torch, method="taylor")
-                leg["taylor"] = {"value": 0.02 / sec, "unit": "sim-us/s", "taylor_order": stats["last_order"],
-                                 "roofline": roofline_hbm(20, 1, stats, kms, kl, KAPPLY_NAME, "cfg5:k_apply")}
-            also.append(leg)
-            del psi1
-            eng.close()
+        # cfg4 end to end: 1024 noise trajectories through run_ensemble (BASELINE configs[3]); the --workload cfg4 line
+        # of an N-GPU run shards the same ensemble
+        c4 = cfg4_line(1024, 1, 1, None, torch, 1, {})
+        also.append({"workload": "cfg4: 1024 noise trajectories of the 12-atom anneal sequence, END TO END (noise draws, "
+                                 "factored lowering, solve, reference-order sampling) through run_ensemble",
+                     "value": c4["value"], "unit": "trajectories/s", "ms_per_ensemble": c4["ms_per_step"],
+                     "sim_us_per_s": c4["config"]["sim_us_per_s"],
+                     "with_density_matrix": c4["config"]["with_density_matrix"],
+                     "histogram_total": c4["config"]["histogram_total"], "n_measures": c4["config"]["n_measures"]})
+        # cfg5: 20 atoms over the FULL 3.1 us: split-operator passes (default) with the Lanczos exponential (the solver
+        # configs[4] names) and CF4 + Taylor beside it; 24 atoms = the HBM-bound regime (40 ns slice at t = 1 us)
+        eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")
+        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, 1, 1, None, torch)
+        leg = {"workload": "cfg5: 20-atom 4x5 register, sesolve, FULL 3.1 us (default: split-operator passes)",
+               "value": T_SEQ_US / sec, "unit": "sim-us/s", "seconds": sec, "stages": stats["n_applications"],
+               "passes_per_stage": stats["passes"], "local_error_estimate": stats["reserved"][0],
+               "norm": float(occ[-1].item()),
+               "roofline": roofline_hbm(20, 1, stats, kms, kl, KSPLIT_NAME, "cfg5:k_split")}
+        psi_split = timed_run.last_state.clone()
+        sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, 1, 0, None, torch, method="krylov")
+        leg["krylov"] = {"workload": "the same full 3.1 us on the Lanczos exponential (ryd_opts.method = 1)",
+                         "value": T_SEQ_US / sec, "unit": "sim-us/s", "seconds": sec,
+                         "applications": stats["n_applications"], "krylov_dimension": stats["last_order"],
+                         "max_abs_vs_split": float((timed_run.last_state - psi_split).abs().max().item()),
+                         "roofline": roofline_hbm(20, 1, stats, kms, kl, "k_apply<sesolve> inside the Lanczos process "
+                                                                        "(+ k_krylov dot / axpy kernels)", None)}
+        psi1 = eng.new_state()
+        eng.evolve(psi1, 0.0, 1.0)
+        sec, stats, kms, kl, occ = timed_run(eng, psi1.clone, 1.0, 1.02, 2, 1, None, torch, method="taylor")
+        leg["taylor"] = {"workload": "20 ns slice at t = 1 us on CF4 + Taylor", "value": 0.02 / sec, "unit": "sim-us/s",
+                         "taylor_order": stats["last_order"],
+                         "roofline": roofline_hbm(20, 1, stats, kms, kl, KAPPLY_NAME, "cfg5:k_apply")}
+        also.append(leg)
+        del psi1, psi_split
+        eng.close()
+        eng = Engine.from_problems([rect_problem(4, 6)], mode="sesolve")
+        psi1 = eng.new_state()
+        eng.evolve(psi1, 0.0, 1.0)  # the slice starts from the state the sequence has reached at 1 us
+        sec, stats, kms, kl, occ = timed_run(eng, psi1.clone, 1.0, 1.04, 2, 1, None, torch)
+        also.append({"workload": "cfg5: 24-atom 4x6 register, sesolve, 40 ns slice at t = 1 us",
+                     "value": 0.04 / sec, "unit": "sim-us/s", "stages": stats["n_applications"],
+                     "passes_per_stage": stats["passes"], "local_error_estimate": stats["reserved"][0],
+                     "roofline": roofline_hbm(24, 1, stats, kms, kl, KSPLIT_NAME, "cfg5_24atoms:k_split")})
+        del psi1
+        eng.close()
         out["also"] = also
         bw = device_copy_bandwidth(torch)
         out["device_copy_GBps"] = bw
@@ -738,6 +836,8 @@ def main() -> None:
 
     if rank == 0:
         out["cpu_baseline"] = cpu_result
+        if collective is not None:
+            out["collective"] = collective
 
     if rank == 0:
         print(json.dumps(out))

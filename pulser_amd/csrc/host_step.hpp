@@ -519,6 +519,9 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
   };
   h->split14_auto = false;
   h->stats.reserved[0] = 0.0;  // accumulated local-error estimate of THIS solve (the split-operator paths book it)
+  // RYD_HOST_TIMING=1 (dev): host milliseconds of a solve before its first launch (schedule building) on stderr
+  static const bool host_timing = [] { const char* e = std::getenv("RYD_HOST_TIMING"); return e && e[0] == '1'; }();
+  const auto host_t0 = std::chrono::steady_clock::now();
   double share = -1.0;
   // (round 4: k_split_reg covers 12 - 14 atoms and any batch size, so the same choice is made for 12 / 13 atoms against
   // k_traj / k_ket / the tiled kernels)
@@ -571,6 +574,10 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
       }
     }
   }
+  if (host_timing)
+    std::fprintf(stderr, "[ryd] solve over [%g, %g] us: %zu schedule steps built in %.3f ms on the host\n", times[0],
+                 times[n_times - 1], sched.size(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count());
   return run_steps(h, state, sched, snaps, st, o);
 }
 

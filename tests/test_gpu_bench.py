@@ -51,7 +51,18 @@ def test_default_workload_with_two_ranks_prints_the_contract_line_and_the_same_e
         assert line["n_gpus"] == n and line["scaling"] == "weak" and line["higher_is_better"] is True
         assert line["config"]["sequences_per_gpu"] == 16 and "14-atom" in line["config"]["workload"]
         assert line["roofline"]["bound"] == "valu_f64" and 0 < line["roofline"]["frac"] <= 1
+        # the time per stage and the bare algorithmic count stand beside the ISA-counted fraction
+        assert 1.0 < line["roofline"]["us_per_stage"] < 100.0 and "isa_flops_per_launch" in line["roofline"]
+        assert 0 < line["roofline"]["frac_algorithmic"] < line["roofline"]["frac"]
+        assert line["roofline"]["algorithmic_flops_per_amplitude_per_stage"] == 62.0
+        # the timed kernels' own result against the tight-oracle fixture of the headline register, in the bench process
+        assert 0 <= line["parity_max_abs"] < 1e-7 and "ns_tri14_anneal.npz" in line["parity_reference"]
         assert abs(line["ensemble_mean_norm"] - 1.0) < 1e-8
+    # N > 1: the line proves what the collectives ran on (under RCCL: N distinct PCI bus ids; here both ranks share the GPU)
+    assert "collective" not in one
+    col = two["collective"]
+    assert col["backend"] == "gloo" and col["world_size"] == 2 and col["allreduce_of_ones"] == 2.0
+    assert [r["rank"] for r in col["ranks"]] == [0, 1] and all(r["pci"] for r in col["ranks"]) and col["distinct_devices"] == 1
     # every rank runs the same 16 sequences: the all-reduced ensemble mean is independent of the world size
     assert np.allclose(one["ensemble_mean_occupations"], two["ensemble_mean_occupations"], rtol=0, atol=1e-12)
     assert two["config"]["stages_per_sequence"] == one["config"]["stages_per_sequence"]

@@ -1619,7 +1619,7 @@ def test_bench_flop_constants_match_the_compiled_kernels():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "bench.py")).read()
     ns = {}
-    for name in ("KKET_FLOPS_PER_AMP_STAGE", "KSPLIT14_FLOPS_PER_AMP_STAGE"):
+    for name in ("KKET_FLOPS_PER_AMP_STAGE", "KSPLIT14_FLOPS_PER_AMP_STAGE", "KSPLITREG_FLOPS_PER_AMP_STAGE"):
         exec(re.search(r"^%s = .*$" % name, src, re.M).group(0), ns)
     import tempfile
 
@@ -1631,6 +1631,12 @@ def test_bench_flop_constants_match_the_compiled_kernels():
     cells = [c.strip() for c in row.strip("|").split("|")]
     assert abs(float(cells[-1]) - ns["KSPLIT14_FLOPS_PER_AMP_STAGE"]) < 0.01 * ns["KSPLIT14_FLOPS_PER_AMP_STAGE"], row
     assert int(cells[6]) <= 16, row  # scratch instructions in the stage loop: reloads of loop invariants at most
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "count_isa.py"), "splitreg"], check=True,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, RYD_ISA_TEXT=asm)).stdout
+    row = [l for l in out.splitlines() if re.match(r"^\| \d+ \|", l)][0]
+    cells = [c.strip() for c in row.strip("|").split("|")]
+    assert abs(float(cells[-1]) - ns["KSPLITREG_FLOPS_PER_AMP_STAGE"]) < 0.01 * ns["KSPLITREG_FLOPS_PER_AMP_STAGE"], row
+    assert int(cells[8]) <= 8 and int(cells[9]) == 4, row  # scratch reloads of loop invariants at most; 4 barriers per stage
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "count_isa.py"), "0"], check=True,
                          capture_output=True, text=True, timeout=900, env=dict(os.environ, RYD_ISA_TEXT=asm)).stdout
     per_half = [float(l.strip("|").split("|")[-1]) for l in out.splitlines() if re.match(r"^\| \d+\.\.\d+ \|", l)]

@@ -14,6 +14,31 @@ else:
         text = open(asm).read()
     if os.environ.get("RYD_ISA_KEEP"):
         open(os.environ["RYD_ISA_KEEP"], "w").write(text)
+if len(sys.argv) > 1 and sys.argv[1] == "splitreg":
+    # k_split_reg<14, 5, false>: fp64 work of the stage loop (ONE stage body per iteration, 32 amplitudes per lane)
+    m = re.search(r"^(_Z\d+k_split_regILi14ELi5ELb0E\w*):(.*?)s_endpgm", text, re.S | re.M)
+    body = m.group(2).split("\n")
+    best = None
+    for hdr in [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]:
+        lab = body[hdr].split(":")[0]
+        backs = [i for i, l in enumerate(body) if re.search(r"s_c?branch\w*\s+%s\b" % re.escape(lab), l)]
+        if backs and (best is None or backs[-1] - hdr > best[1] - best[0]):
+            best = (hdr, backs[-1])
+    reg = body[best[0]:best[1] + 1]
+    c = lambda pat: sum(1 for l in reg if re.search(pat, l))
+    fma, mul, add, rnd = c(r"\sv_fmac?_f64"), c(r"\sv_mul_f64"), c(r"\sv_add_f64"), c(r"v_rndne_f64")
+    valu = c(r"^\s+v_")
+    print("# r04: instruction count of the stage loop of `k_split_reg<14, 5>` (hipcc 7.2, gfx950, -O3)\n")
+    print("The loop body holds ONE stage (positions, not parities: the same code runs even and odd stages), 32 amplitudes per lane.\n")
+    print("| v_fma/v_fmac_f64 | v_mul_f64 | v_add_f64 | v_rndne_f64 | v_mov_b32_dpp | v_permlane*_swap | other VALU | ds ops | scratch ops | barriers | flops / amplitude / stage |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    dpp, swp, n_ds = c(r"v_mov_b32_dpp"), c(r"v_permlane\d+_swap"), c(r"^\s+ds_")
+    print(f"| {fma} | {mul} | {add} | {rnd} | {dpp} | {swp} | {valu - fma - mul - add - rnd - dpp - swp} | {n_ds} | {c('scratch_')} | {c('s_barrier')} | {(2 * fma + mul + add + rnd) / 32:.2f} |")
+    print("\nPer stage and amplitude: 14 tan-form rotations x 2 FMAs + the phase factor as a product (tree over the register bits, the")
+    print("uniform factor, the amplitude: three complex multiplications) + 7 table-and-series sin / cos per lane.  On paper a stage")
+    print("needs 14 x 2 FMAs + one complex multiplication = 62 flops per amplitude (bench.py: SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE).")
+    print("bench.py uses KSPLITREG_FLOPS_PER_AMP_STAGE = the last column; re-run after changing the kernel.")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "split14":
     # k_split14_loop<true>: fp64 work of the stage loop (two unrolled stage bodies, 32 amplitudes per lane)
     m = re.search(r"^(_Z\d+k_split14_loopILb1E\w*):(.*?)s_endpgm", text, re.S | re.M)
