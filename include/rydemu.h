@@ -299,13 +299,17 @@ int ryd_general_solve_many(ryd_handle** hs, int32_t n, void* const* states_dev, 
  * the ket kernel from 10 atoms and any batch size on, 128 = keep the Taylor
  * polynomial where ryd_opts.method 0 would choose the split-operator ket passes,
  * 256 = switch their step-size control off (one sub-step per schedule step),
- * 512 = 12- and 14-atom kets pass by pass instead of the one-launch loops over the stages
- * (k_split12_loop, k_split14_loop),
+ * 512 = 12- to 14-atom kets pass by pass instead of the one-launch loops over the stages
+ * (k_split_reg; k_split12_loop, k_split14_loop),
  * 1024 = keep every CF4 step inside one knot interval (no multi-knot steps),
  * 2048 = 2^12-amplitude tiles of the split-operator passes where 2^13 ones are the default (21 - 23 atoms),
  * 4096 = general path: term-by-term kernel instead of the site-fused one,
  * 8192 = split-operator passes: the 4th-order 6-stage scheme with sub-steps that end at every knot,
- * 16384 = batches of 14-atom sequences stay on the register-resident polynomial kernel (k_ket).
+ * 16384 = sequences of 12 - 14 atoms stay on the polynomial kernels (k_traj, k_ket) where ryd_solve would choose the
+ * register-resident split-operator kernel (k_split_reg),
+ * 32768 = one-launch split-operator runs of 14-atom kets on the round-3 kernel (k_split14_loop: two LDS turns per
+ * stage) instead of k_split_reg,
+ * 65536 = split-operator master equation: the row passes on the polynomial kernel (k_ket) instead of k_split_reg.
  * Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);
 

@@ -139,9 +139,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    # dev probes (tools/): an alternative build of the same library, e.g. with another RYD_KET_F0
+    # dev probes (tools/) may load an alternative build of the same library (variant switches): only with the explicit
+    # opt-in RYD_DEV=1 next to RYD_LIB - a stray environment variable must not swap the native library of a product run
     global LIB_PATH
-    LIB_PATH = os.environ.get("RYD_LIB") or LIB_PATH
+    dev_lib = os.environ.get("RYD_LIB") if os.environ.get("RYD_DEV") == "1" else None
+    LIB_PATH = dev_lib or LIB_PATH
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP library first "
@@ -156,7 +158,7 @@ def load() -> C.CDLL:
         pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
-        if not hasattr(lib, name) and os.environ.get("RYD_LIB"):
+        if not hasattr(lib, name) and dev_lib:
             continue  # dev probes against an older build of the library
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res

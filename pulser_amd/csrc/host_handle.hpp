@@ -81,6 +81,7 @@ struct ryd_handle {
   bool split_small_tiles = false; // test / bench hook: keep 2^12 tiles for every register size
   bool split14_auto = false;      // this solve: a 14-atom batch goes to k_split14_loop instead of k_ket (host_step.hpp)
   bool no_split14 = false;        // test / bench hook: keep 14-atom batches on k_ket
+  bool rows_ket = false;          // test / bench hook: row passes of the split-operator master equation on k_ket
   bool split_turns = false;       // test / bench hook: 14-atom one-launch runs on k_split14_loop (two LDS turns per stage,
                                   // round 3) instead of k_split_reg
   bool split_s10 = false;         // scheme of the current split-operator solve (host_step.hpp decides per call)
@@ -725,6 +726,14 @@ static void compute_bounds(ryd_handle* h) {
     const double cap = 4000.0;  // rad/us: a phase that turns faster than this inside a step is not gauged
     for (int sidx = 0; sidx < h->n_series && ok; ++sidx) {
       if (series_real[sidx]) continue;
+      // The kernel follows a drive's direction w = c / |c| through theta' alone.  While |c| is below the threshold it
+      // HOLDS the last direction, and theta' is not sampled there - so a drive that falls to zero and comes back with
+      // another phase (Ramsey / echo: pulse, delay, phase-shifted pulse) would lose the phase step: the frame of
+      // psi~ is never turned by conj(w_old) w_new (round-3 ADVICE: 0.50 error in the final amplitudes for a pi / 2
+      // step).  Such series are not gauged: the direction before a sub-threshold stretch must be the direction
+      // after it, up to the sign that a zero crossing of the signed modulus r takes care of.
+      std::complex<double> w_last(0.0, 0.0);  // direction at the last sample above the threshold
+      bool in_gap = false;
       for (int i = 0; i < n_int && ok; ++i) {
         const std::complex<double>* pc = &h->pp_host[((size_t)sidx * n_int + i) * 4];
         const double dt = h->tknots[i + 1] - h->tknots[i];
@@ -734,7 +743,11 @@ static void compute_bounds(ryd_handle* h) {
           const std::complex<double> c = ((pc[0] * u + pc[1]) * u + pc[2]) * u + pc[3];
           const std::complex<double> dc = (3.0 * pc[0] * u + 2.0 * pc[1]) * u + pc[2];
           const double m2 = std::norm(c);
-          if (m2 <= h->gauge_eps2) continue;
+          if (m2 <= h->gauge_eps2) { in_gap = true; continue; }
+          const std::complex<double> w_now = c / std::sqrt(m2);
+          if (in_gap && std::norm(w_last) > 0.0 && std::fabs((std::conj(w_last) * w_now).imag()) > 1e-8) ok = false;
+          in_gap = false;
+          w_last = w_now;
           const double thd = (dc * std::conj(c)).imag() / m2;
           hi = std::max(hi, thd);
           lo = std::min(lo, thd);

@@ -330,10 +330,21 @@ static bool row_uniform_g(const ryd_handle* h) {
 // Half a block of the split-operator master equation, in knot intervals (what a multi-knot CF4
 // step must not exceed).
 static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
+  static const int kh_env = [] { const char* e = std::getenv("RYD_ROWS_KH"); return e ? std::atoi(e) : 0; }();  // dev A/B
+  if (kh_env > 0 && o.split_steps <= 0) return kh_env;
   int Kh = row_block_steps(h, o);
   if ((!row_uniform_g(h) || h->has_dbl) && o.split_steps <= 0) Kh = 1;
   return Kh;
 }
+
+// Row passes on the register-resident split-operator kernel (k_split_reg<N, 5, false, ROWS>, host_split.hpp; round 4):
+// the unitary of a half block as 6th-order (4th-order for one-knot steps) split-operator sub-steps, one per CF4 step of
+// the schedule, instead of CF4 + in-place symplectic exponentials on k_ket.  Returns 1 when the run cannot take the
+// tan-form rotations (|beta c| > 1: drives of hundreds of rad/us) - the caller then uses k_ket for this conjugation.
+static bool rows_split_ok(const ryd_handle* h);
+static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>& sb, size_t i0, size_t i1, bool use_pre,
+                           bool use_post, const double* tdev, double kick_pre, double kick_post, int kick_idx,
+                           double kick_u, size_t n_rows, bool count_stages, hipStream_t st);
 
 // mesolve by operator splitting (header of this file).  Blocks of two halves, 4th order
 // (Chin's scheme 4A: all coefficients positive, so the dissipative factor never runs backwards):
@@ -414,6 +425,7 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
   if ((rc = to_ket_steps(h, sb, o, -1.0, ks))) return rc;
   for (KetStep& k : ks) k.snap = -1;  // snapshots are whole-matrix copies between blocks
   if ((rc = upload_ket_steps(h, ks, st))) return rc;
+  bool rsplit = rows_split_ok(h);  // (the k_ket schedule stays uploaded: a conjugation may fall back to it)
   // |change of d under one bit flip|: (0,0)<->(0,1)/(1,0) and (1,1)<->(0,1)/(1,0)
   const double g01 = h->Sd[1].x - h->Sd[0].x, g10 = h->Sd[2].x - h->Sd[0].x;
   const double g31 = h->Sd[1].x - h->Sd[3].x, g32 = h->Sd[2].x - h->Sd[3].x;
@@ -473,7 +485,13 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     A.state = cur;
     A.use_pre = !dbl && f_in != 0.0;
     int rc2;
-    if ((rc2 = launch_ket(h, A, n_rows, st, KET_ROWS))) return rc2;
+    bool this_split = rsplit;
+    if (this_split) {
+      rc2 = rows_split_pass(h, cur, sb, i0, i1, A.use_pre != 0, false, tdev, kick_pre, kick_post, kick_idx, kick_u, n_rows, false, st);
+      if (rc2 == 1) this_split = false;  // (nothing has been launched)
+      else if (rc2) return rc2;
+    }
+    if (!this_split && (rc2 = launch_ket(h, A, n_rows, st, KET_ROWS))) return rc2;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (h->timing) { if ((rc2 = timing_begin(h, st, ev))) return rc2; }
     hipLaunchKernelGGL(k_transpose_conj, dim3(nt, nt, h->B), dim3(256), 0, st, cur, other, h->N);
@@ -484,9 +502,12 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     A.state = cur;
     A.use_pre = 0;
     A.use_post = !dbl && f_out != 0.0;
-    if ((rc2 = launch_ket(h, A, n_rows, st, KET_ROWS))) return rc2;
+    if (this_split) {
+      if ((rc2 = rows_split_pass(h, cur, sb, i0, i1, false, A.use_post != 0, tdev, kick_pre, kick_post, kick_idx, kick_u, n_rows, true, st)))
+        return rc2 == 1 ? fail(RYD_ERR_STATE, "split-operator row pass refused after its first half ran") : rc2;
+    } else if ((rc2 = launch_ket(h, A, n_rows, st, KET_ROWS))) return rc2;
     if (dbl) pending += f_out;
-    count_ket_work(h, ks, i0, i1, 1);  // one Lindbladian application ~ one two-sided ket stage
+    if (!this_split) count_ket_work(h, ks, i0, i1, 1);  // one Lindbladian application ~ one two-sided ket stage
     h->stats.n_steps += (int64_t)(i1 - i0);
     return RYD_OK;
   };

@@ -159,23 +159,31 @@ static bool split_loop14(const ryd_handle* h) {
 // round 4), the ket register-resident, one workgroup per sequence (14 atoms: one per CU; 13: two; 12: three).
 // Quantum-jump solves included (the decay factor of H_eff rides on the phase factors: template parameter DECAY).
 template <int N>
-static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R, hipStream_t st) {
+static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R, hipStream_t st, size_t n_rows = 0) {
   constexpr int NT = 64 << (N - 11);
   // RYD_SPLIT_NR=6 (dev A/B, 14 atoms only): 64 amplitudes per lane on 256 lanes instead of 32 on 512 (measured slower)
   static const int nr_env = [] { const char* e = std::getenv("RYD_SPLIT_NR"); return e ? std::atoi(e) : 5; }();
   const size_t lds = (size_t)2 * NT * 8 * 16 + SPLITR_TRIG * 16 + (size_t)(NT / 64) * 32 * 16 +
-                     (SPLIT_MAX_SUB * SPLIT_MAX_STAGES + 2) * 8 + (SPLITR_EMODE ? 4 * NT * 8 : 0);
+                     (SPLIT_MAX_SUB * SPLIT_MAX_STAGES + 2) * 8 + (SPLITR_EMODE ? 4 * NT * 8 : 0) + (128 + 32) * 8;
   const int dev = h->cfg.device;
   static bool attr[64] = {};
   if (dev < 0 || dev >= 64 || !attr[dev]) {
     HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if constexpr (N == 14)
       HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<14, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (dev >= 0 && dev < 64) attr[dev] = true;
   }
   const long long stride = (long long)h->B * N * 4;
-  if (h->mc)
+  if (n_rows) {  // rows of density matrices as kets (run_rows): persistent workgroups, as many as the chip holds
+    static int n_cu = 0;
+    if (!n_cu) HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev < 0 ? 0 : dev));
+    const unsigned per_cu = N == 14 ? 1u : N == 13 ? 2u : 3u;
+    const unsigned workers = std::min<unsigned>(1u << N, (unsigned)std::max(n_cu, 1) * per_cu);
+    hipLaunchKernelGGL((k_split_reg<N, 5, false, true>), dim3(1, workers, (unsigned)h->B), dim3(NT), lds, st, A, R, stride);
+  }
+  else if (h->mc)
     hipLaunchKernelGGL((k_split_reg<N, 5, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
   else if (N == 14 && nr_env == 6) {
     if constexpr (N == 14)
@@ -387,6 +395,82 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   }
   h->stats.n_applications += n_stages - 1;
   h->stats.passes = m > 1 ? m - 1 : 1;
+  return RYD_OK;
+}
+
+// ---- rows of a density matrix on k_split_reg (declared in host_ket.hpp: run_rows) ----
+static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, double tau_t, std::vector<SubStep>& out);
+static bool rows_split_ok(const ryd_handle* h) {
+  return h->cfg.mode == RYD_MESOLVE && h->N >= 12 && h->N <= 14 && h->drive_real && !h->rows_ket && !h->split_no_loop;
+}
+static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>& sb, size_t i0, size_t i1, bool use_pre,
+                           bool use_post, const double* tdev, double kick_pre, double kick_post, int kick_idx,
+                           double kick_u, size_t n_rows, bool count_stages, hipStream_t st) {
+  int rc;
+  const int N = h->N, B = h->B;
+  std::vector<SubStep> subs;
+  bool multi = false;
+  for (size_t k = i0; k < i1; ++k) {
+    split_substeps(h, sb[k], 0.0, 1e300, subs);  // one sub-step per CF4 step of the schedule
+    multi = multi || sb[k].pad > 2;
+  }
+  // half blocks are two knot intervals at most by default (row_half_knots): the 4th-order 6-stage composition holds
+  // one- and two-knot sub-steps at ~3e-9 over the anneal (measured against the k_ket rows at 12 atoms, dephasing 0.05
+  // and 0.5 / us: 2.7e-9 / 3.2e-9 with S6, 3.2e-9 / 2.8e-9 with S10) with 6 stages instead of 10; longer sub-steps
+  // (split_steps set by the caller) take the 6th-order one
+  static const int s_env = [] { const char* e = std::getenv("RYD_ROWS_S"); return e ? std::atoi(e) : 0; }();  // dev A/B
+  const SplitScheme& sc = s_env == 6 ? kSplitS6 : s_env == 10 ? kSplitS10 : multi ? kSplitS10 : kSplitS6;
+  double bmax = 0.0;
+  for (int i = 0; i < sc.S; ++i) bmax = std::max(bmax, std::fabs(sc.b[i]));
+  for (const SubStep& s : subs) {
+    const int span = std::max(1, (int)std::ceil((s.u0 + s.tau) / (h->tknots[s.idx + 1] - h->tknots[s.idx]) - 1e-9));
+    if (span_max(h->bd_c1, s.idx, std::min(span, (int)h->bd_c1.size() - s.idx)) * bmax * s.tau > 1.0) return 1;
+  }
+  for (size_t at = 0; at < subs.size(); at += kSplitMaxSub) {
+    const int nsub = (int)std::min<size_t>(kSplitMaxSub, subs.size() - at);
+    const bool first = at == 0, last = at + nsub == subs.size();
+    SplitRun R;
+    std::memset(&R, 0, sizeof R);
+    R.nsub = nsub;
+    R.S = sc.S;
+    for (int i = 0; i <= sc.S; ++i) R.a[i] = sc.a[i];
+    for (int i = 0; i < sc.S; ++i) R.b[i] = sc.b[i];
+    for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[at + s].idx; R.u0[s] = subs[at + s].u0; R.tau[s] = subs[at + s].tau; }
+    R.tan_form = 1;
+    // V = exp(+i kick H_drive) of the un-conjugated propagator = a rotation exp(-i beta X) with beta = -kick
+    R.kick_pre = first ? -kick_pre : 0.0;
+    R.kick_post = last ? -kick_post : 0.0;
+    R.kick_idx = kick_idx;
+    R.kick_u = kick_u;
+    const int n_stages = sc.S * nsub + 1 + (R.kick_pre != 0.0 ? 1 : 0);
+    if ((rc = split_ensure_tables(h, n_stages))) return rc;
+    const int total = B * N;
+    hipLaunchKernelGGL(k_split_coefs, dim3(h->dterms_dev ? (total + 3) / 4 : (total + 255) / 256, n_stages), dim3(256), 0, st,
+                       h->pp_dev, h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);
+    HIPCHK(hipGetLastError());
+    SplitArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.state = buf;
+    A.e0 = h->e0_dev;
+    A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << N);
+    A.ccur = h->split_coefs;
+    A.N = N;
+    A.T = N;
+    A.conj = 1;
+    A.use_pre = use_pre && first;
+    A.use_post = use_post && last;
+    A.ftab = tdev;
+    std::pair<hipEvent_t, hipEvent_t> ev1;
+    if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
+    rc = N == 14 ? launch_split_reg<14>(h, A, R, st, n_rows) : N == 13 ? launch_split_reg<13>(h, A, R, st, n_rows)
+                                                                       : launch_split_reg<12>(h, A, R, st, n_rows);
+    if (rc) return rc;
+    if (h->timing) { HIPCHK(hipEventRecord(ev1.second, st)); h->ev_used.push_back(ev1); }
+    h->stats.n_launches++;
+    // accounting as on k_ket: the two passes of a conjugation together are ONE two-sided stage per stage of the scheme
+    if (count_stages) h->stats.n_applications += sc.S * nsub;
+    h->stats.last_order = sc.S;
+  }
   return RYD_OK;
 }
 

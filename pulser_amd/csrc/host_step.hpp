@@ -693,6 +693,7 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
     h->no_merge = (force_generic & 1024) != 0;
     h->no_split14 = (force_generic & 16384) != 0;  // 14-atom batches stay on k_ket
     h->split_turns = (force_generic & 32768) != 0; // one-launch runs on the round-3 kernel (A/B)
+    h->rows_ket = (force_generic & 65536) != 0;    // master-equation row passes on k_ket (A/B)
     {
       const bool s6 = (force_generic & 8192) != 0;  // split-operator passes: S6, sub-steps end at every knot
       if (s6 != h->split_s6_only) { h->split_s6_only = s6; h->split_known = false; }

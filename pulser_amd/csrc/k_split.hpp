@@ -38,6 +38,12 @@ struct SplitArgs {
   // carries the real factor exp(wE (dec_a + dec_b popc(index))) (template parameter DECAY of the pass kernels:
   // the plain passes carry neither the table nor the test)
   double dec_a, dec_b;
+  // rows of a density matrix as kets (k_split_reg<.., ROWS>, the split-operator master equation of host_ket.hpp):
+  // conj = 1 evolves with the complex-conjugate propagator (row <- row W^dagger); ftab = [2][4][16] elementwise factor
+  // tables exp(f d(a, b)) by the counts n00, n01, n10, n11 of (row bit, column bit) pairs, [0] applied at the load
+  // (use_pre), [1] at the store (use_post)
+  int conj, use_pre, use_post;
+  const double* ftab;
 };
 
 // One closed run of the composition: consecutive sub-steps (knot interval, start offset, length),
@@ -54,6 +60,12 @@ struct SplitRun {
   double a[SPLIT_MAX_STAGES + 1];  // D(a_1) R(b_1) ... R(b_S) D(a_{S+1})
   double b[SPLIT_MAX_STAGES];
   int tan_form;  // real drives on k_split14_loop: the Re g slot (zero there) carries Im g / C
+  // drive-only rotations exp(-i kick X(t_kick)) before the first stage (an extra stage 0 without D) / after the
+  // last D (the closing stage's rotation): the commutator correction of the 4th-order operator splitting of the
+  // master equation (host_ket.hpp); t_kick = knot interval kick_idx, offset kick_u
+  double kick_pre, kick_post;
+  int kick_idx;
+  double kick_u;
 };
 
 // out[stage][b][k] = (C, Re g, Im g, Delta): the rotation exp(-i beta (c |1><0| + conj(c) |0><1|)) =
@@ -70,9 +82,30 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
   const int i = per_lane ? (int)(blockIdx.x * 256 + threadIdx.x) : (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int lane = per_lane ? 0 : (int)(threadIdx.x & 63);
   if (i >= total) return;
-  const int j = blockIdx.y;
   const int ns = R.nsub;
   const int S = R.S;
+  const bool pre_kick = R.kick_pre != 0.0 && blockIdx.y == 0;  // the extra stage 0: no D, rotation by kick_pre
+  const int j = (int)blockIdx.y - (R.kick_pre != 0.0 ? 1 : 0);
+  if (pre_kick) {
+    if (lane == 0) {
+      const ryd_qdesc d0 = desc[i];
+      double C = 1.0, gi = 0.0;
+      if (d0.drive_series >= 0) {
+        const cplx* p = pp + ((size_t)d0.drive_series * n_int + R.kick_idx) * 4;
+        const double cr = d0.drive_scale * fma(fma(fma(p[0].x, R.kick_u, p[1].x), R.kick_u, p[2].x), R.kick_u, p[3].x);
+        double sn, cs;
+        sincos(R.kick_pre * cr, &sn, &cs);
+        C = cs;
+        gi = -sn;
+      }
+      double* o = out + ((size_t)blockIdx.y * total + i) * 4;
+      o[0] = C;
+      o[1] = R.tan_form ? gi / C : 0.0;
+      o[2] = gi;
+      o[3] = 0.0;
+    }
+    return;
+  }
   const bool closing = j == S * ns;
   const int s = closing ? ns - 1 : j / S, st = closing ? S : j % S;
   // D intervals: (knot interval, start offset, length)
@@ -88,9 +121,9 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
     us_d[1] = R.u0[s - 1] + (1.0 - R.a[S]) * R.tau[s - 1];
     len_d[1] = R.a[S] * R.tau[s - 1];
   }
-  const int idx_c = R.idx[s];
-  const double u_c = us_d[0] + len_d[0];
-  const double beta = closing ? 0.0 : R.b[st] * R.tau[s];
+  const int idx_c = closing ? R.kick_idx : R.idx[s];
+  const double u_c = closing ? R.kick_u : us_d[0] + len_d[0];
+  const double beta = closing ? R.kick_post : R.b[st] * R.tau[s];
 
   const ryd_qdesc d = desc[i];
   auto val = [&](int sr, int idx, double u) -> cplx {
@@ -137,7 +170,7 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
       gi = -S * cr;
     }
     if (R.tan_form) gr = gi / C;  // (real drives: gr was 0; the host keeps |beta c| <= 1, so C >= 0.54)
-    double* o = out + ((size_t)j * total + i) * 4;
+    double* o = out + ((size_t)blockIdx.y * total + i) * 4;
     o[0] = C;
     o[1] = gr;
     o[2] = gi;

@@ -129,7 +129,15 @@ __device__ __forceinline__ double splitr_partner(double v) {
   else return splitr_dpp<0x1B>(splitr_dpp<0x141>(v));      // xor 4 = (xor 3) o (xor 7): row_half_mirror, quad reverse
 }
 
-template <int N, int NR, bool DECAY>
+// ROWS: the kets are the rows of a density matrix (the split-operator master equation of host_ket.hpp): blockIdx.z = the
+// matrix, and the workgroups of a matrix are PERSISTENT - workgroup blockIdx.y takes the rows blockIdx.y, + gridDim.y, ...
+// one after another (tables, E0 pieces and stage weights are set up once, and the store of a row overlaps the load of
+// the next).  The coefficients and E0 of the matrix serve its 2^N rows, the propagator
+// may be the complex conjugate one (SplitArgs.conj), the elementwise dissipator factors are applied at the load and /
+// or the store (SplitArgs.ftab: exponentials of linear functions of the bit-pair counts, so the factor of an
+// amplitude is (a factor of its lane) x (a factor of its register)), and the run may open with / close on the
+// drive-only kick of the 4th-order splitting (SplitRun.kick_*).
+template <int N, int NR, bool DECAY, bool ROWS = false>
 __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per_eu(1, NR >= 6 ? 1 : 2))) void k_split_reg(const SplitArgs A, const SplitRun R, long long stage_stride) {
   typedef SplitRegLayout<N, NR> L;
   constexpr int NW = L::NW, NTB = L::NTB, ND = L::ND;
@@ -149,20 +157,24 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
 
   const unsigned t = threadIdx.x;
   const unsigned l = t & 63u, w = t >> 6;
-  const int b = blockIdx.y;
-  const int n_stages = R.S * R.nsub + 1;
-  cplx* __restrict__ st = A.state + ((size_t)b << N);
+  const int b = ROWS ? (int)blockIdx.z : (int)blockIdx.y;
+  const int n_pre = R.kick_pre != 0.0 ? 1 : 0;  // the opening kick is an extra stage 0 (no D)
+  const int n_stages = R.S * R.nsub + 1 + n_pre;
+  // (SplitArgs.conj: conj(U) psi = conj(U conj(psi)) - the ket is conjugated at the load and at the store, the stages
+  // in between are the ordinary ones: nothing in the stage loop knows about it)
+  const double csgn = (ROWS && A.conj) ? -1.0 : 1.0;
   const double* __restrict__ coefs = A.ccur + (size_t)b * N * 4;
   const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride;
 
   if (SPLITR_WMODE) {
     // weight of E0 in the D of stage j: a_i tau (+ the last a tau carried over from the previous sub-step)
-    for (int j = (int)t; j < n_stages; j += NT) {
-      const bool last = j == n_stages - 1;
+    for (int jj = (int)t; jj < n_stages; jj += NT) {
+      const int j = jj - n_pre;
+      const bool last = jj == n_stages - 1;
       const int sub = last ? R.nsub - 1 : j / R.S, i = last ? R.S : j % R.S;
       double wgt = R.a[i] * R.tau[sub];
       if (!last && i == 0 && sub > 0) wgt += R.a[R.S] * R.tau[sub - 1];
-      wtab[j] = wgt;
+      wtab[jj] = j < 0 ? 0.0 : wgt;
     }
   }
   for (unsigned k = t; k < SPLITR_TRIG; k += NT) {  // (before the state is loaded: the library routine wants registers)
@@ -184,15 +196,21 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       etab[(2 * o + 1) * NT + t] = eg[o];
     }
   }
+  // ROWS: elementwise factor of amplitude (row a, column i) = prod_k tab_k[n_k], n = the counts of (row bit, column bit)
+  // = (0,0), (0,1), (1,0), (1,1); every table is an exponential of a linear function, so the product splits into a
+  // factor of the lane's column bits and one of the register's column bits (uniform: table of NA per layout use)
+  double* ftl = etab + (SPLITR_EMODE ? 4 * NT : 0);  // [128] the host's tables, [NA] register factors (rewritten per use)
+  unsigned a_row = 0;  // ROWS: the current row
+  auto row_factor = [&](int which, unsigned col_bits, unsigned mask) -> double {
+    const unsigned a = a_row;
+    const int n11 = __popc(a & col_bits & mask), n10 = __popc(a & ~col_bits & mask), n01 = __popc(~a & col_bits & mask);
+    const int n00 = __popc(mask) - n11 - n10 - n01;
+    const double* tb = ftl + 64 * which;
+    return tb[n00] * tb[16 + n01] * tb[32 + n10] * tb[48 + n11];
+  };
+  if (ROWS && (A.use_pre || A.use_post) && t < 128) ftl[t] = A.ftab[t];
   __syncthreads();
-  double xr[NA], xi[NA];
-  splitr_for<0, NA>([&](auto Rc) {
-    constexpr int r = decltype(Rc)::value;
-    const cplx v = st[L::index(false, t, r)];
-    xr[r] = v.x;
-    xi[r] = v.y;
-  });
-
+  typedef const __attribute__((address_space(4))) double* cptr_t;
   // exp(-i phi) = (cos, -sin): table of exp(2 pi i k / SPLITR_TRIG), series on |rr| <= pi / SPLITR_TRIG
   auto expmi = [&](double phi) -> cplx {
     const double kk = rint(phi * (SPLITR_TRIG / 6.283185307179586));
@@ -211,6 +229,28 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     return make_double2(fma(tb.x, cr, -tb.y * sr), -fma(tb.y, cr, tb.x * sr));
   };
   auto cm = [](cplx a, cplx c) -> cplx { return make_double2(fma(a.x, c.x, -a.y * c.y), fma(a.x, c.y, a.y * c.x)); };
+  // private slice of buffer 0: the slots a wave's own pass stores go to (slot = l + 64 (w + NG q), q < CH)
+  cplx* __restrict__ const tslice = pbuf + 64 * w;
+  const unsigned la = l & ((1u << ND) - 1u), lT = l >> ND;
+
+  for (unsigned row = ROWS ? blockIdx.y : 0u; row < (ROWS ? (1u << N) : 1u); row += ROWS ? gridDim.y : 1u) {
+  a_row = row;
+  cplx* __restrict__ st = A.state + ((((size_t)b << (ROWS ? N : 0)) + (ROWS ? row : 0u)) << N);
+  if (ROWS) __syncthreads();  // the previous row's readers of the factor table are done
+  if (ROWS && A.use_pre && t < NA) ftl[128 + t] = row_factor(0, L::index(false, 0u, t), L::index(false, 0u, NA - 1));
+  if (ROWS && A.use_pre) __syncthreads();
+  double xr[NA], xi[NA];
+  {
+    const double fl = (ROWS && A.use_pre) ? row_factor(0, L::index(false, t, 0u), L::index(false, NT - 1, 0u)) : 1.0;
+    splitr_for<0, NA>([&](auto Rc) {
+      constexpr int r = decltype(Rc)::value;
+      const cplx v = st[L::index(false, t, r)];
+      const double f = (ROWS && A.use_pre) ? fl * ftl[128 + r] : 1.0;
+      xr[r] = v.x * f;
+      xi[r] = v.y * (ROWS ? f * csgn : f);
+    });
+  }
+
 
   // rotation of register bit J (tan T) on the registers r with (r & MASK) == VAL
   auto rot_reg = [&](auto J, double T, auto MASK, auto VAL) {
@@ -228,11 +268,6 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     });
   };
 
-  // private slice of buffer 0: the slots a wave's own pass stores go to (slot = l + 64 (w + NG q), q < CH)
-  cplx* __restrict__ const tslice = pbuf + 64 * w;
-  const unsigned la = l & ((1u << ND) - 1u), lT = l >> ND;
-
-  typedef const __attribute__((address_space(4))) double* cptr_t;
   double cprod = 1.0;  // product of the cosines of the previous stage's rotations (tan form): rides on B
   bool odd = false;
   // (SPLITR_PREF) the detuning integrals by position and the E0 weight of the next stage, loaded a stage ahead
@@ -283,10 +318,12 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     } else if (SPLITR_WMODE) {
       wE = uniform_d(wtab[sg]);
     } else {
+      const int sj = sg - n_pre;
       const bool last = sg == n_stages - 1;
-      const int sub = last ? R.nsub - 1 : sg / R.S, i = last ? R.S : sg % R.S;
+      const int sub = last ? R.nsub - 1 : sj / R.S, i = last ? R.S : sj % R.S;
       wE = R.a[i] * R.tau[sub];
       if (!last && i == 0 && sub > 0) wE += R.a[R.S] * R.tau[sub - 1];
+      if (sj < 0) wE = 0.0;
     }
     double et_s, eg_s;
     if (SPLITR_EMODE) {
@@ -310,13 +347,11 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       if (DECAY)  // H_eff: the real factor exp(wE (dec_a + dec_b popc(index))): lane part here, register part in F
         sc *= exp(wE * (A.dec_a + A.dec_b * (double)(__popc(t) + NR)));
       Bf = make_double2(Bf.x * sc, Bf.y * sc);
+      const double dF = DECAY ? exp(-wE * A.dec_b) : 1.0;  // an excited register atom: one set bit fewer
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         F[j] = expmi(fma(wE, odd ? ev[1][j] : ev[0][j], -Dr[j]));
-        if (DECAY) {
-          const double d = exp(-wE * A.dec_b);  // an excited register atom: one set bit fewer
-          F[j] = make_double2(F[j].x * d, F[j].y * d);
-        }
+        if (DECAY) F[j] = make_double2(F[j].x * dF, F[j].y * dF);
       }
       Gl = expmi(wE * eg_s);
       if (!SPLITR_GMODE) {
@@ -523,8 +558,17 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     if (SPLITR_KWARM) asm volatile("" ::"s"(warm));
   }
   // n_stages stages ran: the layout is the odd one when that number is odd
+  double fl = 1.0;
+  if (ROWS && A.use_post) {
+    __syncthreads();
+    if (t < NA) ftl[128 + t] = row_factor(1, odd ? L::index(true, 0u, t) : L::index(false, 0u, t), odd ? L::index(true, 0u, NA - 1) : L::index(false, 0u, NA - 1));
+    __syncthreads();
+    fl = row_factor(1, odd ? L::index(true, t, 0u) : L::index(false, t, 0u), odd ? L::index(true, NT - 1, 0u) : L::index(false, NT - 1, 0u));
+  }
   splitr_for<0, NA>([&](auto Rc) {
     constexpr int r = decltype(Rc)::value;
-    st[odd ? L::index(true, t, r) : L::index(false, t, r)] = make_double2(xr[r], xi[r]);
+    const double f = (ROWS && A.use_post) ? fl * ftl[128 + r] : 1.0;
+    st[odd ? L::index(true, t, r) : L::index(false, t, r)] = make_double2(xr[r] * f, xi[r] * (ROWS ? f * csgn : f));
   });
+  }  // rows
 }

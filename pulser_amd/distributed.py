@@ -328,106 +328,112 @@ def run_ensemble(
     lower_pool = None
     lowered: dict[int, Any] = {}
     pending: list[Any] = []
-    for start in range(lo, hi, batch):
-        block = list(range(start, min(hi, start + batch)))
-        if mc_seeds is not None:  # a trajectory's jumps depend on its seed only, not on the sharding
-            emulator._mc_seed_override = mc_seeds[block]
-        try:
-            if fast:
-                # factored lowering (shared spline tables + per-(trajectory, atom) scales); the states
-                # stay on the device: occupations / norms are reduced there (ryd_occupations), the
-                # reps-weighted sum of |psi><psi| is formed there (ryd_outer_accumulate_dim, fp64 matrix
-                # cores) and only the kets (or, for density matrices, their diagonals) of the
-                # bit-exact sampling replay cross PCIe - no D x D array exists on the host
-                import torch as _t
+    try:
+        for start in range(lo, hi, batch):
+            block = list(range(start, min(hi, start + batch)))
+            if mc_seeds is not None:  # a trajectory's jumps depend on its seed only, not on the sharding
+                emulator._mc_seed_override = mc_seeds[block]
+            try:
+                if fast:
+                    # factored lowering (shared spline tables + per-(trajectory, atom) scales); the states
+                    # stay on the device: occupations / norms are reduced there (ryd_occupations), the
+                    # reps-weighted sum of |psi><psi| is formed there (ryd_outer_accumulate_dim, fp64 matrix
+                    # cores) and only the kets (or, for density matrices, their diagonals) of the
+                    # bit-exact sampling replay cross PCIe - no D x D array exists on the host
+                    import torch as _t
 
-                from .engine import accumulate, outer_accumulate
+                    from .engine import accumulate, outer_accumulate
 
-                # the factored lowering of the NEXT block runs on a worker thread while this block is solved
-                if lower_pool is None:
-                    from concurrent.futures import ThreadPoolExecutor as _TPE
+                    # the factored lowering of the NEXT block runs on a worker thread while this block is solved
+                    if lower_pool is None:
+                        from concurrent.futures import ThreadPoolExecutor as _TPE
 
-                    lower_pool = _TPE(max_workers=1)
-                if start not in lowered:
-                    lowered[start] = lower_pool.submit(hd.device_tables, [trajs[i] for i in block], emulator._sampling_rate)
-                nxt = start + batch
-                if nxt < hi and nxt not in lowered:
-                    lowered[nxt] = lower_pool.submit(
-                        hd.device_tables, [trajs[i] for i in range(nxt, min(hi, nxt + batch))], emulator._sampling_rate)
-                tables = lowered.pop(start).result()
-                first_dev, snaps_dev, occ = emulator._solve_batch([], False, options, tables=tables, raw=True)
-                is_ket = first_dev.dim() == 2
-                rb = reps[block].astype(np.float64)
-                norm = occ[..., n]  # [n_eval, B]
-                if not matching:  # weights = delta_0 (qutip_result.py:119-122): every measured bit is 0
-                    bits = np.zeros_like(occ[..., :n])
-                elif emulator._meas_basis == "ground-rydberg":  # bit 1 <=> |r> = local index 0
-                    bits = occ[..., :n] / norm[..., None]
-                else:  # digital: bit 1 <=> |h> = local index 1
-                    bits = (norm[..., None] - occ[..., :n]) / norm[..., None]
-                occ_sum[:, :n] += np.einsum("b,tbk->tk", rb, bits)
-                occ_sum[:, n] += norm @ rb
-                if density_matrix:
-                    D = int(first_dev.shape[1])
-                    if rho_dev is None:
-                        rho_dev = _t.zeros((n_eval, D, D), dtype=_t.complex128, device=first_dev.device)
-                    for ti in range(n_eval):
-                        x = first_dev if ti == 0 else snaps_dev[ti - 1]
-                        if is_ket:
-                            outer_accumulate(x, rho_dev[ti], rb / n_traj)
-                        else:
-                            for j in range(len(block)):
-                                accumulate(x[j], rho_dev[ti], float(rb[j]) / n_traj)
-                if is_ket:
-                    host = _t.cat([first_dev[None], snaps_dev]).cpu().numpy()  # [n_eval, B, D]
-                else:
-                    host = _t.cat([_t.diagonal(first_dev, dim1=-2, dim2=-1)[None],
-                                   _t.diagonal(snaps_dev, dim1=-2, dim2=-1)]).cpu().numpy()
-                del first_dev, snaps_dev
-                # the reference's weights and cumulative sums (qutip_result.py:101-158, multinomial.py:32-36) for
-                # the whole block at once: the same elementwise operations and the same sequential row sums
-                # ... on a worker thread, so that the replay of this block overlaps the solve of the next one
-                # (the GPU work is asynchronous C calls; the histogram is only read after the last block)
-                def replay(host: np.ndarray = host, block: list[int] = block, is_ket: bool = is_ket) -> None:
-                    cum = cumulative_weights(host, is_ket, emulator._meas_basis, matching)
-                    for j, i in enumerate(block):
+                        lower_pool = _TPE(max_workers=1)
+                    if start not in lowered:
+                        lowered[start] = lower_pool.submit(hd.device_tables, [trajs[i] for i in block], emulator._sampling_rate)
+                    nxt = start + batch
+                    if nxt < hi and nxt not in lowered:
+                        lowered[nxt] = lower_pool.submit(
+                            hd.device_tables, [trajs[i] for i in range(nxt, min(hi, nxt + batch))], emulator._sampling_rate)
+                    tables = lowered.pop(start).result()
+                    first_dev, snaps_dev, occ = emulator._solve_batch([], False, options, tables=tables, raw=True)
+                    is_ket = first_dev.dim() == 2
+                    rb = reps[block].astype(np.float64)
+                    norm = occ[..., n]  # [n_eval, B]
+                    if not matching:  # weights = delta_0 (qutip_result.py:119-122): every measured bit is 0
+                        bits = np.zeros_like(occ[..., :n])
+                    elif emulator._meas_basis == "ground-rydberg":  # bit 1 <=> |r> = local index 0
+                        bits = occ[..., :n] / norm[..., None]
+                    else:  # digital: bit 1 <=> |h> = local index 1
+                        bits = (norm[..., None] - occ[..., :n]) / norm[..., None]
+                    occ_sum[:, :n] += np.einsum("b,tbk->tk", rb, bits)
+                    occ_sum[:, n] += norm @ rb
+                    if density_matrix:
+                        D = int(first_dev.shape[1])
+                        if rho_dev is None:
+                            rho_dev = _t.zeros((n_eval, D, D), dtype=_t.complex128, device=first_dev.device)
                         for ti in range(n_eval):
-                            k = i * n_eval + ti
-                            ind = np.searchsorted(cum[ti, j], rnd_all[offs[k]:offs[k + 1]])
-                            ind = flips_with(ind, n, mat_all[offs[k]:offs[k + 1]] if meas_err else None,
-                                             nm.p_false_pos, nm.p_false_neg)
-                            hist[ti] += np.bincount(ind, minlength=2**n)
+                            x = first_dev if ti == 0 else snaps_dev[ti - 1]
+                            if is_ket:
+                                outer_accumulate(x, rho_dev[ti], rb / n_traj)
+                            else:
+                                for j in range(len(block)):
+                                    accumulate(x[j], rho_dev[ti], float(rb[j]) / n_traj)
+                    if is_ket:
+                        host = _t.cat([first_dev[None], snaps_dev]).cpu().numpy()  # [n_eval, B, D]
+                    else:
+                        host = _t.cat([_t.diagonal(first_dev, dim1=-2, dim2=-1)[None],
+                                       _t.diagonal(snaps_dev, dim1=-2, dim2=-1)]).cpu().numpy()
+                    del first_dev, snaps_dev
+                    # the reference's weights and cumulative sums (qutip_result.py:101-158, multinomial.py:32-36) for
+                    # the whole block at once: the same elementwise operations and the same sequential row sums
+                    # ... on a worker thread, so that the replay of this block overlaps the solve of the next one
+                    # (the GPU work is asynchronous C calls; the histogram is only read after the last block)
+                    def replay(host: np.ndarray = host, block: list[int] = block, is_ket: bool = is_ket) -> None:
+                        cum = cumulative_weights(host, is_ket, emulator._meas_basis, matching)
+                        for j, i in enumerate(block):
+                            for ti in range(n_eval):
+                                k = i * n_eval + ti
+                                ind = np.searchsorted(cum[ti, j], rnd_all[offs[k]:offs[k + 1]])
+                                ind = flips_with(ind, n, mat_all[offs[k]:offs[k + 1]] if meas_err else None,
+                                                 nm.p_false_pos, nm.p_false_neg)
+                                hist[ti] += np.bincount(ind, minlength=2**n)
 
-                if pool is None:
-                    from concurrent.futures import ThreadPoolExecutor
+                    if pool is None:
+                        from concurrent.futures import ThreadPoolExecutor
 
-                    pool = ThreadPoolExecutor(max_workers=1)  # one worker: the replays run in block order
-                pending.append(pool.submit(replay))
-                continue
-            states = solve_fn([hd.problem(trajs[i], emulator._sampling_rate) for i in block])
-        finally:
-            emulator._mc_seed_override = None
-        for j, i in enumerate(block):
-            for ti in range(n_eval):
-                st = QState(states[j][ti])
-                w = sample(i, ti, st)
-                # measured-bit occupations from the 2^N weights: valid for every basis (2-, 3-, 4-level)
-                occ_sum[ti, :n] += reps[i] * (w @ bit_of)
-                occ_sum[ti, n] += reps[i] * (float(np.vdot(st, st).real) if st.isket else float(st.tr().real))
-                if density_matrix:
-                    # explicit-term general path (multi-level / XY registers of a few atoms) and the
-                    # host ``solve_fn`` of the CPU tests
-                    a = np.asarray(st)
-                    r1 = (a @ a.conj().T) if st.isket else a
-                    if rho_sum is None:
-                        rho_sum = np.zeros((n_eval,) + r1.shape, dtype=np.complex128)
-                    rho_sum[ti] += reps[i] * r1
-    for fut in pending:
-        fut.result()  # (re-raises what a replay raised)
-    if pool is not None:
-        pool.shutdown()
-    if lower_pool is not None:
-        lower_pool.shutdown()
+                        pool = ThreadPoolExecutor(max_workers=1)  # one worker: the replays run in block order
+                    pending.append(pool.submit(replay))
+                    continue
+                states = solve_fn([hd.problem(trajs[i], emulator._sampling_rate) for i in block])
+            finally:
+                emulator._mc_seed_override = None
+            for j, i in enumerate(block):
+                for ti in range(n_eval):
+                    st = QState(states[j][ti])
+                    w = sample(i, ti, st)
+                    # measured-bit occupations from the 2^N weights: valid for every basis (2-, 3-, 4-level)
+                    occ_sum[ti, :n] += reps[i] * (w @ bit_of)
+                    occ_sum[ti, n] += reps[i] * (float(np.vdot(st, st).real) if st.isket else float(st.tr().real))
+                    if density_matrix:
+                        # explicit-term general path (multi-level / XY registers of a few atoms) and the
+                        # host ``solve_fn`` of the CPU tests
+                        a = np.asarray(st)
+                        r1 = (a @ a.conj().T) if st.isket else a
+                        if rho_sum is None:
+                            rho_sum = np.zeros((n_eval,) + r1.shape, dtype=np.complex128)
+                        rho_sum[ti] += reps[i] * r1
+        for fut in pending:
+            fut.result()  # (re-raises what a replay raised)
+    finally:
+        # on an error too: nothing may keep running behind the caller's back (a prefetched lowering holds device
+        # tables, a queued replay would go on adding to `hist`)
+        for fut in list(lowered.values()) + pending:
+            fut.cancel()
+        if pool is not None:
+            pool.shutdown(wait=True)
+        if lower_pool is not None:
+            lower_pool.shutdown(wait=True)
     # -- the one collective per accumulator: sum over ranks -----------------
     on_device = fast and density_matrix
     if density_matrix and not on_device and rho_sum is None:  # an empty shard still takes part in the all-reduce

@@ -263,9 +263,9 @@ class Engine:
     def _split_budget_check(self, method: str, tol: float) -> None:
         """The split-operator controller books its local-error estimates in ``ryd_stats.reserved[0]``;
         when it could not hold the sequence budget (retries used up, nothing to roll back to) say so."""
-        if not (method == "split" or (method == "auto" and self.mode == RYD_SESOLVE and self.n >= 14
-                                      and not self.monte_carlo)):
-            return
+        if not (method == "split" or (method == "auto" and self.mode == RYD_SESOLVE and self.n >= 12)):
+            return  # (12 - 14 atoms may, 15+ atoms do take the split-operator path by default; quantum jumps included:
+            #          a jump solve cannot roll back, so an overrun is only ever booked - and must be reported)
         est = self.stats()["reserved"][0]
         budget = 500.0 * tol if tol > 0 else 5e-8
         if est > 2.0 * budget:
@@ -365,6 +365,7 @@ class Engine:
                 self._stream(),
             )
         )
+        self._split_budget_check(method, float(tol))
         return out
 
     def mc_jumps(self) -> np.ndarray:
@@ -379,7 +380,7 @@ class Engine:
                  force_ket: bool = False, no_split: bool = False,
                  split_fixed: bool = False, split_no_loop: bool = False,
                  no_merge: bool = False, split_small_tiles: bool = False, split_s6: bool = False,
-                 no_split14: bool = False, split_turns: bool = False) -> None:
+                 no_split14: bool = False, split_turns: bool = False, rows_ket: bool = False) -> None:
         """Test/bench hook: disable the persistent small-N kernel and/or the 2^14
         register-tile kernel with the Hermitian mesolve path (the tiled
         multi-pass kernels are used instead), or force the register tiles;
@@ -392,6 +393,7 @@ class Engine:
         ``split_small_tiles`` keeps the 2^12 tiles of the split-operator passes where 2^14 tiles are the default
         (21 - 23 atoms); ``no_split14`` keeps batches of 14-atom sequences on the polynomial
         register-resident kernel (k_ket) instead of the split-operator one (k_split14_loop);
+        ``rows_ket`` keeps the row passes of the split-operator master equation on k_ket (round 3) instead of k_split_reg;
         ``split_turns`` runs them on the round-3 kernel (two LDS turns per stage) instead of k_split_reg;
         ``split_s6`` keeps the 4th-order composition with sub-steps that end at every knot
         (round 2) where the 6th-order one with multi-knot sub-steps is the default."""
@@ -402,7 +404,7 @@ class Engine:
             | (64 if force_ket else 0) | (128 if no_split else 0)
             | (256 if split_fixed else 0) | (512 if split_no_loop else 0)
             | (1024 if no_merge else 0) | (2048 if split_small_tiles else 0) | (8192 if split_s6 else 0)
-            | (16384 if no_split14 else 0) | (32768 if split_turns else 0)))
+            | (16384 if no_split14 else 0) | (32768 if split_turns else 0) | (65536 if rows_ket else 0)))
 
     def apply_generator(self, x: Any, t: float) -> Any:
         """``G(t) x`` with ``G = -iH`` (sesolve) or the Lindbladian (mesolve)."""

@@ -375,6 +375,35 @@ def test_complex_global_drive_starting_from_zero_amplitude_against_the_oracle():
         assert np.max(np.abs(snaps[k - 1] - ref[k])) < AMP_TOL, k
 
 
+@pytest.mark.parametrize("dphi", [0.0, 1.0, np.pi / 2])
+def test_pulse_delay_phase_shifted_pulse_against_the_oracle(dphi):
+    """Ramsey / echo shape (round-3 ADVICE, high): a pulse, 60 ns at zero amplitude, a second pulse whose phase is shifted
+    by dphi.  While the amplitude is zero the gauged kernel holds the drive's old direction and theta' is not sampled, so
+    following the direction through theta' alone would lose the step (0.50 error in the amplitudes at dphi = pi / 2 in a
+    NumPy replica of the kernel logic).  The host now refuses the gauge when a series re-emerges from a sub-threshold
+    stretch with another direction (compute_bounds: the complex-coefficient kernels take over); dphi = 0 stays gauged.
+    10 atoms, tight oracle."""
+    from oracle import qutip_path as qp
+
+    n, T = 10, 311
+    prob = tri_problem(2, 5)
+    t = np.arange(T)
+    amp = np.zeros(T)
+    for a, b in ((0, 125), (185, 310)):
+        amp[a:b + 1] = 9.0 * np.sin(np.pi * (t[a:b + 1] - a) / (b - a)) ** 2
+    g = {"amp": amp, "det": np.full(T, -3.0), "phase": np.where(t < 150, 0.4, 0.4 + dphi)}
+    prob = dict(prob, duration=T, samples={"Global": {"ground-rydberg": g}, "Local": {}})
+    times = np.array([0.0, 0.125, 0.16, 0.31])
+    opts = dict(qp.default_options([np.stack([g["amp"], g["det"]])], T - 1))
+    opts.update(qp.TIGHT)
+    ref = qp.sesolve(qp.build_hamiltonian(prob), qp.all_ground_state(n, prob["eigenbasis"]), times, **opts)
+    with _engine([prob], "sesolve") as eng:
+        eng.set_path(False, force_ket=True)
+        snaps = eng.solve(eng.new_state(), times).cpu().numpy()[:, 0]
+    for k in (1, 2, 3):
+        assert np.max(np.abs(snaps[k - 1] - ref[k])) < AMP_TOL, (dphi, k, np.max(np.abs(snaps[k - 1] - ref[k])))
+
+
 def test_a_drive_through_zero_with_a_turning_phase_is_not_gauged():
     """theta' = Im(c' conj c) / |c|^2 is unbounded where a drive passes by zero while its phase turns - e.g. a
     phase jump of almost pi at constant amplitude: the complex spline takes c from A e^{-i phi_1} to A e^{-i phi_2}

@@ -535,3 +535,17 @@ def test_results_container():
             getattr(blank, attr)
     with pytest.raises(AttributeError, match="'not_an_attr' is not in the results"):
         blank.not_an_attr
+
+
+def test_density_matrix_aggregator_fails_loudly_without_a_gpu():
+    """The backend has no CPU path: on a host without a GPU the aggregator says so itself instead of failing
+    somewhere inside torch (round-3 ADVICE)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the -m gpu test covers the aggregator")
+    from pulser_amd.backend import density_matrix_aggregator
+
+    s1 = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rgr": 1.0})
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        density_matrix_aggregator([s1, s1])
