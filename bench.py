@@ -609,8 +609,8 @@ def main() -> None:
             # Lindblad leg (cfg3)
             ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
             eng = Engine.from_problems([tri_problem(2, 7, ops)], mode="mesolve")
-            if args.no_ket:
-                eng.set_path(False, no_ket=True)
+            if args.no_ket or os.environ.get("RYD_BENCH_ROWS_KET"):
+                eng.set_path(False, no_ket=args.no_ket, rows_ket=bool(os.environ.get("RYD_BENCH_ROWS_KET")))
             args.full_lindblad = args.full_lindblad or args.lindblad_ns <= 0
             if args.full_lindblad:
                 t0, t1 = 0.0, T_SEQ_US
@@ -625,12 +625,17 @@ def main() -> None:
                    "extrapolated_full_sequence_s": sl * T_SEQ_US / (t1 - t0)}
             if not args.no_ket:
                 # two row passes per conjugation, each a full ket stage on 2^14 rows of 2^14 amplitudes
-                leg["integrator"] = ("4th-order operator splitting (Chin 4A + exact commutator kick), blocks of 2 + 2 "
-                                     "CF4 steps; U rho U^+ as two row passes of k_ket + one conjugate transposition")
+                rows_ket = bool(os.environ.get("RYD_BENCH_ROWS_KET"))
+                leg["integrator"] = ("4th-order operator splitting (Chin 4A + exact commutator kick), blocks of 2 + 2 ns; "
+                                     "U rho U^+ as two row passes + one conjugate transposition; the unitary of a half "
+                                     "block by " + ("CF4 steps on k_ket (round 3)" if rows_ket else
+                                                    "split-operator sub-steps (4th-order 6-stage composition) on k_split_reg"))
                 leg["roofline"] = roofline_valu(
-                    2.0**n, 2.0**n * 2, stl["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kl_ms, kl_n,
-                    "k_ket<14> row passes (+ k_transpose_conj)", "cfg3:k_ket",
-                    note="kernel time includes the transpositions (HBM-bound, 8.6 GB each)")
+                    2.0**n, 2.0**n * 2, stl["n_applications"], KKET_FLOPS_PER_AMP_STAGE if rows_ket else KSPLITREG_FLOPS_PER_AMP_STAGE,
+                    kl_ms, kl_n, ("k_ket<14> row passes" if rows_ket else "k_split_reg<14, 5, ROWS> row passes (persistent "
+                                  "workgroups, 64 rows each)") + " (+ k_transpose_conj)", "cfg3:k_ket" if rows_ket else "cfg3:k_split_reg",
+                    note="kernel time includes the transpositions (HBM-bound, 8.6 GB each) and the kick stages",
+                    algorithmic_flops_per_amp_stage=None if rows_ket else SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE)
             else:
                 leg["roofline"] = roofline_hbm(28, 1, stl, kl_ms, kl_n,
                                                "k_apply14<mesolve> + k_symm (Hermitian path)", "cfg3:k_apply")

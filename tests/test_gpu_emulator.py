@@ -122,7 +122,9 @@ def test_noisy_doppler_amplitude_trajectories_against_oracle():
     for b in range(3):
         for i in range(len(extra["eval_times"])):
             assert np.max(np.abs(np.asarray(got[b].states[i])[:, 0] - ref[b][i])) < 1e-7
-    assert emu.last_engine_stats["n_launches"] == 1  # one persistent launch for the batch
+    # round 4: a 12-atom batch whose schedule is mostly multi-knot steps takes the register-resident split-operator
+    # kernel (a launch per closed run and its coefficient table) instead of the one persistent launch of k_traj
+    assert 1 <= emu.last_engine_stats["n_launches"] < 100
 
 
 def test_cfg4_noisy_run_factored_equals_general_path():

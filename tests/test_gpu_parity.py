@@ -220,6 +220,7 @@ def test_persistent_kernel_matches_generic_and_oracle(n):
 def test_persistent_kernel_cfg2_chain12_snapshots():
     prob, extra = load_fixture("cfg2_chain12_anneal.npz")
     eng = _engine([with_anneal_samples(prob)])
+    eng.set_path(False, no_split14=True)  # k_traj itself (round 4: 12 - 14 atoms may take k_split_reg by default)
     st = eng.new_state()
     snaps = eng.solve(st, np.asarray(extra["eval_times"])).cpu().numpy()
     ref = np.asarray(extra["oracle_states_tight"])
