@@ -41,8 +41,12 @@ static SplitScheme make_s10() {
 }
 static const SplitScheme kSplitS10 = make_s10();
 static const int kSplitMaxSub = SPLIT_MAX_SUB;
-static const int kSplitMergeMax = 8;  // knot intervals a sub-step of the 6th-order scheme may span (16: measured worse -
-                                      // the controller overshoots and rolls back: 8 760 -> 16 050 stages at 14 atoms)
+// Knot intervals a step of the 6th-order scheme may span.  The controller cuts a step into k equal sub-steps, so the
+// cap quantises what it can choose: with 8-knot steps the anneal sat at k = 2 (4 ns) although its budget allowed ~5 ns;
+// 9-knot steps give 4.5 ns (round 4: 8 064 -> 7 360 stages at 14 atoms, true error 2.1e-9 -> 3.8e-9 at T, estimate
+// 5.3e-9); 10: 1.3e-8 at t = 0.5 us with an estimate of 3e-9 (the estimate stops covering the error), 12 and 16: the
+// controller overshoots and rolls back (23 362 / 16 050 stages).  RYD_SPLIT_CAP: dev A/B.
+static const int kSplitMergeMax = [] { const char* e = std::getenv("RYD_SPLIT_CAP"); return e ? std::atoi(e) : 9; }();
 
 // May this handle use the 6th-order scheme at all?  (At least half of the knots removable, not switched off.)
 static bool split_s10_allowed(const ryd_handle* h) {
@@ -196,11 +200,11 @@ static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R
 
 // Advance `buf` over `subs` (consecutive sub-steps, at most split_max_sub) from a closed state to
 // a closed state: one k_split_coefs launch, then one k_split launch per pass.
-static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hipStream_t st) {
+static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hipStream_t st, bool s6_run = false) {
   int rc;
   split_plan(h);
   const int N = h->N, B = h->B;
-  const SplitScheme& sc = split_scheme(h);
+  const SplitScheme& sc = s6_run ? kSplitS6 : split_scheme(h);  // (s6_run: split_advance, one-knot stretches)
   const int n_stages = sc.S * nsub + 1;
   if ((rc = split_ensure_tables(h, n_stages))) return rc;
   bool reg_loop = split_reg_shape(h);
@@ -477,10 +481,21 @@ static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>
 // Advance over any number of sub-steps (closed runs of at most split_max_sub).
 static int split_advance(ryd_handle* h, cplx* buf, const std::vector<SubStep>& subs, hipStream_t st) {
   const int cap = split_max_sub(h);
-  for (size_t at = 0; at < subs.size(); at += cap) {
-    const int n = (int)std::min<size_t>(cap, subs.size() - at);
-    int rc = split_run(h, buf, subs.data() + at, n, st);
+  // Under the 6th-order scheme the stretches of ONE-KNOT sub-steps (the ~25 knots of spline ringing next to every
+  // waveform kink, where nothing can be merged: 182 of the 547 schedule steps of the anneal) still run the 4th-order
+  // 6-stage composition: at one knot interval its error is 1e-13 per sub-step (NumPy model), far below
+  // what the controller books for them, and it costs 6 stages instead of 10 (round 4: 8 290 -> 7 560 stages at 14 atoms).
+  auto one_knot = [&](const SubStep& s) {
+    return h->split_s10 && !h->split_s6_only && s.u0 + s.tau <= (h->tknots[s.idx + 1] - h->tknots[s.idx]) * (1.0 + 1e-9);
+  };
+  size_t at = 0;
+  while (at < subs.size()) {
+    const bool s6 = one_knot(subs[at]);
+    size_t end = at + 1;
+    while (end < subs.size() && end - at < (size_t)cap && one_knot(subs[end]) == s6) ++end;
+    int rc = split_run(h, buf, subs.data() + at, (int)(end - at), st, s6);
     if (rc) return rc;
+    at = end;
   }
   return RYD_OK;
 }
@@ -627,7 +642,10 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
         h->stats.reserved[0] += std::max(0.0, e / s0.tau - err_rate) * h->split_since_len;
       }
       retries = 0;
-      if (fac < 0.9 || fac > 1.6) tau_t = tau_new;
+      static const double grow_env = [] { const char* e = std::getenv("RYD_SPLIT_GROW"); return e ? std::atof(e) : 1.3; }();  // dev A/B
+      // (growth hysteresis: 1.6 until round 3; at 6th order x 1.3 in tau is x 4.8 in error - the sub-step follows its
+      // budget more closely: 7 360 -> 6 890 stages on the anneal, estimate 5.3e-9 -> 5.7e-9)
+      if (fac < 0.9 || fac > grow_env) tau_t = tau_new;
       if (tau_t > 0.99 * d.h && fac >= 1.0) tau_t = 1e300;
       h->stats.reserved[0] += e / two_p;  // the two halves are what was kept
       off += s0.tau;

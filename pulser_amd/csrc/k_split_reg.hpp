@@ -43,7 +43,8 @@
 #define SPLITR_KO 0
 #endif
 // A/B switches (dev builds, profiles/r04_ksplit14_variants.md):
-//   SPLITR_TMODE 1: lane bits 4, 5 by v_permlane16_swap / v_permlane32_swap instead of the LDS transposition (NTB == 2)
+//   SPLITR_TMODE 1: lane bits 4, 5 by v_permlane16_swap / v_permlane32_swap instead of the LDS transposition (NTB == 2);
+//                2: the LDS transposition, D first and half of the DPP rotations as its filler
 //   SPLITR_GMODE 1: the uniform factor G(r) by v_readlane from the lane that computed it instead of the LDS table
 //   SPLITR_WMODE 1: the stages' E0 weights from an LDS table filled at launch (no kernel-argument loads per stage)
 #ifndef SPLITR_TMODE
@@ -449,51 +450,72 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
         rot_reg(splitr_c<NW + m>{}, Tl[ND + m], splitr_c<PW>{}, Gc);
       });
     };
-    splitr_for<0, NG>([&](auto Ic) {
-      constexpr int g = NG - 1 - decltype(Ic)::value;
-      phase_group(splitr_c<g>{});
-      rot_t_old(splitr_c<g>{});
-      if constexpr (SPLITR_TMODE == 1 && NTB == 2) {
-        t_swap(splitr_c<g>{});
-        rot_t_new(splitr_c<g>{});
-      } else {
-        t_write(splitr_c<g>{});
-        t_read(splitr_c<g>{});
-        if constexpr (g + 1 < NG) rot_t_new(splitr_c<g + 1>{});
-      }
-    });
-    if constexpr (!(SPLITR_TMODE == 1 && NTB == 2)) rot_t_new(splitr_c<0>{});
-
-    // ---- per chunk (top two T bits fixed): the pass bits and the DPP lane bits, then the pass ----
-    auto rot_lane = [&](auto Rc) {
-      constexpr int r = decltype(Rc)::value;
+    // rotations of the DPP lane bits in MASK on register r (any time between this stage's D and the next one's: they
+    // commute with every other rotation and exchange of the stage)
+    auto rot_lane = [&](auto Rc, auto MASK) {
+      constexpr int r = decltype(Rc)::value, mask = decltype(MASK)::value;
       if (SPLITR_KO & 2) return;
-      if constexpr (ND > 0) {
+      if constexpr (ND > 0 && (mask & 1)) {
         const double T = Tl[0], px = splitr_partner<0>(xr[r]), py = splitr_partner<0>(xi[r]);
         xr[r] = fma(-T, py, xr[r]);
         xi[r] = fma(T, px, xi[r]);
       }
-      if constexpr (ND > 1) {
+      if constexpr (ND > 1 && (mask & 2)) {
         const double T = Tl[1], px = splitr_partner<1>(xr[r]), py = splitr_partner<1>(xi[r]);
         xr[r] = fma(-T, py, xr[r]);
         xi[r] = fma(T, px, xi[r]);
       }
-      if constexpr (ND > 3) {
+      if constexpr (ND > 3 && (mask & 8)) {
         const double T = Tl[3], px = splitr_partner<3>(xr[r]), py = splitr_partner<3>(xi[r]);
         xr[r] = fma(-T, py, xr[r]);
         xi[r] = fma(T, px, xi[r]);
       }
-      if constexpr (ND > 2) {
+      if constexpr (ND > 2 && (mask & 4)) {
         const double T = Tl[2], px = splitr_partner<2>(xr[r]), py = splitr_partner<2>(xi[r]);
         xr[r] = fma(-T, py, xr[r]);
         xi[r] = fma(T, px, xi[r]);
       }
     };
+    // SPLITR_TMODE 2: the transposition through LDS with the vector work arranged around it - D on every group first
+    // (its G-table reads would otherwise sit in the LDS queue between a group's stores and loads and every wait for a
+    // G value would wait for the transposition too), then per group the old T bits, the DPP bits TMASK (filler: the
+    // LDS takes ~540 cycles per group for the 8 waves), the stores, the loads; the other DPP bits stay with the pass
+    constexpr int TMASK = SPLITR_TMODE == 2 ? 3 : 0;           // DPP lane bits rotated inside the transposition loop
+    constexpr int PMASK = ((1 << ND) - 1) & ~TMASK;            // ... and with the pass chunks
+    if constexpr (SPLITR_TMODE == 2) {
+      splitr_for<0, NG>([&](auto Ic) { phase_group(splitr_c<(NG - 1 - decltype(Ic)::value)>{}); });
+      splitr_for<0, NG>([&](auto Ic) {
+        constexpr int g = NG - 1 - decltype(Ic)::value;
+        rot_t_old(splitr_c<g>{});
+        splitr_for<0, GR>([&](auto Qc) { rot_lane(splitr_c<(g | (decltype(Qc)::value << NW))>{}, splitr_c<TMASK>{}); });
+        t_write(splitr_c<g>{});
+        t_read(splitr_c<g>{});
+        if constexpr (g + 1 < NG) rot_t_new(splitr_c<g + 1>{});
+      });
+      rot_t_new(splitr_c<0>{});
+    } else {
+      splitr_for<0, NG>([&](auto Ic) {
+        constexpr int g = NG - 1 - decltype(Ic)::value;
+        phase_group(splitr_c<g>{});
+        rot_t_old(splitr_c<g>{});
+        if constexpr (SPLITR_TMODE == 1 && NTB == 2) {
+          t_swap(splitr_c<g>{});
+          rot_t_new(splitr_c<g>{});
+        } else {
+          t_write(splitr_c<g>{});
+          t_read(splitr_c<g>{});
+          if constexpr (g + 1 < NG) rot_t_new(splitr_c<g + 1>{});
+        }
+      });
+      if constexpr (!(SPLITR_TMODE == 1 && NTB == 2)) rot_t_new(splitr_c<0>{});
+    }
+
+    // ---- per chunk (top two T bits fixed): the pass bits and the DPP lane bits, then the pass ----
     constexpr int CM = 3 << (NR - 2);  // the chunk's bits of the register index
     auto pre = [&](auto Cc) {
       constexpr int c = decltype(Cc)::value;
       splitr_for<0, NW>([&](auto Jc) { rot_reg(Jc, Tr[decltype(Jc)::value], splitr_c<CM>{}, splitr_c<(c << (NR - 2))>{}); });
-      splitr_for<0, CH>([&](auto Kc) { rot_lane(splitr_c<(decltype(Kc)::value | (c << (NR - 2)))>{}); });
+      splitr_for<0, CH>([&](auto Kc) { rot_lane(splitr_c<(decltype(Kc)::value | (c << (NR - 2)))>{}, splitr_c<PMASK>{}); });
     };
     auto post = [&](auto Cc) {  // the wave bits, now register bits 0 .. NW-1
       constexpr int c = decltype(Cc)::value;
