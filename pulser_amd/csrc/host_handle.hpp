@@ -94,6 +94,7 @@ struct ryd_handle {
   double split_eps = 0.0;         // tolerance the state was measured for
   int split_since = 0;            // schedule steps since the last check
   double split_since_len = 0.0;   // simulated time (us) covered since the last check
+  double split_t_last = -1e300;   // end time (us) of the last split-operator solve: the state above belongs to its continuation
   // general path (explicit CSR terms)
   bool general = false;
   std::vector<GenTermHost> gen_host;
