@@ -300,7 +300,7 @@ int ryd_general_solve_many(ryd_handle** hs, int32_t n, void* const* states_dev, 
  * polynomial where ryd_opts.method 0 would choose the split-operator ket passes,
  * 256 = switch their step-size control off (one sub-step per schedule step),
  * 512 = 12- to 14-atom kets pass by pass instead of the one-launch loops over the stages
- * (k_split_reg; k_split12_loop, k_split14_loop),
+ * (k_split_reg; k_split14_loop),
  * 1024 = keep every CF4 step inside one knot interval (no multi-knot steps),
  * 2048 = 2^12-amplitude tiles of the split-operator passes where 2^13 ones are the default (21 - 23 atoms),
  * 4096 = general path: term-by-term kernel instead of the site-fused one,

@@ -265,30 +265,6 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
     h->stats.passes = 1;
     return RYD_OK;
   }
-  if (m == 1 && N == 12 && !h->split_no_loop && !h->mc) {
-    // the whole ket is one tile: every stage of the run in one launch, the ket stays in registers
-    SplitArgs A;
-    std::memset(&A, 0, sizeof A);
-    A.state = buf;
-    A.e0 = h->e0_dev;
-    A.e0_stride = h->e0_mats == 1 ? 0 : ((long long)1 << N);
-    A.ccur = h->split_coefs;
-    A.N = N;
-    A.T = 12;
-    const size_t lds = ((size_t)16 << 12) + 64 * 16 + 2 * SPLIT_TMAX * 4 * 8 + 128 * 8 + 2 * SPLIT_NMAX * 4 * 8;
-    std::pair<hipEvent_t, hipEvent_t> ev1;
-    if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
-    if (h->drive_real)
-      hipLaunchKernelGGL(k_split12_loop<true>, dim3(1, B), dim3(SPLIT_NT), lds, st, A, R, (long long)B * N * 4);
-    else
-      hipLaunchKernelGGL(k_split12_loop<false>, dim3(1, B), dim3(SPLIT_NT), lds, st, A, R, (long long)B * N * 4);
-    HIPCHK(hipGetLastError());
-    if (h->timing) { HIPCHK(hipEventRecord(ev1.second, st)); h->ev_used.push_back(ev1); }
-    h->stats.n_launches++;
-    h->stats.n_applications += n_stages - 1;
-    h->stats.passes = 1;
-    return RYD_OK;
-  }
   if (loop14) {
     // 14 atoms, a batch: one workgroup per sequence, every stage of the run in one launch (k_split14_loop)
     SplitArgs A;

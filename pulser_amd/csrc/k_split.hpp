@@ -575,154 +575,8 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   for (int r = 0; r < 16; ++r) st[g2 | deposit((unsigned long long)(r << 8), A.tile)] = x[r];
 }
 
-// Whole kets of exactly 12 atoms (one tile = one sequence): every stage of a closed run in ONE launch,
-// the ket stays in registers.  A stage is D + the 12 rotations; the layouts alternate
-//   even stages: L2 (D, bits 8-11) -> L0 (bits 0-3) -> L1 (bits 4-7)
-//   odd stages:  L1 (D, bits 4-7)  -> L0 (bits 0-3) -> L2 (bits 8-11)
-// so a stage costs two turns through LDS and no global traffic but its 12 x 4 coefficients.
-// E0 is loaded once, in both layouts D meets.  grid = (1, B).
-template <bool REAL>
-__global__ __launch_bounds__(SPLIT_NT) void k_split12_loop(const SplitArgs A, const SplitRun R, long long stage_stride) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int T = 12;
-  cplx* xs = reinterpret_cast<cplx*>(smem);
-  cplx* trig = xs + (1 << T);
-  double* rot = reinterpret_cast<double*>(trig + 64);  // [SPLIT_TMAX][4]
-  double* dlo = rot + 2 * SPLIT_TMAX * 4;
-  double* dhi = dlo + 64;
-  double* cfs = dhi + 64;
-
-  const unsigned tid = threadIdx.x;
-  const int N = A.N;  // == 12
-  const int b = blockIdx.y;
-  const int n_stages = R.S * R.nsub + 1;
-  cplx* __restrict__ st = A.state + ((size_t)b << N);
-  const double* __restrict__ coefs = A.ccur + (size_t)b * N * 4;
-  const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride;
-
-  const unsigned s2 = tid ^ ((tid >> 4) & 15u);
-  const unsigned s1 = (tid & 15u) | ((tid >> 4) << 8);
-  const unsigned s0 = tid << 4;
-  cplx x[16];
-  double ev1[16], ev2[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) x[r] = st[tid | (r << 8)];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    ev2[r] = e0[tid | (r << 8)];
-    ev1[r] = e0[s1 | (r << 4)];
-  }
-  if (tid < 64) trig[tid] = make_double2(kSplitTrig[tid][0], kSplitTrig[tid][1]);
-  double cnext = tid < 4u * N ? coefs[tid] : 0.0;  // stage 0's coefficients
-
-  auto rotate = [&](int pos) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double* c = rot + (pos + j) * 4;
-      const double C = c[0], gr = c[1], gi = c[2];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (r & (1 << j)) continue;
-        const cplx a0 = x[r], a1 = x[r | (1 << j)];
-        if (REAL) {
-          x[r] = make_double2(fma(-gi, a1.y, C * a0.x), fma(gi, a1.x, C * a0.y));
-          x[r | (1 << j)] = make_double2(fma(-gi, a0.y, C * a1.x), fma(gi, a0.x, C * a1.y));
-        } else {
-          x[r] = make_double2(fma(-gr, a1.x, fma(-gi, a1.y, C * a0.x)), fma(-gr, a1.y, fma(gi, a1.x, C * a0.y)));
-          x[r | (1 << j)] = make_double2(fma(gr, a0.x, fma(-gi, a0.y, C * a1.x)), fma(gr, a0.y, fma(gi, a0.x, C * a1.y)));
-        }
-      }
-    }
-  };
-  auto phase = [&](double wE, const double (&ev)[16], unsigned ibase, int shift) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned i = ibase | (unsigned)(r << shift);
-      const double phi = fma(wE, ev[r], -(dlo[i & 63u] + dhi[i >> 6]));
-      double c, s;
-      split_sincos(phi, trig, c, s);
-      const cplx a = x[r];
-      x[r] = make_double2(fma(a.x, c, a.y * s), fma(a.y, c, -a.x * s));
-    }
-  };
-
-  for (int sgi = 0; sgi < n_stages; ++sgi) {
-    // ---- this stage's tables (the coefficients were fetched during the previous stage) ----
-    __syncthreads();  // previous stage's readers of rot / dlo / dhi / xs are done
-    if (tid < 4u * N) cfs[tid] = cnext;
-    __syncthreads();
-    if (sgi + 1 < n_stages && tid < 4u * N) cnext = coefs[(size_t)(sgi + 1) * stage_stride + tid];
-    if (tid < (unsigned)T) {
-      const double* c = cfs + 4 * (N - 1 - tid);  // tile-local bit q = global bit q
-      double* o = rot + tid * 4;
-      o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
-    }
-    if (tid >= 128) {
-      const int e = tid - 128;
-      const bool hiHalf = e >= 64;
-      const int v = e & 63;
-      const int q0 = hiHalf ? 6 : 0;
-      double s = 0.0;
-      for (int q = 0; q < 6; ++q)
-        if (!((v >> q) & 1)) s += cfs[4 * (N - 1 - (q0 + q)) + 3];
-      (hiHalf ? dhi : dlo)[v] = s;
-    }
-    __syncthreads();
-    const bool last = sgi == n_stages - 1;
-    // weight of E0 in this stage's D: a_i tau (+ the a_7 tau carried over from the previous sub-step)
-    double w;
-    {
-      const int sub = last ? R.nsub - 1 : sgi / R.S, i = last ? R.S : sgi % R.S;
-      w = R.a[i] * R.tau[sub];
-      if (!last && i == 0 && sub > 0) w += R.a[R.S] * R.tau[sub - 1];
-    }
-    if (!(sgi & 1)) {
-      phase(w, ev2, tid, 8);
-      if (!last) {
-        rotate(8);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xs[s2 + (r << 8)] = x[r];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = xs[s0 | ((unsigned)r ^ (tid & 15u))];
-        rotate(0);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xs[s0 | ((unsigned)r ^ (tid & 15u))] = x[r];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = xs[(s1 ^ (unsigned)r) | (unsigned)(r << 4)];
-        rotate(4);
-      }
-    } else {
-      phase(w, ev1, s1, 4);
-      if (!last) {
-        rotate(4);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xs[(s1 ^ (unsigned)r) | (unsigned)(r << 4)] = x[r];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = xs[s0 | ((unsigned)r ^ (tid & 15u))];
-        rotate(0);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xs[s0 | ((unsigned)r ^ (tid & 15u))] = x[r];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = xs[s2 + (r << 8)];
-        rotate(8);
-      }
-    }
-  }
-  // the closing stage (index n_stages - 1) leaves the layout of its parity
-  if ((n_stages - 1) & 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[s1 | (r << 4)] = x[r];
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[tid | (r << 8)] = x[r];
-  }
-}
+// (k_split12_loop, the 12-atom one-launch loop of round 2 with its parity branch, is gone: real drives run on k_split_reg<12>
+// (k_split_reg.hpp), complex drives pass by pass on k_split12.)
 
 // Whole kets of exactly 14 atoms, one workgroup (512 lanes x 32 amplitudes = 5 register bits) per sequence: every stage
 // of a closed run in ONE launch, the ket stays in registers (the headline batch: 256 sequences = one per CU).  A stage
