@@ -148,7 +148,8 @@ static int split_max_sub(const ryd_handle* h) {
 
 // Whole kets of 12 - 14 atoms with real drives run on k_split_reg (below)
 static bool split_reg_shape(const ryd_handle* h) {
-  return h->N >= 12 && h->N <= 14 && h->drive_real && !h->split_turns && !h->split_no_loop;
+  // (complex drives included since round 4: k_split_reg<.., CPLX>)
+  return h->N >= 12 && h->N <= 14 && !h->split_turns && !h->split_no_loop;
 }
 
 // 14-atom kets in one launch per closed run (k_split_reg: register-resident, one workgroup per sequence)?  Any batch
@@ -175,6 +176,8 @@ static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R
     HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if constexpr (N == 14)
       HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<14, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (dev >= 0 && dev < 64) attr[dev] = true;
@@ -187,6 +190,10 @@ static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R
     const unsigned workers = std::min<unsigned>(1u << N, (unsigned)std::max(n_cu, 1) * per_cu);
     hipLaunchKernelGGL((k_split_reg<N, 5, false, true>), dim3(1, workers, (unsigned)h->B), dim3(NT), lds, st, A, R, stride);
   }
+  else if (!h->drive_real && h->mc)
+    hipLaunchKernelGGL((k_split_reg<N, 5, true, false, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
+  else if (!h->drive_real)
+    hipLaunchKernelGGL((k_split_reg<N, 5, false, false, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
   else if (h->mc)
     hipLaunchKernelGGL((k_split_reg<N, 5, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
   else if (N == 14 && nr_env == 6) {
@@ -209,7 +216,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   if ((rc = split_ensure_tables(h, n_stages))) return rc;
   bool reg_loop = split_reg_shape(h);
   bool loop14 = N == 14 && split_loop14(h) && ((n_stages & 1) || reg_loop);  // (k_split14_loop runs its stages in pairs + the closing one)
-  if ((loop14 || reg_loop) && h->drive_real) {
+  if ((loop14 && h->drive_real) || reg_loop) {
     // tan-form rotations need cos(beta |c|) away from zero: |beta c| <= 1 for every atom over every sub-step
     double bmax = 0.0;
     for (int i = 0; i < sc.S; ++i) bmax = std::max(bmax, std::fabs(sc.b[i]));
@@ -226,7 +233,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   for (int i = 0; i <= sc.S; ++i) R.a[i] = sc.a[i];
   for (int i = 0; i < sc.S; ++i) R.b[i] = sc.b[i];
   for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[s].idx; R.u0[s] = subs[s].u0; R.tau[s] = subs[s].tau; }
-  R.tan_form = (loop14 || reg_loop) && h->drive_real ? 1 : 0;
+  R.tan_form = reg_loop ? (h->drive_real ? 1 : 2) : (loop14 && h->drive_real ? 1 : 0);
   const int total = B * N;
   hipLaunchKernelGGL(k_split_coefs, dim3(h->dterms_dev ? (total + 3) / 4 : (total + 255) / 256, n_stages), dim3(256), 0, st,
                      h->pp_dev, h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);

@@ -527,7 +527,7 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
   // k_traj / k_ket / the tiled kernels)
   const bool reg_shape = split_reg_shape(h);
   if ((h->N == 14 || reg_shape) && o.method == 0 && o.taylor_order <= 0 && !h->force_generic && !h->no_split && !h->force_ket &&
-      !h->no_split14 && split_capable(h) && (reg_shape || ket_path(h)) && h->drive_real && (reg_shape || split_loop14(h)) &&
+      !h->no_split14 && split_capable(h) && (reg_shape || ket_path(h)) && (reg_shape || h->drive_real) && (reg_shape || split_loop14(h)) &&
       split_s10_allowed(h)) {
     share = merged_share();
     h->split14_auto = share >= 0.5;

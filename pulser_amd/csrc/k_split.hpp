@@ -59,7 +59,8 @@ struct SplitRun {
   double tau[SPLIT_MAX_SUB];
   double a[SPLIT_MAX_STAGES + 1];  // D(a_1) R(b_1) ... R(b_S) D(a_{S+1})
   double b[SPLIT_MAX_STAGES];
-  int tan_form;  // real drives on k_split14_loop: the Re g slot (zero there) carries Im g / C
+  int tan_form;  // 1: real drives (k_split14_loop, k_split_reg): the Re g slot (zero there) carries Im g / C;
+                 // 2: complex drives on k_split_reg<.., CPLX>: Re g / C and Im g / C in their own slots
   // drive-only rotations exp(-i kick X(t_kick)) before the first stage (an extra stage 0 without D) / after the
   // last D (the closing stage's rotation): the commutator correction of the 4th-order operator splitting of the
   // master equation (host_ket.hpp); t_kick = knot interval kick_idx, offset kick_u
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
       gr = S * ci;  // g = -i S c
       gi = -S * cr;
     }
-    if (R.tan_form) gr = gi / C;  // (real drives: gr was 0; the host keeps |beta c| <= 1, so C >= 0.54)
+    if (R.tan_form == 1) gr = gi / C;  // (real drives: gr was 0; the host keeps |beta c| <= 1, so C >= 0.54)
+    else if (R.tan_form == 2) { gr /= C; gi /= C; }  // complex drives on k_split_reg<.., CPLX>: both parts over C
     double* o = out + ((size_t)blockIdx.y * total + i) * 4;
     o[0] = C;
     o[1] = gr;

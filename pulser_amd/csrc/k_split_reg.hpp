@@ -68,6 +68,13 @@
 #ifndef SPLITR_PREF
 #define SPLITR_PREF 0
 #endif
+//   SPLITR_LATE 1: complex drives: the rotation coefficients are loaded after the phase factors (scalar register pressure)
+#ifndef SPLITR_LATE
+#define SPLITR_LATE 1
+#endif
+#ifndef SPLITR_LATE_REAL
+#define SPLITR_LATE_REAL 0  /* the same for real drives (A/B) */
+#endif
 
 template <int N, int NR>
 struct SplitRegLayout {
@@ -138,7 +145,10 @@ __device__ __forceinline__ double splitr_partner(double v) {
 // or the store (SplitArgs.ftab: exponentials of linear functions of the bit-pair counts, so the factor of an
 // amplitude is (a factor of its lane) x (a factor of its register)), and the run may open with / close on the
 // drive-only kick of the 4th-order splitting (SplitRun.kick_*).
-template <int N, int NR, bool DECAY, bool ROWS = false>
+// CPLX: complex drive coefficients (a pulse with a phase, local addressing with per-atom phases): the rotation of an atom
+// is C (1 + u |1><0| - conj(u) |0><1|), u = (Re g + i Im g) / C (SplitRun.tan_form 2: both slots of the table) - 4 FMAs
+// per amplitude and bit instead of 2; on the DPP bits the sign of the Re part depends on the lane's own bit.
+template <int N, int NR, bool DECAY, bool ROWS = false, bool CPLX = false>
 __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per_eu(1, NR >= 6 ? 1 : 2))) void k_split_reg(const SplitArgs A, const SplitRun R, long long stage_stride) {
   typedef SplitRegLayout<N, NR> L;
   constexpr int NW = L::NW, NTB = L::NTB, ND = L::ND;
@@ -254,17 +264,24 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
 
 
   // rotation of register bit J (tan T) on the registers r with (r & MASK) == VAL
-  auto rot_reg = [&](auto J, double T, auto MASK, auto VAL) {
+  auto rot_reg = [&](auto J, double T, double U, auto MASK, auto VAL) {  // T = Im g / C, U = Re g / C (CPLX only)
     if (SPLITR_KO & 16) return;
     splitr_for<0, NA>([&](auto Rc) {
       constexpr int r = decltype(Rc)::value, j = decltype(J)::value;
       if constexpr ((r & decltype(MASK)::value) == decltype(VAL)::value && !(r & (1 << j))) {
         constexpr int q = r | (1 << j);
         const double a0x = xr[r], a0y = xi[r], a1x = xr[q], a1y = xi[q];
-        xr[r] = fma(-T, a1y, a0x);
-        xi[r] = fma(T, a1x, a0y);
-        xr[q] = fma(-T, a0y, a1x);
-        xi[q] = fma(T, a0x, a1y);
+        if constexpr (CPLX) {
+          xr[r] = fma(-U, a1x, fma(-T, a1y, a0x));
+          xi[r] = fma(-U, a1y, fma(T, a1x, a0y));
+          xr[q] = fma(U, a0x, fma(-T, a0y, a1x));
+          xi[q] = fma(U, a0y, fma(T, a0x, a1y));
+        } else {
+          xr[r] = fma(-T, a1y, a0x);
+          xi[r] = fma(T, a1x, a0y);
+          xr[q] = fma(-T, a0y, a1x);
+          xi[q] = fma(T, a0x, a1y);
+        }
       }
     });
   };
@@ -293,25 +310,45 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       return c4[4 * (N - 1 - p) + field];
     };
     double Tl[6], Dl[6], Tw[NW > 0 ? NW : 1], Dw[NW > 0 ? NW : 1], Tr[NR], Dr[NR];
+    double Ul[6], Uw[NW > 0 ? NW : 1], Ur[NR];  // CPLX: Re g / C by position
+    constexpr int TF = CPLX ? 2 : 1;  // the field that holds Im g / C (SplitRun.tan_form)
     double cnext = 1.0;
+    // the detuning integrals first (the phase factors need them at once); the rotation coefficients follow - for
+    // complex drives only AFTER the phase factors (SPLITR_LATE: the pointer is laundered through an empty asm so that
+    // the loads cannot be hoisted): 14 x (C, Re g / C, Im g / C) on top of the 14 integrals do not fit the scalar
+    // registers (79 spilled, and a spilled scalar load is a serialised one: +1 us per stage, round-4 variants table)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      Tl[j] = coef(L::lanebit(false, j), L::lanebit(true, j), 1);
-      Dl[j] = SPLITR_PREF ? Dn[j] : coef(L::lanebit(false, j), L::lanebit(true, j), 3);
-      cnext *= coef(L::lanebit(false, j), L::lanebit(true, j), 0);
-    }
+    for (int j = 0; j < 6; ++j) Dl[j] = SPLITR_PREF ? Dn[j] : coef(L::lanebit(false, j), L::lanebit(true, j), 3);
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      Tw[j] = coef(L::wavebit(false, j), L::wavebit(true, j), 1);
-      Dw[j] = SPLITR_PREF ? Dn[6 + j] : coef(L::wavebit(false, j), L::wavebit(true, j), 3);
-      cnext *= coef(L::wavebit(false, j), L::wavebit(true, j), 0);
-    }
+    for (int j = 0; j < NW; ++j) Dw[j] = SPLITR_PREF ? Dn[6 + j] : coef(L::wavebit(false, j), L::wavebit(true, j), 3);
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      Tr[j] = coef(L::regbit(false, j), L::regbit(true, j), 1);
-      Dr[j] = SPLITR_PREF ? Dn[6 + NW + j] : coef(L::regbit(false, j), L::regbit(true, j), 3);
-      cnext *= coef(L::regbit(false, j), L::regbit(true, j), 0);
-    }
+    for (int j = 0; j < NR; ++j) Dr[j] = SPLITR_PREF ? Dn[6 + NW + j] : coef(L::regbit(false, j), L::regbit(true, j), 3);
+    auto load_rot = [&](cptr_t cl) {
+      auto coefl = [&](int bit_even, int bit_odd, int field) -> double {
+        const int p = odd ? bit_odd : bit_even;
+        return cl[4 * (N - 1 - p) + field];
+      };
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        Tl[j] = coefl(L::lanebit(false, j), L::lanebit(true, j), TF);
+        Ul[j] = CPLX ? coefl(L::lanebit(false, j), L::lanebit(true, j), 1) : 0.0;
+        cnext *= coefl(L::lanebit(false, j), L::lanebit(true, j), 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        Tw[j] = coefl(L::wavebit(false, j), L::wavebit(true, j), TF);
+        Uw[j] = CPLX ? coefl(L::wavebit(false, j), L::wavebit(true, j), 1) : 0.0;
+        cnext *= coefl(L::wavebit(false, j), L::wavebit(true, j), 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        Tr[j] = coefl(L::regbit(false, j), L::regbit(true, j), TF);
+        Ur[j] = CPLX ? coefl(L::regbit(false, j), L::regbit(true, j), 1) : 0.0;
+        cnext *= coefl(L::regbit(false, j), L::regbit(true, j), 0);
+      }
+    };
+    constexpr bool kLate = (SPLITR_LATE && CPLX) || (SPLITR_LATE_REAL && !CPLX);
+    if (!kLate) load_rot(c4);
     // weight of E0 in this stage's D: a_i tau (+ the last a tau carried over from the previous sub-step)
     double wE;
     if (SPLITR_WMODE && SPLITR_PREF) {
@@ -359,6 +396,11 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
         gtab[w * NA + (l & (NA - 1))] = Gl;
         __builtin_amdgcn_wave_barrier();
       }
+    }
+    if (kLate) {
+      unsigned long long cl = (unsigned long long)(coefs + (size_t)sg * stage_stride);
+      asm volatile("" : "+s"(cl));
+      load_rot((cptr_t)cl);
     }
     cprod = cnext;
     const cplx* __restrict__ gw = gtab + w * NA;
@@ -441,15 +483,21 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     auto rot_t_old = [&](auto Gc) {  // the T bits this layout holds
       splitr_for<0, NTB>([&](auto Mc) {
         constexpr int m = decltype(Mc)::value;
-        rot_reg(splitr_c<NW + m>{}, Tr[NW + m], splitr_c<PW>{}, Gc);
+        rot_reg(splitr_c<NW + m>{}, Tr[NW + m], Ur[NW + m], splitr_c<PW>{}, Gc);
       });
     };
     auto rot_t_new = [&](auto Gc) {  // the upper lane bits, now in the T registers
       splitr_for<0, NTB>([&](auto Mc) {
         constexpr int m = decltype(Mc)::value;
-        rot_reg(splitr_c<NW + m>{}, Tl[ND + m], splitr_c<PW>{}, Gc);
+        rot_reg(splitr_c<NW + m>{}, Tl[ND + m], Ul[ND + m], splitr_c<PW>{}, Gc);
       });
     };
+    // CPLX: Re g / C of the DPP bits with the sign of the lane's own bit (+ on bit 1, - on bit 0)
+    double Us[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (CPLX) {
+#pragma unroll
+      for (int j = 0; j < ND; ++j) Us[j] = ((l >> j) & 1u) ? Ul[j] : -Ul[j];
+    }
     // rotations of the DPP lane bits in MASK on register r (any time between this stage's D and the next one's: they
     // commute with every other rotation and exchange of the stage)
     auto rot_lane = [&](auto Rc, auto MASK) {
@@ -457,23 +505,43 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       if (SPLITR_KO & 2) return;
       if constexpr (ND > 0 && (mask & 1)) {
         const double T = Tl[0], px = splitr_partner<0>(xr[r]), py = splitr_partner<0>(xi[r]);
-        xr[r] = fma(-T, py, xr[r]);
-        xi[r] = fma(T, px, xi[r]);
+        if constexpr (CPLX) {
+          xr[r] = fma(Us[0], px, fma(-T, py, xr[r]));
+          xi[r] = fma(Us[0], py, fma(T, px, xi[r]));
+        } else {
+          xr[r] = fma(-T, py, xr[r]);
+          xi[r] = fma(T, px, xi[r]);
+        }
       }
       if constexpr (ND > 1 && (mask & 2)) {
         const double T = Tl[1], px = splitr_partner<1>(xr[r]), py = splitr_partner<1>(xi[r]);
-        xr[r] = fma(-T, py, xr[r]);
-        xi[r] = fma(T, px, xi[r]);
+        if constexpr (CPLX) {
+          xr[r] = fma(Us[1], px, fma(-T, py, xr[r]));
+          xi[r] = fma(Us[1], py, fma(T, px, xi[r]));
+        } else {
+          xr[r] = fma(-T, py, xr[r]);
+          xi[r] = fma(T, px, xi[r]);
+        }
       }
       if constexpr (ND > 3 && (mask & 8)) {
         const double T = Tl[3], px = splitr_partner<3>(xr[r]), py = splitr_partner<3>(xi[r]);
-        xr[r] = fma(-T, py, xr[r]);
-        xi[r] = fma(T, px, xi[r]);
+        if constexpr (CPLX) {
+          xr[r] = fma(Us[3], px, fma(-T, py, xr[r]));
+          xi[r] = fma(Us[3], py, fma(T, px, xi[r]));
+        } else {
+          xr[r] = fma(-T, py, xr[r]);
+          xi[r] = fma(T, px, xi[r]);
+        }
       }
       if constexpr (ND > 2 && (mask & 4)) {
         const double T = Tl[2], px = splitr_partner<2>(xr[r]), py = splitr_partner<2>(xi[r]);
-        xr[r] = fma(-T, py, xr[r]);
-        xi[r] = fma(T, px, xi[r]);
+        if constexpr (CPLX) {
+          xr[r] = fma(Us[2], px, fma(-T, py, xr[r]));
+          xi[r] = fma(Us[2], py, fma(T, px, xi[r]));
+        } else {
+          xr[r] = fma(-T, py, xr[r]);
+          xi[r] = fma(T, px, xi[r]);
+        }
       }
     };
     // SPLITR_TMODE 2: the transposition through LDS with the vector work arranged around it - D on every group first
@@ -514,12 +582,12 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     constexpr int CM = 3 << (NR - 2);  // the chunk's bits of the register index
     auto pre = [&](auto Cc) {
       constexpr int c = decltype(Cc)::value;
-      splitr_for<0, NW>([&](auto Jc) { rot_reg(Jc, Tr[decltype(Jc)::value], splitr_c<CM>{}, splitr_c<(c << (NR - 2))>{}); });
+      splitr_for<0, NW>([&](auto Jc) { rot_reg(Jc, Tr[decltype(Jc)::value], Ur[decltype(Jc)::value], splitr_c<CM>{}, splitr_c<(c << (NR - 2))>{}); });
       splitr_for<0, CH>([&](auto Kc) { rot_lane(splitr_c<(decltype(Kc)::value | (c << (NR - 2)))>{}, splitr_c<PMASK>{}); });
     };
     auto post = [&](auto Cc) {  // the wave bits, now register bits 0 .. NW-1
       constexpr int c = decltype(Cc)::value;
-      splitr_for<0, NW>([&](auto Jc) { rot_reg(Jc, Tw[decltype(Jc)::value], splitr_c<CM>{}, splitr_c<(c << (NR - 2))>{}); });
+      splitr_for<0, NW>([&](auto Jc) { rot_reg(Jc, Tw[decltype(Jc)::value], Uw[decltype(Jc)::value], splitr_c<CM>{}, splitr_c<(c << (NR - 2))>{}); });
     };
     // slot = l + 64 (A + NG (B + NG s)):  writer A = wave, B = its pass bits;  reader A = its pass bits, B = its wave;
     // s = the chunk's T bits below the top two

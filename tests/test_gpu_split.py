@@ -480,3 +480,37 @@ def test_14_atom_batches_choose_their_kernel_from_the_schedule_of_the_call():
     assert res["auto"][1]["n_launches"] > 1 and res["auto"][1]["reserved"][0] > 0
     assert res["auto"][1]["n_applications"] < 0.5 * res["k_ket"][1]["n_applications"]
     assert np.max(np.abs(res["auto"][0] - res["k_ket"][0])) < 2e-8
+
+
+# ---- k_split_reg<.., CPLX>: complex drives (a pulse with a phase) on the register-resident split-operator kernel ----
+
+@pytest.mark.parametrize("n_cols", [6, 7])
+def test_anneal_with_a_pulse_phase_takes_the_register_resident_split_kernel_against_the_oracle(n_cols):
+    """The anneal with a constant pulse phase (complex drive coefficients, hamiltonian.py:349-351): the waveforms are
+    still one polynomial across knots, so the default path of a 12- / 14-atom register is the 6th-order split-operator
+    kernel with complex rotations (k_split_reg<N, 5, false, false, true>: 4 FMAs per amplitude and bit).  First 0.62 us
+    (across the kink at 0.5 us) against the tight oracle integrated here, and against the gauged polynomial kernel."""
+    from oracle import qutip_path as qp
+
+    n = 2 * n_cols
+    coords = P.register_coords(P.triangular_rect(2, n_cols), blockade_radius())
+    base = P.anneal_samples()
+    T = 621
+    g = {"amp": base["amp"][:T].copy(), "det": base["det"][:T].copy(), "phase": np.full(T, 0.9)}
+    prob = P.make_ising_problem(coords, g)
+    times = np.array([0.0, 0.3, 0.62])
+    outs, stats = {}, {}
+    for name, kw in (("default", {}), ("polynomial", {"no_split14": True})):
+        with _engine([prob] * 8) as eng:
+            eng.set_path(False, **kw)
+            outs[name] = eng.solve(eng.new_state(), times).cpu().numpy()[:, 0]
+            stats[name] = eng.stats()
+    assert stats["default"]["reserved"][0] > 0 and 1 < stats["default"]["n_launches"] < stats["default"]["n_applications"] / 20
+    assert stats["polynomial"]["n_launches"] == 1
+    assert np.max(np.abs(outs["default"] - outs["polynomial"])) < 2e-8
+    if n == 12:  # (the 14-atom oracle takes minutes: the 12-atom one pins the complex rotations)
+        opts = dict(qp.default_options([np.stack([g["amp"], g["det"]])], T - 1))
+        opts.update(qp.TIGHT)
+        ref = qp.sesolve(qp.build_hamiltonian(prob), qp.all_ground_state(n, prob["eigenbasis"]), times, **opts)
+        for k in (1, 2):
+            assert np.max(np.abs(outs["default"][k - 1] - ref[k])) < 1e-7, k
