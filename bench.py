@@ -70,6 +70,20 @@ KSPLITREG_FLOPS_PER_AMP_STAGE = (2 * (687 + 475) + 241 + 9 + 7) / 32.0
 # the same stage counted on paper: 14 tan-form rotations (2 FMAs each) + one complex multiplication by the phase
 # factor; everything else the kernel spends (building the phase factors, range reduction) is overhead, not work
 SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE = 14 * 2 * 2 + 6.0
+
+
+def split_reg_roofline(n, batch, stats, kms, kl, traffic_key=None, note=None):
+    """Roofline of a solve that ran on k_split_reg<n, 5>: one atom fewer = one tan-form rotation (2 FMAs) fewer per
+    amplitude and stage, by ISA count (checked for n = 14 by tests/test_host_logic.py) and on paper."""
+    return roofline_valu(2.0**n, batch, stats["n_applications"], KSPLITREG_FLOPS_PER_AMP_STAGE - 4.0 * (14 - n), kms, kl,
+                         KSPLITREG_NAME.replace("<14, 5>", f"<{n}, 5>"), traffic_key, note=note,
+                         algorithmic_flops_per_amp_stage=SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE - 4.0 * (14 - n))
+
+
+def ran_split_reg(stats):
+    """A solve that took the register-resident split-operator kernel: the controller booked an estimate and a launch
+    covered a closed run of stages (the pass-by-pass launches have one launch per stage)."""
+    return stats["reserved"][0] > 0.0 and stats["n_launches"] * 20 < stats["n_applications"]
 KSPLITREG_NAME = ("k_split_reg<14, 5> (register-resident split-operator kernel: one workgroup per sequence, exact phases x "
                   "single-atom rotations, 6th-order composition over multi-knot sub-steps; lane bits over the DPP crossbar / "
                   "permlane swaps, one chunked LDS pass per stage; one launch per closed run of <= 64 sub-steps)")
@@ -656,10 +670,12 @@ def main() -> None:
             "config": {"workload": "BASELINE configs[1]: 12-atom chain at the blockade radius, analog Ising "
                                    "anneal 3100 ns, sesolve complex128; batch of independent sequences per GPU",
                        "n_atoms": n, "sequences_per_gpu": B, "sim_us_per_sequence": T_SEQ_US,
-                       "integrator": "CF4 Magnus + Taylor(Horner), tol 1e-10/exponential",
+                       "integrator": "split-operator, 6th-order composition over multi-knot sub-steps (k_split_reg<12, 5>)"
+                                     if ran_split_reg(stats) else "CF4 Magnus + Taylor(Horner), tol 1e-10/exponential",
                        "generator_applications_per_sequence": stats["n_applications"],
                        "parallelism": f"dp{n_gpus} (independent sequences, all-reduce of ensemble sums only)"},
-            "roofline": roofline_valu(2.0**n, B, stats["n_applications"], KTRAJ_FLOPS_PER_AMP_STAGE, kms, kl,
+            "roofline": split_reg_roofline(n, B, stats, kms, kl, "cfg2:k_split_reg") if ran_split_reg(stats) else
+                        roofline_valu(2.0**n, B, stats["n_applications"], KTRAJ_FLOPS_PER_AMP_STAGE, kms, kl,
                                       "k_traj<12,1024,1> (persistent, LDS-resident)", "cfg2:k_traj"),
         }
         eng.close()
@@ -717,8 +733,15 @@ def main() -> None:
         sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, 2, 1, None, torch)
         also.append({"workload": "cfg2: 256 independent 12-atom chain sequences, full 3.1 us", "value": 256 * T_SEQ_US / sec,
                      "unit": "sim-us/s", "ms_per_batch": sec * 1e3, "applications_per_sequence": stats["n_applications"],
-                     "roofline": roofline_valu(4096.0, 256, stats["n_applications"], KTRAJ_FLOPS_PER_AMP_STAGE, kms, kl,
+                     "roofline": split_reg_roofline(12, 256, stats, kms, kl, "cfg2:k_split_reg") if ran_split_reg(stats) else
+                                 roofline_valu(4096.0, 256, stats["n_applications"], KTRAJ_FLOPS_PER_AMP_STAGE, kms, kl,
                                                "k_traj<12,1024,1> (persistent, LDS-resident)", "cfg2:k_traj")})
+        # ... and the same batch on the polynomial persistent kernel (the round-1 - 3 kernel of this line)
+        eng.set_path(False, no_split14=True)
+        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, 2, 1, None, torch)
+        also[-1]["k_traj"] = {"value": 256 * T_SEQ_US / sec, "unit": "sim-us/s", "applications_per_sequence": stats["n_applications"],
+                              "roofline": roofline_valu(4096.0, 256, stats["n_applications"], KTRAJ_FLOPS_PER_AMP_STAGE, kms, kl,
+                                                        "k_traj<12,1024,1> (persistent, LDS-resident)", "cfg2:k_traj")}
         eng.close()
         # the same with per-atom complex drives (MODEL 0 of the persistent kernel): local addressing
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -103,6 +103,35 @@ def test_split_operator_rows_interacting_10_atoms_against_tight_oracle(no_merge)
     assert abs(np.trace(snaps[-1]).real - 1.0) < 2e-8  # in-place exponentials: unitary to ~1e-12 each, 12 000 of them
 
 
+@pytest.mark.parametrize("rows_ket", [False, True])
+def test_split_operator_rows_interacting_12_atoms_default_path_against_tight_oracle(rows_ket):
+    """cfg3's physics on an INTERACTING 2 x 6 triangular register, the size from which the split-operator row path is
+    the DEFAULT (no force_ket): run_rows with its row passes on k_split_reg<12, 5, false, ROWS> (round 4: persistent
+    workgroups, 4th-order 6-stage sub-steps, the commutator kick as a stage) and, for comparison, on k_ket (round 3),
+    against zvode rtol 1e-13 through the C restatement of the Lindblad right-hand side (tests/golden/make_fixtures.py
+    cfg3_12: hours of CPU), every stored time, sketch format (32 rows, diagonal, 4 probe products, purity)."""
+    import os
+
+    from helpers import GOLDEN
+
+    if not os.path.exists(os.path.join(GOLDEN, "cfg3_tri12_dephasing.npz")):
+        pytest.skip("tests/golden/cfg3_tri12_dephasing.npz has not been generated (make_fixtures.py cfg3_12)")
+    prob, extra = load_fixture("cfg3_tri12_dephasing.npz")
+    prob = with_anneal_samples(prob)
+    times = np.asarray(extra["eval_times"])
+    with _engine([prob], "mesolve") as eng:
+        if rows_ket:
+            eng.set_path(False, rows_ket=True)
+        snaps = eng.solve(eng.new_state(), times)
+        st = eng.stats()
+        for k in range(1, len(times)):
+            errs = sketch_errors(snaps[k - 1, 0].cpu().numpy(), extra, k)
+            assert max(errs.values()) < AMP_TOL, (rows_ket, k, errs)
+        tr = float(snaps[-1, 0].diagonal().real.sum().item())
+    assert abs(tr - 1.0) < 2e-8
+    assert st["n_launches"] > 1000  # the split-operator row path (two row passes + a transposition per conjugation)
+
+
 @pytest.mark.parametrize("fixture,n", [("cfg3_tri8_dephasing.npz", 8), ("cfg3_tri10_dephasing.npz", 10)])
 def test_multi_launch_lindbladian_interacting_against_tight_oracle(fixture, n):
     prob, extra = load_fixture(fixture)

@@ -10,6 +10,7 @@ rm -rf $OUT; mkdir -p $OUT
 run() { name=$1; shift; echo "== $name: $*"; timeout 900 "$@" > $OUT/$name.log 2>&1; echo "rc=$?"; tail -2 $OUT/$name.log | cut -c1-300; }
 NS="python bench.py --no-cpu --no-extras --no-legs"
 run ns_stats rocprofv3 --kernel-trace --stats -d $OUT/ns_stats -o ns --output-format csv -- $NS --steps 2 --warmup 1
+run nst_stats rocprofv3 --kernel-trace --stats -d $OUT/nst_stats -o nst --output-format csv -- $NS --split-turns --steps 2 --warmup 1
 run nsk_stats rocprofv3 --kernel-trace --stats -d $OUT/nsk_stats -o nsk --output-format csv -- $NS --no-split14 --steps 2 --warmup 1
 run cfg3_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg3_stats -o cfg3 --output-format csv -- python bench.py --workload cfg3 --steps 1 --warmup 0 --slice-ns 8
 run cfg5_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5_stats -o cfg5 --output-format csv -- python bench.py --workload cfg5 --steps 2 --warmup 1 --slice-ns 50
@@ -19,6 +20,8 @@ run cfg5c_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg5c_stats -o cfg5c --
 run cfg2_stats rocprofv3 --kernel-trace --stats -d $OUT/cfg2_stats -o cfg2 --output-format csv -- python bench.py --workload cfg2 --steps 2 --warmup 1
 run ns_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/ns_fetch -o ns --output-format csv -- $NS --steps 1 --warmup 0
 run ns_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/ns_write -o ns --output-format csv -- $NS --steps 1 --warmup 0
+run nst_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/nst_fetch -o nst --output-format csv -- $NS --split-turns --steps 1 --warmup 0
+run nst_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/nst_write -o nst --output-format csv -- $NS --split-turns --steps 1 --warmup 0
 run nsk_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/nsk_fetch -o nsk --output-format csv -- $NS --no-split14 --steps 1 --warmup 0
 run nsk_write rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/nsk_write -o nsk --output-format csv -- $NS --no-split14 --steps 1 --warmup 0
 run cfg3_fetch rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg3_fetch -o cfg3 --output-format csv -- python bench.py --workload cfg3 --steps 1 --warmup 0 --slice-ns 4

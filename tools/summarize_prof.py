@@ -5,7 +5,7 @@ import csv, json, os, sys
 from collections import defaultdict
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 os.makedirs("profiles", exist_ok=True)
 
 def stats(name):
@@ -34,13 +34,13 @@ md = [f"# {rnd}: rocprofv3 summaries (MI355X, gfx950)", "",
       "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x",
       "(MI355X_MICROARCH.md, HBM section), so HBM read bytes = 2 x FETCH_SIZE x 1024.", ""]
 traffic = {}
-for name in ("ns", "nsk", "cfg3", "cfg5", "cfg5t", "cfg5b", "cfg5c", "cfg2"):
+for name in ("ns", "nst", "nsk", "cfg3", "cfg5", "cfg5t", "cfg5b", "cfg5c", "cfg2"):
     try:
         text, rows = stats(name)
         md += [text, ""]
     except FileNotFoundError:
         continue
-for name, kern_sub in (("ns", "k_split14_loop"), ("nsk", "k_ket"), ("cfg3", "k_ket"), ("cfg3", "k_transpose_conj"), ("cfg5", "k_split12"), ("cfg5t", "k_apply<"), ("cfg5b", "k_split12"), ("cfg5c", "k_split_t"), ("cfg2", "k_traj")):
+for name, kern_sub in (("ns", "k_split_reg"), ("nst", "k_split14_loop"), ("nsk", "k_ket"), ("cfg3", "k_split_reg"), ("cfg3", "k_transpose_conj"), ("cfg5", "k_split12"), ("cfg5t", "k_apply<"), ("cfg5b", "k_split12"), ("cfg5c", "k_split_t"), ("cfg2", "k_split_reg"), ("cfg2", "k_traj")):
     try:
         f = pmc(name, "FETCH_SIZE"); w = pmc(name, "WRITE_SIZE")
     except FileNotFoundError:
@@ -54,7 +54,7 @@ for name, kern_sub in (("ns", "k_split14_loop"), ("nsk", "k_ket"), ("cfg3", "k_k
         nf, sf = f[k]; nw, sw = w.get(k, [1, 0.0])
         rd = 2 * sf / nf * 1024; wr = sw / max(nw, 1) * 1024
         md.append(f"| `{k[:60]}` | {nf} | {sf/nf:.1f} | {rd:.4g} | {sw/max(nw,1):.1f} | {rd+wr:.4g} |")
-        key = {"ns": "north_star", "nsk": "north_star", "cfg3": "cfg3", "cfg5": "cfg5", "cfg5t": "cfg5", "cfg5b": "cfg5_24atoms",
+        key = {"ns": "north_star", "nst": "north_star", "nsk": "north_star", "cfg3": "cfg3", "cfg5": "cfg5", "cfg5t": "cfg5", "cfg5b": "cfg5_24atoms",
                "cfg5c": "cfg5_22atoms", "cfg2": "cfg2"}[name] + ":" + {"k_split12": "k_split", "k_split_t": "k_split", "k_split14_loop": "k_split14"}.get(kern_sub, kern_sub.rstrip("<"))
         traffic[key] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                                          "total_bytes_per_launch": rd + wr, "launches_sampled": nf}
