@@ -692,7 +692,7 @@ def main() -> None:
                 eng.set_path(False, no_ket=True)
             t0, t1, nb = 1.0, 1.0 + 1e-3 * args.slice_ns, 28
             kname = ("k_apply14<mesolve> + k_symm (Hermitian path)" if args.no_ket
-                     else "k_ket<14> row passes + k_transpose_conj (split-operator path)")
+                     else "k_split_reg<14, 5, ROWS> row passes + k_transpose_conj (split-operator master equation)")
             wl = f"BASELINE configs[2]: 14-atom triangular register, dephasing mesolve (rho = 4.29 GB), {args.slice_ns} ns slice at t = 1 us"
         else:
             shape = {20: (4, 5), 22: (2, 11), 24: (4, 6)}[args.atoms]
@@ -709,7 +709,8 @@ def main() -> None:
             state_fn = psi1.clone
         sec, stats, kms, kl, occ = timed_run(eng, state_fn, t0, t1, args.steps, args.warmup, dist, torch, **mopt)
         if args.workload == "cfg3" and not args.no_ket:
-            roof = roofline_valu(2.0**14, 2.0**15, stats["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kms, kl, kname, "cfg3:k_ket")
+            roof = roofline_valu(2.0**14, 2.0**15, stats["n_applications"], KSPLITREG_FLOPS_PER_AMP_STAGE, kms, kl, kname, "cfg3:k_split_reg",
+                                 algorithmic_flops_per_amp_stage=SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE)
         else:
             key = "cfg3:k_apply" if args.workload == "cfg3" else (
                 "cfg5_24atoms:k_split" if (args.atoms == 24 and kname == KSPLIT_NAME) else
