@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round evidence run (gpurun): smoke, full GPU test suite, bench lines.  Profiles: tools/profile.sh.
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-R=${1:-r3}
+R=${1:-r4}
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${R}_smoke.log 2>&1; echo "smoke rc=$?"
 python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/${R}_pytest_final.log; tail -2 gpurun_out/${R}_pytest_final.log
 python bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err; echo "bench rc=$?"
