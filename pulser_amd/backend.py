@@ -1092,11 +1092,7 @@ def density_matrix_aggregator(values: Sequence[RydState]) -> RydState:
 
     if len(values) == 0:
         raise ValueError("Cannot average an empty list of states.")
-    torch = _torch()
-    if not torch.cuda.is_available():
-        # the backend has no CPU path anywhere: say so instead of failing inside torch
-        raise RuntimeError("density_matrix aggregation forms sum |psi><psi| on the GPU (librydemu: "
-                           "ryd_outer_accumulate_dim); no GPU is visible to this process and the backend has no CPU path")
+    torch = _torch()  # (raises "pulser_amd needs an AMD GPU ... there is no CPU fallback" on a host without one)
     dev = torch.device("cuda", torch.cuda.current_device())
     D = int(values[0].to_qobj().shape[0])
     w = 1.0 / len(values)

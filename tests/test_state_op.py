@@ -547,5 +547,5 @@ def test_density_matrix_aggregator_fails_loudly_without_a_gpu():
     from pulser_amd.backend import density_matrix_aggregator
 
     s1 = RydState.from_state_amplitudes(eigenstates=("r", "g"), amplitudes={"rgr": 1.0})
-    with pytest.raises(RuntimeError, match="no CPU path"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         density_matrix_aggregator([s1, s1])
