@@ -44,7 +44,8 @@
 #endif
 // A/B switches (dev builds, profiles/r04_ksplit14_variants.md):
 //   SPLITR_TMODE 1: lane bits 4, 5 by v_permlane16_swap / v_permlane32_swap instead of the LDS transposition (NTB == 2);
-//                2: the LDS transposition, D first and half of the DPP rotations as its filler
+//                2: the LDS transposition, D first and half of the DPP rotations as its filler;
+//                3: no exchange: partners of lane bits 4, 5 over the LDS crossbar (ds_swizzle / ds_bpermute; NTB == 2)
 //   SPLITR_GMODE 1: the uniform factor G(r) by v_readlane from the lane that computed it instead of the LDS table
 //   SPLITR_WMODE 1: the stages' E0 weights from an LDS table filled at launch (no kernel-argument loads per stage)
 #ifndef SPLITR_TMODE
@@ -83,12 +84,15 @@ struct SplitRegLayout {
   static constexpr int ND = 6 - NTB;      // lane bits served by the DPP crossbar
   static_assert(NW >= 0 && NW <= 3 && NTB >= 2 && ND >= 1 && ND <= 4, "unsupported shape");
   // index bit held by a position at the start of an even / odd stage
+  // (SPLITR_TMODE 3: the T registers and the upper lane bits never change places - those lane bits get their rotation
+  // through partner fetches over the LDS crossbar)
+  static constexpr bool kXchg = SPLITR_TMODE != 3;
   __host__ __device__ static constexpr int regbit(bool odd, int j) {
     if (!odd) return 6 + NW + j;
-    return j < NW ? 6 + j : ND + (j - NW);
+    return j < NW ? 6 + j : (kXchg ? ND + (j - NW) : 6 + NW + j);
   }
   __host__ __device__ static constexpr int lanebit(bool odd, int j) {
-    if (j < ND || !odd) return j;
+    if (j < ND || !odd || !kXchg) return j;
     return 6 + 2 * NW + (j - ND);
   }
   __host__ __device__ static constexpr int wavebit(bool odd, int j) { return odd ? 6 + NW + j : 6 + j; }
@@ -493,11 +497,40 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       });
     };
     // CPLX: Re g / C of the DPP bits with the sign of the lane's own bit (+ on bit 1, - on bit 0)
-    double Us[4] = {0.0, 0.0, 0.0, 0.0};
+    double Us[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if constexpr (CPLX) {
 #pragma unroll
-      for (int j = 0; j < ND; ++j) Us[j] = ((l >> j) & 1u) ? Ul[j] : -Ul[j];
+      for (int j = 0; j < 6; ++j) Us[j] = ((l >> j) & 1u) ? Ul[j] : -Ul[j];
     }
+    // SPLITR_TMODE 3: partner of lane bit 4 (ds_swizzle, xor 16 inside 32 lanes) / 5 (ds_bpermute) of a double - the LDS
+    // crossbar, no LDS memory, no vector-pipe cycles beyond the issue
+    auto xpartner = [&](double v, auto Jc) -> double {
+      int lo = __double2loint(v), hi = __double2hiint(v);
+      if constexpr (decltype(Jc)::value == 4) {
+        lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
+        hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+      } else {
+        const int addr = (int)((l ^ 32u) << 2);
+        lo = __builtin_amdgcn_ds_bpermute(addr, lo);
+        hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+      }
+      return __hiloint2double(hi, lo);
+    };
+    auto rot_lane_x = [&](auto Rc) {
+      constexpr int r = decltype(Rc)::value;
+      if (SPLITR_KO & 1) return;
+      splitr_for<4, 6>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        const double T = Tl[j], px = xpartner(xr[r], Jc), py = xpartner(xi[r], Jc);
+        if constexpr (CPLX) {
+          xr[r] = fma(Us[j], px, fma(-T, py, xr[r]));
+          xi[r] = fma(Us[j], py, fma(T, px, xi[r]));
+        } else {
+          xr[r] = fma(-T, py, xr[r]);
+          xi[r] = fma(T, px, xi[r]);
+        }
+      });
+    };
     // rotations of the DPP lane bits in MASK on register r (any time between this stage's D and the next one's: they
     // commute with every other rotation and exchange of the stage)
     auto rot_lane = [&](auto Rc, auto MASK) {
@@ -566,7 +599,9 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
         constexpr int g = NG - 1 - decltype(Ic)::value;
         phase_group(splitr_c<g>{});
         rot_t_old(splitr_c<g>{});
-        if constexpr (SPLITR_TMODE == 1 && NTB == 2) {
+        if constexpr (SPLITR_TMODE == 3) {
+          // nothing to exchange
+        } else if constexpr (SPLITR_TMODE == 1 && NTB == 2) {
           t_swap(splitr_c<g>{});
           rot_t_new(splitr_c<g>{});
         } else {
@@ -575,7 +610,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
           if constexpr (g + 1 < NG) rot_t_new(splitr_c<g + 1>{});
         }
       });
-      if constexpr (!(SPLITR_TMODE == 1 && NTB == 2)) rot_t_new(splitr_c<0>{});
+      if constexpr (!(SPLITR_TMODE == 1 && NTB == 2) && SPLITR_TMODE != 3) rot_t_new(splitr_c<0>{});
     }
 
     // ---- per chunk (top two T bits fixed): the pass bits and the DPP lane bits, then the pass ----
@@ -583,7 +618,10 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     auto pre = [&](auto Cc) {
       constexpr int c = decltype(Cc)::value;
       splitr_for<0, NW>([&](auto Jc) { rot_reg(Jc, Tr[decltype(Jc)::value], Ur[decltype(Jc)::value], splitr_c<CM>{}, splitr_c<(c << (NR - 2))>{}); });
-      splitr_for<0, CH>([&](auto Kc) { rot_lane(splitr_c<(decltype(Kc)::value | (c << (NR - 2)))>{}, splitr_c<PMASK>{}); });
+      splitr_for<0, CH>([&](auto Kc) {
+        rot_lane(splitr_c<(decltype(Kc)::value | (c << (NR - 2)))>{}, splitr_c<PMASK>{});
+        if constexpr (SPLITR_TMODE == 3) rot_lane_x(splitr_c<(decltype(Kc)::value | (c << (NR - 2)))>{});
+      });
     };
     auto post = [&](auto Cc) {  // the wave bits, now register bits 0 .. NW-1
       constexpr int c = decltype(Cc)::value;
