@@ -306,7 +306,11 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
   };
   if (SPLITR_PREF) load_next(0, false);
   unsigned warm = 0;
-  for (int sg = 0; sg < n_stages; ++sg, odd = !odd) {
+  // One stage.  PLAIN_CLOSE: the closing stage of a run without a closing kick - D only (its rotation angles are zero):
+  // the phase factors and nothing else, the layout stays (an instantiation of the same body after the loop: the loop's
+  // back edge sees one register assignment)
+  auto stage = [&](const int sg, auto plain_close_t) {
+    constexpr bool PLAIN_CLOSE = decltype(plain_close_t)::value;
     // ---- coefficients by POSITION (uniform: scalar loads; the index bit of a position depends on the parity) ----
     cptr_t c4 = (cptr_t)(unsigned long long)(coefs + (size_t)sg * stage_stride);
     auto coef = [&](int bit_even, int bit_odd, int field) -> double {
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       }
     };
     constexpr bool kLate = (SPLITR_LATE && CPLX) || (SPLITR_LATE_REAL && !CPLX);
-    if (!kLate) load_rot(c4);
+    if (!kLate && !PLAIN_CLOSE) load_rot(c4);
     // weight of E0 in this stage's D: a_i tau (+ the last a tau carried over from the previous sub-step)
     double wE;
     if (SPLITR_WMODE && SPLITR_PREF) {
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
         __builtin_amdgcn_wave_barrier();
       }
     }
-    if (kLate) {
+    if (kLate && !PLAIN_CLOSE) {
       unsigned long long cl = (unsigned long long)(coefs + (size_t)sg * stage_stride);
       asm volatile("" : "+s"(cl));
       load_rot((cptr_t)cl);
@@ -581,6 +585,9 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     // (its G-table reads would otherwise sit in the LDS queue between a group's stores and loads and every wait for a
     // G value would wait for the transposition too), then per group the old T bits, the DPP bits TMASK (filler: the
     // LDS takes ~540 cycles per group for the 8 waves), the stores, the loads; the other DPP bits stay with the pass
+    if constexpr (PLAIN_CLOSE) {
+      splitr_for<0, NG>([&](auto Ic) { phase_group(splitr_c<(NG - 1 - decltype(Ic)::value)>{}); });
+    } else {
     constexpr int TMASK = SPLITR_TMODE == 2 ? 3 : 0;           // DPP lane bits rotated inside the transposition loop
     constexpr int PMASK = ((1 << ND) - 1) & ~TMASK;            // ... and with the pass chunks
     if constexpr (SPLITR_TMODE == 2) {
@@ -683,9 +690,14 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       post(C2{});
       post(C3{});
     }
+    odd = !odd;
+    }
     if (SPLITR_KWARM) asm volatile("" ::"s"(warm));
-  }
-  // n_stages stages ran: the layout is the odd one when that number is odd
+  };
+  const int n_full = R.kick_post == 0.0 ? n_stages - 1 : n_stages;
+  for (int sg = 0; sg < n_full; ++sg) stage(sg, std::false_type{});
+  if (n_full < n_stages) stage(n_stages - 1, std::true_type{});
+  // the layout is the odd one when an odd number of full stages ran
   double fl = 1.0;
   if (ROWS && A.use_post) {
     __syncthreads();
