@@ -452,3 +452,23 @@ def test_emulator_noise_trajectories_with_a_pulse_phase_run_on_the_ket_kernel():
     assert outs[""][1] == 1 and outs["no_ket"][1] >= 1
     assert np.max(np.abs(outs[""][0] - outs["no_ket"][0])) < 2e-8
     assert np.max(np.abs(outs[""][0][-1, 0] - outs[""][0][-1, 5])) > 1e-3  # the trajectories differ (noise)
+
+
+def test_split_operator_rows_batch_of_two_different_12_atom_registers():
+    """Two DIFFERENT density matrices in one handle (other geometry, other dephasing-free drive scale): the row kernel of
+    round 4 (k_split_reg<12, 5, false, ROWS>: blockIdx.z = the matrix, persistent workgroups over its rows, per-matrix
+    E0 and coefficients) against the k_ket rows of round 3."""
+    ops = [(float(np.sqrt(2 * 0.2)), "sigma_rr")]
+    probs = [real_local_problem(12, seed=3, duration=41, collapse_ops=ops),
+             real_local_problem(12, seed=8, duration=41, collapse_ops=ops, spacing=6.5)]
+    outs = {}
+    for rows_ket in (False, True):
+        with _engine(probs, "mesolve") as eng:
+            eng.set_path(False, rows_ket=rows_ket)
+            st = eng.new_state()
+            eng.evolve(st, 0.0, 0.04)
+            outs[rows_ket] = st.cpu().numpy()
+    assert np.max(np.abs(outs[False] - outs[True])) < 2e-8
+    assert np.max(np.abs(outs[False][0] - outs[False][1])) > 1e-3  # the matrices really differ
+    for b in range(2):
+        assert abs(np.trace(outs[False][b]).real - 1.0) < 1e-10
