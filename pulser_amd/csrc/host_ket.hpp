@@ -329,11 +329,21 @@ static bool row_uniform_g(const ryd_handle* h) {
 
 // Half a block of the split-operator master equation, in knot intervals (what a multi-knot CF4
 // step must not exceed).
+static bool rows_split_ok(const ryd_handle* h);
 static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
   static const int kh_env = [] { const char* e = std::getenv("RYD_ROWS_KH"); return e ? std::atoi(e) : 0; }();  // dev A/B
   if (kh_env > 0 && o.split_steps <= 0) return kh_env;
   int Kh = row_block_steps(h, o);
   if ((!row_uniform_g(h) || h->has_dbl) && o.split_steps <= 0) Kh = 1;
+  // Round 4, row passes on k_split_reg: the splitting error of a block grows with g tau^4 (measured over the whole
+  // anneal on the interacting 12-atom register against two-knot halves, tools/rows_tune2.py: four-knot halves 5.5e-9
+  // at g = 0.05, 2.2e-8 at g = 0.2), so slow dephasing (g <= 0.1 / us: <= 1.1e-8) takes blocks of 4 + 4 knots - the
+  // unitary of a half is then ONE 6th-order sub-step where the waveforms are one polynomial: 18.4 -> 13 s at 14 atoms
+  if (Kh == 2 && o.split_steps <= 0 && rows_split_ok(h) && row_uniform_g(h) && !h->has_dbl) {
+    double g = 0.0;
+    for (int k = 0; k < 4; ++k) g = std::max(g, std::fabs(h->Sd[k].x));
+    if (g <= 0.1) Kh = 4;
+  }
   return Kh;
 }
 
@@ -341,7 +351,6 @@ static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
 // the unitary of a half block as 6th-order (4th-order for one-knot steps) split-operator sub-steps, one per CF4 step of
 // the schedule, instead of CF4 + in-place symplectic exponentials on k_ket.  Returns 1 when the run cannot take the
 // tan-form rotations (|beta c| > 1: drives of hundreds of rad/us) - the caller then uses k_ket for this conjugation.
-static bool rows_split_ok(const ryd_handle* h);
 static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>& sb, size_t i0, size_t i1, bool use_pre,
                            bool use_post, const double* tdev, double kick_pre, double kick_post, int kick_idx,
                            double kick_u, size_t n_rows, bool count_stages, hipStream_t st);
@@ -488,7 +497,12 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     bool this_split = rsplit;
     if (this_split) {
       rc2 = rows_split_pass(h, cur, sb, i0, i1, A.use_pre != 0, false, tdev, kick_pre, kick_post, kick_idx, kick_u, n_rows, false, st);
-      if (rc2 == 1) this_split = false;  // (nothing has been launched)
+      if (rc2 == 1) {  // (nothing has been launched)
+        // the k_ket schedule of a handle that merges without the a-priori estimate (four-knot halves) is not one
+        // the polynomial kernel may run
+        if (Kh > 2) return fail(RYD_ERR_UNSUPPORTED, "drive too strong for the tan-form rotations of the split-operator rows");
+        this_split = false;
+      }
       else if (rc2) return rc2;
     }
     if (!this_split && (rc2 = launch_ket(h, A, n_rows, st, KET_ROWS))) return rc2;
