@@ -644,10 +644,12 @@ def main() -> None:
             if not args.no_ket:
                 # two row passes per conjugation, each a full ket stage on 2^14 rows of 2^14 amplitudes
                 rows_ket = bool(os.environ.get("RYD_BENCH_ROWS_KET"))
-                leg["integrator"] = ("4th-order operator splitting (Chin 4A + exact commutator kick), blocks of 2 + 2 ns; "
+                leg["integrator"] = ("4th-order operator splitting (Chin 4A + exact commutator kick), blocks of "
+                                     + ("2 + 2" if rows_ket else "4 + 4") + " knot intervals; "
                                      "U rho U^+ as two row passes + one conjugate transposition; the unitary of a half "
                                      "block by " + ("CF4 steps on k_ket (round 3)" if rows_ket else
-                                                    "split-operator sub-steps (4th-order 6-stage composition) on k_split_reg"))
+                                                    "split-operator sub-steps (6th-order 10-stage composition over the four knots where the "
+                                                    "waveforms are one polynomial, 4th-order 6-stage ones elsewhere) on k_split_reg"))
                 leg["roofline"] = roofline_valu(
                     2.0**n, 2.0**n * 2, stl["n_applications"], KKET_FLOPS_PER_AMP_STAGE if rows_ket else KSPLITREG_FLOPS_PER_AMP_STAGE,
                     kl_ms, kl_n, ("k_ket<14> row passes" if rows_ket else "k_split_reg<14, 5, ROWS> row passes (persistent "

@@ -438,7 +438,7 @@ def test_emulator_noise_trajectories_with_a_pulse_phase_run_on_the_ket_kernel():
     inputs = single_global_channel(coords, s, P.C6_LEVEL70, extended=False)
     nm = NoiseModel(temperature=50.0, amp_sigma=0.05)
     outs = {}
-    for env in ("", "no_ket"):
+    for env in ("", "no_ket", "default"):
         np.random.seed(4)
         emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=16, evaluation_times="Minimal")
         hd = emu._hamiltonian_data
@@ -446,12 +446,14 @@ def test_emulator_noise_trajectories_with_a_pulse_phase_run_on_the_ket_kernel():
         from pulser_amd.engine import Engine
 
         with Engine(tables, mode="sesolve") as eng:
-            eng.set_path(False, no_ket=bool(env))
+            # (round 4: the default path of 12 - 14 atoms is the split-operator kernel, complex drives included)
+            eng.set_path(False, no_ket=env == "no_ket", no_split14=env == "")
             st = eng.new_state()
             snaps = eng.solve(st, np.asarray(emu._eval_times_array)).cpu().numpy()
             outs[env] = (snaps, eng.stats()["n_launches"])
     assert outs[""][1] == 1 and outs["no_ket"][1] >= 1
     assert np.max(np.abs(outs[""][0] - outs["no_ket"][0])) < 2e-8
+    assert np.max(np.abs(outs["default"][0] - outs["no_ket"][0])) < 1e-7  # k_split_reg<13, 5, false, false, CPLX>
     assert np.max(np.abs(outs[""][0][-1, 0] - outs[""][0][-1, 5])) > 1e-3  # the trajectories differ (noise)
 
 
