@@ -216,16 +216,21 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   if ((rc = split_ensure_tables(h, n_stages))) return rc;
   bool reg_loop = split_reg_shape(h);
   bool loop14 = N == 14 && split_loop14(h) && ((n_stages & 1) || reg_loop);  // (k_split14_loop runs its stages in pairs + the closing one)
-  if ((loop14 && h->drive_real) || reg_loop) {
+  // the pass kernel k_split12 in tan form (real drives, tiles of 2^12 in every tiling, no quantum jumps); RYD_SPLIT_PASS_TAN=0: dev A/B
+  static const bool pass_tan_env = [] { const char* e = std::getenv("RYD_SPLIT_PASS_TAN"); return !(e && e[0] == '0'); }();
+  bool pass_tan = pass_tan_env && !reg_loop && !loop14 && h->drive_real && !h->mc && !h->split_tilings.empty();
+  for (const Pass& p : h->split_tilings) pass_tan = pass_tan && p.T == 12;
+  if ((loop14 && h->drive_real) || reg_loop || pass_tan) {
     // tan-form rotations need cos(beta |c|) away from zero: |beta c| <= 1 for every atom over every sub-step
     double bmax = 0.0;
     for (int i = 0; i < sc.S; ++i) bmax = std::max(bmax, std::fabs(sc.b[i]));
-    for (int s = 0; s < nsub && (loop14 || reg_loop); ++s) {
+    for (int s = 0; s < nsub && (loop14 || reg_loop || pass_tan); ++s) {
       const int span = std::max(1, (int)std::ceil((subs[s].u0 + subs[s].tau) / (h->tknots[subs[s].idx + 1] - h->tknots[subs[s].idx]) - 1e-9));
-      if (span_max(h->bd_c1, subs[s].idx, std::min(span, (int)h->bd_c1.size() - subs[s].idx)) * bmax * subs[s].tau > 1.0) loop14 = reg_loop = false;
+      if (span_max(h->bd_c1, subs[s].idx, std::min(span, (int)h->bd_c1.size() - subs[s].idx)) * bmax * subs[s].tau > 1.0) loop14 = reg_loop = pass_tan = false;
     }
   }
   if (reg_loop && N == 14 && !loop14) reg_loop = false;
+  if (reg_loop || loop14) pass_tan = false;
   SplitRun R;
   std::memset(&R, 0, sizeof R);
   R.nsub = nsub;
@@ -233,7 +238,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   for (int i = 0; i <= sc.S; ++i) R.a[i] = sc.a[i];
   for (int i = 0; i < sc.S; ++i) R.b[i] = sc.b[i];
   for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[s].idx; R.u0[s] = subs[s].u0; R.tau[s] = subs[s].tau; }
-  R.tan_form = reg_loop ? (h->drive_real ? 1 : 2) : (loop14 && h->drive_real ? 1 : 0);
+  R.tan_form = reg_loop ? (h->drive_real ? 1 : 2) : ((loop14 || pass_tan) && h->drive_real ? 1 : 0);
   const int total = B * N;
   hipLaunchKernelGGL(k_split_coefs, dim3(h->dterms_dev ? (total + 3) / 4 : (total + 255) / 256, n_stages), dim3(256), 0, st,
                      h->pp_dev, h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);
@@ -328,6 +333,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
       if ((F >> b) & 1ull) A.fin_mask |= 1u << local_of(p.tile, b);
     if (done == ALL && si < n_stages) {
       A.do_diag = 1;
+      A.pend = si > 0;
       A.ccur = h->split_coefs + (size_t)si * stride;
       A.wE = wE[si];
       A.dec_a = h->mc_a;  // H_eff: the decay diagonal a + b popc(index) over the D time of this stage
@@ -348,7 +354,10 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
                                    2 * SPLIT_NMAX * 4 * 8 + (SPLIT_NMAX + 1) * 8;
       if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
       const dim3 grid(1u << (N - p.T), B);
-      if (p.T == 12 && !(A.fin_mask & 0xFu)) {
+      if (pass_tan) {
+        if (A.fin_mask & 0xFu) return fail(RYD_ERR_STATE, "split-operator pass: a finishing rotation on the low tile bits");
+        hipLaunchKernelGGL((k_split12<true, false, true>), grid, dim3(SPLIT_NT), lds, st, A);
+      } else if (p.T == 12 && !(A.fin_mask & 0xFu)) {
         if (h->mc) {
           if (h->drive_real) hipLaunchKernelGGL((k_split12<true, true>), grid, dim3(SPLIT_NT), lds, st, A);
           else hipLaunchKernelGGL((k_split12<false, true>), grid, dim3(SPLIT_NT), lds, st, A);

@@ -44,6 +44,7 @@ struct SplitArgs {
   // (use_pre), [1] at the store (use_post)
   int conj, use_pre, use_post;
   const double* ftab;
+  int pend;  // k_split12<.., TAN>: a rotation precedes this pass's D (its cosine product is applied with D)
 };
 
 // One closed run of the composition: consecutive sub-steps (knot interval, start offset, length),
@@ -434,7 +435,16 @@ __global__ __launch_bounds__(NT) void k_split_t(const SplitArgs A) {
 //   L2: finish bits 8-11 | L1: finish bits 4-7, D, start bits 4-7 | L0: start bits 0-3 | L2: start bits 8-11
 // (the tilings keep >= 4 low bits, so a finishing rotation never touches bits 0-3).  LDS slots and
 // global offsets fold into immediates; REAL: every drive coefficient is real (g = -i S c is imaginary).
-template <bool REAL, bool DECAY>
+#ifndef SPLIT12_NT
+#define SPLIT12_NT 1  /* 1: non-temporal stores of the state (20 atoms: 13.4 -> 12.8 us per pass), 2: non-temporal loads too (no gain) */
+#endif
+#ifndef SPLIT12_KO
+#define SPLIT12_KO 0  /* dev knock-outs (timing only): 1 no E0 read, 2 no rotations, 4 no turns, 8 no phase */
+#endif
+// TAN (real drives, SplitRun.tan_form = 1): rotations in tan form  x' = x - T y_p, y' = y + T x_p  (T = Im g / C in the
+// Re g slot: 2 FMAs per amplitude and bit instead of 4 instructions); the product of the N cosines of a stage's rotation,
+// one number per sequence, rides on the phase factors of the NEXT D (A.pend: a rotation is pending; its coefficients = cfin).
+template <bool REAL, bool DECAY, bool TAN = false>
 __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = 12;
@@ -459,65 +469,97 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   const unsigned long long g1 = deposit((unsigned long long)((tid & 15u) | ((tid >> 4) << 8)), A.tile);
   cplx x[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) x[r] = st[g2 | deposit((unsigned long long)(r << 8), A.tile)];
+  for (int r = 0; r < 16; ++r) {
+    const cplx* src = st + (g2 | deposit((unsigned long long)(r << 8), A.tile));
+    if (SPLIT12_NT & 2) x[r] = make_double2(__builtin_nontemporal_load(&src->x), __builtin_nontemporal_load(&src->y));
+    else x[r] = (SPLIT12_KO & 64) ? make_double2((double)tid, (double)r) : *src;
+  }
+  if (SPLIT12_KO & 16) {  // bare copy (16), load only (16 | 32), store only (16 | 64), launch floor (16 | 32 | 64)
+    if (!(SPLIT12_KO & 32) || x[3].x == 1.2345e300) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[g2 | deposit((unsigned long long)(r << 8), A.tile)] = x[r];
+    }
+    return;
+  }
   double ev[16];
   if (A.do_diag) {
     const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride + base;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ev[r] = e0[g1 | deposit((unsigned long long)(r << 4), A.tile)];
+    for (int r = 0; r < 16; ++r) ev[r] = (SPLIT12_KO & 1) ? 0.001 * (double)r : e0[g1 | deposit((unsigned long long)(r << 4), A.tile)];
   }
 
-  if (tid < 4u * N) {
-    cfs[tid] = cfin[tid];
-    cfs[4 * SPLIT_NMAX + tid] = ccur[tid];
-  }
-  if (tid >= 128 && tid < 192) trig[tid - 128] = make_double2(kSplitTrig[tid - 128][0], kSplitTrig[tid - 128][1]);
-  if constexpr (DECAY) {  // factor by number of excited atoms ne: popc(index) = N - ne
-    if (tid >= 192 && tid < 192 + SPLIT_NMAX + 1) dlut[tid - 192] = exp(A.wE * (A.dec_a + A.dec_b * (double)(N - ((int)tid - 192))));
-  }
-  __syncthreads();
+  // Per-pass tables, ONE barrier: every entry comes from independent global loads of the coefficient rows (L2 hits after the first
+  // workgroup of an XCD).  (Rounds 2 - 3 staged the coefficients in LDS and built the tables from there with serial loops: two
+  // barriers, 1.2 us more of the 18 us pass at 20 atoms.)
+  if (tid < 64) trig[tid] = make_double2(kSplitTrig[tid][0], kSplitTrig[tid][1]);
   if (tid < 2 * T) {
     const int set = tid / T, q = tid % T;
     const int k = N - 1 - tile_bit_pos(A.tile, q);
-    const double* c = cfs + set * 4 * SPLIT_NMAX + 4 * k;
-    double* o = rot + (set * SPLIT_TMAX + q) * 4;
-    o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+    const double2* c = reinterpret_cast<const double2*>((set ? ccur : cfin) + 4 * k);
+    double2 c01 = c[0], c23 = c[1];
+    double2* o = reinterpret_cast<double2*>(rot + (set * SPLIT_TMAX + q) * 4);
+    // every rotation runs, bits outside the pass's masks as the identity (C = 1, g = 0; TAN: T = 0): no branches in the
+    // rotation code (a branch per bit left 843 v_mov_b64 register copies at the joins: 2 471 -> 1 777 vector instructions)
+    if (!(((set ? A.cur_mask : A.fin_mask) >> q) & 1u)) { c01 = make_double2(1.0, 0.0); c23.x = 0.0; }
+    o[0] = c01;
+    o[1] = c23;
   }
-  double d_outer = 0.0;
-  int nexc_outer = 0;
   if (A.do_diag) {
-    const double* cc = cfs + 4 * SPLIT_NMAX;
+    if (tid >= 64 && tid < 128) {  // bits outside the tile (fixed per workgroup): lane = bit
+      const int p = tid - 64;
+      bool out_exc = p < N && !((base >> p) & 1ull);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) out_exc &= !(p >= A.tile.lo[i] && p < A.tile.lo[i] + A.tile.len[i]);
+      double v = out_exc ? ccur[4 * (N - 1 - p) + 3] : 0.0;
+      const unsigned long long mk = __ballot(out_exc);
+      double pc = 1.0;
+      if constexpr (TAN) pc = (A.pend && p < N) ? cfin[4 * p] : 1.0;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        v += __shfl_xor(v, o, 64);
+        if constexpr (TAN) pc *= __shfl_xor(pc, o, 64);
+      }
+      if (p == 0) { cfs[0] = v; cfs[1] = (double)__popcll(mk); cfs[2] = pc; }
+      if constexpr (DECAY) {  // factor by number of excited atoms ne: popc(index) = N - ne
+        if (p < SPLIT_NMAX + 1) dlut[p] = exp(A.wE * (A.dec_a + A.dec_b * (double)(N - p)));
+      }
+    }
     if (tid >= 128) {
       const int e = tid - 128;
       const bool hiHalf = e >= 64;
       const int v = e & 63;
       const int q0 = hiHalf ? 6 : 0;
-      double s = 0.0;
-      for (int q = 0; q < 6; ++q)
-        if (!((v >> q) & 1)) s += cc[4 * (N - 1 - tile_bit_pos(A.tile, q0 + q)) + 3];
-      (hiHalf ? dhi : dlo)[v] = s;
-    }
-    for (int p = 0; p < N; ++p) {
-      bool in_tile = false;
+      double dq[6];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) in_tile |= (p >= A.tile.lo[i] && p < A.tile.lo[i] + A.tile.len[i]);
-      if (!in_tile && !((base >> p) & 1ull)) { d_outer += cc[4 * (N - 1 - p) + 3]; ++nexc_outer; }
+      for (int q = 0; q < 6; ++q) dq[q] = ccur[4 * (N - 1 - tile_bit_pos(A.tile, q0 + q)) + 3];
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        if (!((v >> q) & 1)) s += dq[q];
+      (hiHalf ? dhi : dlo)[v] = s;
     }
   }
   __syncthreads();
+  const double d_outer = A.do_diag ? cfs[0] : 0.0;
+  const int nexc_outer = A.do_diag ? (int)cfs[1] : 0;
+  const double pend = (TAN && A.do_diag) ? cfs[2] : 1.0;
 
   // rotations of the 4 register bits at tile-local bits [pos, pos + 4)
   auto rotate = [&](int pos, unsigned mask, int set) {
+    if (SPLIT12_KO & 2) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (!((mask >> (pos + j)) & 1u)) continue;
+      // (TAN: T by scalar loads from the coefficient rows instead of this LDS table: 15.0 -> 17.1 us per pass at 20 atoms)
       const double* c = rot + (set * SPLIT_TMAX + pos + j) * 4;
       const double C = c[0], gr = c[1], gi = c[2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (r & (1 << j)) continue;
         const cplx a0 = x[r], a1 = x[r | (1 << j)];
-        if (REAL) {
+        if (TAN) {  // (gr holds T = gi / C)
+          x[r] = make_double2(fma(-gr, a1.y, a0.x), fma(gr, a1.x, a0.y));
+          x[r | (1 << j)] = make_double2(fma(-gr, a0.y, a1.x), fma(gr, a0.x, a1.y));
+        } else if (REAL) {
           x[r] = make_double2(fma(-gi, a1.y, C * a0.x), fma(gi, a1.x, C * a0.y));
           x[r | (1 << j)] = make_double2(fma(-gi, a0.y, C * a1.x), fma(gi, a0.x, C * a1.y));
         } else {
@@ -533,14 +575,16 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   const unsigned s0 = tid << 4;                             // (r ^ (tid & 15)) | tid << 4
 
   rotate(8, A.fin_mask, 0);
+  if (!(SPLIT12_KO & 4)) {
   // ---- L2 -> L1 ----
 #pragma unroll
   for (int r = 0; r < 16; ++r) xs[s2 + (r << 8)] = x[r];
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 16; ++r) x[r] = xs[(s1 ^ (unsigned)r) | (unsigned)(r << 4)];
+  }
   rotate(4, A.fin_mask, 0);
-  if (A.do_diag) {
+  if (A.do_diag && !(SPLIT12_KO & 8)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned i = s1 | (unsigned)(r << 4);
@@ -552,11 +596,16 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
         c *= f;
         s *= f;
       }
+      if constexpr (TAN) {
+        c *= pend;
+        s *= pend;
+      }
       const cplx a = x[r];
       x[r] = make_double2(fma(a.x, c, a.y * s), fma(a.y, c, -a.x * s));
     }
   }
   rotate(4, A.cur_mask, 1);
+  if (!(SPLIT12_KO & 4)) {
   __syncthreads();
   // ---- L1 -> L0 ----
 #pragma unroll
@@ -564,7 +613,9 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 16; ++r) x[r] = xs[s0 | ((unsigned)r ^ (tid & 15u))];
+  }
   rotate(0, A.cur_mask, 1);
+  if (!(SPLIT12_KO & 4)) {
   __syncthreads();
   // ---- L0 -> L2 ----
 #pragma unroll
@@ -572,9 +623,14 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 16; ++r) x[r] = xs[s2 + (r << 8)];
+  }
   rotate(8, A.cur_mask, 1);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) st[g2 | deposit((unsigned long long)(r << 8), A.tile)] = x[r];
+  for (int r = 0; r < 16; ++r) {
+    cplx* dst = st + (g2 | deposit((unsigned long long)(r << 8), A.tile));
+    if (SPLIT12_NT & 1) { __builtin_nontemporal_store(x[r].x, &dst->x); __builtin_nontemporal_store(x[r].y, &dst->y); }
+    else *dst = x[r];
+  }
 }
 
 // (k_split12_loop, the 12-atom one-launch loop of round 2 with its parity branch, is gone: real drives run on k_split_reg<12>

@@ -21,7 +21,7 @@ for n in [int(v) for v in sys.argv[1:] if v.isdigit()] or ([] if "batch" in sys.
         eng.evolve(st, 0.0, 0.01, method="split")
         ns = 200 if n <= 20 else 50
         for fixed in (True, False):
-            eng.set_path(False, split_fixed=fixed)
+            eng.set_path(False, split_fixed=fixed, split_small_tiles=bool(os.environ.get("RYD_BENCH_SMALL")))
             eng.reset_stats()
             torch.cuda.synchronize(); t0 = time.time()
             eng.evolve(st, 1.0, 1.0 + ns * 1e-3, method="split")
