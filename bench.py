@@ -92,8 +92,9 @@ KSPLITREG_NAME = ("k_split_reg<14, 5> (register-resident split-operator kernel: 
 KTRAJ_FLOPS_PER_AMP_STAGE = 120 * 1.85 / 4.0
 
 
-KSPLIT_NAME = ("k_split12 (split-operator passes: exact diagonal phase x single-atom rotations, 2^12-amplitude "
-               "register / LDS tiles, one pass per stage; algorithmic bytes = 32 B per amplitude and stage)")
+KSPLIT_NAME = ("k_split_s (split-operator passes: exact diagonal phase x single-atom rotations in tan form, 2^12-amplitude "
+               "register / LDS tiles (2^13 at 21 - 22 atoms), one pass per stage up to 22 atoms; algorithmic bytes = 32 B per "
+               "amplitude and stage)")
 KAPPLY_NAME = "k_apply<sesolve> (single-launch plan: 2^12 LDS tiles + 8 partner tiles through the Infinity Cache)"
 
 

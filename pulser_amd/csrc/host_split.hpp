@@ -93,14 +93,16 @@ static bool split_selected(const ryd_handle* h, const ryd_opts& o) {
 
 // Tilings: the low T bits, then tilings of the remaining high bits (at most 8 each) that keep
 // the low T - n_high bits for coalescing (runs of >= 16 amplitudes = 256 B).
-// Tile size: 2^12 (the static kernel k_split12) covers N <= 20 in two tilings, i.e. one pass per stage (a
-// 21st atom needs 9 > 8 high bits: three tilings = two passes); 2^13 tiles (k_split_t<512>) cover 21 - 23
-// atoms in two tilings (23 atoms: 10 high bits + 3 low ones, 128-B runs).
+// Tile size: 2^12 (the static kernel k_split_s<12>) covers N <= 20 in two tilings, i.e. one pass per stage (a
+// 21st atom needs 9 > 8 high bits: three tilings = two passes); 2^13 tiles cover 21 - 22 atoms in two tilings
+// (k_split_s<13> for real drives: 24 / 46 us per stage at 21 / 22 atoms against 2 x 17.6 / 2 x 32 us on 2^12 tiles;
+// k_split_t<512> for the rest).  23 atoms would need 10 high bits + 3 low ones (a finishing rotation on tile bit 3:
+// the runtime-indexed k_split_t, 173 us per stage) - two passes of 2^12 tiles take 2 x 65.5 us, so 23+ atoms stay there.
 static int split_tile_bits(const ryd_handle* h) {
   const int N = h->N;
   static const bool env_small = [] { const char* e = std::getenv("RYD_SPLIT_SMALL_TILES"); return e && e[0] == '1'; }();
   if (h->split_small_tiles || env_small) return std::min(N, SPLIT_TMAX);  // (environment: A/B runs of bench.py)
-  if (N >= 21 && N <= 23) return 13;
+  if (N >= 21 && N <= 22) return 13;
   return std::min(N, SPLIT_TMAX);
 }
 
@@ -216,10 +218,10 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   if ((rc = split_ensure_tables(h, n_stages))) return rc;
   bool reg_loop = split_reg_shape(h);
   bool loop14 = N == 14 && split_loop14(h) && ((n_stages & 1) || reg_loop);  // (k_split14_loop runs its stages in pairs + the closing one)
-  // the pass kernel k_split12 in tan form (real drives, tiles of 2^12 in every tiling, no quantum jumps); RYD_SPLIT_PASS_TAN=0: dev A/B
+  // the pass kernel k_split_s in tan form (real drives, static tiles in every tiling, no quantum jumps); RYD_SPLIT_PASS_TAN=0: dev A/B
   static const bool pass_tan_env = [] { const char* e = std::getenv("RYD_SPLIT_PASS_TAN"); return !(e && e[0] == '0'); }();
   bool pass_tan = pass_tan_env && !reg_loop && !loop14 && h->drive_real && !h->mc && !h->split_tilings.empty();
-  for (const Pass& p : h->split_tilings) pass_tan = pass_tan && p.T == 12;
+  for (const Pass& p : h->split_tilings) pass_tan = pass_tan && (p.T == 12 || (p.T == 13 && N <= 22));
   if ((loop14 && h->drive_real) || reg_loop || pass_tan) {
     // tan-form rotations need cos(beta |c|) away from zero: |beta c| <= 1 for every atom over every sub-step
     double bmax = 0.0;
@@ -346,42 +348,39 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
       ++si;
     }
     if (A.fin_mask || A.do_diag) {
-      const bool big = p.T > SPLIT_TMAX;
-      const size_t lds = p.T == 12 && !(A.fin_mask & 0xFu)
-                             ? ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TMAX * 4 * 8 + 128 * 8 + 2 * SPLIT_NMAX * 4 * 8 +
-                                   (SPLIT_NMAX + 1) * 8
-                             : ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TBIG * 4 * 8 + 256 * 8 +
-                                   2 * SPLIT_NMAX * 4 * 8 + (SPLIT_NMAX + 1) * 8;
+      // the static kernel k_split_s: tiles of 2^12 / 2^13 whose finishing rotations stay off the low 4 tile bits
+      // (2^13: the tan-form instantiation only - the others do not fit the registers with 32 amplitudes per lane)
+      const bool stat = (p.T == 12 || (p.T == 13 && pass_tan)) && !(A.fin_mask & 0xFu);
+      const size_t lds = stat ? ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TS * 4 * 8 + 64 * 8 + 128 * 8 + 4 * 8 + (SPLIT_NMAX + 1) * 8
+                              : ((size_t)16 << p.T) + 64 * 16 + 2 * SPLIT_TBIG * 4 * 8 + 256 * 8 +
+                                    2 * SPLIT_NMAX * 4 * 8 + (SPLIT_NMAX + 1) * 8;
       if (h->timing) { if ((rc = timing_begin(h, st, ev))) return rc; }
       const dim3 grid(1u << (N - p.T), B);
-      if (pass_tan) {
-        if (A.fin_mask & 0xFu) return fail(RYD_ERR_STATE, "split-operator pass: a finishing rotation on the low tile bits");
-        hipLaunchKernelGGL((k_split12<true, false, true>), grid, dim3(SPLIT_NT), lds, st, A);
-      } else if (p.T == 12 && !(A.fin_mask & 0xFu)) {
-        if (h->mc) {
-          if (h->drive_real) hipLaunchKernelGGL((k_split12<true, true>), grid, dim3(SPLIT_NT), lds, st, A);
-          else hipLaunchKernelGGL((k_split12<false, true>), grid, dim3(SPLIT_NT), lds, st, A);
-        } else {
-          if (h->drive_real) hipLaunchKernelGGL((k_split12<true, false>), grid, dim3(SPLIT_NT), lds, st, A);
-          else hipLaunchKernelGGL((k_split12<false, false>), grid, dim3(SPLIT_NT), lds, st, A);
-        }
+      static bool attr[64] = {};
+      const int dev = h->cfg.device;
+      if (dev < 0 || dev >= 64 || !attr[dev]) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_split_t<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_split_t<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_split_t<SPLIT_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_split_t<SPLIT_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_split_s<13, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev >= 0 && dev < 64) attr[dev] = true;
+      }
+      if (pass_tan && !stat) return fail(RYD_ERR_STATE, "split-operator pass: a finishing rotation on the low tile bits");
+      if (stat && p.T == 12) {
+        if (pass_tan) hipLaunchKernelGGL((k_split_s<12, true, false, true>), grid, dim3(SPLIT_NT), lds, st, A);
+        else if (h->mc && h->drive_real) hipLaunchKernelGGL((k_split_s<12, true, true>), grid, dim3(SPLIT_NT), lds, st, A);
+        else if (h->mc) hipLaunchKernelGGL((k_split_s<12, false, true>), grid, dim3(SPLIT_NT), lds, st, A);
+        else if (h->drive_real) hipLaunchKernelGGL((k_split_s<12, true, false>), grid, dim3(SPLIT_NT), lds, st, A);
+        else hipLaunchKernelGGL((k_split_s<12, false, false>), grid, dim3(SPLIT_NT), lds, st, A);
+      } else if (stat) {
+        hipLaunchKernelGGL((k_split_s<13, true, false, true>), grid, dim3(SPLIT_NT), lds, st, A);
+      } else if (p.T > SPLIT_TMAX) {
+        if (h->mc) hipLaunchKernelGGL((k_split_t<512, true>), grid, dim3(512), lds, st, A);
+        else hipLaunchKernelGGL((k_split_t<512, false>), grid, dim3(512), lds, st, A);
       } else {
-        static bool attr[64] = {};
-        const int dev = h->cfg.device;
-        if (dev < 0 || dev >= 64 || !attr[dev]) {
-          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<SPLIT_NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          HIPCHK(hipFuncSetAttribute((const void*)k_split_t<SPLIT_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          if (dev >= 0 && dev < 64) attr[dev] = true;
-        }
-        if (big) {
-          if (h->mc) hipLaunchKernelGGL((k_split_t<512, true>), grid, dim3(512), lds, st, A);
-          else hipLaunchKernelGGL((k_split_t<512, false>), grid, dim3(512), lds, st, A);
-        } else {
-          if (h->mc) hipLaunchKernelGGL((k_split_t<SPLIT_NT, true>), grid, dim3(SPLIT_NT), lds, st, A);
-          else hipLaunchKernelGGL((k_split_t<SPLIT_NT, false>), grid, dim3(SPLIT_NT), lds, st, A);
-        }
+        if (h->mc) hipLaunchKernelGGL((k_split_t<SPLIT_NT, true>), grid, dim3(SPLIT_NT), lds, st, A);
+        else hipLaunchKernelGGL((k_split_t<SPLIT_NT, false>), grid, dim3(SPLIT_NT), lds, st, A);
       }
       HIPCHK(hipGetLastError());
       if (h->timing) { HIPCHK(hipEventRecord(ev.second, st)); h->ev_used.push_back(ev); }

@@ -19,6 +19,7 @@
 // Roofline: HBM / Infinity-Cache streaming, 40 B per amplitude and stage.
 
 #define SPLIT_TMAX 12
+#define SPLIT_TS 13    /* largest tile of the static pass kernel k_split_s */
 #define SPLIT_TBIG 14  /* table sizing of the generic pass kernel k_split_t (tiles of up to 2^14 amplitudes) */
 #define SPLIT_NT 256
 #define SPLIT_NMAX 32
@@ -430,31 +431,39 @@ __global__ __launch_bounds__(NT) void k_split_t(const SplitArgs A) {
   }
 }
 
-// The same pass for tiles of exactly 2^12 amplitudes with everything static: layouts L2 (register
-// bits 8-11, the load / store layout), L1 (bits 4-7) and L0 (bits 0-3) in the fixed order
-//   L2: finish bits 8-11 | L1: finish bits 4-7, D, start bits 4-7 | L0: start bits 0-3 | L2: start bits 8-11
-// (the tilings keep >= 4 low bits, so a finishing rotation never touches bits 0-3).  LDS slots and
-// global offsets fold into immediates; REAL: every drive coefficient is real (g = -i S c is imaginary).
-#ifndef SPLIT12_NT
-#define SPLIT12_NT 1  /* 1: non-temporal stores of the state (20 atoms: 13.4 -> 12.8 us per pass), 2: non-temporal loads too (no gain) */
-#endif
-#ifndef SPLIT12_KO
-#define SPLIT12_KO 0  /* dev knock-outs (timing only): 1 no E0 read, 2 no rotations, 4 no turns, 8 no phase */
-#endif
+// The same pass with everything static, for tiles of 2^12 (N <= 20: one pass per stage) and 2^13 amplitudes (21 - 22
+// atoms: one pass per stage): 256 lanes x R = 2^(T - 8) amplitudes.  Layouts (tile-local index of register r)
+//   LA: tid | r << 8                                                    register bits 8 .. T-1 (the load / store layout)
+//   LB: (tid & 15) | (r & 15) << 4 | (tid >> 4) << 8 | (r >> 4) << 12   register bits 4-7 (+ bit 12 along for the ride)
+//   LC: (r & 15) | tid << 4 | (r >> 4) << 12                            register bits 0-3 (+ bit 12)
+// in the fixed order
+//   LA: finish bits 8.. | LB: finish bits 4-7, D, start bits 4-7 | LC: start bits 0-3 | LA: start bits 8..
+// (the tilings keep >= 4 low bits, so a finishing rotation never touches bits 0-3).  LDS slots (XOR-swizzled: i ^ (i >> 4 &
+// 15)) and global offsets fold into immediates; REAL: every drive coefficient is real (g = -i S c is imaginary).
 // TAN (real drives, SplitRun.tan_form = 1): rotations in tan form  x' = x - T y_p, y' = y + T x_p  (T = Im g / C in the
 // Re g slot: 2 FMAs per amplitude and bit instead of 4 instructions); the product of the N cosines of a stage's rotation,
 // one number per sequence, rides on the phase factors of the NEXT D (A.pend: a rotation is pending; its coefficients = cfin).
-template <bool REAL, bool DECAY, bool TAN = false>
-__global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
+// Round 4, measured at 20 atoms (tools/pass_variants.sh, profiles/r04_cfg5_pass_variants.md): 17.6 -> 12.8 us per pass -
+// the per-pass tables behind ONE barrier (every entry from independent global loads), no branch per bit in the rotation
+// code (bits outside the pass's masks rotate by the identity; the branches had left 843 v_mov_b64 copies at their joins),
+// tan form, non-temporal stores.  What remains: ~3 us launch-to-launch floor + ~6 us of loads and store drain + ~3.8 us
+// of vector instructions on one wave per SIMD.
+#ifndef SPLITS_NT
+#define SPLITS_NT 1  /* 1: non-temporal stores of the state (20 atoms: 13.4 -> 12.8 us per pass); 2: loads too (no gain) */
+#endif
+template <int T, bool REAL, bool DECAY, bool TAN = false>
+__global__ __launch_bounds__(SPLIT_NT) void k_split_s(const SplitArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int T = 12;
+  static_assert(T == 12 || T == 13, "tiles of 2^12 or 2^13 amplitudes");
+  constexpr int RB = T - 8, R = 1 << RB;  // register bits of LA, amplitudes per lane
+  constexpr int NHI = 1 << (T - 6);       // entries of the detuning table of tile bits 6 .. T-1
   cplx* xs = reinterpret_cast<cplx*>(smem);
   cplx* trig = xs + (1 << T);
-  double* rot = reinterpret_cast<double*>(trig + 64);
-  double* dlo = rot + 2 * SPLIT_TMAX * 4;
-  double* dhi = dlo + 64;
-  double* cfs = dhi + 64;
-  double* dlut = cfs + 2 * SPLIT_NMAX * 4;
+  double* rot = reinterpret_cast<double*>(trig + 64);  // [2][SPLIT_TS][4]
+  double* dlo = rot + 2 * SPLIT_TS * 4;                // [64]
+  double* dhi = dlo + 64;                              // [128]
+  double* cfs = dhi + 128;                             // [4] per-workgroup scalars
+  double* dlut = cfs + 4;                              // [SPLIT_NMAX + 1]
 
   const unsigned tid = threadIdx.x;
   const int N = A.N;
@@ -464,42 +473,34 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   const double* __restrict__ cfin = A.cfin + (size_t)b * N * 4;
   const double* __restrict__ ccur = A.ccur + (size_t)b * N * 4;
 
-  // tile-local index of register r: L2: tid | r << 8;  L1: (tid & 15) | r << 4 | (tid >> 4) << 8;  L0: r | tid << 4
-  const unsigned long long g2 = deposit((unsigned long long)tid, A.tile);
-  const unsigned long long g1 = deposit((unsigned long long)((tid & 15u) | ((tid >> 4) << 8)), A.tile);
-  cplx x[16];
+  const unsigned long long gA = deposit((unsigned long long)tid, A.tile);
+  const unsigned long long gB = deposit((unsigned long long)((tid & 15u) | ((tid >> 4) << 8)), A.tile);
+  auto offA = [&](int r) { return gA | deposit((unsigned long long)(r << 8), A.tile); };
+  auto offB = [&](int r) { return gB | deposit((unsigned long long)(((r & 15) << 4) | ((r >> 4) << 12)), A.tile); };
+  cplx x[R];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const cplx* src = st + (g2 | deposit((unsigned long long)(r << 8), A.tile));
-    if (SPLIT12_NT & 2) x[r] = make_double2(__builtin_nontemporal_load(&src->x), __builtin_nontemporal_load(&src->y));
-    else x[r] = (SPLIT12_KO & 64) ? make_double2((double)tid, (double)r) : *src;
+  for (int r = 0; r < R; ++r) {
+    const cplx* src = st + offA(r);
+    if (SPLITS_NT & 2) x[r] = make_double2(__builtin_nontemporal_load(&src->x), __builtin_nontemporal_load(&src->y));
+    else x[r] = *src;
   }
-  if (SPLIT12_KO & 16) {  // bare copy (16), load only (16 | 32), store only (16 | 64), launch floor (16 | 32 | 64)
-    if (!(SPLIT12_KO & 32) || x[3].x == 1.2345e300) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[g2 | deposit((unsigned long long)(r << 8), A.tile)] = x[r];
-    }
-    return;
-  }
-  double ev[16];
+  double ev[R];
   if (A.do_diag) {
     const double* __restrict__ e0 = A.e0 + (size_t)b * A.e0_stride + base;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ev[r] = (SPLIT12_KO & 1) ? 0.001 * (double)r : e0[g1 | deposit((unsigned long long)(r << 4), A.tile)];
+    for (int r = 0; r < R; ++r) ev[r] = e0[offB(r)];
   }
 
-  // Per-pass tables, ONE barrier: every entry comes from independent global loads of the coefficient rows (L2 hits after the first
-  // workgroup of an XCD).  (Rounds 2 - 3 staged the coefficients in LDS and built the tables from there with serial loops: two
-  // barriers, 1.2 us more of the 18 us pass at 20 atoms.)
+  // Per-pass tables, ONE barrier: every entry comes from independent global loads of the coefficient rows (L2 hits after
+  // the first workgroup of an XCD).
   if (tid < 64) trig[tid] = make_double2(kSplitTrig[tid][0], kSplitTrig[tid][1]);
   if (tid < 2 * T) {
     const int set = tid / T, q = tid % T;
     const int k = N - 1 - tile_bit_pos(A.tile, q);
     const double2* c = reinterpret_cast<const double2*>((set ? ccur : cfin) + 4 * k);
     double2 c01 = c[0], c23 = c[1];
-    double2* o = reinterpret_cast<double2*>(rot + (set * SPLIT_TMAX + q) * 4);
-    // every rotation runs, bits outside the pass's masks as the identity (C = 1, g = 0; TAN: T = 0): no branches in the
-    // rotation code (a branch per bit left 843 v_mov_b64 register copies at the joins: 2 471 -> 1 777 vector instructions)
+    double2* o = reinterpret_cast<double2*>(rot + (set * SPLIT_TS + q) * 4);
+    // every rotation runs, bits outside the pass's masks as the identity (C = 1, g = 0; TAN: T = 0)
     if (!(((set ? A.cur_mask : A.fin_mask) >> q) & 1u)) { c01 = make_double2(1.0, 0.0); c23.x = 0.0; }
     o[0] = c01;
     o[1] = c23;
@@ -524,19 +525,24 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
         if (p < SPLIT_NMAX + 1) dlut[p] = exp(A.wE * (A.dec_a + A.dec_b * (double)(N - p)));
       }
     }
-    if (tid >= 128) {
-      const int e = tid - 128;
-      const bool hiHalf = e >= 64;
-      const int v = e & 63;
-      const int q0 = hiHalf ? 6 : 0;
-      double dq[6];
+    if (tid >= 128) {  // detuning integral part of the phase, sum_k Delta_k n_k (n_k = 1 - bit): tile bits 0-5 | 6 .. T-1
 #pragma unroll
-      for (int q = 0; q < 6; ++q) dq[q] = ccur[4 * (N - 1 - tile_bit_pos(A.tile, q0 + q)) + 3];
-      double s = 0.0;
+      for (int it = 0; it < (64 + NHI + 127) / 128; ++it) {
+        const int e = (int)tid - 128 + 128 * it;
+        if (e >= 64 + NHI) break;
+        const bool hiHalf = e >= 64;
+        const int v = hiHalf ? e - 64 : e;
+        const int q0 = hiHalf ? 6 : 0;
+        const int nq = hiHalf ? T - 6 : 6;
+        double dq[7];
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
-        if (!((v >> q) & 1)) s += dq[q];
-      (hiHalf ? dhi : dlo)[v] = s;
+        for (int q = 0; q < 7; ++q) dq[q] = q < nq ? ccur[4 * (N - 1 - tile_bit_pos(A.tile, q0 + q)) + 3] : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+          if (!((v >> q) & 1)) s += dq[q];
+        (hiHalf ? dhi : dlo)[v] = s;
+      }
     }
   }
   __syncthreads();
@@ -544,16 +550,16 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
   const int nexc_outer = A.do_diag ? (int)cfs[1] : 0;
   const double pend = (TAN && A.do_diag) ? cfs[2] : 1.0;
 
-  // rotations of the 4 register bits at tile-local bits [pos, pos + 4)
-  auto rotate = [&](int pos, unsigned mask, int set) {
-    if (SPLIT12_KO & 2) return;
+  // rotations of register bits 0 .. nb-1 = tile-local bits [pos, pos + nb)
+  auto rotate = [&](int pos, int nb, int set) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RB; ++j) {
+      if (j >= nb) continue;
       // (TAN: T by scalar loads from the coefficient rows instead of this LDS table: 15.0 -> 17.1 us per pass at 20 atoms)
-      const double* c = rot + (set * SPLIT_TMAX + pos + j) * 4;
+      const double* c = rot + (set * SPLIT_TS + pos + j) * 4;
       const double C = c[0], gr = c[1], gi = c[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < R; ++r) {
         if (r & (1 << j)) continue;
         const cplx a0 = x[r], a1 = x[r | (1 << j)];
         if (TAN) {  // (gr holds T = gi / C)
@@ -570,29 +576,30 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
     }
   };
   // swizzled LDS slot of tile-local index i: i ^ ((i >> 4) & 15)
-  const unsigned s2 = tid ^ ((tid >> 4) & 15u);             // + (r << 8)
-  const unsigned s1 = (tid & 15u) | ((tid >> 4) << 8);      // ((tid & 15) ^ r) | r << 4 | (tid >> 4) << 8
-  const unsigned s0 = tid << 4;                             // (r ^ (tid & 15)) | tid << 4
+  const unsigned sA = tid ^ ((tid >> 4) & 15u);             // + (r << 8)
+  const unsigned sB = (tid & 15u) | ((tid >> 4) << 8);      // ((tid & 15) ^ (r & 15)) | (r & 15) << 4 | (tid >> 4) << 8 | (r >> 4) << 12
+  const unsigned sC = tid << 4;                             // ((r & 15) ^ (tid & 15)) | tid << 4 | (r >> 4) << 12
+  auto slotA = [&](int r) { return sA + (unsigned)(r << 8); };
+  auto slotB = [&](int r) { return (sB ^ (unsigned)(r & 15)) | (unsigned)((r & 15) << 4) | (unsigned)((r >> 4) << 12); };
+  auto slotC = [&](int r) { return sC | ((unsigned)(r & 15) ^ (tid & 15u)) | (unsigned)((r >> 4) << 12); };
 
-  rotate(8, A.fin_mask, 0);
-  if (!(SPLIT12_KO & 4)) {
-  // ---- L2 -> L1 ----
+  rotate(8, RB, 0);
+  // ---- LA -> LB ----
 #pragma unroll
-  for (int r = 0; r < 16; ++r) xs[s2 + (r << 8)] = x[r];
+  for (int r = 0; r < R; ++r) xs[slotA(r)] = x[r];
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) x[r] = xs[(s1 ^ (unsigned)r) | (unsigned)(r << 4)];
-  }
-  rotate(4, A.fin_mask, 0);
-  if (A.do_diag && !(SPLIT12_KO & 8)) {
+  for (int r = 0; r < R; ++r) x[r] = xs[slotB(r)];
+  rotate(4, 4, 0);
+  if (A.do_diag) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned i = s1 | (unsigned)(r << 4);
+    for (int r = 0; r < R; ++r) {
+      const unsigned i = sB | (unsigned)((r & 15) << 4) | (unsigned)((r >> 4) << 12);
       const double phi = fma(A.wE, ev[r], -(d_outer + dlo[i & 63u] + dhi[i >> 6]));
       double c, s;
       split_sincos(phi, trig, c, s);
       if constexpr (DECAY) {
-        const double f = dlut[nexc_outer + 12 - __popc(i)];
+        const double f = dlut[nexc_outer + T - __popc(i)];
         c *= f;
         s *= f;
       }
@@ -604,37 +611,33 @@ __global__ __launch_bounds__(SPLIT_NT) void k_split12(const SplitArgs A) {
       x[r] = make_double2(fma(a.x, c, a.y * s), fma(a.y, c, -a.x * s));
     }
   }
-  rotate(4, A.cur_mask, 1);
-  if (!(SPLIT12_KO & 4)) {
+  rotate(4, 4, 1);
   __syncthreads();
-  // ---- L1 -> L0 ----
+  // ---- LB -> LC ----
 #pragma unroll
-  for (int r = 0; r < 16; ++r) xs[(s1 ^ (unsigned)r) | (unsigned)(r << 4)] = x[r];
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) x[r] = xs[s0 | ((unsigned)r ^ (tid & 15u))];
-  }
-  rotate(0, A.cur_mask, 1);
-  if (!(SPLIT12_KO & 4)) {
-  __syncthreads();
-  // ---- L0 -> L2 ----
-#pragma unroll
-  for (int r = 0; r < 16; ++r) xs[s0 | ((unsigned)r ^ (tid & 15u))] = x[r];
+  for (int r = 0; r < R; ++r) xs[slotB(r)] = x[r];
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) x[r] = xs[s2 + (r << 8)];
-  }
-  rotate(8, A.cur_mask, 1);
+  for (int r = 0; r < R; ++r) x[r] = xs[slotC(r)];
+  rotate(0, 4, 1);
+  __syncthreads();
+  // ---- LC -> LA ----
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    cplx* dst = st + (g2 | deposit((unsigned long long)(r << 8), A.tile));
-    if (SPLIT12_NT & 1) { __builtin_nontemporal_store(x[r].x, &dst->x); __builtin_nontemporal_store(x[r].y, &dst->y); }
+  for (int r = 0; r < R; ++r) xs[slotC(r)] = x[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) x[r] = xs[slotA(r)];
+  rotate(8, RB, 1);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    cplx* dst = st + offA(r);
+    if (SPLITS_NT & 1) { __builtin_nontemporal_store(x[r].x, &dst->x); __builtin_nontemporal_store(x[r].y, &dst->y); }
     else *dst = x[r];
   }
 }
 
 // (k_split12_loop, the 12-atom one-launch loop of round 2 with its parity branch, is gone: real drives run on k_split_reg<12>
-// (k_split_reg.hpp), complex drives pass by pass on k_split12.)
+// (k_split_reg.hpp), complex drives pass by pass on k_split_s<12>.)
 
 // Whole kets of exactly 14 atoms, one workgroup (512 lanes x 32 amplitudes = 5 register bits) per sequence: every stage
 // of a closed run in ONE launch, the ket stays in registers (the headline batch: 256 sequences = one per CU).  A stage

@@ -103,7 +103,7 @@ def test_split_local_complex_drives_against_taylor(n, seed):
 
 @pytest.mark.parametrize("n, rows, cols, ns", [(15, 3, 5, 40), (16, 4, 4, 40), (20, 4, 5, 30), (22, 2, 11, 6)])
 def test_split_is_the_default_from_15_atoms_and_matches_taylor(n, rows, cols, ns):
-    """cfg5 sizes (20 atoms = BASELINE configs[4]; 22 atoms = three tilings, two passes per stage):
+    """cfg5 sizes (20 atoms = BASELINE configs[4]; 22 atoms = 2^13 tiles, one pass per stage):
     the default path is the split-operator one and agrees with CF4 + Taylor far inside the bar."""
     prob = rect_problem(rows, cols)
     outs = {}
@@ -118,7 +118,7 @@ def test_split_is_the_default_from_15_atoms_and_matches_taylor(n, rows, cols, ns
             s = eng.stats()
             if method == "auto":
                 assert s["n_applications"] >= 10 * ns // 8 and s["reserved"][0] > 0  # stages; error estimate kept
-                assert s["passes"] == 1  # 21 - 23 atoms: 2^13 tiles keep one pass per stage
+                assert s["passes"] == 1  # 21 - 22 atoms: 2^13 tiles keep one pass per stage
     assert np.max(np.abs(outs["taylor"] - outs["auto"])) < 2e-9
     assert abs(np.linalg.norm(outs["auto"]) - 1.0) < 1e-9
 
@@ -308,9 +308,10 @@ def test_sixteen_atom_sequence_end_to_end_through_the_emulator():
 
 @pytest.mark.parametrize("n", [21, 22, 23])
 def test_large_tiles_give_21_to_23_atoms_one_pass_per_stage(n):
-    """2^13-amplitude tiles (k_split_t<512>): two tilings instead of three, so a stage is ONE pass over the
-    ket; identical amplitudes to the 2^12 tiles (the same arithmetic in another order of the tile bits), and
-    the exact product-state solution of far-apart atoms."""
+    """2^13-amplitude tiles (k_split_s<13>; 21 - 22 atoms): two tilings instead of three, so a stage is ONE pass over
+    the ket; identical amplitudes to the 2^12 tiles (the same arithmetic in another order of the tile bits), and
+    the exact product-state solution of far-apart atoms.  23 atoms stay on 2^12 tiles (two passes per stage: measured
+    faster than the runtime-indexed kernel a 10 + 3 bit tiling would need)."""
     T = 6
     coords = P.register_coords(P.square_rect(1, n), 40.0)
     rng = np.random.default_rng(n)
@@ -324,7 +325,7 @@ def test_large_tiles_give_21_to_23_atoms_one_pass_per_stage(n):
             st = eng.new_state()
             eng.evolve(st, 0.0, 0.003)
             s = eng.stats()
-            assert s["passes"] == (2 if small else 1)
+            assert s["passes"] == (2 if small or n == 23 else 1)
             outs[small] = st[0, idx].cpu().numpy()
     assert np.max(np.abs(outs[False] - outs[True])) < 1e-14
     h1 = np.array([[2.0, 3.0], [3.0, 0.0]])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the split-operator pass kernel k_split12 (20-atom ket, 20 ns slice = ~125 passes)
+# SQ counters of the split-operator pass kernel k_split_s (20-atom ket, 20 ns slice = ~125 passes)
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 OUT=gpurun_out/pmc_split; rm -rf $OUT; mkdir -p $OUT
 SET1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
@@ -15,7 +15,7 @@ import csv, glob
 for i in (1,2,3):
     f=glob.glob(f"gpurun_out/pmc_split/p{i}/c_counter_collection.csv")
     if not f: print("pass", i, "no output"); continue
-    rows=[r for r in csv.DictReader(open(f[0])) if 'k_split12' in r['Kernel_Name']]
+    rows=[r for r in csv.DictReader(open(f[0])) if 'k_split_s' in r['Kernel_Name']]
     acc={}
     for r in rows: acc.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
     print({k: (len(v), round(sum(v)/1e6,3)) for k,v in acc.items()})

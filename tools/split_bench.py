@@ -9,7 +9,7 @@ from helpers import blockade_radius
 from pulser_amd import problem as P
 from pulser_amd.engine import Engine
 
-SHAPES = {14: (2, 7), 16: (4, 4), 18: (3, 6), 20: (4, 5), 21: (3, 7), 22: (2, 11), 24: (4, 6)}
+SHAPES = {14: (2, 7), 15: (3, 5), 16: (4, 4), 17: (1, 17), 18: (3, 6), 19: (1, 19), 20: (4, 5), 21: (3, 7), 22: (2, 11), 23: (1, 23), 24: (4, 6), 25: (5, 5)}
 
 def rect(rows, cols):
     coords = P.register_coords(P.square_rect(rows, cols), blockade_radius())

@@ -40,7 +40,7 @@ for name in ("ns", "nst", "nsk", "cfg3", "cfg5", "cfg5t", "cfg5b", "cfg5c", "cfg
         md += [text, ""]
     except FileNotFoundError:
         continue
-for name, kern_sub in (("ns", "k_split_reg"), ("nst", "k_split14_loop"), ("nsk", "k_ket"), ("cfg3", "k_split_reg"), ("cfg3", "k_transpose_conj"), ("cfg5", "k_split12"), ("cfg5t", "k_apply<"), ("cfg5b", "k_split12"), ("cfg5c", "k_split_t"), ("cfg2", "k_split_reg"), ("cfg2", "k_traj")):
+for name, kern_sub in (("ns", "k_split_reg"), ("nst", "k_split14_loop"), ("nsk", "k_ket"), ("cfg3", "k_split_reg"), ("cfg3", "k_transpose_conj"), ("cfg5", "k_split_s"), ("cfg5t", "k_apply<"), ("cfg5b", "k_split_s"), ("cfg5c", "k_split_t"), ("cfg2", "k_split_reg"), ("cfg2", "k_traj")):
     try:
         f = pmc(name, "FETCH_SIZE"); w = pmc(name, "WRITE_SIZE")
     except FileNotFoundError:
@@ -55,7 +55,7 @@ for name, kern_sub in (("ns", "k_split_reg"), ("nst", "k_split14_loop"), ("nsk",
         rd = 2 * sf / nf * 1024; wr = sw / max(nw, 1) * 1024
         md.append(f"| `{k[:60]}` | {nf} | {sf/nf:.1f} | {rd:.4g} | {sw/max(nw,1):.1f} | {rd+wr:.4g} |")
         key = {"ns": "north_star", "nst": "north_star", "nsk": "north_star", "cfg3": "cfg3", "cfg5": "cfg5", "cfg5t": "cfg5", "cfg5b": "cfg5_24atoms",
-               "cfg5c": "cfg5_22atoms", "cfg2": "cfg2"}[name] + ":" + {"k_split12": "k_split", "k_split_t": "k_split", "k_split14_loop": "k_split14"}.get(kern_sub, kern_sub.rstrip("<"))
+               "cfg5c": "cfg5_22atoms", "cfg2": "cfg2"}[name] + ":" + {"k_split_s": "k_split", "k_split_t": "k_split", "k_split14_loop": "k_split14"}.get(kern_sub, kern_sub.rstrip("<"))
         traffic[key] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                                          "total_bytes_per_launch": rd + wr, "launches_sampled": nf}
     md.append("")
