@@ -40,7 +40,7 @@ for name in ("ns", "nst", "nsk", "cfg3", "cfg5", "cfg5t", "cfg5b", "cfg5c", "cfg
         md += [text, ""]
     except FileNotFoundError:
         continue
-for name, kern_sub in (("ns", "k_split_reg"), ("nst", "k_split14_loop"), ("nsk", "k_ket"), ("cfg3", "k_split_reg"), ("cfg3", "k_transpose_conj"), ("cfg5", "k_split_s"), ("cfg5t", "k_apply<"), ("cfg5b", "k_split_s"), ("cfg5c", "k_split_t"), ("cfg2", "k_split_reg"), ("cfg2", "k_traj")):
+for name, kern_sub in (("ns", "k_split_reg"), ("nst", "k_split14_loop"), ("nsk", "k_ket"), ("cfg3", "k_split_reg"), ("cfg3", "k_transpose_conj"), ("cfg5", "k_split_s"), ("cfg5t", "k_apply<"), ("cfg5b", "k_split_s"), ("cfg5c", "k_split_s"), ("cfg2", "k_split_reg"), ("cfg2", "k_traj")):
     try:
         f = pmc(name, "FETCH_SIZE"); w = pmc(name, "WRITE_SIZE")
     except FileNotFoundError:
