@@ -91,6 +91,7 @@ struct ryd_handle {
   bool split_known = false;       // controller state below is valid for the current tables
   double split_tau = 1e300;       // target sub-step (us); 1e300 = whole schedule steps
   double split_rate = 0.0;        // last measured local error per us at that sub-step
+  double split_amp = 0.0;  // drive bound at the controller's last check
   double split_eps = 0.0;         // tolerance the state was measured for
   int split_since = 0;            // schedule steps since the last check
   double split_since_len = 0.0;   // simulated time (us) covered since the last check

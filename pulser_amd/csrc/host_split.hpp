@@ -507,7 +507,12 @@ static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, d
 // local errors of a whole pulse sequence add up to the tolerance; a check that finds the last stretch more
 // than 4x over its allowance restores the checkpoint taken at the previous check and repeats the
 // stretch with the shorter sub-step.
-static const int kSplitCheckEvery = 48;
+// Round 4: the period counts KNOT INTERVALS, not schedule steps (with steps of up to 9 knots, 48 steps were 430 ns: a
+// 300-ns sequence got the one check of its first multi-knot step, at the foot of the amplitude ramp, and ran the rest
+// of the ramp with whole 9-knot steps - 9.8e-8 from a tight run with an estimate of 1.7e-8, tools/gauge_probe.py), and a
+// check is also due when the drive bound has grown by half since the last one (above a tenth of its maximum): the
+// local error of a sub-step goes with a high power of the drive amplitude.
+static const int kSplitCheckEvery = 128;
 
 static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
                      const ryd_opts& o, hipStream_t st) {
@@ -552,6 +557,10 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   std::vector<double> errs(h->B);
   h->stats.reserved[0] = 0.0;  // accumulated local-error estimate of this solve
   double err_rate = control ? h->split_rate : 0.0;  // last measured local error per us
+  double amp_max = 0.0;
+  for (double v : h->bd_c1) amp_max = std::max(amp_max, v);
+  auto amp_at = [&](const StepDesc& d) { return span_max(h->bd_c1, d.idx, std::max(1, d.pad)); };
+  double amp_ck = control && h->split_known ? h->split_amp : 0.0;  // drive bound at the last check
   if (control && h->split_known && since > 0 && since < kSplitCheckEvery) {
     // a front end that advances in slices shorter than the check period would otherwise never own a
     // checkpoint when the periodic check fires: the start of the call is one (a device copy, no check)
@@ -573,7 +582,8 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     const bool new_regime = control && off == 0.0 && sched[i].pad > 1 && (i == 0 || sched[i - 1].pad <= 1) &&
                             i != last_regime_check;
     if (new_regime) last_regime_check = i;
-    if (control && (!h->split_known || since >= kSplitCheckEvery || new_regime)) {
+    const bool amp_grown = control && off == 0.0 && amp_at(sched[i]) > std::max(1.5 * amp_ck, 0.1 * amp_max);
+    if (control && (!h->split_known || since >= kSplitCheckEvery || new_regime || amp_grown)) {
       // ---- check: one sub-step whole (wA) against two halves (state) ----
       const StepDesc& d = sched[i];
       subs.clear();
@@ -660,15 +670,23 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       have_ck = true;
       err_rate = (e / s0.tau) * std::pow(std::min(tau_t, s0.tau) / s0.tau, (double)p_ord);
       since = 0;
+      amp_ck = amp_at(d);
       h->split_known = true;
       h->split_eps = eps;
     }
     // ---- the stretch up to the next check ----
     size_t stop = control ? std::min(sched.size(), i + (size_t)std::max(kSplitCheckEvery - since, 1))
                           : sched.size();
-    if (control)  // the stretch ends where a run of multi-knot steps begins: that step is checked (above)
-      for (size_t q = i + 1; q < stop; ++q)
-        if (sched[q].pad > 1 && sched[q - 1].pad <= 1) { stop = q; break; }
+    if (control) {
+      // the stretch ends where a run of multi-knot steps begins, after kSplitCheckEvery knot intervals, or where the
+      // drive bound has grown by half: that step is checked (above)
+      int knots = since;
+      for (size_t q = i; q < stop; ++q) {
+        if (q > i && ((sched[q].pad > 1 && sched[q - 1].pad <= 1) || knots >= kSplitCheckEvery ||
+                      amp_at(sched[q]) > std::max(1.5 * amp_ck, 0.1 * amp_max))) { stop = q; break; }
+        knots += std::max(1, sched[q].pad);
+      }
+    }
     subs.clear();
     while (i < stop) {
       const StepDesc& d = sched[i];
@@ -680,7 +698,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       }
       off = 0.0;
       h->stats.n_steps++;
-      ++since;
+      since += std::max(1, d.pad);
       const bool snap = snaps && d.snap >= 0;
       if (snap || jumps || i + 1 == stop) {
         if ((rc = split_advance(h, state, subs, st))) return rc;
@@ -694,6 +712,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     h->split_tau = tau_t;
     h->split_rate = err_rate;
     h->split_since = since;
+    h->split_amp = amp_ck;
   }
   {
     const StepDesc& e = sched.back();

@@ -447,13 +447,14 @@ def test_emulator_noise_trajectories_with_a_pulse_phase_run_on_the_ket_kernel():
 
         with Engine(tables, mode="sesolve") as eng:
             # (round 4: the default path of 12 - 14 atoms is the split-operator kernel, complex drives included)
-            eng.set_path(False, no_ket=env == "no_ket", no_split14=env == "")
+            eng.set_path(False, no_ket=env == "no_ket", no_split14=env != "default")
             st = eng.new_state()
             snaps = eng.solve(st, np.asarray(emu._eval_times_array)).cpu().numpy()
             outs[env] = (snaps, eng.stats()["n_launches"])
     assert outs[""][1] == 1 and outs["no_ket"][1] >= 1
     assert np.max(np.abs(outs[""][0] - outs["no_ket"][0])) < 2e-8
-    assert np.max(np.abs(outs["default"][0] - outs["no_ket"][0])) < 1e-7  # k_split_reg<13, 5, false, false, CPLX>
+    # k_split_reg<13, 5, false, false, CPLX>; 9.8e-8 before the controller checked on the amplitude ramp (test_gpu_split.py)
+    assert np.max(np.abs(outs["default"][0] - outs["no_ket"][0])) < 5e-8
     assert np.max(np.abs(outs[""][0][-1, 0] - outs[""][0][-1, 5])) > 1e-3  # the trajectories differ (noise)
 
 

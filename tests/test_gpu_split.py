@@ -335,6 +335,30 @@ def test_large_tiles_give_21_to_23_atoms_one_pass_per_stage(n):
     assert np.max(np.abs(outs[False] - ref)) < 1e-10
 
 
+def test_controller_checks_on_the_amplitude_ramp_of_a_short_sequence():
+    """The first 300 ns of the anneal (amplitude ramp + the first knots of the sweep) on a strongly interacting 13-atom
+    chain: with a check period counted in schedule steps (48 steps of up to 9 knots) the only check of this sequence was
+    the one of its first multi-knot step at the foot of the ramp, whole 9-knot sub-steps ran up the ramp, and the state
+    was 9.8e-8 from a tight run with an estimate of 1.7e-8 (round 4, tools/gauge_probe.py).  The period counts knot
+    intervals now and a check is due when the drive bound has grown by half: error and estimate agree."""
+    n = 13
+    coords = P.register_coords(P.square_rect(1, n), 8.0)
+    samples = {k: np.asarray(v)[:300].copy() for k, v in P.anneal_samples().items()}
+    prob = P.make_ising_problem(coords, samples)
+    with _engine([prob]) as eng:
+        ref = eng.new_state()
+        eng.evolve(ref, 0.0, 0.3, method="taylor", tol=1e-13, magnus_tol=1e-12)
+        ref = ref.cpu().numpy()[0]
+    with _engine([prob]) as eng:
+        st = eng.new_state()
+        eng.evolve(st, 0.0, 0.3)
+        s = eng.stats()
+        err = np.max(np.abs(st.cpu().numpy()[0] - ref))
+    assert s["reserved"][0] > 0  # the split-operator path under its controller
+    assert err < 5e-8
+    assert s["reserved"][0] > 0.3 * err  # the estimate covers the error (it was a sixth of it)
+
+
 # ---- 6th-order scheme with multi-knot sub-steps (host_split.hpp: kSplitS10) ----
 
 def test_sixth_order_multi_knot_substeps_against_tight_oracle():
@@ -401,8 +425,8 @@ def test_scheme_follows_the_schedule_of_the_call():
         end = eng.solve(start.clone(), every[[0, -1]], method="split")
         s_end = eng.stats()
     assert s_every["n_steps"] == 60 and s_end["n_steps"] <= 10
-    assert s_every["n_applications"] % 6 == 0 and s_end["n_applications"] % 10 == 0
-    assert s_end["n_applications"] < 0.5 * s_every["n_applications"]
+    assert s_every["n_applications"] % 6 == 0 and s_end["n_applications"] % 10 == 0, (s_every, s_end)
+    assert s_end["n_applications"] < 0.6 * s_every["n_applications"]  # (its checks included: 190 against 372)
     assert float((snaps[-1] - end[-1]).abs().max()) < 2e-9
 
 
