@@ -342,7 +342,11 @@ static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
   if (Kh == 2 && o.split_steps <= 0 && rows_split_ok(h) && row_uniform_g(h) && !h->has_dbl) {
     double g = 0.0;
     for (int k = 0; k < 4; ++k) g = std::max(g, std::fabs(h->Sd[k].x));
-    if (g <= 0.1) Kh = 4;
+    // (the block error comes from the commutators of the dissipator with the DRIVE - the diagonal part of H commutes with
+    // dephasing - so the drive bound caps the rule too: measured at |c| = Omega / 2 = 12.6 rad / us, allowed up to 16)
+    double cmax = 0.0;
+    for (double v : h->bd_c1) cmax = std::max(cmax, v);
+    if (g <= 0.1 && cmax <= 16.0) Kh = 4;
   }
   return Kh;
 }
@@ -498,9 +502,6 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
     if (this_split) {
       rc2 = rows_split_pass(h, cur, sb, i0, i1, A.use_pre != 0, false, tdev, kick_pre, kick_post, kick_idx, kick_u, n_rows, false, st);
       if (rc2 == 1) {  // (nothing has been launched)
-        // the k_ket schedule of a handle that merges without the a-priori estimate (four-knot halves) is not one
-        // the polynomial kernel may run
-        if (Kh > 2) return fail(RYD_ERR_UNSUPPORTED, "drive too strong for the tan-form rotations of the split-operator rows");
         this_split = false;
       }
       else if (rc2) return rc2;

@@ -554,14 +554,11 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
   }
   const int merge_cap = split_selected(h, o) ? (split_merge ? kSplitMergeMax : 1)
                         : (row_path(h) && !use_persistent_dm(h)) ? row_half_knots(h, o) : kMergeMax;
-  // split-operator rows with four-knot halves: the steps are merged without the a-priori Magnus estimate (their unitary is
-  // a 6th-order split-operator sub-step, not a CF4 step)
-  const bool rows_noest = row_path(h) && !use_persistent_dm(h) && !split_selected(h, o) && rows_split_ok(h) && row_half_knots(h, o) > 2;
   std::vector<StepDesc> sched;
   // snapshot slot i-1 receives the state at times[i]
   for (int i = 1; i < n_times; ++i) {
     const size_t before = sched.size();
-    build_schedule(h, times[i - 1], times[i], o, sched, in_place, merge_cap, split_merge || rows_noest);
+    build_schedule(h, times[i - 1], times[i], o, sched, in_place, merge_cap, split_merge);
     if (snaps) {
       if (sched.size() > before) {
         sched.back().snap = i - 1;
