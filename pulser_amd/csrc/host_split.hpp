@@ -526,7 +526,7 @@ static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, d
 // of the ramp with whole 9-knot steps - 9.8e-8 from a tight run with an estimate of 1.7e-8, tools/gauge_probe.py), and a
 // check is also due when the drive bound has grown by half since the last one (above a tenth of its maximum): the
 // local error of a sub-step goes with a high power of the drive amplitude.
-static const int kSplitCheckEvery = 128;
+static const int kSplitCheckEvery = 256;  // (128: 24 + 6 checks on the headline anneal, 0.35 ms each for 256 kets = 14 % of the step)
 
 static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
                      const ryd_opts& o, hipStream_t st) {
