@@ -405,6 +405,10 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
       bool cut = false;
       double tau = 0.0;
       while (j < sched.size() && u < 2 * Kh && !cut) {
+        // four-knot halves: a block does not grow past 2 Kh knot intervals (where the estimate accepts three-knot steps the
+        // old rule gathered 3 + 3 + 3 knots and cut the middle step: halves of a three-knot and a 1.5-knot sub-step, 20 + 1
+        // stage bodies per 4.5 knots on the last third of the anneal; now 3 + 3: 10 + 1 per 3 knots)
+        if (Kh > 2 && j > i && u + std::max(sched[j].pad, 1) > 2 * Kh) break;
         tau += sched[j].h; u += std::max(sched[j].pad, 1); cut = sched[j].snap >= 0; ++j;
       }
       Block b{sb.size(), 0, 0, tau};
