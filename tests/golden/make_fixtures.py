@@ -7,7 +7,7 @@
 Names (default: rydberg digital three cfg1 cfg2 cfg3 cfg4): rydberg, digital, xy, all, three, cfg1..cfg4,
 spam_all, results_noisy, final_state_noisy, slm_effective_size, slm_masks, modulation, eom_limit_det,
 multichannel_noise, dmm, results, waist, config, ns14 (14-atom headline, tight), cfg3_8 / cfg3_10 / cfg3_12
-(interacting 8- / 10- / 12-atom Lindblad, tight), rect16 (16-atom square register, tight).
+(interacting 8- / 10- / 12-atom Lindblad, tight; cfg3_12_to1300: the first 1.3 us of the 12-atom one), rect16 (16-atom square register, tight).
 
 * Inputs are captured by importing the reference's ``pulser-core`` (read-only,
   never shipped; needs the no-op ``jsonschema``/``referencing`` stand-in of
@@ -1130,7 +1130,7 @@ def gen_ns_rect16(rows=4, cols=4, name="ns_rect16_anneal"):
     )
 
 
-def gen_cfg3_tight(rows=2, cols=4):
+def gen_cfg3_tight(rows=2, cols=4, t_stop=None):
     """cfg3 physics on an INTERACTING triangular register large enough for the split-operator row
     path (k_ket rows need >= 10 atoms; 8 atoms for the multi-launch kernels): tight oracle only."""
     import time
@@ -1144,6 +1144,8 @@ def gen_cfg3_tight(rows=2, cols=4):
     coords = P.register_coords(P.triangular_rect(rows, cols), rb)
     assert np.allclose(coords, p["coords"], rtol=0, atol=1e-12), (coords, p["coords"])
     sel_t = np.array([0.0, 0.5, 1.3, 2.1, 3.099, 3.1])
+    if t_stop is not None:  # (cfg3_12_to1300: the first 1.3 us only - the 12-atom right-hand side takes ~1 s, the whole anneal hours)
+        sel_t = sel_t[sel_t <= t_stop + 1e-12]
     opts = dict(aux["options"])
     opts.update(qp.TIGHT)
     counter = [0]
@@ -1165,7 +1167,7 @@ def gen_cfg3_tight(rows=2, cols=4):
     small = {k: v for k, v in p.items() if k != "samples"}
     small["samples"] = {"Global": {}, "Local": {}}
     P.save_problem(
-        os.path.join(HERE, f"cfg3_tri{n}_dephasing.npz"), small,
+        os.path.join(HERE, f"cfg3_tri{n}_dephasing" + ("" if t_stop is None else f"_to{round(t_stop * 1000)}") + ".npz"), small,
         aux={k: v for k, v in aux.items() if k not in ("eval_times", "channel_amp_det")},
         rows=rows, cols=cols, blockade_radius=float(rb),
         eval_times=sel_t, seed=123,
@@ -1475,6 +1477,8 @@ if __name__ == "__main__":
         gen_cfg3_tight(2, 5)
     if "cfg3_12" in which:
         gen_cfg3_tight(2, 6)
+    if "cfg3_12_to1300" in which:
+        gen_cfg3_tight(2, 6, t_stop=1.3)
     if "rect16" in which:
         gen_ns_rect16()
     if "spam_all" in which:
