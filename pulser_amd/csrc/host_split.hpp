@@ -149,6 +149,13 @@ static int split_max_sub(const ryd_handle* h) {
 }
 
 // Whole kets of 12 - 14 atoms with real drives run on k_split_reg (below)
+// Complex drives on the real kernels (SplitRun.gauge; RYD_SPLIT_GAUGE=0: dev A/B against the complex-arithmetic kernels)
+static bool split_gauged(const ryd_handle* h) {
+  static const bool env = [] { const char* e = std::getenv("RYD_SPLIT_GAUGE"); return !(e && e[0] == '0'); }();
+  return !h->drive_real && env;
+}
+static bool split_real(const ryd_handle* h) { return h->drive_real || split_gauged(h); }
+
 static bool split_reg_shape(const ryd_handle* h) {
   // (complex drives included since round 4: k_split_reg<.., CPLX>)
   return h->N >= 12 && h->N <= 14 && !h->split_turns && !h->split_no_loop;
@@ -192,9 +199,9 @@ static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R
     const unsigned workers = std::min<unsigned>(1u << N, (unsigned)std::max(n_cu, 1) * per_cu);
     hipLaunchKernelGGL((k_split_reg<N, 5, false, true>), dim3(1, workers, (unsigned)h->B), dim3(NT), lds, st, A, R, stride);
   }
-  else if (!h->drive_real && h->mc)
+  else if (!split_real(h) && h->mc)
     hipLaunchKernelGGL((k_split_reg<N, 5, true, false, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
-  else if (!h->drive_real)
+  else if (!split_real(h))
     hipLaunchKernelGGL((k_split_reg<N, 5, false, false, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
   else if (h->mc)
     hipLaunchKernelGGL((k_split_reg<N, 5, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
@@ -220,9 +227,9 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   bool loop14 = N == 14 && split_loop14(h) && ((n_stages & 1) || reg_loop);  // (k_split14_loop runs its stages in pairs + the closing one)
   // the pass kernel k_split_s in tan form (real drives, static tiles in every tiling, no quantum jumps); RYD_SPLIT_PASS_TAN=0: dev A/B
   static const bool pass_tan_env = [] { const char* e = std::getenv("RYD_SPLIT_PASS_TAN"); return !(e && e[0] == '0'); }();
-  bool pass_tan = pass_tan_env && !reg_loop && !loop14 && h->drive_real && !h->mc && !h->split_tilings.empty();
+  bool pass_tan = pass_tan_env && !reg_loop && !loop14 && split_real(h) && !h->mc && !h->split_tilings.empty();
   for (const Pass& p : h->split_tilings) pass_tan = pass_tan && (p.T == 12 || (p.T == 13 && N <= 22));
-  if ((loop14 && h->drive_real) || reg_loop || pass_tan) {
+  if ((loop14 && split_real(h)) || reg_loop || pass_tan) {
     // tan-form rotations need cos(beta |c|) away from zero: |beta c| <= 1 for every atom over every sub-step
     double bmax = 0.0;
     for (int i = 0; i < sc.S; ++i) bmax = std::max(bmax, std::fabs(sc.b[i]));
@@ -240,7 +247,8 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   for (int i = 0; i <= sc.S; ++i) R.a[i] = sc.a[i];
   for (int i = 0; i < sc.S; ++i) R.b[i] = sc.b[i];
   for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[s].idx; R.u0[s] = subs[s].u0; R.tau[s] = subs[s].tau; }
-  R.tan_form = reg_loop ? (h->drive_real ? 1 : 2) : ((loop14 || pass_tan) && h->drive_real ? 1 : 0);
+  R.tan_form = reg_loop ? (split_real(h) ? 1 : 2) : ((loop14 || pass_tan) && split_real(h) ? 1 : 0);
+  R.gauge = split_gauged(h) ? 1 : 0;
   const int total = B * N;
   hipLaunchKernelGGL(k_split_coefs, dim3(h->dterms_dev ? (total + 3) / 4 : (total + 255) / 256, n_stages), dim3(256), 0, st,
                      h->pp_dev, h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);
@@ -299,7 +307,7 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
     }
     std::pair<hipEvent_t, hipEvent_t> ev1;
     if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
-    if (h->drive_real)
+    if (split_real(h))
       hipLaunchKernelGGL(k_split14_loop<true>, dim3(1, B), dim3(SPLIT14_NT), lds, st, A, R, (long long)B * N * 4);
     else
       hipLaunchKernelGGL(k_split14_loop<false>, dim3(1, B), dim3(SPLIT14_NT), lds, st, A, R, (long long)B * N * 4);
@@ -369,9 +377,9 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
       if (pass_tan && !stat) return fail(RYD_ERR_STATE, "split-operator pass: a finishing rotation on the low tile bits");
       if (stat && p.T == 12) {
         if (pass_tan) hipLaunchKernelGGL((k_split_s<12, true, false, true>), grid, dim3(SPLIT_NT), lds, st, A);
-        else if (h->mc && h->drive_real) hipLaunchKernelGGL((k_split_s<12, true, true>), grid, dim3(SPLIT_NT), lds, st, A);
+        else if (h->mc && split_real(h)) hipLaunchKernelGGL((k_split_s<12, true, true>), grid, dim3(SPLIT_NT), lds, st, A);
         else if (h->mc) hipLaunchKernelGGL((k_split_s<12, false, true>), grid, dim3(SPLIT_NT), lds, st, A);
-        else if (h->drive_real) hipLaunchKernelGGL((k_split_s<12, true, false>), grid, dim3(SPLIT_NT), lds, st, A);
+        else if (split_real(h)) hipLaunchKernelGGL((k_split_s<12, true, false>), grid, dim3(SPLIT_NT), lds, st, A);
         else hipLaunchKernelGGL((k_split_s<12, false, false>), grid, dim3(SPLIT_NT), lds, st, A);
       } else if (stat) {
         hipLaunchKernelGGL((k_split_s<13, true, false, true>), grid, dim3(SPLIT_NT), lds, st, A);

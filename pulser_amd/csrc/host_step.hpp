@@ -527,10 +527,22 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
   // k_traj / k_ket / the tiled kernels)
   const bool reg_shape = split_reg_shape(h);
   if ((h->N == 14 || reg_shape) && o.method == 0 && o.taylor_order <= 0 && !h->force_generic && !h->no_split && !h->force_ket &&
-      !h->no_split14 && split_capable(h) && (reg_shape || ket_path(h)) && (reg_shape || h->drive_real) && (reg_shape || split_loop14(h)) &&
-      split_s10_allowed(h)) {
-    share = merged_share();
-    h->split14_auto = share >= 0.5;
+      !h->no_split14 && split_capable(h) && (reg_shape || ket_path(h)) && (reg_shape || h->drive_real) && (reg_shape || split_loop14(h))) {
+    if (split_s10_allowed(h)) {
+      share = merged_share();
+      h->split14_auto = share >= 0.5;
+    }
+    // Waveforms with nothing to merge (noise series, modulated local drives): since the complex drives run on the real
+    // kernel too (SplitRun.gauge) the 6-stage composition with one-knot sub-steps beats the polynomial kernels at 12 - 14
+    // atoms as well - 256 sequences with per-atom complex modulated drives, 400 ns: 4 150 against 3 480 sim-us/s (12
+    // atoms, k_traj), 2 640 against 1 790 (13), 1 520 against 810 (14, gauged k_ket); tools/cplx_bench.py.  Not for calls
+    // with evaluation times at (nearly) every knot - the persistent kernels take their snapshots inside ONE launch where
+    // this path closes a run per evaluation time - and not for quantum jumps (jumps on the device, one launch).
+    // RYD_SPLIT_ALWAYS=0: dev A/B.
+    static const bool always_env = [] { const char* e = std::getenv("RYD_SPLIT_ALWAYS"); return !(e && e[0] == '0'); }();
+    const double span_knots = h->n_knots > 1 ? (times[n_times - 1] - times[0]) / ((h->tknots.back() - h->tknots.front()) / (h->n_knots - 1)) : 0.0;
+    if (!h->split14_auto && reg_shape && !h->mc && !h->split_fixed && always_env && 8.0 * (n_times - 1) <= span_knots)
+      h->split14_auto = true;
   }
   // the in-place schemes split an exponential themselves and a Lanczos process takes whole
   // steps: both skip build_schedule's Taylor sub-stepping

@@ -69,6 +69,11 @@ struct SplitRun {
   double kick_pre, kick_post;
   int kick_idx;
   double kick_u;
+  // complex drives on the REAL kernels (round 4): the rotation by c = |c| e^{i theta} is Z R(|c|) Z^+ with the diagonal
+  // Z = exp(-i theta n), and Z commutes with every D - so stage j rotates by |c_j| and its D carries the extra per-atom
+  // phase exp(i (theta_j - theta_{j-1}) n) (theta_0 = 0; the closing D returns to theta = 0): exact, for any per-atom,
+  // time-dependent phase.  k_split_coefs adds theta_j - theta_{j-1} to the detuning integral.
+  int gauge;
 };
 
 // out[stage][b][k] = (C, Re g, Im g, Delta): the rotation exp(-i beta (c |1><0| + conj(c) |0><1|)) =
@@ -163,14 +168,27 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
     double C = 1.0, gr = 0.0, gi = 0.0;
     if (d.drive_series >= 0 && beta != 0.0) {
       const cplx a = val(d.drive_series, idx_c, u_c);
-      const double cr = d.drive_scale * a.x, ci = d.drive_scale * a.y;
+      double cr = d.drive_scale * a.x, ci = d.drive_scale * a.y;
       const double m = sqrt(cr * cr + ci * ci);
+      if (R.gauge) { cr = m; ci = 0.0; }  // (the phase of c goes to the D factors, below)
       double sn, cs;
       sincos(beta * m, &sn, &cs);
       const double S = m > 1e-300 ? sn / m : beta;  // sin(beta |c|) / |c|
       C = cs;
       gr = S * ci;  // g = -i S c
       gi = -S * cr;
+    }
+    if (R.gauge && d.drive_series >= 0) {
+      auto theta = [&](int idx, double u) {
+        const cplx a = val(d.drive_series, idx, u);
+        const double cr = d.drive_scale * a.x, ci = d.drive_scale * a.y;
+        return (cr * cr + ci * ci > 1e-300) ? atan2(ci, cr) : 0.0;
+      };
+      const double th_cur = closing ? 0.0 : theta(idx_c, u_c);
+      // the rotation before this stage's D: the previous stage of the sub-step, the last one of the previous sub-step,
+      // or none (the run starts in the laboratory frame)
+      const double th_prev = (st > 0) ? theta(R.idx[s], us_d[0]) : (s > 0 ? theta(idx_d[1], us_d[1]) : 0.0);
+      dl += th_cur - th_prev;
     }
     if (R.tan_form == 1) gr = gi / C;  // (real drives: gr was 0; the host keeps |beta c| <= 1, so C >= 0.54)
     else if (R.tan_form == 2) { gr /= C; gi /= C; }  // complex drives on k_split_reg<.., CPLX>: both parts over C

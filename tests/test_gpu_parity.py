@@ -201,7 +201,7 @@ def test_persistent_kernel_matches_generic_and_oracle(n):
     outs = {}
     for force in (False, True):
         eng = _engine(probs)
-        eng.set_path(force)
+        eng.set_path(force, no_split14=True)  # the persistent kernel itself (round 4: 12 - 13 atoms take k_split_reg by default)
         st = eng.new_state()
         snaps = eng.solve(st, times).cpu().numpy()
         assert np.array_equal(snaps[-1], st.cpu().numpy())
@@ -442,5 +442,6 @@ def test_single_launch_plan_with_different_problems_per_batch_entry(mode, n):
     assert np.max(np.abs(outs["single"] - outs["multi"])) < 1e-13
     if mode == "sesolve" and n <= 13:
         eng = _engine(probs, mode=mode)
+        eng.set_path(False, no_split14=True)  # the persistent kernel (round 4: the default here is k_split_reg)
         assert np.max(np.abs(eng.solve(eng.new_state(), times).cpu().numpy() - outs["single"])) < 1e-12
     assert np.max(np.abs(outs["single"][-1][0] - outs["single"][-1][1])) > 1e-3  # really different problems

@@ -545,6 +545,28 @@ def test_14_atom_batches_choose_their_kernel_from_the_schedule_of_the_call():
     assert np.max(np.abs(res["auto"][0] - res["k_ket"][0])) < 2e-8
 
 
+def test_modulated_local_complex_drives_take_the_split_kernel_by_default():
+    """Per-atom complex drives with time-dependent phases (local addressing; nothing in the waveforms to merge): since
+    round 4 the phase of a drive is carried by the D factors (SplitRun.gauge: the rotation by c = |c| e^{i theta} is
+    Z R(|c|) Z^+ with a diagonal Z, exact), the real tan-form kernel runs them, and the 6-stage composition with one-knot
+    sub-steps is the default at 12 - 14 atoms for calls without an evaluation time at every knot.  Against the
+    polynomial kernels (complex arithmetic, k_traj / gauged k_ket) on the same batch."""
+    from helpers import local_problem
+
+    for n in (12, 13):
+        probs = [local_problem(n, seed=s, duration=201) for s in range(4)]
+        res = {}
+        for name, kw in (("auto", {}), ("poly", {"no_split14": True})):
+            with _engine(probs) as eng:
+                eng.set_path(False, **kw)
+                st = eng.new_state()
+                eng.evolve(st, 0.0, 0.2)
+                res[name] = (st.cpu().numpy(), eng.stats())
+        assert res["auto"][1]["reserved"][0] > 0 and res["poly"][1]["reserved"][0] == 0  # controller booked / not
+        assert res["auto"][1]["n_applications"] < 0.7 * res["poly"][1]["n_applications"]
+        assert np.max(np.abs(res["auto"][0] - res["poly"][0])) < 2e-8
+
+
 # ---- k_split_reg<.., CPLX>: complex drives (a pulse with a phase) on the register-resident split-operator kernel ----
 
 @pytest.mark.parametrize("n_cols", [6, 7])
