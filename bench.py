@@ -751,25 +751,30 @@ def main() -> None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import local_problem
 
-        eng = Engine.from_problems([local_problem(12, seed=s, duration=401) for s in range(8)] * 32, mode="sesolve")
-        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, 0.4, 2, 1, None, torch)
-        also.append({"workload": "256 x 12-atom sequences with per-atom complex drives (MODEL 0), 400 ns",
-                     "value": 256 * 0.4 / sec, "unit": "sim-us/s", "ms_per_batch": sec * 1e3,
-                     "applications_per_sequence": stats["n_applications"],
-                     "kernel": "k_traj<12,1024,0> (persistent, per-atom complex coefficients)"})
-        eng.close()
-        # 14 atoms with per-atom complex drives: gauged away inside the register-resident kernel (KET_GAUGE);
-        # round 2 sent these to the multi-launch kernels (250 sim-us/s on a round-1 figure)
-        eng = Engine.from_problems([local_problem(14, seed=s, duration=401) for s in range(8)] * 32, mode="sesolve")
-        sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, 0.4, 2, 1, None, torch)
-        also.append({"workload": "256 x 14-atom sequences with per-atom complex, time-dependent drives, 400 ns",
-                     "value": 256 * 0.4 / sec, "unit": "sim-us/s", "ms_per_batch": sec * 1e3,
-                     "stages_per_sequence": stats["n_applications"], "launches": stats["n_launches"],
-                     "kernel": "k_ket<14, KET_GAUGE> (complex drives gauged away: 4-point Gauss moments of |c| and "
-                               "d/dt arg c per step and atom)",
-                     "roofline": roofline_valu(2.0**14, 256, stats["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kms, kl,
-                                               "k_ket<14, KET_GAUGE>")})
-        eng.close()
+        # round 4: the phase of a drive rides on the D factors of the split-operator stages (SplitRun.gauge), so these run
+        # on the real tan-form kernel by default; the polynomial kernels of rounds 1 - 3 beside it (set_path(no_split14))
+        for n_c, poly_name, poly_flops in ((12, "k_traj<12,1024,0> (persistent, per-atom complex coefficients)", None),
+                                           (14, "k_ket<14, KET_GAUGE> (complex drives gauged away: 4-point Gauss moments of |c| "
+                                                "and d/dt arg c per step and atom)", KKET_FLOPS_PER_AMP_STAGE)):
+            eng = Engine.from_problems([local_problem(n_c, seed=s, duration=401) for s in range(8)] * 32, mode="sesolve")
+            sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, 0.4, 2, 1, None, torch)
+            leg = {"workload": f"256 x {n_c}-atom sequences with per-atom complex, time-dependent drives (local addressing), 400 ns",
+                   "value": 256 * 0.4 / sec, "unit": "sim-us/s", "ms_per_batch": sec * 1e3,
+                   "stages_per_sequence": stats["n_applications"], "launches": stats["n_launches"],
+                   "kernel": (KSPLITREG_NAME.replace("14, 5", f"{n_c}, 5") + "; the drive phases carried by the D factors, "
+                              "4th-order 6-stage composition with one-knot sub-steps (modulated drives: nothing to merge)")
+                             if ran_split_reg(stats) else poly_name}
+            if ran_split_reg(stats):
+                leg["roofline"] = split_reg_roofline(n_c, 256, stats, kms, kl, None)
+            eng.set_path(False, no_split14=True)
+            sec, stats, kms, kl, _ = timed_run(eng, eng.new_state, 0.0, 0.4, 2, 1, None, torch)
+            leg["polynomial_kernel"] = {"value": 256 * 0.4 / sec, "unit": "sim-us/s", "stages_per_sequence": stats["n_applications"],
+                                        "launches": stats["n_launches"], "kernel": poly_name}
+            if poly_flops:
+                leg["polynomial_kernel"]["roofline"] = roofline_valu(2.0**n_c, 256, stats["n_applications"], poly_flops, kms, kl,
+                                                                     "k_ket<14, KET_GAUGE>")
+            also.append(leg)
+            eng.close()
         # quantum-jump trajectories (what Solver.DEFAULT runs for dissipation + stochastic noise)
         mc_prob = chain_problem(12)
         mc_prob["collapse_ops"] = [(float(np.sqrt(2 * 0.05)), "sigma_rr"), (float(np.sqrt(0.02)), "sigma_gr")]
