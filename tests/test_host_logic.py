@@ -1641,3 +1641,39 @@ def test_bench_flop_constants_match_the_compiled_kernels():
                          capture_output=True, text=True, timeout=900, env=dict(os.environ, RYD_ISA_TEXT=asm)).stdout
     per_half = [float(l.strip("|").split("|")[-1]) for l in out.splitlines() if re.match(r"^\| \d+\.\.\d+ \|", l)]
     assert per_half and abs(2 * sum(per_half) / len(per_half) - ns["KKET_FLOPS_PER_AMP_STAGE"]) < 0.02 * ns["KKET_FLOPS_PER_AMP_STAGE"]
+
+
+def test_phase_gauge_of_the_split_operator_stages_is_an_identity():
+    """SplitRun.gauge (k_split.hpp: k_split_coefs): a rotation by a complex drive c = |c| e^{i theta} is Z R(|c|) Z^+ with
+    the diagonal Z = exp(-i theta n), and Z commutes with the D factors - so the composition D R(c_S) D ... R(c_1) D equals
+    the one with real rotations R(|c_j|) whose D factors carry theta_j - theta_{j-1} on top of the detuning integral
+    (theta_0 = 0, the closing D returns to theta = 0).  The kernel's conventions restated in NumPy for one atom: index 0 =
+    bit clear (n = 1), index 1 = bit set (n = 0); y0 = C a0 + g' a1, y1 = C a1 + g a0 with g = -i S c, g' = (-Re g, Im g);
+    D = diag(exp(i Delta), 1).  A drive that vanishes at a stage (theta undefined -> 0) is included."""
+    rng = np.random.default_rng(0)
+    S = 10
+    beta = rng.normal(size=S) * 0.3
+    c = rng.normal(size=S) + 1j * rng.normal(size=S)
+    c[3] = 0.0
+    delta = rng.normal(size=S + 1)
+
+    def rot(cj, b):
+        m = abs(cj)
+        C, Sn = np.cos(b * m), (np.sin(b * m) / m if m > 1e-300 else b)
+        g = -1j * Sn * cj
+        return np.array([[C, complex(-g.real, g.imag)], [g, C]])
+
+    def diag(d):
+        return np.diag([np.exp(1j * d), 1.0])
+
+    U = np.eye(2, dtype=complex)
+    for j in range(S):
+        U = rot(c[j], beta[j]) @ diag(delta[j]) @ U
+    U = diag(delta[S]) @ U
+    theta = [np.angle(x) if abs(x) > 1e-300 else 0.0 for x in c]
+    V, prev = np.eye(2, dtype=complex), 0.0
+    for j in range(S):
+        V = rot(abs(c[j]), beta[j]) @ diag(delta[j] + theta[j] - prev) @ V
+        prev = theta[j]
+    V = diag(delta[S] - prev) @ V
+    assert np.max(np.abs(U - V)) < 1e-14
