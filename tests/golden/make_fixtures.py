@@ -1197,6 +1197,9 @@ def sketch_density_matrices(tight, n):
     the product of its row), trace and purity; up to 8 atoms the full upper triangle too."""
     D = 2**n
     rows, V = sketch_rows(D), sketch_probes(D)
+    keep = 8 if n >= 12 else 0  # (12 atoms: every 4th of the 32 drawn rows - 32 rows x 6 times would be 12.6 MB)
+    if keep:
+        rows = rows[np.round(np.linspace(0, len(rows) - 1, keep)).astype(int)]
     out = {
         "oracle_rows": rows,
         "oracle_rows_tight": np.stack([t[rows] for t in tight]),
@@ -1204,12 +1207,25 @@ def sketch_density_matrices(tight, n):
         "oracle_probe_products_tight": np.stack([t @ V for t in tight]),
         "oracle_purity_tight": np.array([np.vdot(t, t).real for t in tight]),
         "oracle_hermiticity_defect": max(float(np.max(np.abs(t - t.conj().T))) for t in tight),
-        "sketch": {"rows": SKETCH_ROWS, "probes": SKETCH_PROBES, "seed": SKETCH_SEED},
+        "sketch": {"rows": SKETCH_ROWS, "probes": SKETCH_PROBES, "seed": SKETCH_SEED, **({"keep": keep} if keep else {})},
     }
     if n <= 8:
         iu = np.triu_indices(D)
         out["oracle_states_tight_triu"] = np.stack([t[iu] for t in tight])
     return out
+
+
+def thin_sketch(name, keep=8):
+    """Rewrite a sketch fixture that was generated with all 32 rows (cfg3_tri12_dephasing.npz: 7.8 h of CPU before the
+    `keep` rule of sketch_density_matrices existed) with the rows that rule keeps - the file a fresh run would write."""
+    path = os.path.join(HERE, name)
+    problem, extra = P.load_problem(path)
+    rows = np.asarray(extra["oracle_rows"])
+    sel = np.round(np.linspace(0, len(rows) - 1, keep)).astype(int)
+    extra["oracle_rows"] = rows[sel]
+    extra["oracle_rows_tight"] = np.asarray(extra["oracle_rows_tight"])[:, sel]
+    extra["sketch"] = dict(extra["sketch"], keep=keep)
+    P.save_problem(path, problem, **extra)
 
 
 def gen_cfg4(n=12, ntraj=1024, keep=3):
@@ -1477,6 +1493,8 @@ if __name__ == "__main__":
         gen_cfg3_tight(2, 5)
     if "cfg3_12" in which:
         gen_cfg3_tight(2, 6)
+    if "thin_cfg3_12" in which:
+        thin_sketch("cfg3_tri12_dephasing.npz")
     if "cfg3_12_to1300" in which:
         gen_cfg3_tight(2, 6, t_stop=1.3)
     if "rect16" in which:

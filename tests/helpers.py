@@ -96,6 +96,8 @@ def sketch_errors(rho, extra, k):
     D = rho.shape[0]
     sk = extra["sketch"]
     rows = sketch_rows(D, sk["rows"], sk["seed"])
+    if sk.get("keep"):  # (12 atoms: every 4th of the 32 drawn rows - a 2^12-entry row is 64 KiB per stored time)
+        rows = rows[np.round(np.linspace(0, len(rows) - 1, int(sk["keep"]))).astype(int)]
     assert np.array_equal(rows, np.asarray(extra["oracle_rows"]))
     V = sketch_probes(D, sk["probes"], sk["seed"])
     return {
