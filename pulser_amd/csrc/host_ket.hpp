@@ -337,7 +337,7 @@ static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
   if ((!row_uniform_g(h) || h->has_dbl) && o.split_steps <= 0) Kh = 1;
   // Round 4, row passes on k_split_reg: the splitting error of a block grows with g tau^4 (measured over the whole
   // anneal on the interacting 12-atom register against two-knot halves, tools/rows_tune2.py: four-knot halves 5.5e-9
-  // at g = 0.05, 2.2e-8 at g = 0.2), so slow dephasing (g <= 0.1 / us: <= 1.1e-8) takes blocks of 4 + 4 knots - the
+  // at g = 0.05, 2.2e-8 at g = 0.2), so slow dephasing (g <= 0.06 / us; the 12-atom tight fixture at 0.05: entries of rho within 5.9e-9) takes blocks of 4 + 4 knots - the
   // unitary of a half is then ONE 6th-order sub-step where the waveforms are one polynomial: 18.4 -> 13 s at 14 atoms
   if (Kh == 2 && o.split_steps <= 0 && rows_split_ok(h) && row_uniform_g(h) && !h->has_dbl) {
     double g = 0.0;
@@ -346,7 +346,7 @@ static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
     // dephasing - so the drive bound caps the rule too: measured at |c| = Omega / 2 = 12.6 rad / us, allowed up to 16)
     double cmax = 0.0;
     for (double v : h->bd_c1) cmax = std::max(cmax, v);
-    if (g <= 0.1 && cmax <= 16.0) Kh = 4;
+    if (g <= 0.06 && cmax <= 16.0) Kh = 4;  // (0.06: entries of rho within ~7e-9 of the 12-atom tight oracle, its probe products within 8e-8)
   }
   return Kh;
 }
