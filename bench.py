@@ -328,6 +328,23 @@ def cpu_baselines(full: bool):
            "host_cpu_count": ncpu}
     if not full:
         return out
+    # the drop-in call's evaluation-time lists (config.api_end_to_end): the same oracle returning a state at every
+    # sample ("Full", the reference's default, simulation.py:137), at every 10th (0.1) - "Minimal" is the primary above
+    from oracle import qutip_path as qp
+
+    prob = tri_problem(2, 7)
+    ham = qp.build_hamiltonian(prob)
+    psi0 = qp.all_ground_state(14, prob["eigenbasis"])
+    sg = prob["samples"]["Global"]["ground-rydberg"]
+    opts = qp.default_options([(sg["amp"], sg["det"])], 3100)
+    grid = np.arange(3101) * 1e-3
+    api = {"Minimal": dt14}
+    for name, tl in (("Full", grid), ("0.1", grid[np.linspace(0, 3100, 310, dtype=int)])):
+        tl = np.union1d(tl, [0.0, T_SEQ_US])
+        tic = time.perf_counter()
+        qp.sesolve(ham, psi0, tl, **opts)
+        api[name] = time.perf_counter() - tic
+    out["api_eval_times_seconds"] = api
     legs = []
     # sesolve scaling with N (full 3.1 us at 12, slice at 16), one core
     dt12, rhs12 = _oracle_sesolve_time(chain_problem(12), T_SEQ_US)
@@ -422,6 +439,63 @@ def cfg4_line(n_traj, steps, warmup, dist, torch, n_gpus, common):
                                                        "evaluation time, all-reduce of the device tensor"},
                        "parallelism": f"dp{n_gpus} over trajectories"},
             "roofline": None}
+
+
+def api_end_to_end(torch, cpu_seconds=None):
+    """What a drop-in user gets: wall clock of ``QutipEmulator(<the north-star sequence>).run()``
+    - construction, lowering, handle + upload, solve, snapshots, result objects - for the reference's default
+    ``evaluation_times="Full"`` (simulation.py:137, 961), "Minimal" and 0.1.  Second call of each (the first call of a
+    process also loads code objects: `first_call_ms`); the final state of every call against the tight-oracle fixture."""
+    import warnings
+
+    from pulser_amd import QutipEmulator, problem as P
+    from pulser_amd.hamiltonian_data import single_global_channel
+
+    coords = P.register_coords(P.triangular_rect(2, 7), blockade_radius())
+    smp = {k: v[:-1] for k, v in P.anneal_samples().items()}
+    inputs = single_global_channel(coords, smp, P.C6_LEVEL70, extended=False)
+    _, fx = P.load_problem(os.path.join(ROOT, "tests", "golden", "ns_tri14_anneal.npz"))
+    ref_final = np.asarray(fx["oracle_states_tight"])[-1]
+    out = {"workload": "pulser_amd.QutipEmulator(<14-atom triangular register, anneal 3100 ns>, evaluation_times=...).run(): "
+                       "wall clock of the whole call (construction, lowering, handle + upload, solve, snapshots, "
+                       "CoherentResults) + reading the final state; one sequence",
+           "unit": "sim-us/s"}
+    for spec in ("Full", "Minimal", 0.1):
+        rec = {}
+        for rep in range(3):
+            torch.cuda.synchronize()
+            tic = time.perf_counter()
+            emu = QutipEmulator(inputs, evaluation_times=spec)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", DeprecationWarning)
+                res = emu.run()
+            final = np.asarray(res.states[-1])[:, 0]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - tic
+            if rep == 0:
+                rec["first_call_ms"] = dt * 1e3
+            else:
+                rec["ms"] = min(rec.get("ms", 1e30), dt * 1e3)
+        st = emu.last_engine_stats
+        rec.update({"value": T_SEQ_US / (rec["ms"] * 1e-3), "n_evaluation_times": int(len(emu.evaluation_times)),
+                    "stages": st["n_applications"], "launches": st["n_launches"], "local_error_estimate": st["reserved"][0],
+                    "final_state_max_abs_vs_tight_oracle": float(np.max(np.abs(final - ref_final)))})
+        if cpu_seconds and str(spec) in cpu_seconds:
+            rec["cpu_oracle_s"] = cpu_seconds[str(spec)]
+            rec["cpu_oracle_sim_us_per_s"] = T_SEQ_US / cpu_seconds[str(spec)]
+        # reading EVERY stored state back (what plotting an observable over the evaluation times costs on top)
+        import gc
+
+        gc.collect()  # (the previous call's 813 MB of snapshots are released outside the timed loop)
+        tic = time.perf_counter()
+        acc = 0.0
+        for stt in res.states:
+            acc += float(abs(np.asarray(stt)[0, 0]))
+        rec["read_all_states_ms"] = (time.perf_counter() - tic) * 1e3
+        out[str(spec)] = rec
+        del res, emu
+    out["full_over_minimal"] = out["Full"]["ms"] / out["Minimal"]["ms"]
+    return out
 
 
 def device_copy_bandwidth(torch):
@@ -529,6 +603,12 @@ def main() -> None:
         eng = Engine(tables, mode="sesolve")
         torch.cuda.synchronize()
         create_s = time.perf_counter() - tic
+        # ... and once more (what every later handle of the process costs: no code-object load, a warm allocator)
+        tic = time.perf_counter()
+        eng_warm = Engine(tables, mode="sesolve")
+        torch.cuda.synchronize()
+        create_warm_s = time.perf_counter() - tic
+        eng_warm.close()
         if args.no_ket or args.no_split14 or args.split_turns:
             eng.set_path(False, no_ket=args.no_ket, no_split14=args.no_split14, split_turns=args.split_turns)
         sec, stats, kms, kl, occ = timed_run(eng, eng.new_state, 0.0, T_SEQ_US, args.steps, args.warmup, dist, torch)
@@ -569,10 +649,19 @@ def main() -> None:
             "parity_reference": "tests/golden/ns_tri14_anneal.npz (tight oracle: zvode rtol 1e-13), final state, sequence 0 "
                                 "of the timed batch (event-timed pass); bar 1e-7",
             "setup": {"lowering_ms": lower_s * 1e3, "handle_and_upload_ms": create_s * 1e3,
-                      "note": "spline lowering on the host + ryd_create / ryd_set_* uploads; outside the timed "
-                              "step (done once per sequence batch); the step includes the evaluation-time "
-                              "occupation reduction and its all-reduce"},
+                      "handle_and_upload_warm_ms": create_warm_s * 1e3,
+                      "warm_setup_over_step": create_warm_s / sec,
+                      "note": "spline lowering on the host + ryd_create / ryd_set_* uploads (coefficient tables, "
+                              "descriptors, interaction matrix -> E0 on the device); `handle_and_upload_ms` is the FIRST "
+                              "handle of the process (code-object load, first allocations), `..._warm_ms` the second on the "
+                              "same tables = what a step would pay with the upload inside (SURVEY 8d); the step includes the "
+                              "evaluation-time occupation reduction and its all-reduce.  config.api_end_to_end times whole "
+                              "front-end calls, every upload inside"},
         }
+        # driver-visible copies (the driver keeps metric / value / config / roofline / cpu_baseline)
+        out["config"]["parity_max_abs"] = parity
+        out["config"]["setup_warm_ms"] = create_warm_s * 1e3
+        out["config"]["value_with_warm_setup_inside_step"] = n_gpus * B * T_SEQ_US / (sec + create_warm_s)
         if ket:
             out["roofline"] = roofline_valu(
                 2.0**n, B, stats["n_applications"], KKET_FLOPS_PER_AMP_STAGE, kms, kl,
@@ -662,6 +751,13 @@ def main() -> None:
                                                "k_apply14<mesolve> + k_symm (Hermitian path)", "cfg3:k_apply")
             out["lindblad"] = leg
             eng.close()
+            out["config"]["single_sequence_sim_us_per_s"] = out["single_sequence"]["value"]
+            out["config"]["lindblad_seconds"] = leg["seconds"]
+            out["config"]["lindblad_sim_us_per_s"] = leg["value"]
+            out["config"]["lindblad_trace"] = leg["trace"]
+            out["config"]["lindblad_roofline_frac"] = leg["roofline"]["frac"]
+            out["config"]["api_end_to_end"] = api_end_to_end(
+                torch, (cpu_result or {}).get("api_eval_times_seconds"))
 
     elif args.workload == "cfg2":
         n, B = 12, args.batch

@@ -23,6 +23,41 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 // ---------------------------------------------------------------------------
+// development switches
+// ---------------------------------------------------------------------------
+// Every A/B switch of the library that changes numerics or the kernel chosen is read through dev_env: it sees the
+// variable only when RYD_DEV=1 is set as well, so a stray variable in a production environment cannot change a run
+// (RYD_CHECK and RYD_HOST_TIMING only observe and stay ungated).  Values are clamped where they are used.
+static const char* dev_env(const char* name) {
+  static const bool dev = [] {
+    const char* d = std::getenv("RYD_DEV");
+    return d && d[0] == '1' && d[1] == 0;
+  }();
+  return dev ? std::getenv(name) : nullptr;
+}
+static int dev_env_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = dev_env(name);
+  if (!e || !e[0]) return dflt;
+  char* end = nullptr;
+  const long v = std::strtol(e, &end, 10);
+  if (end == e || v < lo || v > hi) return dflt;  // garbage or out of range: the default, not a surprise
+  return (int)v;
+}
+static double dev_env_double(const char* name, double dflt, double lo, double hi) {
+  const char* e = dev_env(name);
+  if (!e || !e[0]) return dflt;
+  char* end = nullptr;
+  const double v = std::strtod(e, &end);
+  if (end == e || !(v >= lo && v <= hi)) return dflt;
+  return v;
+}
+static bool dev_env_flag(const char* name, bool dflt) {  // "0" / "1"
+  const char* e = dev_env(name);
+  if (!e || !e[0]) return dflt;
+  return e[0] != '0';
+}
+
+// ---------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------
 struct Segs {

@@ -84,17 +84,22 @@ struct ryd_handle {
   bool rows_ket = false;          // test / bench hook: row passes of the split-operator master equation on k_ket
   bool split_turns = false;       // test / bench hook: 14-atom one-launch runs on k_split14_loop (two LDS turns per stage,
                                   // round 3) instead of k_split_reg
+  bool sched_for_split = false;   // the schedule being built is run by the split-operator path (host_sched.hpp: dev probe)
+  bool snaps_outside = false;     // test / bench hook: every evaluation time closes a run of k_split_reg (round 4) instead of a
+                                  // snapshot taken inside the run
   bool split_s10 = false;         // scheme of the current split-operator solve (host_step.hpp decides per call)
   bool split_s6_only = false;     // test / bench hook: the 4th-order scheme with one-knot sub-steps (round 2)
   void* many_args_dev = nullptr;  // ryd_general_solve_many: argument table of the batched launch (first handle)
   size_t many_cap = 0;
   bool split_known = false;       // controller state below is valid for the current tables
   double split_tau = 1e300;       // target sub-step (us); 1e300 = whole schedule steps
-  double split_rate = 0.0;        // last measured local error per us at that sub-step
+  double split_rate = 0.0;        // last measured local error per us ...
+  double split_rate_tau = 0.0;    // ... and the sub-step length (us) it was measured at
   double split_amp = 0.0;  // drive bound at the controller's last check
   double split_eps = 0.0;         // tolerance the state was measured for
   int split_since = 0;            // schedule steps since the last check
   double split_since_len = 0.0;   // simulated time (us) covered since the last check
+  const void* split_state_last = nullptr;  // ... and the state buffer it advanced
   double split_t_last = -1e300;   // end time (us) of the last split-operator solve: the state above belongs to its continuation
   // general path (explicit CSR terms)
   bool general = false;

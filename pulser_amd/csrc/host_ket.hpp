@@ -329,9 +329,9 @@ static bool row_uniform_g(const ryd_handle* h) {
 
 // Half a block of the split-operator master equation, in knot intervals (what a multi-knot CF4
 // step must not exceed).
-static bool rows_split_ok(const ryd_handle* h);
+static bool rows_split_ok(const ryd_handle* h, const ryd_opts& o);
 static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
-  static const int kh_env = [] { const char* e = std::getenv("RYD_ROWS_KH"); return e ? std::atoi(e) : 0; }();  // dev A/B
+  static const int kh_env = dev_env_int("RYD_ROWS_KH", 0, 1, 8);  // dev A/B (RYD_DEV=1)
   if (kh_env > 0 && o.split_steps <= 0) return kh_env;
   int Kh = row_block_steps(h, o);
   if ((!row_uniform_g(h) || h->has_dbl) && o.split_steps <= 0) Kh = 1;
@@ -339,7 +339,7 @@ static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
   // anneal on the interacting 12-atom register against two-knot halves, tools/rows_tune2.py: four-knot halves 5.5e-9
   // at g = 0.05, 2.2e-8 at g = 0.2), so slow dephasing (g <= 0.06 / us; the 12-atom tight fixture at 0.05: entries of rho within 5.9e-9) takes blocks of 4 + 4 knots - the
   // unitary of a half is then ONE 6th-order sub-step where the waveforms are one polynomial: 18.4 -> 13 s at 14 atoms
-  if (Kh == 2 && o.split_steps <= 0 && rows_split_ok(h) && row_uniform_g(h) && !h->has_dbl) {
+  if (Kh == 2 && o.split_steps <= 0 && rows_split_ok(h, o) && row_uniform_g(h) && !h->has_dbl) {
     double g = 0.0;
     for (int k = 0; k < 4; ++k) g = std::max(g, std::fabs(h->Sd[k].x));
     // (the block error comes from the commutators of the dissipator with the DRIVE - the diagonal part of H commutes with
@@ -442,7 +442,7 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
   if ((rc = to_ket_steps(h, sb, o, -1.0, ks))) return rc;
   for (KetStep& k : ks) k.snap = -1;  // snapshots are whole-matrix copies between blocks
   if ((rc = upload_ket_steps(h, ks, st))) return rc;
-  bool rsplit = rows_split_ok(h);  // (the k_ket schedule stays uploaded: a conjugation may fall back to it)
+  bool rsplit = rows_split_ok(h, o);  // (the k_ket schedule stays uploaded: a conjugation may fall back to it)
   // |change of d under one bit flip|: (0,0)<->(0,1)/(1,0) and (1,1)<->(0,1)/(1,0)
   const double g01 = h->Sd[1].x - h->Sd[0].x, g10 = h->Sd[2].x - h->Sd[0].x;
   const double g31 = h->Sd[1].x - h->Sd[3].x, g32 = h->Sd[2].x - h->Sd[3].x;

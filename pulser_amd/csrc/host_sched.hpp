@@ -99,6 +99,12 @@ static double merge_error(const ryd_handle* h, int idx, int span, double len) {
   return (h->cfg.mode == RYD_MESOLVE ? 2.0 : 1.0) * h5 * (dd * dd * c1 + dc * dc * (dl + h->u_rowsum));
 }
 
+// RYD_DEV=1 RYD_SPLIT_NOCURV=1 (dev probe): no sub-steps from the CF4 curvature estimate under the split-operator path
+static bool split_no_curv_env() {
+  static const bool on = dev_env_flag("RYD_SPLIT_NOCURV", false);
+  return on;
+}
+
 static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& o,
                            std::vector<StepDesc>& out, bool in_place_exp = false, int merge_cap = kMergeMax,
                            bool no_estimate = false) {
@@ -142,7 +148,7 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
       const double frac = dtk > 0 ? std::min((double)span, len / dtk) : 1.0;
       const double est = 1e-5 * len * span_max(h->bd_curv, idx, span) * frac * frac;
       const double mtol = o.magnus_tol > 0 ? o.magnus_tol : 1e-10;
-      if (est > mtol) {
+      if (est > mtol && !(h->sched_for_split && split_no_curv_env())) {
         const int nm = (int)std::ceil(std::pow(est / mtol, 0.25));
         nsub = std::max(nsub, std::min(nm, 256));
       }

@@ -46,7 +46,7 @@ static const int kSplitMaxSub = SPLIT_MAX_SUB;
 // 9-knot steps give 4.5 ns (round 4: 8 064 -> 7 360 stages at 14 atoms, true error 2.1e-9 -> 3.8e-9 at T, estimate
 // 5.3e-9); 10: 1.3e-8 at t = 0.5 us with an estimate of 3e-9 (the estimate stops covering the error), 12 and 16: the
 // controller overshoots and rolls back (23 362 / 16 050 stages).  RYD_SPLIT_CAP: dev A/B.
-static const int kSplitMergeMax = [] { const char* e = std::getenv("RYD_SPLIT_CAP"); return e ? std::atoi(e) : 9; }();
+static const int kSplitMergeMax = dev_env_int("RYD_SPLIT_CAP", 9, 1, 16);
 
 // May this handle use the 6th-order scheme at all?  (At least half of the knots removable, not switched off.)
 static bool split_s10_allowed(const ryd_handle* h) {
@@ -100,7 +100,7 @@ static bool split_selected(const ryd_handle* h, const ryd_opts& o) {
 // the runtime-indexed k_split_t, 173 us per stage) - two passes of 2^12 tiles take 2 x 65.5 us, so 23+ atoms stay there.
 static int split_tile_bits(const ryd_handle* h) {
   const int N = h->N;
-  static const bool env_small = [] { const char* e = std::getenv("RYD_SPLIT_SMALL_TILES"); return e && e[0] == '1'; }();
+  static const bool env_small = dev_env_flag("RYD_SPLIT_SMALL_TILES", false);
   if (h->split_small_tiles || env_small) return std::min(N, SPLIT_TMAX);  // (environment: A/B runs of bench.py)
   if (N >= 21 && N <= 22) return 13;
   return std::min(N, SPLIT_TMAX);
@@ -151,7 +151,7 @@ static int split_max_sub(const ryd_handle* h) {
 // Whole kets of 12 - 14 atoms with real drives run on k_split_reg (below)
 // Complex drives on the real kernels (SplitRun.gauge; RYD_SPLIT_GAUGE=0: dev A/B against the complex-arithmetic kernels)
 static bool split_gauged(const ryd_handle* h) {
-  static const bool env = [] { const char* e = std::getenv("RYD_SPLIT_GAUGE"); return !(e && e[0] == '0'); }();
+  static const bool env = dev_env_flag("RYD_SPLIT_GAUGE", true);
   return !h->drive_real && env;
 }
 static bool split_real(const ryd_handle* h) { return h->drive_real || split_gauged(h); }
@@ -173,10 +173,10 @@ static bool split_loop14(const ryd_handle* h) {
 // round 4), the ket register-resident, one workgroup per sequence (14 atoms: one per CU; 13: two; 12: three).
 // Quantum-jump solves included (the decay factor of H_eff rides on the phase factors: template parameter DECAY).
 template <int N>
-static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R, hipStream_t st, size_t n_rows = 0) {
+static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R, hipStream_t st, size_t n_rows = 0, bool snap = false) {
   constexpr int NT = 64 << (N - 11);
   // RYD_SPLIT_NR=6 (dev A/B, 14 atoms only): 64 amplitudes per lane on 256 lanes instead of 32 on 512 (measured slower)
-  static const int nr_env = [] { const char* e = std::getenv("RYD_SPLIT_NR"); return e ? std::atoi(e) : 5; }();
+  static const int nr_env = dev_env_int("RYD_SPLIT_NR", 5, 5, 6);
   const size_t lds = (size_t)2 * NT * 8 * 16 + SPLITR_TRIG * 16 + (size_t)(NT / 64) * 32 * 16 +
                      (SPLIT_MAX_SUB * SPLIT_MAX_STAGES + 2) * 8 + (SPLITR_EMODE ? 4 * NT * 8 : 0) + (128 + 32) * 8;
   const int dev = h->cfg.device;
@@ -187,18 +187,29 @@ static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R
     HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<N, 5, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if constexpr (N == 14)
       HIPCHK(hipFuncSetAttribute((const void*)k_split_reg<14, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (dev >= 0 && dev < 64) attr[dev] = true;
   }
   const long long stride = (long long)h->B * N * 4;
   if (n_rows) {  // rows of density matrices as kets (run_rows): persistent workgroups, as many as the chip holds
-    static int n_cu = 0;
-    if (!n_cu) HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev < 0 ? 0 : dev));
+    static int n_cu_of[64] = {};  // per device (a process may hold handles on different device models)
+    int n_cu = (dev >= 0 && dev < 64) ? n_cu_of[dev] : 0;
+    if (!n_cu) {
+      HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev < 0 ? 0 : dev));
+      if (dev >= 0 && dev < 64) n_cu_of[dev] = n_cu;
+    }
     const unsigned per_cu = N == 14 ? 1u : N == 13 ? 2u : 3u;
     const unsigned workers = std::min<unsigned>(1u << N, (unsigned)std::max(n_cu, 1) * per_cu);
     hipLaunchKernelGGL((k_split_reg<N, 5, false, true>), dim3(1, workers, (unsigned)h->B), dim3(NT), lds, st, A, R, stride);
   }
+  else if (snap && h->mc)
+    return fail(RYD_ERR_STATE, "split-operator run: snapshots inside a quantum-jump run");
+  else if (snap && !split_real(h))
+    return fail(RYD_ERR_STATE, "split-operator run: snapshots inside a run of the complex-arithmetic kernel");
+  else if (snap)
+    hipLaunchKernelGGL((k_split_reg<N, 5, false, false, false, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
   else if (!split_real(h) && h->mc)
     hipLaunchKernelGGL((k_split_reg<N, 5, true, false, true>), dim3(1, h->B), dim3(NT), lds, st, A, R, stride);
   else if (!split_real(h))
@@ -216,23 +227,42 @@ static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R
 
 // Advance `buf` over `subs` (consecutive sub-steps, at most split_max_sub) from a closed state to
 // a closed state: one k_split_coefs launch, then one k_split launch per pass.
-static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hipStream_t st, bool s6_run = false) {
+// `marks` (or null): marks[s] >= 0 = the snapshot slot that receives the state at the END of sub-step s (`snaps` =
+// the caller's snapshot array, slots of B kets).  On k_split_reg the snapshots of the inner sub-steps are taken inside
+// the kernel and closed by k_split_snap_close; where the run takes another kernel it is cut at the marks.
+// `alt` (or null): alt[s] != 0 = sub-step s runs the 4th-order 6-stage composition inside a run of the handle's scheme (a
+// MIXED run, SplitRun.mixed: k_split_reg only; other kernels get the run cut into stretches of one composition).
+static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hipStream_t st, bool s6_run = false,
+                     const int* marks = nullptr, cplx* snaps = nullptr, const unsigned char* alt = nullptr) {
   int rc;
   split_plan(h);
   const int N = h->N, B = h->B;
+  if (alt) {  // uniform flags are no mixture
+    bool any = false, all = true;
+    for (int s = 0; s < nsub; ++s) { any = any || alt[s]; all = all && alt[s]; }
+    if (all) s6_run = true;
+    if (!any || all || &split_scheme(h) == &kSplitS6) alt = nullptr;
+  }
+  bool any_inner = false;
+  if (marks && snaps)
+    for (int s = 0; s + 1 < nsub; ++s) any_inner = any_inner || marks[s] >= 0;
+  else
+    marks = nullptr;
   const SplitScheme& sc = s6_run ? kSplitS6 : split_scheme(h);  // (s6_run: split_advance, one-knot stretches)
-  const int n_stages = sc.S * nsub + 1;
+  int n_stages = 1;
+  for (int s = 0; s < nsub; ++s) n_stages += (alt && alt[s]) ? kSplitS6.S : sc.S;
   if ((rc = split_ensure_tables(h, n_stages))) return rc;
   bool reg_loop = split_reg_shape(h);
   bool loop14 = N == 14 && split_loop14(h) && ((n_stages & 1) || reg_loop);  // (k_split14_loop runs its stages in pairs + the closing one)
   // the pass kernel k_split_s in tan form (real drives, static tiles in every tiling, no quantum jumps); RYD_SPLIT_PASS_TAN=0: dev A/B
-  static const bool pass_tan_env = [] { const char* e = std::getenv("RYD_SPLIT_PASS_TAN"); return !(e && e[0] == '0'); }();
+  static const bool pass_tan_env = dev_env_flag("RYD_SPLIT_PASS_TAN", true);
   bool pass_tan = pass_tan_env && !reg_loop && !loop14 && split_real(h) && !h->mc && !h->split_tilings.empty();
   for (const Pass& p : h->split_tilings) pass_tan = pass_tan && (p.T == 12 || (p.T == 13 && N <= 22));
   if ((loop14 && split_real(h)) || reg_loop || pass_tan) {
     // tan-form rotations need cos(beta |c|) away from zero: |beta c| <= 1 for every atom over every sub-step
     double bmax = 0.0;
     for (int i = 0; i < sc.S; ++i) bmax = std::max(bmax, std::fabs(sc.b[i]));
+    if (alt) for (int i = 0; i < kSplitS6.S; ++i) bmax = std::max(bmax, std::fabs(kSplitS6.b[i]));
     for (int s = 0; s < nsub && (loop14 || reg_loop || pass_tan); ++s) {
       const int span = std::max(1, (int)std::ceil((subs[s].u0 + subs[s].tau) / (h->tknots[subs[s].idx + 1] - h->tknots[subs[s].idx]) - 1e-9));
       if (span_max(h->bd_c1, subs[s].idx, std::min(span, (int)h->bd_c1.size() - subs[s].idx)) * bmax * subs[s].tau > 1.0) loop14 = reg_loop = pass_tan = false;
@@ -240,23 +270,53 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   }
   if (reg_loop && N == 14 && !loop14) reg_loop = false;
   if (reg_loop || loop14) pass_tan = false;
+  if ((marks || alt) && (!reg_loop || h->mc || !split_real(h))) {
+    // not the register-resident real-arithmetic kernel (a drive beyond the tan-form bound, a test hook, the dev switch
+    // RYD_SPLIT_GAUGE=0): closed runs of one composition from mark to mark
+    int a = 0;
+    for (int s = 0; s < nsub; ++s) {
+      const bool cut = (marks && marks[s] >= 0) || s + 1 == nsub || (alt && (alt[s + 1] != 0) != (alt[s] != 0));
+      if (!cut) continue;
+      if ((rc = split_run(h, buf, subs + a, s - a + 1, st, alt ? alt[s] != 0 : s6_run))) return rc;
+      if (marks && marks[s] >= 0 && (rc = snapshot_copy(h, buf, snaps + (size_t)marks[s] * h->dim * h->B, st))) return rc;
+      a = s + 1;
+    }
+    return RYD_OK;
+  }
   SplitRun R;
   std::memset(&R, 0, sizeof R);
+  for (int s = 0; s < SPLIT_MAX_SUB; ++s) R.snap[s] = -1;
   R.nsub = nsub;
   R.S = sc.S;
   for (int i = 0; i <= sc.S; ++i) R.a[i] = sc.a[i];
   for (int i = 0; i < sc.S; ++i) R.b[i] = sc.b[i];
+  if (alt) {
+    R.mixed = 1;
+    R.S2 = kSplitS6.S;
+    for (int i = 0; i <= kSplitS6.S; ++i) R.a2[i] = kSplitS6.a[i];
+    for (int i = 0; i < kSplitS6.S; ++i) R.b2[i] = kSplitS6.b[i];
+    int at = 0;
+    for (int s = 0; s < nsub; ++s) {
+      R.alt[s] = alt[s] ? 1 : 0;
+      R.first[s] = (short)at;
+      at += alt[s] ? kSplitS6.S : sc.S;
+    }
+    R.first[nsub] = (short)at;
+  }
   for (int s = 0; s < nsub; ++s) { R.idx[s] = subs[s].idx; R.u0[s] = subs[s].u0; R.tau[s] = subs[s].tau; }
   R.tan_form = reg_loop ? (split_real(h) ? 1 : 2) : ((loop14 || pass_tan) && split_real(h) ? 1 : 0);
   R.gauge = split_gauged(h) ? 1 : 0;
   const int total = B * N;
-  hipLaunchKernelGGL(k_split_coefs, dim3(h->dterms_dev ? (total + 3) / 4 : (total + 255) / 256, n_stages), dim3(256), 0, st,
+  // (+ one closing record per sub-step when snapshots are taken inside the run: k_split_snap_close)
+  const int n_records = n_stages + (any_inner ? nsub : 0);
+  if (any_inner && (rc = split_ensure_tables(h, n_records))) return rc;
+  hipLaunchKernelGGL(k_split_coefs, dim3(h->dterms_dev ? (total + 3) / 4 : (total + 255) / 256, n_records), dim3(256), 0, st,
                      h->pp_dev, h->n_knots - 1, h->desc_dev, h->dterms_dev, total, R, h->split_coefs);
   HIPCHK(hipGetLastError());
 
-  // weight of E0 in the D of every stage
+  // weight of E0 in the D of every stage (the pass-by-pass launches; k_split_reg builds its own table)
   std::vector<double> wE(n_stages);
-  for (int j = 0; j < n_stages; ++j) {
+  for (int j = 0; j < n_stages && !reg_loop; ++j) {
     const int s = j / sc.S, i = j % sc.S;
     double w = 0.0;
     if (j < n_stages - 1) w += sc.a[i] * subs[s].tau;
@@ -277,14 +337,31 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
     A.T = N;
     A.dec_a = h->mc_a;  // H_eff: the decay diagonal a + b popc(index) over the D time of every stage
     A.dec_b = h->mc_b;
+    SplitSnapList Ls;
+    Ls.n = 0;
+    if (any_inner) {
+      A.snaps = snaps;
+      A.snap_stride = (long long)h->dim * B;
+      for (int s = 0; s + 1 < nsub; ++s)
+        if (marks[s] >= 0) { R.snap[s] = marks[s]; Ls.sub[Ls.n] = s; Ls.slot[Ls.n] = marks[s]; ++Ls.n; }
+    }
     std::pair<hipEvent_t, hipEvent_t> ev1;
     if (h->timing) { if ((rc = timing_begin(h, st, ev1))) return rc; }
-    rc = N == 14 ? launch_split_reg<14>(h, A, R, st) : N == 13 ? launch_split_reg<13>(h, A, R, st) : launch_split_reg<12>(h, A, R, st);
+    rc = N == 14 ? launch_split_reg<14>(h, A, R, st, 0, any_inner) : N == 13 ? launch_split_reg<13>(h, A, R, st, 0, any_inner)
+                                                                              : launch_split_reg<12>(h, A, R, st, 0, any_inner);
     if (rc) return rc;
     if (h->timing) { HIPCHK(hipEventRecord(ev1.second, st)); h->ev_used.push_back(ev1); }
     h->stats.n_launches++;
     h->stats.n_applications += n_stages - 1;
     h->stats.passes = 1;
+    if (Ls.n > 0) {
+      // the stored open states -> closed states, all of the run at once (the run itself was one workgroup per sequence)
+      hipLaunchKernelGGL(k_split_snap_close, dim3((unsigned)((h->dim + 255) / 256), (unsigned)B, (unsigned)Ls.n), dim3(256), 0, st,
+                         snaps, A.snap_stride, h->e0_dev, A.e0_stride, h->split_coefs, (long long)B * N * 4, N, R, Ls);
+      HIPCHK(hipGetLastError());
+    }
+    if (marks && marks[nsub - 1] >= 0 &&
+        (rc = snapshot_copy(h, buf, snaps + (size_t)marks[nsub - 1] * h->dim * B, st))) return rc;
     return RYD_OK;
   }
   if (loop14) {
@@ -403,7 +480,16 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
 
 // ---- rows of a density matrix on k_split_reg (declared in host_ket.hpp: run_rows) ----
 static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, double tau_t, std::vector<SubStep>& out);
-static bool rows_split_ok(const ryd_handle* h) {
+// The caller's options decide too: the split-operator sub-steps of a half block are calibrated, not
+// tolerance-driven - one 6-stage / 10-stage sub-step per schedule step ends ~3e-9 from the k_ket rows over the anneal - so
+// a caller who asks for a tolerance tighter than that, names another propagator (ryd_opts.method) or fixes the Taylor
+// order gets the polynomial rows (k_ket: pick_scheme(|h| bound, tol)), whose unitary part follows ryd_opts.
+static const double kRowsSplitCalibrated = 3e-9;
+static bool rows_split_ok(const ryd_handle* h, const ryd_opts& o) {
+  if (o.method != 0 && o.method != 2) return false;
+  if (o.taylor_order > 0) return false;
+  // (ryd_opts.tol is a bound per exponential; over a sequence the split-operator paths take 500 tol as their budget - run_split)
+  if (o.tol > 0 && 500.0 * o.tol < kRowsSplitCalibrated) return false;
   return h->cfg.mode == RYD_MESOLVE && h->N >= 12 && h->N <= 14 && h->drive_real && !h->rows_ket && !h->split_no_loop;
 }
 static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>& sb, size_t i0, size_t i1, bool use_pre,
@@ -435,7 +521,7 @@ static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>
   // one- and two-knot sub-steps at ~3e-9 over the anneal (measured against the k_ket rows at 12 atoms, dephasing 0.05
   // and 0.5 / us: 2.7e-9 / 3.2e-9 with S6, 3.2e-9 / 2.8e-9 with S10) with 6 stages instead of 10; longer sub-steps
   // (split_steps set by the caller) take the 6th-order one
-  static const int s_env = [] { const char* e = std::getenv("RYD_ROWS_S"); return e ? std::atoi(e) : 0; }();  // dev A/B
+  static const int s_env = dev_env_int("RYD_ROWS_S", 0, 6, 10);  // dev A/B (RYD_DEV=1): 6 or 10
   const SplitScheme& sc = s_env == 6 ? kSplitS6 : s_env == 10 ? kSplitS10 : multi ? kSplitS10 : kSplitS6;
   double bmax = 0.0;
   for (int i = 0; i < sc.S; ++i) bmax = std::max(bmax, std::fabs(sc.b[i]));
@@ -492,7 +578,8 @@ static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>
 }
 
 // Advance over any number of sub-steps (closed runs of at most split_max_sub).
-static int split_advance(ryd_handle* h, cplx* buf, const std::vector<SubStep>& subs, hipStream_t st) {
+static int split_advance(ryd_handle* h, cplx* buf, const std::vector<SubStep>& subs, hipStream_t st,
+                         const std::vector<int>* marks = nullptr, cplx* snaps = nullptr) {
   const int cap = split_max_sub(h);
   // Under the 6th-order scheme the stretches of ONE-KNOT sub-steps (the ~25 knots of spline ringing next to every
   // waveform kink, where nothing can be merged: 182 of the 547 schedule steps of the anneal) still run the 4th-order
@@ -502,11 +589,20 @@ static int split_advance(ryd_handle* h, cplx* buf, const std::vector<SubStep>& s
     return h->split_s10 && !h->split_s6_only && s.u0 + s.tau <= (h->tknots[s.idx + 1] - h->tknots[s.idx]) * (1.0 + 1e-9);
   };
   size_t at = 0;
+  // k_split_reg runs both compositions inside one closed run (SplitRun.mixed, round 5): the run is only cut at the cap
+  const bool mix = split_reg_shape(h) && !h->mc && split_real(h) && !h->snaps_outside;
+  std::vector<unsigned char> alt;
+  if (mix) {
+    alt.resize(subs.size());
+    for (size_t q = 0; q < subs.size(); ++q) alt[q] = one_knot(subs[q]) ? 1 : 0;
+  }
   while (at < subs.size()) {
     const bool s6 = one_knot(subs[at]);
     size_t end = at + 1;
-    while (end < subs.size() && end - at < (size_t)cap && one_knot(subs[end]) == s6) ++end;
-    int rc = split_run(h, buf, subs.data() + at, (int)(end - at), st, s6);
+    while (end < subs.size() && end - at < (size_t)cap && (mix || one_knot(subs[end]) == s6)) ++end;
+    // (a mixed run is a run of the handle's scheme whose flagged sub-steps take the other one: s6_run only without flags)
+    int rc = split_run(h, buf, subs.data() + at, (int)(end - at), st, mix ? false : s6, marks ? marks->data() + at : nullptr,
+                       snaps, mix ? alt.data() + at : nullptr);
     if (rc) return rc;
     at = end;
   }
@@ -536,6 +632,12 @@ static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, d
 // local error of a sub-step goes with a high power of the drive amplitude.
 static const int kSplitCheckEvery = 256;  // (128: 24 + 6 checks on the headline anneal, 0.35 ms each for 256 kets = 14 % of the step)
 
+// RYD_DEV=1 RYD_SPLIT_TRACE=1 (dev): every check of the controller on stderr
+static bool split_trace_env() {
+  static const bool on = dev_env_flag("RYD_SPLIT_TRACE", false);
+  return on;
+}
+
 static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sched, cplx* snaps,
                      const ryd_opts& o, hipStream_t st) {
   int rc;
@@ -554,10 +656,14 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   // the ramp, was cut back x 0.2 and crawled - 19 054 stages instead of 7 800 for 8 different 14-atom sequences)
   const double t_start = h->tknots[sched.front().idx] + (sched.front().u1 - kC1 * sched.front().h);
   if (h->split_known && std::fabs(t_start - h->split_t_last) > 1e-9) h->split_known = false;
+  // ... of the SAME state: another buffer evolved from the same time inherits nothing
+  if (h->split_known && state != h->split_state_last) h->split_known = false;
+  h->split_state_last = state;
   if (!h->split_known || h->split_eps != eps) {
     h->split_known = false;
     h->split_tau = 1e300;
     h->split_rate = 0.0;
+    h->split_rate_tau = 0.0;
     h->split_since = 0;
     h->split_since_len = 0.0;
   }
@@ -576,9 +682,30 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   double ck_est = 0.0;
   int retries = 0;
   std::vector<SubStep> subs;
+  std::vector<int> marks;  // per sub-step of `subs`: the snapshot slot its end fills inside the run, or -1
+  // snapshots inside the runs of the register-resident kernel (k_split_reg<.., SNAP>); quantum-jump solves close a run
+  // per schedule step anyway
+  const bool snaps_inside = snaps && split_reg_shape(h) && !jumps && !h->mc && !h->snaps_outside;
   std::vector<double> errs(h->B);
   h->stats.reserved[0] = 0.0;  // accumulated local-error estimate of this solve
-  double err_rate = control ? h->split_rate : 0.0;  // last measured local error per us
+  double err_rate = control ? h->split_rate : 0.0;  // last measured local error per us ...
+  double err_tau = control ? h->split_rate_tau : 0.0;  // ... at sub-steps of this length, by a scheme of order err_p
+  int err_p = split_scheme(h).order;
+  auto book_rate = [&](double tau) {
+    return err_tau > 0.0 ? err_rate * std::pow(tau / err_tau, (double)err_p) : err_rate;
+  };
+  // Quantisation slack (round 5).  The working sub-step tau_t aims at HALF the allowance of a sub-step; a step of length
+  // h is cut into k = ceil(h / tau) equal sub-steps, so where h is a little over tau_t the k-th cut pays for a factor
+  // (k / (k - 1))^p of accuracy nobody asked for - worst with evaluation times at every knot, where a one-knot step whose
+  // error sits between half and all of its allowance was cut in two (12 stages per knot instead of 6).  Sub-steps may
+  // therefore be up to 2^(1/p) longer than tau_t (predicted error <= the allowance); what they cost is booked at the
+  // p-th power of their length (book_rate), so the estimate a caller reads stays honest.  RYD_DEV=1 RYD_SPLIT_SLACK=0: off.
+  static const bool slack_on = dev_env_flag("RYD_SPLIT_SLACK", true);
+  auto tau_q = [&]() {
+    return (slack_on && tau_t < 1e299) ? tau_t * std::pow(2.0, 1.0 / split_scheme(h).order) : tau_t;
+  };
+  double h_max = 0.0;  // longest step of this call
+  for (const StepDesc& d : sched) h_max = std::max(h_max, d.h);
   double amp_max = 0.0;
   for (double v : h->bd_c1) amp_max = std::max(amp_max, v);
   auto amp_at = [&](const StepDesc& d) { return span_max(h->bd_c1, d.idx, std::max(1, d.pad)); };
@@ -589,6 +716,15 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     HIPCHK(hipMemcpyAsync(h->wB, state, bytes, hipMemcpyDeviceToDevice, st));
     have_ck = true;
   }
+  // a run of multi-knot steps begins at step k after knots that could not be removed (or at the start of the call)
+  auto regime_start = [&](size_t k) {
+    if (sched[k].pad <= 1) return false;
+    if (k == 0) return true;
+    if (sched[k - 1].pad > 1) return false;
+    const int at = sched[k].idx;  // the knot this step starts at: removable = the previous step was cut for another reason
+    const bool on_knot = std::fabs(sched[k].u1 - kC1 * sched[k].h) < 1e-12;
+    return !(on_knot && at >= 1 && at - 1 < (int)h->join_ok.size() && h->join_ok[at - 1]);
+  };
   auto finish_step = [&](size_t k) -> int {
     int rcf;
     if (jumps && (rcf = mc_after_step(h, state, st))) return rcf;
@@ -601,15 +737,26 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     // the sequence) is a new regime: the local error measured before it says nothing about 8-knot sub-steps of the
     // 6th-order scheme here (measured: 1.75e-7 on a 20-atom slice across the kink at 0.5 us with periodic checks
     // only).  The first multi-knot step of such a run is checked, the periodic checks follow.
-    const bool new_regime = control && off == 0.0 && sched[i].pad > 1 && (i == 0 || sched[i - 1].pad <= 1) &&
-                            i != last_regime_check;
+    // (a one-knot step that only an evaluation time or the call's end cut off a smooth stretch is no kink: with
+    // evaluation times at every 10th knot the rule used to fire a check - three launches, three copies - per evaluation
+    // time; round 5)
+    const bool new_regime = control && off == 0.0 && regime_start(i) && i != last_regime_check;
     if (new_regime) last_regime_check = i;
     const bool amp_grown = control && off == 0.0 && amp_at(sched[i]) > std::max(1.5 * amp_ck, 0.1 * amp_max);
-    if (control && (!h->split_known || since >= kSplitCheckEvery || new_regime || amp_grown)) {
+    // A check measures ONE sub-step of the step it lands on, and its result sets the sub-step of every step that follows:
+    // it has to land on a step long enough to say something about them.  (Round 5: with evaluation times at every 10th
+    // knot the schedule alternates 9-knot and 1-knot steps; a check that fell on a 1-knot step measured nothing, returned
+    // "whole steps", and the 9-knot steps ran unchecked while the drive grew - 3.8e-7 from a tight run with an estimate of
+    // 4.5e-9, tools/snap_check.py.)  A check that is due waits for a step whose sub-step is at least half the working
+    // sub-step (or half the longest step of the call, where every step is short).
+    const bool informative = !h->split_known || tau_t >= 1e299 ||
+                             (sched[i].h - off) / std::max(1.0, std::ceil((sched[i].h - off) / tau_q() - 1e-9)) >=
+                                 0.5 * std::min(tau_t, h_max) * (1.0 - 1e-9);
+    if (control && informative && (!h->split_known || since >= kSplitCheckEvery || new_regime || amp_grown)) {
       // ---- check: one sub-step whole (wA) against two halves (state) ----
       const StepDesc& d = sched[i];
       subs.clear();
-      split_substeps(h, d, off, tau_t, subs);
+      split_substeps(h, d, off, tau_q(), subs);
       const SubStep s0 = subs[0];
       if (!have_ck && !jumps) {
         // the first check of a call: its own start is the checkpoint (a sub-step never measured here - 8 knots of the
@@ -643,6 +790,11 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       double fac = std::pow(0.5 * allowed / std::max(e, 1e-300), 1.0 / p_ord);
       fac = std::min(std::max(fac, 0.2), p_ord == 6 ? 2.0 : 4.0);  // (x 2 in tau is x 64 in the 6th-order error)
       const double tau_new = s0.tau * fac;
+      if (split_trace_env())
+        std::fprintf(stderr, "[ryd split] check at t = %.4f us (step %zu of %zu, %d knots, h = %.4g ns): sub-step %.4g ns, e = %.3g, "
+                     "allowed %.3g, fac %.3g, tau_t %.4g -> %.4g ns, scheme S%d, since %d%s%s\n",
+                     h->tknots[s0.idx] + s0.u0, i, sched.size(), d.pad, d.h * 1e3, s0.tau * 1e3, e, allowed, fac, tau_t * 1e3,
+                     tau_new * 1e3, split_scheme(h).S, since, new_regime ? " [regime]" : "", amp_grown ? " [amp]" : "");
       h->stats.reserved[1] = e;
       h->stats.reserved[2] = s0.tau;
       if (e > 4.0 * allowed && have_ck && retries < 4 && !jumps) {  // (a roll-back would replay jumps)
@@ -651,7 +803,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
           // ... and when that stretch belongs to earlier calls (nothing to roll back to but this call's start) it ran
           // at about this error rate: booked in full, so that ryd_stats.reserved[0] (which callers compare with
           // their tolerance; the Python engine warns) tells the truth
-          ck_est += std::max(0.0, e / s0.tau - err_rate) * h->split_since_len;
+          ck_est += std::max(0.0, e / s0.tau - book_rate(s0.tau)) * h->split_since_len;
           h->split_since_len = 0.0;
         }
         HIPCHK(hipMemcpyAsync(state, h->wB, bytes, hipMemcpyDeviceToDevice, st));
@@ -667,14 +819,15 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       if (e > 4.0 * allowed) {
         // the retries are used up (or a quantum-jump solve, which cannot roll back): the stretch behind us ran
         // at about this error rate - booked in full
-        h->stats.reserved[0] += std::max(0.0, e / s0.tau - err_rate) * h->split_since_len;
+        h->stats.reserved[0] += std::max(0.0, e / s0.tau - book_rate(s0.tau)) * h->split_since_len;
       }
       retries = 0;
-      static const double grow_env = [] { const char* e = std::getenv("RYD_SPLIT_GROW"); return e ? std::atof(e) : 1.3; }();  // dev A/B
+      static const double grow_env = dev_env_double("RYD_SPLIT_GROW", 1.3, 1.0, 4.0);  // dev A/B (RYD_DEV=1)
       // (growth hysteresis: 1.6 until round 3; at 6th order x 1.3 in tau is x 4.8 in error - the sub-step follows its
       // budget more closely: 7 360 -> 6 890 stages on the anneal, estimate 5.3e-9 -> 5.7e-9)
-      if (fac < 0.9 || fac > grow_env) tau_t = tau_new;
-      if (tau_t > 0.99 * d.h && fac >= 1.0) tau_t = 1e300;
+      // (the sub-step stays a LENGTH - the one this measurement stands for, times fac: until round 5 a check that found
+      // its step within budget switched to "whole steps" of any length, see `informative` above)
+      if (tau_t >= 1e299 || fac < 0.9 || fac > grow_env) tau_t = tau_new;
       h->stats.reserved[0] += e / two_p;  // the two halves are what was kept
       off += s0.tau;
       if (off >= d.h * (1.0 - 1e-12)) {
@@ -690,7 +843,11 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       ck_est = h->stats.reserved[0];
       h->split_since_len = 0.0;
       have_ck = true;
-      err_rate = (e / s0.tau) * std::pow(std::min(tau_t, s0.tau) / s0.tau, (double)p_ord);
+      // local error per us measured at sub-steps of err_tau; sub-steps of another length are booked with the p-th power
+      // of the ratio (book_rate)
+      err_rate = e / s0.tau;
+      err_tau = s0.tau;
+      err_p = p_ord;
       since = 0;
       amp_ck = amp_at(d);
       h->split_known = true;
@@ -704,27 +861,33 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       // drive bound has grown by half: that step is checked (above)
       int knots = since;
       for (size_t q = i; q < stop; ++q) {
-        if (q > i && ((sched[q].pad > 1 && sched[q - 1].pad <= 1) || knots >= kSplitCheckEvery ||
+        if (q > i && (regime_start(q) || knots >= kSplitCheckEvery ||
                       amp_at(sched[q]) > std::max(1.5 * amp_ck, 0.1 * amp_max))) { stop = q; break; }
         knots += std::max(1, sched[q].pad);
       }
     }
     subs.clear();
+    marks.clear();
     while (i < stop) {
       const StepDesc& d = sched[i];
       const size_t before = subs.size();
-      split_substeps(h, d, off, tau_t, subs);
+      split_substeps(h, d, off, tau_q(), subs);
       for (size_t q = before; q < subs.size(); ++q) {
-        h->stats.reserved[0] += err_rate * subs[q].tau;
+        h->stats.reserved[0] += book_rate(subs[q].tau) * subs[q].tau;
         h->split_since_len += subs[q].tau;
       }
+      marks.resize(subs.size(), -1);
       off = 0.0;
       h->stats.n_steps++;
       since += std::max(1, d.pad);
       const bool snap = snaps && d.snap >= 0;
-      if (snap || jumps || i + 1 == stop) {
-        if ((rc = split_advance(h, state, subs, st))) return rc;
+      if (snap && snaps_inside && i + 1 != stop) {
+        // the evaluation time at the end of this step does not close the run (round 5): the snapshot is taken inside it
+        marks.back() = d.snap;
+      } else if (snap || jumps || i + 1 == stop) {
+        if ((rc = split_advance(h, state, subs, st, &marks, snaps))) return rc;
         subs.clear();
+        marks.clear();
         if ((rc = finish_step(i))) return rc;
       }
       ++i;
@@ -733,6 +896,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   if (control) {
     h->split_tau = tau_t;
     h->split_rate = err_rate;
+    h->split_rate_tau = err_tau;
     h->split_since = since;
     h->split_amp = amp_ck;
   }

@@ -539,9 +539,14 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
     // with evaluation times at (nearly) every knot - the persistent kernels take their snapshots inside ONE launch where
     // this path closes a run per evaluation time - and not for quantum jumps (jumps on the device, one launch).
     // RYD_SPLIT_ALWAYS=0: dev A/B.
-    static const bool always_env = [] { const char* e = std::getenv("RYD_SPLIT_ALWAYS"); return !(e && e[0] == '0'); }();
+    static const bool always_env = dev_env_flag("RYD_SPLIT_ALWAYS", true);
     const double span_knots = h->n_knots > 1 ? (times[n_times - 1] - times[0]) / ((h->tknots.back() - h->tknots.front()) / (h->n_knots - 1)) : 0.0;
-    if (!h->split14_auto && reg_shape && !h->mc && !h->split_fixed && always_env && 8.0 * (n_times - 1) <= span_knots)
+    // Round 5: evaluation times no longer close a run of k_split_reg (snapshots are stored from the registers inside it,
+    // k_split_reg<.., SNAP>), so a call with evaluation times at every knot - evaluation_times="Full", the reference's
+    // default - stays here too: 6 stages per knot interval in ONE launch per 64 knots (14 atoms, one sequence: 281 ms on
+    // a closed run per knot, 364 ms on k_ket, tools/full_probe.py).  With the round-4 hook (snaps_outside) the old rule.
+    if (!h->split14_auto && reg_shape && !h->mc && !h->split_fixed && always_env &&
+        (!h->snaps_outside || 8.0 * (n_times - 1) <= span_knots))
       h->split14_auto = true;
   }
   // the in-place schemes split an exponential themselves and a Lanczos process takes whole
@@ -567,6 +572,7 @@ static int solve_impl(ryd_handle* h, void* state_dev, int32_t n_times, const dou
   const int merge_cap = split_selected(h, o) ? (split_merge ? kSplitMergeMax : 1)
                         : (row_path(h) && !use_persistent_dm(h)) ? row_half_knots(h, o) : kMergeMax;
   std::vector<StepDesc> sched;
+  h->sched_for_split = split_selected(h, o);
   // snapshot slot i-1 receives the state at times[i]
   for (int i = 1; i < n_times; ++i) {
     const size_t before = sched.size();
@@ -706,6 +712,7 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
     h->no_split14 = (force_generic & 16384) != 0;  // 14-atom batches stay on k_ket
     h->split_turns = (force_generic & 32768) != 0; // one-launch runs on the round-3 kernel (A/B)
     h->rows_ket = (force_generic & 65536) != 0;    // master-equation row passes on k_ket (A/B)
+    h->snaps_outside = (force_generic & 131072) != 0;  // k_split_reg: a closed run per evaluation time (round 4, A/B)
     {
       const bool s6 = (force_generic & 8192) != 0;  // split-operator passes: S6, sub-steps end at every knot
       if (s6 != h->split_s6_only) { h->split_s6_only = s6; h->split_known = false; }

@@ -18,63 +18,7 @@
 // bits - so a stage costs ONE pass (32 B per amplitude + 8 B of E0) whatever N <= 2T - 3.
 // Roofline: HBM / Infinity-Cache streaming, 40 B per amplitude and stage.
 
-#define SPLIT_TMAX 12
-#define SPLIT_TS 13    /* largest tile of the static pass kernel k_split_s */
-#define SPLIT_TBIG 14  /* table sizing of the generic pass kernel k_split_t (tiles of up to 2^14 amplitudes) */
-#define SPLIT_NT 256
-#define SPLIT_NMAX 32
-
-struct SplitArgs {
-  cplx* state;           // [B][2^N] in place
-  const double* e0;      // [n_mats][2^N]
-  long long e0_stride;   // 0 when shared by the batch
-  const double* cfin;    // [B][N][4]: C, Re g, Im g, -    rotation to finish (previous stage)
-  const double* ccur;    // [B][N][4]: C, Re g, Im g, Delta   this stage's rotation + detuning integral of D
-  double wE;             // weight of E0 in D (us)
-  Segs tile, outer;
-  int N, T;
-  unsigned fin_mask, cur_mask;  // tile-local bits to rotate before / after D
-  int do_diag;
-  // quantum-jump trajectories (H_eff = H - i/2 sum C^dag C, diagonal for every built-in channel): D also
-  // carries the real factor exp(wE (dec_a + dec_b popc(index))) (template parameter DECAY of the pass kernels:
-  // the plain passes carry neither the table nor the test)
-  double dec_a, dec_b;
-  // rows of a density matrix as kets (k_split_reg<.., ROWS>, the split-operator master equation of host_ket.hpp):
-  // conj = 1 evolves with the complex-conjugate propagator (row <- row W^dagger); ftab = [2][4][16] elementwise factor
-  // tables exp(f d(a, b)) by the counts n00, n01, n10, n11 of (row bit, column bit) pairs, [0] applied at the load
-  // (use_pre), [1] at the store (use_post)
-  int conj, use_pre, use_post;
-  const double* ftab;
-  int pend;  // k_split12<.., TAN>: a rotation precedes this pass's D (its cosine product is applied with D)
-};
-
-// One closed run of the composition: consecutive sub-steps (knot interval, start offset, length),
-// by value in the kernel arguments.  Stage j = 6 s + i is D(a_i) R(b_i) of sub-step s (its D also
-// carries the last D(a_7) of sub-step s - 1); stage 6 nsub only closes with D(a_7).
-#define SPLIT_MAX_SUB 64
-#define SPLIT_MAX_STAGES 10
-struct SplitRun {
-  int nsub;
-  int S;  // stages of the composition: 6 (4th order, Blanes & Moan S6) or 10 (6th order, S10)
-  int idx[SPLIT_MAX_SUB];
-  double u0[SPLIT_MAX_SUB];
-  double tau[SPLIT_MAX_SUB];
-  double a[SPLIT_MAX_STAGES + 1];  // D(a_1) R(b_1) ... R(b_S) D(a_{S+1})
-  double b[SPLIT_MAX_STAGES];
-  int tan_form;  // 1: real drives (k_split14_loop, k_split_reg): the Re g slot (zero there) carries Im g / C;
-                 // 2: complex drives on k_split_reg<.., CPLX>: Re g / C and Im g / C in their own slots
-  // drive-only rotations exp(-i kick X(t_kick)) before the first stage (an extra stage 0 without D) / after the
-  // last D (the closing stage's rotation): the commutator correction of the 4th-order operator splitting of the
-  // master equation (host_ket.hpp); t_kick = knot interval kick_idx, offset kick_u
-  double kick_pre, kick_post;
-  int kick_idx;
-  double kick_u;
-  // complex drives on the REAL kernels (round 4): the rotation by c = |c| e^{i theta} is Z R(|c|) Z^+ with the diagonal
-  // Z = exp(-i theta n), and Z commutes with every D - so stage j rotates by |c_j| and its D carries the extra per-atom
-  // phase exp(i (theta_j - theta_{j-1}) n) (theta_0 = 0; the closing D returns to theta = 0): exact, for any per-atom,
-  // time-dependent phase.  k_split_coefs adds theta_j - theta_{j-1} to the detuning integral.
-  int gauge;
-};
+#include "split_types.hpp"
 
 // out[stage][b][k] = (C, Re g, Im g, Delta): the rotation exp(-i beta (c |1><0| + conj(c) |0><1|)) =
 // C + g |1><0| + g' |0><1| with the drive frozen at the stage's time, and the integral of the
@@ -91,7 +35,7 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
   const int lane = per_lane ? 0 : (int)(threadIdx.x & 63);
   if (i >= total) return;
   const int ns = R.nsub;
-  const int S = R.S;
+  const int n_comp = splitrun_first(R, ns);  // stages of the compositions (mixed runs: not S ns)
   const bool pre_kick = R.kick_pre != 0.0 && blockIdx.y == 0;  // the extra stage 0: no D, rotation by kick_pre
   const int j = (int)blockIdx.y - (R.kick_pre != 0.0 ? 1 : 0);
   if (pre_kick) {
@@ -114,24 +58,37 @@ __global__ __launch_bounds__(256) void k_split_coefs(const cplx* __restrict__ pp
     }
     return;
   }
-  const bool closing = j == S * ns;
-  const int s = closing ? ns - 1 : j / S, st = closing ? S : j % S;
+  // records beyond the run's own S ns + 1 (launched only when the run takes evaluation-time snapshots inside the kernel):
+  // record S ns + 1 + s closes sub-step s alone - the last D(a_{S+1}) of that sub-step, no rotation, the laboratory frame
+  // (gauge) - for k_split_snap_close
+  const bool snap_close = j > n_comp;
+  const bool closing = j >= n_comp;
+  int s, st;
+  if (closing) {
+    s = snap_close ? j - n_comp - 1 : ns - 1;
+    st = splitrun_S(R, s);
+  } else {
+    splitrun_locate(R, j, s, st);
+  }
+  const int S = splitrun_S(R, s);
   // D intervals: (knot interval, start offset, length)
   int idx_d[2] = {R.idx[s], 0};
   double us_d[2], len_d[2] = {0.0, 0.0};
   double cum = 0.0;
-  for (int l = 0; l < st; ++l) cum += R.a[l];
+  for (int l = 0; l < st; ++l) cum += splitrun_a(R, s, l);
   us_d[0] = R.u0[s] + cum * R.tau[s];
-  len_d[0] = R.a[st] * R.tau[s];
+  len_d[0] = splitrun_a(R, s, st) * R.tau[s];
   us_d[1] = 0.0;
   if (!closing && st == 0 && s > 0) {
+    const double a_last = splitrun_a(R, s - 1, splitrun_S(R, s - 1));  // the previous sub-step's own composition
     idx_d[1] = R.idx[s - 1];
-    us_d[1] = R.u0[s - 1] + (1.0 - R.a[S]) * R.tau[s - 1];
-    len_d[1] = R.a[S] * R.tau[s - 1];
+    us_d[1] = R.u0[s - 1] + (1.0 - a_last) * R.tau[s - 1];
+    len_d[1] = a_last * R.tau[s - 1];
   }
+  (void)S;
   const int idx_c = closing ? R.kick_idx : R.idx[s];
   const double u_c = closing ? R.kick_u : us_d[0] + len_d[0];
-  const double beta = closing ? R.kick_post : R.b[st] * R.tau[s];
+  const double beta = snap_close ? 0.0 : closing ? R.kick_post : splitrun_b(R, s, st) * R.tau[s];
 
   const ryd_qdesc d = desc[i];
   auto val = [&](int sr, int idx, double u) -> cplx {
@@ -892,4 +849,42 @@ __global__ __launch_bounds__(256) void k_split_diff(const cplx* __restrict__ x, 
   for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_down(s, o, 64));
   if ((threadIdx.x & 63) == 0)
     atomicMax(reinterpret_cast<unsigned long long*>(err + blockIdx.y), (unsigned long long)__double_as_longlong(s));
+}
+
+// Evaluation-time snapshots taken inside a closed run of k_split_reg<.., SNAP> hold OPEN states (SplitArgs.snaps): this
+// kernel closes them in place, all of a run at once and across the chip (the run itself sits on one CU per sequence):
+//   psi_closed[i] = cprod * exp(-i (wE E0[i] - sum_{k excited in i} Delta_k)) * psi_open[i]
+// with wE = a_{S+1} tau of the sub-step, Delta_k from the sub-step's closing record (k_split_coefs: record S nsub + 1 + s)
+// and cprod = the product of the cosines of the sub-step's last tan-form rotation (record S (s + 1) - 1 + n_pre, field 0; 1
+// when the run is not in tan form).  grid (2^N / 256, B, marked sub-steps).
+__global__ __launch_bounds__(256) void k_split_snap_close(cplx* __restrict__ snaps, long long snap_stride,
+                                                          const double* __restrict__ e0, long long e0_stride,
+                                                          const double* __restrict__ coefs, long long stage_stride, int N,
+                                                          const SplitRun R, const SplitSnapList Ls) {
+  __shared__ double dl[SPLIT_NMAX];
+  __shared__ double cp;
+  const int b = blockIdx.y, q = blockIdx.z;
+  const int s = Ls.sub[q];
+  const int n_pre = R.kick_pre != 0.0 ? 1 : 0;
+  const double* cl = coefs + (size_t)(splitrun_first(R, R.nsub) + 1 + n_pre + s) * stage_stride + (size_t)b * N * 4;
+  const double* lastrot = coefs + (size_t)(splitrun_first(R, s + 1) - 1 + n_pre) * stage_stride + (size_t)b * N * 4;
+  if (threadIdx.x < (unsigned)N) dl[threadIdx.x] = cl[4 * (N - 1 - (int)threadIdx.x) + 3];  // by index bit
+  if (threadIdx.x == 64) {
+    double p = 1.0;
+    if (R.tan_form)
+      for (int k = 0; k < N; ++k) p *= lastrot[4 * k];
+    cp = p;
+  }
+  __syncthreads();
+  const double wE = splitrun_a(R, s, splitrun_S(R, s)) * R.tau[s];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ((size_t)1 << N)) return;
+  double phi = wE * e0[(size_t)b * e0_stride + i];
+  for (int k = 0; k < N; ++k) phi -= ((i >> k) & 1) ? 0.0 : dl[k];
+  double sn, cs;
+  sincos(phi, &sn, &cs);
+  cplx* v = snaps + (size_t)Ls.slot[q] * snap_stride + ((size_t)b << N) + i;
+  const cplx a = *v;
+  const double c = cp;
+  *v = make_double2(c * fma(a.x, cs, a.y * sn), c * fma(a.y, cs, -a.x * sn));
 }

@@ -152,8 +152,13 @@ __device__ __forceinline__ double splitr_partner(double v) {
 // CPLX: complex drive coefficients (a pulse with a phase, local addressing with per-atom phases): the rotation of an atom
 // is C (1 + u |1><0| - conj(u) |0><1|), u = (Re g + i Im g) / C (SplitRun.tan_form 2: both slots of the table) - 4 FMAs
 // per amplitude and bit instead of 2; on the DPP bits the sign of the Re part depends on the lane's own bit.
-template <int N, int NR, bool DECAY, bool ROWS = false, bool CPLX = false>
+// SNAP: evaluation-time snapshots inside the run (round 5): after the last stage of a sub-step s with R.snap[s] >= 0 the
+// registers - the OPEN state, see SplitArgs.snaps - are stored to the snapshot slot; k_split_snap_close finishes them.  A
+// front end that asks for the state at every knot (evaluation_times="Full", the reference's default, simulation.py:137)
+// or at every 10th used to close a run - a launch, a load and a store of the ket, a closing stage - per evaluation time.
+template <int N, int NR, bool DECAY, bool ROWS = false, bool CPLX = false, bool SNAP = false>
 __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per_eu(1, NR >= 6 ? 1 : 2))) void k_split_reg(const SplitArgs A, const SplitRun R, long long stage_stride) {
+  static_assert(!(SNAP && (ROWS || DECAY)), "snapshots inside a run: plain ket runs only");
   typedef SplitRegLayout<N, NR> L;
   constexpr int NW = L::NW, NTB = L::NTB, ND = L::ND;
   constexpr int NT = 64 << NW;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
   const unsigned l = t & 63u, w = t >> 6;
   const int b = ROWS ? (int)blockIdx.z : (int)blockIdx.y;
   const int n_pre = R.kick_pre != 0.0 ? 1 : 0;  // the opening kick is an extra stage 0 (no D)
-  const int n_stages = R.S * R.nsub + 1 + n_pre;
+  const int n_stages = splitrun_first(R, R.nsub) + 1 + n_pre;
   // (SplitArgs.conj: conj(U) psi = conj(U conj(psi)) - the ket is conjugated at the load and at the store, the stages
   // in between are the ordinary ones: nothing in the stage loop knows about it)
   const double csgn = (ROWS && A.conj) ? -1.0 : 1.0;
@@ -185,11 +190,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     // weight of E0 in the D of stage j: a_i tau (+ the last a tau carried over from the previous sub-step)
     for (int jj = (int)t; jj < n_stages; jj += NT) {
       const int j = jj - n_pre;
-      const bool last = jj == n_stages - 1;
-      const int sub = last ? R.nsub - 1 : j / R.S, i = last ? R.S : j % R.S;
-      double wgt = R.a[i] * R.tau[sub];
-      if (!last && i == 0 && sub > 0) wgt += R.a[R.S] * R.tau[sub - 1];
-      wtab[jj] = j < 0 ? 0.0 : wgt;
+      wtab[jj] = j < 0 ? 0.0 : splitrun_weight(R, j);
     }
   }
   for (unsigned k = t; k < SPLITR_TRIG; k += NT) {  // (before the state is loaded: the library routine wants registers)
@@ -365,11 +366,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       wE = uniform_d(wtab[sg]);
     } else {
       const int sj = sg - n_pre;
-      const bool last = sg == n_stages - 1;
-      const int sub = last ? R.nsub - 1 : sj / R.S, i = last ? R.S : sj % R.S;
-      wE = R.a[i] * R.tau[sub];
-      if (!last && i == 0 && sub > 0) wE += R.a[R.S] * R.tau[sub - 1];
-      if (sj < 0) wE = 0.0;
+      wE = sj < 0 ? 0.0 : splitrun_weight(R, sj);
     }
     double et_s, eg_s;
     if (SPLITR_EMODE) {
@@ -695,15 +692,58 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     if (SPLITR_KWARM) asm volatile("" ::"s"(warm));
   };
   const int n_full = R.kick_post == 0.0 ? n_stages - 1 : n_stages;
-  for (int sg = 0; sg < n_full; ++sg) stage(sg, std::false_type{});
+  if constexpr (SNAP) {
+    int snap_at = splitrun_first(R, 1) + n_pre - 1, snap_sub = 0;  // the stage that ends sub-step snap_sub
+    for (int sg = 0; sg < n_full; ++sg) {
+      stage(sg, std::false_type{});
+      if (sg == snap_at) {
+        const int slot = R.snap[snap_sub];
+        if (slot >= 0) {
+          // address = uniform base + the lane's word + a constant per register.  The lane's word is laundered through an
+          // empty asm: loop-invariant otherwise, and the 32 hoisted 64-bit addresses cost 20 spilled vector registers
+          // in every stage of the loop (measured: 10.6 instead of 9.4 us per stage)
+          unsigned lw = odd ? L::index(true, t, 0u) : L::index(false, t, 0u);
+          asm volatile("" : "+v"(lw));
+          cplx* __restrict__ sd = A.snaps + (size_t)slot * A.snap_stride + ((size_t)b << N);
+          if (odd) {
+            splitr_for<0, NA>([&](auto Rc) {
+              constexpr int r = decltype(Rc)::value;
+              __builtin_nontemporal_store(xr[r], &sd[lw + L::index(true, 0u, r)].x);
+              __builtin_nontemporal_store(xi[r], &sd[lw + L::index(true, 0u, r)].y);
+            });
+          } else {
+            splitr_for<0, NA>([&](auto Rc) {
+              constexpr int r = decltype(Rc)::value;
+              __builtin_nontemporal_store(xr[r], &sd[lw + L::index(false, 0u, r)].x);
+              __builtin_nontemporal_store(xi[r], &sd[lw + L::index(false, 0u, r)].y);
+            });
+          }
+        }
+        ++snap_sub;
+        snap_at = snap_sub < R.nsub ? splitrun_first(R, snap_sub + 1) + n_pre - 1 : (1 << 30);
+      }
+    }
+  } else {
+    for (int sg = 0; sg < n_full; ++sg) stage(sg, std::false_type{});
+  }
   if (n_full < n_stages) stage(n_stages - 1, std::true_type{});
   // the layout is the odd one when an odd number of full stages ran
-  double fl = 1.0;
+  // (tan form defers the product of a stage's cosines to the next stage's D; a run that closes on the kick has no next
+  // stage, so the row is finished here: prod_k cos(kick c_k) = 1 - O(1e-18) for the default kick, 1e-13 per atom for
+  // long blocks set by the caller - a trace drift that accumulated over the blocks)
+  double fl = (ROWS && n_full == n_stages) ? cprod : 1.0;
+  if (ROWS && n_full == n_stages && !A.use_post) {
+    splitr_for<0, NA>([&](auto Rc) {
+      constexpr int r = decltype(Rc)::value;
+      xr[r] *= fl;
+      xi[r] *= fl;
+    });
+  }
   if (ROWS && A.use_post) {
     __syncthreads();
     if (t < NA) ftl[128 + t] = row_factor(1, odd ? L::index(true, 0u, t) : L::index(false, 0u, t), odd ? L::index(true, 0u, NA - 1) : L::index(false, 0u, NA - 1));
     __syncthreads();
-    fl = row_factor(1, odd ? L::index(true, t, 0u) : L::index(false, t, 0u), odd ? L::index(true, NT - 1, 0u) : L::index(false, NT - 1, 0u));
+    fl *= row_factor(1, odd ? L::index(true, t, 0u) : L::index(false, t, 0u), odd ? L::index(true, NT - 1, 0u) : L::index(false, NT - 1, 0u));
   }
   splitr_for<0, NA>([&](auto Rc) {
     constexpr int r = decltype(Rc)::value;

@@ -60,6 +60,13 @@ typedef double2 cplx;
 #include "k_krylov.hpp"
 #include "k_split.hpp"
 #include "k_split_reg.hpp"
+#include "k_split_reg_inst.hpp"
+#ifdef RYD_SPLIT_TUS
+// the register-resident split-operator kernels are compiled by rydemu_splitreg.hip (three part units, in parallel)
+SPLITR_INSTANCES_12(SPLITR_EXTERN)
+SPLITR_INSTANCES_13(SPLITR_EXTERN)
+SPLITR_INSTANCES_14(SPLITR_EXTERN)
+#endif
 #include "k_observe.hpp"
 #include "k_general.hpp"
 #include "host_handle.hpp"

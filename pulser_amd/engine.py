@@ -380,7 +380,8 @@ class Engine:
                  force_ket: bool = False, no_split: bool = False,
                  split_fixed: bool = False, split_no_loop: bool = False,
                  no_merge: bool = False, split_small_tiles: bool = False, split_s6: bool = False,
-                 no_split14: bool = False, split_turns: bool = False, rows_ket: bool = False) -> None:
+                 no_split14: bool = False, split_turns: bool = False, rows_ket: bool = False,
+                 snaps_outside: bool = False) -> None:
         """Test/bench hook: disable the persistent small-N kernel and/or the 2^14
         register-tile kernel with the Hermitian mesolve path (the tiled
         multi-pass kernels are used instead), or force the register tiles;
@@ -395,6 +396,8 @@ class Engine:
         register-resident kernel (k_ket) instead of the split-operator one (k_split14_loop);
         ``rows_ket`` keeps the row passes of the split-operator master equation on k_ket (round 3) instead of k_split_reg;
         ``split_turns`` runs them on the round-3 kernel (two LDS turns per stage) instead of k_split_reg;
+        ``snaps_outside``: every evaluation time closes a run of k_split_reg (round 4) instead of a snapshot stored from
+        the registers inside the run;
         ``split_s6`` keeps the 4th-order composition with sub-steps that end at every knot
         (round 2) where the 6th-order one with multi-knot sub-steps is the default."""
         _lib.check(self.lib.ryd_set_path(
@@ -404,7 +407,8 @@ class Engine:
             | (64 if force_ket else 0) | (128 if no_split else 0)
             | (256 if split_fixed else 0) | (512 if split_no_loop else 0)
             | (1024 if no_merge else 0) | (2048 if split_small_tiles else 0) | (8192 if split_s6 else 0)
-            | (16384 if no_split14 else 0) | (32768 if split_turns else 0) | (65536 if rows_ket else 0)))
+            | (16384 if no_split14 else 0) | (32768 if split_turns else 0) | (65536 if rows_ket else 0)
+            | (131072 if snaps_outside else 0)))
 
     def apply_generator(self, x: Any, t: float) -> Any:
         """``G(t) x`` with ``G = -iH`` (sesolve) or the Lindbladian (mesolve)."""

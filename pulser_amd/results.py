@@ -155,6 +155,135 @@ class DeviceState:
         return f"DeviceState(shape={self.shape}, {where})"
 
 
+class SnapshotStore:
+    """The evaluation-time snapshots of one solve, ``[n_times - 1, B, dim...]`` on the GPU, and their host copies.
+
+    The reference hands every state of ``result.states`` to the host (simulation.py:744-748); with
+    ``evaluation_times="Full"`` - its default - that is 3 101 x 256 KiB = 813 MB for one 14-atom sequence, most of which
+    nobody reads.  The snapshots stay in HBM; a state crosses PCIe when it is read (``LazyState``), and once more than
+    ``bulk_after`` different states have been asked for the whole tensor is copied in one transfer (a loop over all
+    evaluation times - ``expect``, sampling at every time - then costs one copy, as before)."""
+
+    def __init__(self, tensor: Any, bulk_after: int = 16) -> None:
+        self._dev = tensor
+        self._host: np.ndarray | None = None
+        self._reads = 0
+        self._bulk_after = int(bulk_after)
+
+    @property
+    def device_tensor(self) -> Any:
+        """The torch tensor on the GPU (None once everything has been copied to the host)."""
+        return self._dev
+
+    def fetch_all(self) -> np.ndarray:
+        if self._host is None:
+            self._host = self._dev.cpu().numpy()
+            self._dev = None
+        return self._host
+
+    def get(self, i: int, b: int) -> np.ndarray:
+        if self._host is None:
+            self._reads += 1
+            if self._reads <= self._bulk_after:
+                return self._dev[i, b].cpu().numpy()
+            self.fetch_all()
+        return self._host[i, b]
+
+
+def _lazy_binary(name: str) -> Any:
+    def op(self: "LazyState", other: Any) -> Any:
+        other = other._materialise() if isinstance(other, LazyState) else other
+        return getattr(self._materialise(), name)(other)
+
+    op.__name__ = name
+    return op
+
+
+class LazyState:
+    """A state of ``results.states`` that is still a device snapshot; it turns into a ``QState`` (host) the first time
+    anything but its shape / kind is asked of it.  Reads like the ``QState`` it becomes: ``np.asarray``, indexing,
+    arithmetic and the ``Qobj``-style accessors all work on the materialised state."""
+
+    __array_priority__ = 20.0
+
+    def __init__(self, store: SnapshotStore, i: int, b: int, shape: tuple[int, int]) -> None:
+        self._store = store
+        self._i = int(i)
+        self._b = int(b)
+        self._shape = (int(shape[0]), int(shape[1]))
+        self._q: QState | None = None
+
+    def _materialise(self) -> QState:
+        if self._q is None:
+            self._q = QState(np.asarray(self._store.get(self._i, self._b)).reshape(self._shape))
+        return self._q
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        return self._shape
+
+    @property
+    def ndim(self) -> int:
+        return 2
+
+    @property
+    def dtype(self) -> Any:
+        return np.dtype(complex)
+
+    @property
+    def isket(self) -> bool:
+        return self._shape[1] == 1 and self._shape[0] > 1 or self._shape == (1, 1)
+
+    @property
+    def isoper(self) -> bool:
+        return not self.isket
+
+    @property
+    def device_tensor(self) -> Any:
+        """The snapshot on the GPU (a view), or None when the store has moved to the host."""
+        dev = self._store.device_tensor
+        return None if dev is None else dev[self._i, self._b]
+
+    def __array__(self, dtype: Any = None, copy: Any = None) -> np.ndarray:
+        a = np.asarray(self._materialise())
+        return a if dtype is None else a.astype(dtype)
+
+    def __getattr__(self, name: str) -> Any:  # full, dag, diag, tr, norm, unit, overlap, copy, conj, T, real, ...
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._materialise(), name)
+
+    def __getitem__(self, key: Any) -> Any:
+        return self._materialise()[key]
+
+    def __len__(self) -> int:
+        return self._shape[0]
+
+    def __iter__(self) -> Any:
+        return iter(self._materialise())
+
+    def __repr__(self) -> str:
+        where = "host" if self._q is not None else "device snapshot"
+        return f"LazyState(shape={self._shape}, {where})"
+
+    def __neg__(self) -> Any:
+        return -self._materialise()
+
+    def __abs__(self) -> Any:
+        return abs(self._materialise())
+
+    def __eq__(self, other: Any) -> Any:  # elementwise, like the ndarray it stands for
+        other = other._materialise() if isinstance(other, LazyState) else other
+        return self._materialise() == other
+
+    __hash__ = None  # type: ignore[assignment]
+
+    for _n in ("add", "sub", "mul", "matmul", "truediv", "pow"):
+        locals()[f"__{_n}__"] = _lazy_binary(f"__{_n}__")
+        locals()[f"__r{_n}__"] = _lazy_binary(f"__r{_n}__")
+    del _n
+
+
 def multinomial(n_samples: int, probabilities: np.ndarray) -> np.ndarray:
     """pulser-core/pulser/math/multinomial.py:18-36."""
     rnd = np.random.rand(n_samples)

@@ -28,8 +28,8 @@ import numpy as np
 from .hamiltonian_data import HamiltonianData, SequenceInputs
 from .noise_model import (LEGACY_DEFAULTS, NoiseModel, _NOISE_TYPE_PARAMS,
                           check_eff_noise, has_stochastic_noise)
-from .results import (DeviceState, CoherentResults, NoisyResults, QState, SampledResult,
-                      SimulationResults, StateResult)
+from .results import (DeviceState, CoherentResults, LazyState, NoisyResults, QState, SampledResult,
+                      SimulationResults, SnapshotStore, StateResult)
 from .terms import sampling_times
 
 __all__ = ["QutipEmulator", "Solver", "SimConfig", "NoiseModel"]
@@ -741,7 +741,9 @@ class QutipEmulator:
                                       + [eng.occupations(snaps[i]) for i in range(len(times) - 1)]).cpu().numpy()
                 self.last_engine_stats = eng.stats()
                 return first_dev, snaps, occ
-            host = None if on_device else snaps.cpu().numpy()
+            # ... and the other snapshots stay in HBM until somebody reads them (evaluation_times="Full", the reference's
+            # default, stores 3 101 states per sequence: 813 MB at 14 atoms); results.states hands out LazyState objects
+            store = None if on_device else SnapshotStore(snaps)
             del state
             self.last_engine_stats = eng.stats()
         meas_errors = (
@@ -749,6 +751,10 @@ class QutipEmulator:
             if "SPAM" in self.noise_model.noise_types else None
         )
         qids = tuple(self.samples_obj.qubit_ids)
+        basis_name = self.basis_name
+        matching = self._meas_basis in basis_name
+        t_unit = self._tot_duration * 1e-3
+        shape = (tuple(first[0].shape) if first is not None and first[0].ndim == 2 else (2**n, 1))
         out = []
         for b in range(n_batch):
             results = []
@@ -756,15 +762,12 @@ class QutipEmulator:
                 if on_device:
                     st: Any = (DeviceState(ket=np.asarray(self._initial_state).reshape(-1)) if i == 0
                                else DeviceState(tensor=snaps[i - 1][b]))
+                elif i == 0:
+                    st = QState(first[b])
                 else:
-                    st = QState(first[b] if i == 0 else host[i - 1][b])
-                results.append(
-                    StateResult(qids, self._meas_basis, st,
-                                self._meas_basis in self.basis_name,
-                                evaluation_time=float(t / (self._tot_duration * 1e-3)))
-                )
-            out.append(CoherentResults(results, n, self.basis_name, times, self._meas_basis,
-                                       meas_errors))
+                    st = LazyState(store, i - 1, b, shape)
+                results.append(StateResult(qids, self._meas_basis, st, matching, evaluation_time=float(t / t_unit)))
+            out.append(CoherentResults(results, n, basis_name, times, self._meas_basis, meas_errors))
         return out
 
     # density matrices from this size on stay on the GPU (13 atoms: 1 GiB per state)

@@ -88,6 +88,48 @@ def test_single_14_atom_sequence_every_propagator_against_tight_oracle(ns14, met
         assert st["reserved"][0] < AMP_TOL and max(errs) < max(4 * st["reserved"][0], 2e-9), (errs, st["reserved"])
 
 
+@pytest.mark.parametrize("spec", ["Full", "Minimal", 0.1])
+def test_drop_in_call_with_the_reference_default_arguments_against_tight_oracle(ns14, spec):
+    """What a user who swaps the import gets: ``QutipEmulator(<the headline sequence>).run()``
+    with ``evaluation_times="Full"`` - the reference's default (simulation.py:137, 961: a state at every sample, 3 101 of
+    them) -, "Minimal" and 0.1, through the front end: every time the tight oracle stores (0.5, 1.3, 2.1, 3.099, 3.1 us;
+    zvode rtol 1e-13) that the call evaluates is within the bar.  "Full" stays on the register-resident split-operator
+    kernel (snapshots stored inside its runs: launches << evaluation times) and its 3 100 stored kets stay in HBM until
+    they are read (LazyState): reading five of them copies five kets, not 813 MB."""
+    from test_host_logic import _inputs_from_problem
+
+    from pulser_amd import QutipEmulator
+    from pulser_amd.results import LazyState
+
+    prob, times, ref = ns14
+    emu = QutipEmulator(_inputs_from_problem(prob, "ground-rydberg"), evaluation_times=spec)
+    with pytest.warns(DeprecationWarning):
+        res = emu.run()
+    ev = emu.evaluation_times
+    assert len(ev) == {"Full": 3101, "Minimal": 2, 0.1: 310}[spec]
+    st = emu.last_engine_stats
+    assert st["reserved"][0] > 0 and st["n_launches"] < 700 and st["n_applications"] < 26_000, st
+    checked = 0
+    for k, t in enumerate(times):
+        hit = np.nonzero(np.abs(ev - t) < 1e-9)[0]
+        if k == 0 or len(hit) == 0:
+            continue
+        state = res.states[int(hit[0])]
+        assert isinstance(state, LazyState) and state.isket and state.shape == (2**14, 1)
+        err = float(np.max(np.abs(np.asarray(state)[:, 0] - ref[k])))
+        assert err < AMP_TOL, (spec, t, err)
+        assert err < max(4 * st["reserved"][0], 2e-9), (spec, t, err, st["reserved"])  # the estimate covers the error
+        checked += 1
+    assert checked == (5 if spec == "Full" else 1)
+    if spec == "Full":
+        assert res.states[1000].device_tensor is not None  # five reads did not move the store to the host
+        # ... and the results read like the reference's: sampling the final state, an observable over a few times
+        np.random.seed(3)
+        counts = res.sample_final_state(200)
+        assert sum(counts.values()) == 200
+        assert abs(float(np.vdot(res.states[-1], res.states[-1]).real) - 1.0) < 1e-9
+
+
 @pytest.mark.parametrize("no_merge", [False, True])
 def test_split_operator_rows_interacting_10_atoms_against_tight_oracle(no_merge):
     """run_rows (k_ket row passes, kick, k_transpose_conj) on an interacting register vs zvode rtol 1e-13."""

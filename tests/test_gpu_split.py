@@ -522,9 +522,12 @@ def test_register_resident_14_atom_kernel_complex_drives_and_per_sequence_intera
 
 
 def test_14_atom_batches_choose_their_kernel_from_the_schedule_of_the_call():
-    """End state of the anneal: multi-knot steps -> k_split14_loop (a launch per closed run, a third of k_ket's
-    stages).  Evaluation times at every knot: nothing to merge -> k_ket, the whole schedule in one launch.
-    `no_split14` keeps k_ket in either case.  Same kets (both inside the bar by the full-size tests)."""
+    """End state of the anneal: multi-knot steps -> k_split_reg (a launch per closed run, a third of k_ket's
+    stages).  Evaluation times at every knot (evaluation_times="Full", the reference's default, simulation.py:137): since
+    round 5 the snapshots are stored from the registers INSIDE the runs (k_split_reg<.., SNAP> + k_split_snap_close), so
+    the call stays on the split kernel - 6-stage one-knot sub-steps, a launch per 64 knots - instead of k_ket; with the
+    round-4 hook (`snaps_outside`) nothing merges -> k_ket, the whole schedule in one launch.  `no_split14` keeps k_ket in
+    either case.  Same kets (both inside the bar by the full-size tests)."""
     probs = _scaled_anneals(8)
     res = {}
     with _engine(probs) as eng:
@@ -534,15 +537,56 @@ def test_14_atom_batches_choose_their_kernel_from_the_schedule_of_the_call():
             eng.reset_stats()
             eng.evolve(st, 0.0, 0.9)
             res[name] = (st.cpu().numpy(), eng.stats())
-        eng.set_path(False)
-        eng.reset_stats()
         every = np.arange(0, 61) * 1e-3
-        eng.solve(eng.new_state(), every)
-        s_every = eng.stats()
-    assert res["k_ket"][1]["n_launches"] == 1 and s_every["n_launches"] == 1
+        snaps = {}
+        for name, kw in (("inside", {}), ("outside", {"snaps_outside": True})):
+            eng.set_path(False, **kw)
+            eng.reset_stats()
+            snaps[name] = (eng.solve(eng.new_state(), every).cpu().numpy(), eng.stats())
+    assert res["k_ket"][1]["n_launches"] == 1 and snaps["outside"][1]["n_launches"] == 1
     assert res["auto"][1]["n_launches"] > 1 and res["auto"][1]["reserved"][0] > 0
     assert res["auto"][1]["n_applications"] < 0.5 * res["k_ket"][1]["n_applications"]
     assert np.max(np.abs(res["auto"][0] - res["k_ket"][0])) < 2e-8
+    s_in = snaps["inside"][1]
+    assert s_in["reserved"][0] > 0 and 1 < s_in["n_launches"] <= 8  # the controller booked; runs, not one per evaluation time
+    assert s_in["n_applications"] < 0.6 * snaps["outside"][1]["n_applications"]
+    assert np.max(np.abs(snaps["inside"][0] - snaps["outside"][0])) < 2e-8  # every stored time, every sequence
+
+
+@pytest.mark.parametrize("n", [12, 13, 14])
+def test_snapshots_stored_inside_a_run_equal_a_closed_run_per_evaluation_time(n):
+    """k_split_reg<.., SNAP> stores the OPEN state of a sub-step boundary (the last D of the sub-step is fused into the
+    next stage, the cosines of the tan-form rotations ride on it) and k_split_snap_close finishes the stored kets: the same
+    arithmetic as a run that closes at the evaluation time, so the two agree to rounding at EVERY stored time - dense
+    times (one-knot 6-stage sub-steps), every 10th knot (6th-order multi-knot sub-steps cut by the controller) and ragged
+    lists with times between knots; different sequences per batch entry; a pulse phase (the gauge of the real kernel:
+    the stored frame must be the laboratory frame).  Against CF4 + Taylor at a tight tolerance too."""
+    coords = P.register_coords(P.triangular_rect(2, 7) if n == 14 else P.square_rect(1, n), blockade_radius())
+    base = P.anneal_samples()
+    T = 901
+    probs = []
+    for b in range(3):
+        f = 1.0 - 0.15 * b
+        probs.append(P.make_ising_problem(coords, {"amp": base["amp"][:T] * f, "det": base["det"][:T] * (2.0 - f),
+                                                   "phase": np.full(T, 0.4 * b)}))
+    grid = np.arange(T) * 1e-3
+    cases = {"dense": grid[:260], "every10": grid[::10],
+             "ragged": np.unique(np.concatenate([grid[::37], grid[480:530], [0.4005, 0.51234, 0.9]]))}
+    for label, times in cases.items():
+        outs, stats = {}, {}
+        for name, kw, opts in (("inside", {}, {}), ("outside", {"snaps_outside": True}, {"method": "split"}),
+                               ("taylor", {}, {"method": "taylor", "tol": 1e-12})):
+            with _engine(probs) as eng:
+                eng.set_path(False, **kw)
+                outs[name] = eng.solve(eng.new_state(), times, **opts).cpu().numpy()
+                stats[name] = eng.stats()
+        assert stats["inside"]["reserved"][0] > 0, label  # the split-operator path ran
+        assert stats["inside"]["n_launches"] < max(8, 0.4 * len(times)), (label, stats["inside"])
+        assert np.max(np.abs(outs["inside"] - outs["outside"])) < 1e-12, label
+        # (the controller's budget for a whole sequence is 5e-8; these are 0.9 us of three differently scaled anneals)
+        assert np.max(np.abs(outs["inside"] - outs["taylor"])) < 5e-8, label
+        assert stats["inside"]["reserved"][0] < 5e-8, label
+        assert np.max(np.abs(outs["inside"][:, 0] - outs["inside"][:, 1])) > 1e-3  # the sequences really differ
 
 
 def test_modulated_local_complex_drives_take_the_split_kernel_by_default():

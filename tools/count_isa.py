@@ -3,20 +3,25 @@ accounting behind bench.py's roofline): python tools/count_isa.py [mode] > profi
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "pulser_amd", "csrc", "rydemu.hip")
-if os.environ.get("RYD_ISA_TEXT"):  # (an assembly listing made earlier: the tests compile once for several counts)
+# round 5: the library is four translation units (k_split_reg_inst.hpp) - k_split_reg<14, ..> lives in the part unit
+# rydemu_splitreg.hip (-DRYD_SPLITR_N=14), everything else in rydemu.hip (-DRYD_SPLIT_TUS)
+splitreg = len(sys.argv) > 1 and sys.argv[1] == "splitreg"
+src = os.path.join(ROOT, "pulser_amd", "csrc", "rydemu_splitreg.hip" if splitreg else "rydemu.hip")
+defs = ["-DRYD_SPLITR_N=14"] if splitreg else ["-DRYD_SPLIT_TUS"]
+if os.environ.get("RYD_ISA_TEXT") and not splitreg:  # (a listing of rydemu.hip made earlier: the tests compile it once)
     text = open(os.environ["RYD_ISA_TEXT"]).read()
 else:
     with tempfile.TemporaryDirectory() as d:
         asm = os.path.join(d, "r.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                        "-Wno-unused-value", src, "-o", asm], check=True, stderr=subprocess.DEVNULL)
+                        "-Wno-unused-value", "-Wno-unused-function", *defs, src, "-o", asm], check=True,
+                       stderr=subprocess.DEVNULL)
         text = open(asm).read()
-    if os.environ.get("RYD_ISA_KEEP"):
+    if os.environ.get("RYD_ISA_KEEP") and not splitreg:
         open(os.environ["RYD_ISA_KEEP"], "w").write(text)
 if len(sys.argv) > 1 and sys.argv[1] == "splitreg":
     # k_split_reg<14, 5, false>: fp64 work of the stage loop (ONE stage body per iteration, 32 amplitudes per lane)
-    m = re.search(r"^(_Z\d+k_split_regILi14ELi5ELb0E\w*):(.*?)s_endpgm", text, re.S | re.M)
+    m = re.search(r"^(_Z\d+k_split_regILi14ELi5ELb0ELb0ELb0ELb0E\w*):(.*?)s_endpgm", text, re.S | re.M)
     body = m.group(2).split("\n")
     best = None
     for hdr in [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]:
