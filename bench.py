@@ -72,11 +72,18 @@ KSPLITREG_FLOPS_PER_AMP_STAGE = (2 * (687 + 475) + 241 + 9 + 7) / 32.0
 SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE = 14 * 2 * 2 + 6.0
 
 
+# ISA counts of the other shapes of the kernel (tools/count_isa.py splitreg N NR; per amplitude and stage).  The plain
+# 12-atom kernel runs 16 amplitudes per lane on 256 lanes since round 5 (NR = 4)
+KSPLITREG_SHAPES = {12: (4, (2 * 543 + 138 + 8 + 6) / 16.0), 13: (5, (2 * 1098 + 240 + 8 + 7) / 32.0),
+                    14: (5, KSPLITREG_FLOPS_PER_AMP_STAGE)}
+
+
 def split_reg_roofline(n, batch, stats, kms, kl, traffic_key=None, note=None):
-    """Roofline of a solve that ran on k_split_reg<n, 5>: one atom fewer = one tan-form rotation (2 FMAs) fewer per
-    amplitude and stage, by ISA count (checked for n = 14 by tests/test_host_logic.py) and on paper."""
-    return roofline_valu(2.0**n, batch, stats["n_applications"], KSPLITREG_FLOPS_PER_AMP_STAGE - 4.0 * (14 - n), kms, kl,
-                         KSPLITREG_NAME.replace("<14, 5>", f"<{n}, 5>"), traffic_key, note=note,
+    """Roofline of a solve that ran on k_split_reg<n, NR>: fp64 flops by ISA count of that shape (checked for (14, 5) and
+    (12, 4) by tests/test_host_logic.py); on paper one atom fewer = one tan-form rotation (2 FMAs) fewer per amplitude."""
+    nr, flops = KSPLITREG_SHAPES[n]
+    return roofline_valu(2.0**n, batch, stats["n_applications"], flops, kms, kl,
+                         KSPLITREG_NAME.replace("<14, 5>", f"<{n}, {nr}>"), traffic_key, note=note,
                          algorithmic_flops_per_amp_stage=SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE - 4.0 * (14 - n))
 
 
@@ -769,7 +776,7 @@ def main() -> None:
             "config": {"workload": "BASELINE configs[1]: 12-atom chain at the blockade radius, analog Ising "
                                    "anneal 3100 ns, sesolve complex128; batch of independent sequences per GPU",
                        "n_atoms": n, "sequences_per_gpu": B, "sim_us_per_sequence": T_SEQ_US,
-                       "integrator": "split-operator, 6th-order composition over multi-knot sub-steps (k_split_reg<12, 5>)"
+                       "integrator": "split-operator, 6th-order composition over multi-knot sub-steps (k_split_reg<12, 4>)"
                                      if ran_split_reg(stats) else "CF4 Magnus + Taylor(Horner), tol 1e-10/exponential",
                        "generator_applications_per_sequence": stats["n_applications"],
                        "parallelism": f"dp{n_gpus} (independent sequences, all-reduce of ensemble sums only)"},
@@ -857,7 +864,7 @@ def main() -> None:
             leg = {"workload": f"256 x {n_c}-atom sequences with per-atom complex, time-dependent drives (local addressing), 400 ns",
                    "value": 256 * 0.4 / sec, "unit": "sim-us/s", "ms_per_batch": sec * 1e3,
                    "stages_per_sequence": stats["n_applications"], "launches": stats["n_launches"],
-                   "kernel": (KSPLITREG_NAME.replace("14, 5", f"{n_c}, 5") + "; the drive phases carried by the D factors, "
+                   "kernel": (KSPLITREG_NAME.replace("14, 5", f"{n_c}, {KSPLITREG_SHAPES[n_c][0]}") + "; the drive phases carried by the D factors, "
                               "4th-order 6-stage composition with one-knot sub-steps (modulated drives: nothing to merge)")
                              if ran_split_reg(stats) else poly_name}
             if ran_split_reg(stats):

@@ -2,6 +2,18 @@
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// State of the split-operator step-size controller for one kind of step (host_split.hpp: run_split)
+struct SplitCtl {
+  double tau = 1e300;     // working sub-step (us); 1e300 = never measured: whole steps until the first check
+  double rate = 0.0;      // last measured local error per us ...
+  double rate_tau = 0.0;  // ... at sub-steps of this length (us)
+  double amp = 0.0;       // drive bound at the last check
+  int since = 0;          // knot intervals of this kind since the last check
+  int period = 0;         // knot intervals until the next periodic check (0: kSplitCheckFirst; doubles up to kSplitCheckEvery)
+  double len_since = 0.0; // simulated time (us) this kind's sub-steps have covered since its last check
+  bool known = false;
+};
+
 struct Pass {
   Segs tile, outer;
   int T = 0;
@@ -92,12 +104,8 @@ struct ryd_handle {
   void* many_args_dev = nullptr;  // ryd_general_solve_many: argument table of the batched launch (first handle)
   size_t many_cap = 0;
   bool split_known = false;       // controller state below is valid for the current tables
-  double split_tau = 1e300;       // target sub-step (us); 1e300 = whole schedule steps
-  double split_rate = 0.0;        // last measured local error per us ...
-  double split_rate_tau = 0.0;    // ... and the sub-step length (us) it was measured at
-  double split_amp = 0.0;  // drive bound at the controller's last check
+  SplitCtl split_ctl[2];          // the controller's state by kind of step (run_split: kind_of)
   double split_eps = 0.0;         // tolerance the state was measured for
-  int split_since = 0;            // schedule steps since the last check
   double split_since_len = 0.0;   // simulated time (us) covered since the last check
   const void* split_state_last = nullptr;  // ... and the state buffer it advanced
   double split_t_last = -1e300;   // end time (us) of the last split-operator solve: the state above belongs to its continuation

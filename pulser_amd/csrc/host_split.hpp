@@ -72,6 +72,8 @@ struct SubStep {
   int idx;     // knot interval
   double u0;   // start - tknots[idx]
   double tau;
+  int alt;     // 1: a sub-step of a ONE-KNOT step under the 6th-order scheme - it runs the 4th-order 6-stage composition
+               // (decided by the step, run_split: kind_of - not by the sub-step's own length; round 5)
 };
 
 // (quantum-jump trajectories included: H_eff only adds a real decay factor to the D stages, the jump
@@ -172,11 +174,43 @@ static bool split_loop14(const ryd_handle* h) {
 // Whole kets of 12 - 14 atoms with real drives: every stage of a closed run in ONE launch of k_split_reg (k_split_reg.hpp,
 // round 4), the ket register-resident, one workgroup per sequence (14 atoms: one per CU; 13: two; 12: three).
 // Quantum-jump solves included (the decay factor of H_eff rides on the phase factors: template parameter DECAY).
+static int device_cu_count(int dev) {
+  static int n_cu_of[64] = {};  // per device (a process may hold handles on different device models)
+  int n_cu = (dev >= 0 && dev < 64) ? n_cu_of[dev] : 0;
+  if (!n_cu) {
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev < 0 ? 0 : dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    if (dev >= 0 && dev < 64) n_cu_of[dev] = n_cu;
+  }
+  return n_cu;
+}
+
 template <int N>
 static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R, hipStream_t st, size_t n_rows = 0, bool snap = false) {
   constexpr int NT = 64 << (N - 11);
-  // RYD_SPLIT_NR=6 (dev A/B, 14 atoms only): 64 amplitudes per lane on 256 lanes instead of 32 on 512 (measured slower)
-  static const int nr_env = dev_env_int("RYD_SPLIT_NR", 5, 5, 6);
+  // RYD_SPLIT_NR (dev A/B, RYD_DEV=1): 6 = 64 amplitudes per lane on 256 lanes (14 atoms only; measured slower), 4 / 5 at
+  // 12 atoms = force the shape below
+  static const int nr_env = dev_env_int("RYD_SPLIT_NR", 0, 4, 6);
+  // 12 atoms: 16 amplitudes per lane on 256 lanes (NR = 4, four waves per sequence; round 5).  With NR = 5 a sequence is two
+  // waves: 256 sequences on 256 CUs ran with half the SIMDs idle.  Measured on the cfg2 batch (sim-us/s, NR 4
+  // against 5): 256 sequences 29 900 / 22 600, 512: 41 300 / 30 400, 1024: 43 600 / 35 200 - the shorter register runs win
+  // at every batch size (160 instead of 223 vector registers: three workgroups of a CU overlap each other's LDS passes),
+  // so NR = 4 is the shape of the plain 12-atom kernel; quantum jumps, density-matrix rows and the complex-arithmetic
+  // kernel keep NR = 5
+  if constexpr (N == 12) {
+    const bool nr4 = nr_env != 5;
+    if (nr4 && !n_rows && !h->mc && split_real(h)) {
+      constexpr int NT4 = 256;
+      const size_t lds4 = (size_t)2 * NT4 * 4 * 16 + SPLITR_TRIG * 16 + (size_t)(NT4 / 64) * 16 * 16 +
+                          (SPLIT_MAX_SUB * SPLIT_MAX_STAGES + 2) * 8 + (SPLITR_EMODE ? 4 * NT4 * 8 : 0) + (128 + 32) * 8;
+      const long long stride4 = (long long)h->B * N * 4;
+      if (snap)
+        hipLaunchKernelGGL((k_split_reg<12, 4, false, false, false, true>), dim3(1, h->B), dim3(NT4), lds4, st, A, R, stride4);
+      else
+        hipLaunchKernelGGL((k_split_reg<12, 4, false>), dim3(1, h->B), dim3(NT4), lds4, st, A, R, stride4);
+      HIPCHK(hipGetLastError());
+      return RYD_OK;
+    }
+  }
   const size_t lds = (size_t)2 * NT * 8 * 16 + SPLITR_TRIG * 16 + (size_t)(NT / 64) * 32 * 16 +
                      (SPLIT_MAX_SUB * SPLIT_MAX_STAGES + 2) * 8 + (SPLITR_EMODE ? 4 * NT * 8 : 0) + (128 + 32) * 8;
   const int dev = h->cfg.device;
@@ -194,12 +228,7 @@ static int launch_split_reg(ryd_handle* h, const SplitArgs& A, const SplitRun& R
   }
   const long long stride = (long long)h->B * N * 4;
   if (n_rows) {  // rows of density matrices as kets (run_rows): persistent workgroups, as many as the chip holds
-    static int n_cu_of[64] = {};  // per device (a process may hold handles on different device models)
-    int n_cu = (dev >= 0 && dev < 64) ? n_cu_of[dev] : 0;
-    if (!n_cu) {
-      HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev < 0 ? 0 : dev));
-      if (dev >= 0 && dev < 64) n_cu_of[dev] = n_cu;
-    }
+    const int n_cu = device_cu_count(dev);
     const unsigned per_cu = N == 14 ? 1u : N == 13 ? 2u : 3u;
     const unsigned workers = std::min<unsigned>(1u << N, (unsigned)std::max(n_cu, 1) * per_cu);
     hipLaunchKernelGGL((k_split_reg<N, 5, false, true>), dim3(1, workers, (unsigned)h->B), dim3(NT), lds, st, A, R, stride);
@@ -479,7 +508,8 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
 }
 
 // ---- rows of a density matrix on k_split_reg (declared in host_ket.hpp: run_rows) ----
-static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, double tau_t, std::vector<SubStep>& out);
+static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, double tau_t, std::vector<SubStep>& out,
+                           int alt = 0);
 // The caller's options decide too: the split-operator sub-steps of a half block are calibrated, not
 // tolerance-driven - one 6-stage / 10-stage sub-step per schedule step ends ~3e-9 from the k_ket rows over the anneal - so
 // a caller who asks for a tolerance tighter than that, names another propagator (ryd_opts.method) or fixes the Taylor
@@ -585,9 +615,10 @@ static int split_advance(ryd_handle* h, cplx* buf, const std::vector<SubStep>& s
   // waveform kink, where nothing can be merged: 182 of the 547 schedule steps of the anneal) still run the 4th-order
   // 6-stage composition: at one knot interval its error is 1e-13 per sub-step (NumPy model), far below
   // what the controller books for them, and it costs 6 stages instead of 10 (round 4: 8 290 -> 7 560 stages at 14 atoms).
-  auto one_knot = [&](const SubStep& s) {
-    return h->split_s10 && !h->split_s6_only && s.u0 + s.tau <= (h->tknots[s.idx + 1] - h->tknots[s.idx]) * (1.0 + 1e-9);
-  };
+  // (the flag is set by run_split from the STEP a sub-step belongs to; until round 5 it was re-derived here from the
+  // sub-step's own extent, which also caught the first of the 0.9-ns sub-steps of a 9-knot step - a 4th-order sub-step
+  // where the controller had measured the 6th-order one: 8.7e-8 on a strongly interacting chain, tools/fuzz_ctrl.py seed 40)
+  auto one_knot = [&](const SubStep& s) { return h->split_s10 && !h->split_s6_only && s.alt != 0; };
   size_t at = 0;
   // k_split_reg runs both compositions inside one closed run (SplitRun.mixed, round 5): the run is only cut at the cap
   const bool mix = split_reg_shape(h) && !h->mc && split_real(h) && !h->snaps_outside;
@@ -611,12 +642,12 @@ static int split_advance(ryd_handle* h, cplx* buf, const std::vector<SubStep>& s
 
 // Sub-steps of target length tau_t covering the part of step d after offset `off`.
 static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, double tau_t,
-                           std::vector<SubStep>& out) {
+                           std::vector<SubStep>& out, int alt) {
   const double rem = d.h - off;
   const int k = std::max(1, (int)std::ceil(rem / tau_t - 1e-9));
   const double tau = rem / k;
   const double u_start = d.u1 - kC1 * d.h + off;  // step start relative to its knot
-  for (int s = 0; s < k; ++s) out.push_back({d.idx, u_start + s * tau, tau});
+  for (int s = 0; s < k; ++s) out.push_back({d.idx, u_start + s * tau, tau, alt});
 }
 
 // The solve loop of the split-operator path.  Step-size control: every kSplitCheckEvery steps one
@@ -631,6 +662,12 @@ static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, d
 // check is also due when the drive bound has grown by half since the last one (above a tenth of its maximum): the
 // local error of a sub-step goes with a high power of the drive amplitude.
 static const int kSplitCheckEvery = 256;  // (128: 24 + 6 checks on the headline anneal, 0.35 ms each for 256 kets = 14 % of the step)
+// Round 5: after a COLD start the period grows 16 -> 32 -> ... -> 256 knot intervals.  The local error of a sub-step is
+// measured on the state at hand, and the product state a sequence starts from is the least representative one: on a
+// 16-atom chain under a square pulse (constant drive from t = 0, so no amplitude trigger) the first 9-ns step measured
+// 1.0e-9, the steps 100 ns later erred six times that, and the one check of the 283-ns sequence booked 2.8e-8 for a true
+// 1.85e-7 (tools/fuzz_ctrl.py seed 263).  Any check (amplitude, regime) counts as one doubling.
+static const int kSplitCheckFirst = 16;
 
 // RYD_DEV=1 RYD_SPLIT_TRACE=1 (dev): every check of the controller on stderr
 static bool split_trace_env() {
@@ -649,6 +686,24 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   t_total = std::max(t_total, h->tknots.back() - h->tknots.front());
   const double eps = o.tol > 0 ? 500.0 * o.tol : kSplitTolTotal;
   const bool control = !h->split_fixed;
+  // Two KINDS of steps, two controllers (round 5).  Under the 6th-order scheme the steps that lie inside one knot interval
+  // (spline ringing next to a kink, a knot an evaluation time cuts off) run the 4th-order 6-stage composition: another
+  // integrator with another error law, so it gets its own measured sub-step, error rate and check period (kind 1); every
+  // other step - and every step when the call runs the 6-stage scheme throughout - is kind 0.  Until round 5 one state
+  // served both: a check that fell on a one-knot step measured the 6TH-order scheme on it, and one-knot steps ran whole
+  // whatever the interaction strength (fuzz: 1 240 unchecked one-knot steps on a 5-um chain, then a roll-back to t = 0).
+  // (a one-knot step in the middle of a SMOOTH stretch - the knot an evaluation time cuts off a 9-knot step - is kind 0:
+  // the 10 stages of the 6th-order scheme over 1 ns cost less than the two 4th-order sub-steps a strong drive asks for,
+  // and their error is the measured kind-0 error scaled down by (1 ns / tau)^7)
+  auto kind_of = [&](const StepDesc& d) {
+    if (!h->split_s10 || h->split_s6_only || d.pad > 1) return 0;
+    const double u0 = d.u1 - kC1 * d.h;
+    if (u0 + d.h > (h->tknots[d.idx + 1] - h->tknots[d.idx]) * (1.0 + 1e-9)) return 0;
+    const int nj = (int)h->join_ok.size();
+    const bool smooth = (d.idx == 0 || (d.idx - 1 < nj && h->join_ok[d.idx - 1])) && d.idx < nj && h->join_ok[d.idx];
+    return smooth ? 0 : 1;
+  };
+  auto scheme_of = [&](int k) -> const SplitScheme& { return k == 1 ? kSplitS6 : split_scheme(h); };
   // the controller's state survives between calls on the same tables (a front end that advances
   // from evaluation time to evaluation time must not pay a check per call)
   // ... but only for a call that CONTINUES where the last one ended: a sub-step measured at the end of a sequence says
@@ -661,14 +716,11 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   h->split_state_last = state;
   if (!h->split_known || h->split_eps != eps) {
     h->split_known = false;
-    h->split_tau = 1e300;
-    h->split_rate = 0.0;
-    h->split_rate_tau = 0.0;
-    h->split_since = 0;
+    for (SplitCtl& c : h->split_ctl) c = SplitCtl();
     h->split_since_len = 0.0;
   }
-  double tau_t = control ? h->split_tau : 1e300;  // target sub-step (us); 1e300 = whole steps
-  int since = h->split_since;                     // schedule steps since the last check
+  SplitCtl ctl[2] = {h->split_ctl[0], h->split_ctl[1]};
+  if (!control) ctl[0] = ctl[1] = SplitCtl();
   // (a sub-step measured on another time region or state is caught by the next periodic check, which can
   // roll back to the checkpoint taken at the start of this call)
   size_t i = 0;
@@ -688,29 +740,28 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   const bool snaps_inside = snaps && split_reg_shape(h) && !jumps && !h->mc && !h->snaps_outside;
   std::vector<double> errs(h->B);
   h->stats.reserved[0] = 0.0;  // accumulated local-error estimate of this solve
-  double err_rate = control ? h->split_rate : 0.0;  // last measured local error per us ...
-  double err_tau = control ? h->split_rate_tau : 0.0;  // ... at sub-steps of this length, by a scheme of order err_p
-  int err_p = split_scheme(h).order;
-  auto book_rate = [&](double tau) {
-    return err_tau > 0.0 ? err_rate * std::pow(tau / err_tau, (double)err_p) : err_rate;
+  // local error per us measured at sub-steps of rate_tau; sub-steps of another length are booked with the p-th power of
+  // the ratio
+  auto book_rate = [&](int k, double tau) {
+    const SplitCtl& c = ctl[k];
+    return c.rate_tau > 0.0 ? c.rate * std::pow(tau / c.rate_tau, (double)scheme_of(k).order) : c.rate;
   };
-  // Quantisation slack (round 5).  The working sub-step tau_t aims at HALF the allowance of a sub-step; a step of length
-  // h is cut into k = ceil(h / tau) equal sub-steps, so where h is a little over tau_t the k-th cut pays for a factor
+  // Quantisation slack (round 5).  The working sub-step tau aims at HALF the allowance of a sub-step; a step of length
+  // h is cut into k = ceil(h / tau) equal sub-steps, so where h is a little over tau the k-th cut pays for a factor
   // (k / (k - 1))^p of accuracy nobody asked for - worst with evaluation times at every knot, where a one-knot step whose
   // error sits between half and all of its allowance was cut in two (12 stages per knot instead of 6).  Sub-steps may
-  // therefore be up to 2^(1/p) longer than tau_t (predicted error <= the allowance); what they cost is booked at the
+  // therefore be up to 2^(1/p) longer than tau (predicted error <= the allowance); what they cost is booked at the
   // p-th power of their length (book_rate), so the estimate a caller reads stays honest.  RYD_DEV=1 RYD_SPLIT_SLACK=0: off.
   static const bool slack_on = dev_env_flag("RYD_SPLIT_SLACK", true);
-  auto tau_q = [&]() {
-    return (slack_on && tau_t < 1e299) ? tau_t * std::pow(2.0, 1.0 / split_scheme(h).order) : tau_t;
+  auto tau_q = [&](int k) {
+    return (slack_on && ctl[k].tau < 1e299) ? ctl[k].tau * std::pow(2.0, 1.0 / scheme_of(k).order) : ctl[k].tau;
   };
-  double h_max = 0.0;  // longest step of this call
-  for (const StepDesc& d : sched) h_max = std::max(h_max, d.h);
+  double h_max[2] = {0.0, 0.0};  // longest step of this call, by kind
+  for (const StepDesc& d : sched) { const int k = kind_of(d); h_max[k] = std::max(h_max[k], d.h); }
   double amp_max = 0.0;
   for (double v : h->bd_c1) amp_max = std::max(amp_max, v);
   auto amp_at = [&](const StepDesc& d) { return span_max(h->bd_c1, d.idx, std::max(1, d.pad)); };
-  double amp_ck = control && h->split_known ? h->split_amp : 0.0;  // drive bound at the last check
-  if (control && h->split_known && since > 0 && since < kSplitCheckEvery) {
+  if (control && h->split_known && (ctl[0].since > 0 || ctl[1].since > 0)) {
     // a front end that advances in slices shorter than the check period would otherwise never own a
     // checkpoint when the periodic check fires: the start of the call is one (a device copy, no check)
     HIPCHK(hipMemcpyAsync(h->wB, state, bytes, hipMemcpyDeviceToDevice, st));
@@ -724,6 +775,19 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     const int at = sched[k].idx;  // the knot this step starts at: removable = the previous step was cut for another reason
     const bool on_knot = std::fabs(sched[k].u1 - kC1 * sched[k].h) < 1e-12;
     return !(on_knot && at >= 1 && at - 1 < (int)h->join_ok.size() && h->join_ok[at - 1]);
+  };
+  // is a check due at step q (of kind k)?  `knots`: knot intervals of that kind since its last check
+  auto period_of = [&](int k) { return ctl[k].period > 0 ? ctl[k].period : kSplitCheckFirst; };
+  auto check_due = [&](size_t q, int k, int knots) {
+    return !ctl[k].known || knots >= period_of(k) || amp_at(sched[q]) > std::max(1.5 * ctl[k].amp, 0.1 * amp_max);
+  };
+  // the composition a step of kind 1 RUNS: its own (4th order, 6 stages per sub-step) or, once both kinds are measured,
+  // the 6th-order one where that takes fewer stages (10 per sub-step, but far longer sub-steps)
+  auto run_kind = [&](const StepDesc& d, double rem) {
+    const int k = kind_of(d);
+    if (k == 0 || !control || !ctl[0].known || !ctl[1].known) return k;
+    const double n6 = std::max(1.0, std::ceil(rem / tau_q(1) - 1e-9)), n10 = std::max(1.0, std::ceil(rem / tau_q(0) - 1e-9));
+    return kSplitS6.S * n6 > split_scheme(h).S * n10 ? 0 : 1;
   };
   auto finish_step = [&](size_t k) -> int {
     int rcf;
@@ -740,23 +804,25 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     // (a one-knot step that only an evaluation time or the call's end cut off a smooth stretch is no kink: with
     // evaluation times at every 10th knot the rule used to fire a check - three launches, three copies - per evaluation
     // time; round 5)
+    const int kd = kind_of(sched[i]);
+    const SplitScheme& sck = scheme_of(kd);
     const bool new_regime = control && off == 0.0 && regime_start(i) && i != last_regime_check;
     if (new_regime) last_regime_check = i;
-    const bool amp_grown = control && off == 0.0 && amp_at(sched[i]) > std::max(1.5 * amp_ck, 0.1 * amp_max);
-    // A check measures ONE sub-step of the step it lands on, and its result sets the sub-step of every step that follows:
-    // it has to land on a step long enough to say something about them.  (Round 5: with evaluation times at every 10th
-    // knot the schedule alternates 9-knot and 1-knot steps; a check that fell on a 1-knot step measured nothing, returned
-    // "whole steps", and the 9-knot steps ran unchecked while the drive grew - 3.8e-7 from a tight run with an estimate of
-    // 4.5e-9, tools/snap_check.py.)  A check that is due waits for a step whose sub-step is at least half the working
-    // sub-step (or half the longest step of the call, where every step is short).
-    const bool informative = !h->split_known || tau_t >= 1e299 ||
-                             (sched[i].h - off) / std::max(1.0, std::ceil((sched[i].h - off) / tau_q() - 1e-9)) >=
-                                 0.5 * std::min(tau_t, h_max) * (1.0 - 1e-9);
-    if (control && informative && (!h->split_known || since >= kSplitCheckEvery || new_regime || amp_grown)) {
+    const bool amp_grown = control && off == 0.0 && amp_at(sched[i]) > std::max(1.5 * ctl[kd].amp, 0.1 * amp_max);
+    // A check measures ONE sub-step of the step it lands on, and its result sets the sub-step of every step of its kind
+    // that follows: it has to land on a step long enough to say something about them.  (Round 5: with evaluation times at
+    // every 10th knot the schedule alternates 9-knot and 1-knot steps; a check that fell on a 1-knot step measured
+    // nothing, returned "whole steps", and the 9-knot steps ran unchecked while the drive grew - 3.8e-7 from a tight run
+    // with an estimate of 4.5e-9, tools/snap_check.py.)  A check that is due waits for a step whose sub-step is at least
+    // half the working sub-step of its kind (or half the longest step of that kind, where every step is short).
+    const bool informative = !ctl[kd].known || ctl[kd].tau >= 1e299 ||
+                             (sched[i].h - off) / std::max(1.0, std::ceil((sched[i].h - off) / tau_q(kd) - 1e-9)) >=
+                                 0.5 * std::min(ctl[kd].tau, h_max[kd]) * (1.0 - 1e-9);
+    if (control && informative && (check_due(i, kd, ctl[kd].since) || new_regime || amp_grown)) {
       // ---- check: one sub-step whole (wA) against two halves (state) ----
       const StepDesc& d = sched[i];
       subs.clear();
-      split_substeps(h, d, off, tau_q(), subs);
+      split_substeps(h, d, off, tau_q(kd), subs, kd);
       const SubStep s0 = subs[0];
       if (!have_ck && !jumps) {
         // the first check of a call: its own start is the checkpoint (a sub-step never measured here - 8 knots of the
@@ -771,9 +837,9 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       }
       const bool ck_here = ck_i == i && ck_off == off;
       HIPCHK(hipMemcpyAsync(h->wA, state, bytes, hipMemcpyDeviceToDevice, st));
-      if ((rc = split_run(h, h->wA, &s0, 1, st))) return rc;
-      const SubStep halves[2] = {{s0.idx, s0.u0, 0.5 * s0.tau}, {s0.idx, s0.u0 + 0.5 * s0.tau, 0.5 * s0.tau}};
-      if ((rc = split_run(h, state, halves, 2, st))) return rc;
+      if ((rc = split_run(h, h->wA, &s0, 1, st, kd == 1))) return rc;
+      const SubStep halves[2] = {{s0.idx, s0.u0, 0.5 * s0.tau, kd}, {s0.idx, s0.u0 + 0.5 * s0.tau, 0.5 * s0.tau, kd}};
+      if ((rc = split_run(h, state, halves, 2, st, kd == 1))) return rc;
       HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)h->B * sizeof(double), st));
       const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(h->dim >> 10, 1), 256);
       hipLaunchKernelGGL(k_split_diff, dim3(nblk, h->B), dim3(256), 0, st, state, h->wA, h->nb, h->split_err);
@@ -783,7 +849,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       double e = 0.0;
       for (double v : errs) e = std::max(e, std::sqrt(std::max(v, 0.0)));
       // whole step against two halves: the difference is (1 - 2^-p) of the local error of the whole step
-      const int p_ord = split_scheme(h).order;
+      const int p_ord = sck.order;
       const double two_p = std::ldexp(1.0, p_ord);
       e *= two_p / (two_p - 1.0);
       const double allowed = eps * s0.tau / t_total;
@@ -791,10 +857,10 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       fac = std::min(std::max(fac, 0.2), p_ord == 6 ? 2.0 : 4.0);  // (x 2 in tau is x 64 in the 6th-order error)
       const double tau_new = s0.tau * fac;
       if (split_trace_env())
-        std::fprintf(stderr, "[ryd split] check at t = %.4f us (step %zu of %zu, %d knots, h = %.4g ns): sub-step %.4g ns, e = %.3g, "
-                     "allowed %.3g, fac %.3g, tau_t %.4g -> %.4g ns, scheme S%d, since %d%s%s\n",
-                     h->tknots[s0.idx] + s0.u0, i, sched.size(), d.pad, d.h * 1e3, s0.tau * 1e3, e, allowed, fac, tau_t * 1e3,
-                     tau_new * 1e3, split_scheme(h).S, since, new_regime ? " [regime]" : "", amp_grown ? " [amp]" : "");
+        std::fprintf(stderr, "[ryd split] check at t = %.4f us (step %zu of %zu, %d knots, h = %.4g ns, kind %d): sub-step %.4g ns, "
+                     "e = %.3g, allowed %.3g, fac %.3g, tau %.4g -> %.4g ns, scheme S%d, since %d%s%s\n",
+                     h->tknots[s0.idx] + s0.u0, i, sched.size(), d.pad, d.h * 1e3, kd, s0.tau * 1e3, e, allowed, fac,
+                     ctl[kd].tau * 1e3, tau_new * 1e3, sck.S, ctl[kd].since, new_regime ? " [regime]" : "", amp_grown ? " [amp]" : "");
       h->stats.reserved[1] = e;
       h->stats.reserved[2] = s0.tau;
       if (e > 4.0 * allowed && have_ck && retries < 4 && !jumps) {  // (a roll-back would replay jumps)
@@ -803,13 +869,13 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
           // ... and when that stretch belongs to earlier calls (nothing to roll back to but this call's start) it ran
           // at about this error rate: booked in full, so that ryd_stats.reserved[0] (which callers compare with
           // their tolerance; the Python engine warns) tells the truth
-          ck_est += std::max(0.0, e / s0.tau - book_rate(s0.tau)) * h->split_since_len;
+          ck_est += std::max(0.0, e / s0.tau - book_rate(kd, s0.tau)) * h->split_since_len;
           h->split_since_len = 0.0;
         }
         HIPCHK(hipMemcpyAsync(state, h->wB, bytes, hipMemcpyDeviceToDevice, st));
         i = ck_i;
         off = ck_off;
-        tau_t = tau_new;
+        ctl[kd].tau = tau_new;
         ++retries;
         h->stats.reserved[3] += 1.0;  // rollbacks
         h->stats.n_steps = ck_steps;  // the repeated stretch is counted (and its error budgeted) once
@@ -819,7 +885,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       if (e > 4.0 * allowed) {
         // the retries are used up (or a quantum-jump solve, which cannot roll back): the stretch behind us ran
         // at about this error rate - booked in full
-        h->stats.reserved[0] += std::max(0.0, e / s0.tau - book_rate(s0.tau)) * h->split_since_len;
+        h->stats.reserved[0] += std::max(0.0, e / s0.tau - book_rate(kd, s0.tau)) * h->split_since_len;
       }
       retries = 0;
       static const double grow_env = dev_env_double("RYD_SPLIT_GROW", 1.3, 1.0, 4.0);  // dev A/B (RYD_DEV=1)
@@ -827,7 +893,11 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       // budget more closely: 7 360 -> 6 890 stages on the anneal, estimate 5.3e-9 -> 5.7e-9)
       // (the sub-step stays a LENGTH - the one this measurement stands for, times fac: until round 5 a check that found
       // its step within budget switched to "whole steps" of any length, see `informative` above)
-      if (tau_t >= 1e299 || fac < 0.9 || fac > grow_env) tau_t = tau_new;
+      if (ctl[kd].tau >= 1e299 || fac < 0.9 || fac > grow_env) ctl[kd].tau = tau_new;
+      // the stretch behind this check was booked at the rate of the PREVIOUS one: where the rate has grown in between the
+      // mean of the two is the better figure (the booked estimate is what callers compare with their tolerance)
+      if (e <= 4.0 * allowed && ctl[kd].known)
+        h->stats.reserved[0] += 0.5 * std::max(0.0, e / s0.tau - book_rate(kd, s0.tau)) * ctl[kd].len_since;
       h->stats.reserved[0] += e / two_p;  // the two halves are what was kept
       off += s0.tau;
       if (off >= d.h * (1.0 - 1e-12)) {
@@ -843,43 +913,46 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       ck_est = h->stats.reserved[0];
       h->split_since_len = 0.0;
       have_ck = true;
-      // local error per us measured at sub-steps of err_tau; sub-steps of another length are booked with the p-th power
-      // of the ratio (book_rate)
-      err_rate = e / s0.tau;
-      err_tau = s0.tau;
-      err_p = p_ord;
-      since = 0;
-      amp_ck = amp_at(d);
+      ctl[kd].rate = e / s0.tau;
+      ctl[kd].rate_tau = s0.tau;
+      ctl[kd].since = 0;
+      ctl[kd].len_since = 0.0;
+      ctl[kd].period = std::min(kSplitCheckEvery, 2 * period_of(kd));
+      ctl[kd].amp = amp_at(d);
+      ctl[kd].known = true;
       h->split_known = true;
       h->split_eps = eps;
+      if (i >= sched.size()) break;
     }
     // ---- the stretch up to the next check ----
-    size_t stop = control ? std::min(sched.size(), i + (size_t)std::max(kSplitCheckEvery - since, 1))
-                          : sched.size();
+    size_t stop = sched.size();
     if (control) {
-      // the stretch ends where a run of multi-knot steps begins, after kSplitCheckEvery knot intervals, or where the
-      // drive bound has grown by half: that step is checked (above)
-      int knots = since;
-      for (size_t q = i; q < stop; ++q) {
-        if (q > i && (regime_start(q) || knots >= kSplitCheckEvery ||
-                      amp_at(sched[q]) > std::max(1.5 * amp_ck, 0.1 * amp_max))) { stop = q; break; }
-        knots += std::max(1, sched[q].pad);
+      // the stretch ends where a run of multi-knot steps begins, after kSplitCheckEvery knot intervals of a kind, where
+      // the drive bound has grown by half since that kind's last check, or at the first step of a kind never measured:
+      // that step is checked (above) - if it can tell (`informative`); the step the stretch starts with is always taken
+      int knots[2] = {ctl[0].since, ctl[1].since};
+      for (size_t q = i; q < sched.size(); ++q) {
+        const int kq = kind_of(sched[q]);
+        if (q > i && (regime_start(q) || check_due(q, kq, knots[kq]))) { stop = q; break; }
+        knots[kq] += std::max(1, sched[q].pad);
       }
     }
     subs.clear();
     marks.clear();
     while (i < stop) {
       const StepDesc& d = sched[i];
+      const int kb = kind_of(d), k = run_kind(d, d.h - off);
       const size_t before = subs.size();
-      split_substeps(h, d, off, tau_q(), subs);
+      split_substeps(h, d, off, tau_q(k), subs, k);
       for (size_t q = before; q < subs.size(); ++q) {
-        h->stats.reserved[0] += book_rate(subs[q].tau) * subs[q].tau;
+        h->stats.reserved[0] += book_rate(k, subs[q].tau) * subs[q].tau;
         h->split_since_len += subs[q].tau;
+        ctl[k].len_since += subs[q].tau;
       }
       marks.resize(subs.size(), -1);
       off = 0.0;
       h->stats.n_steps++;
-      since += std::max(1, d.pad);
+      ctl[kb].since += std::max(1, d.pad);  // (the check period of a kind counts ITS steps, whatever they ran on)
       const bool snap = snaps && d.snap >= 0;
       if (snap && snaps_inside && i + 1 != stop) {
         // the evaluation time at the end of this step does not close the run (round 5): the snapshot is taken inside it
@@ -894,11 +967,8 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     }
   }
   if (control) {
-    h->split_tau = tau_t;
-    h->split_rate = err_rate;
-    h->split_rate_tau = err_tau;
-    h->split_since = since;
-    h->split_amp = amp_ck;
+    h->split_ctl[0] = ctl[0];
+    h->split_ctl[1] = ctl[1];
   }
   {
     const StepDesc& e = sched.back();

@@ -14,7 +14,9 @@
   X(N_, 5, true, false, true, false)   \
   X(N_, 5, false, false, false, true)
 
-#define SPLITR_INSTANCES_12(X) SPLITR_INSTANCES_OF(12, X)
+// 12 atoms, 16 amplitudes per lane on 256 lanes (NR = 4: four waves per sequence instead of two - round 5, batches that
+// leave SIMDs idle with NR = 5; launch_split_reg chooses by the grid)
+#define SPLITR_INSTANCES_12(X) SPLITR_INSTANCES_OF(12, X) X(12, 4, false, false, false, false) X(12, 4, false, false, false, true)
 #define SPLITR_INSTANCES_13(X) SPLITR_INSTANCES_OF(13, X)
 #define SPLITR_INSTANCES_14(X) SPLITR_INSTANCES_OF(14, X) X(14, 6, false, false, false, false)
 

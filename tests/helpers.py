@@ -106,3 +106,123 @@ def sketch_errors(rho, extra, k):
         "probes": float(np.max(np.abs(rho @ V - np.asarray(extra["oracle_probe_products_tight"])[k]))),
         "purity": float(abs(np.vdot(rho, rho).real - np.asarray(extra["oracle_purity_tight"])[k])),
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Seeded random pulse sequences from the waveform families Pulser ships (pulser-core/pulser/waveforms.py: Constant,
+# Ramp, Blackman, Kaiser, Interpolated (PCHIP), Composite; EOM-style square pulses with 1-ns edges and a detuning that
+# jumps with them; back-to-back pulses with phase jumps; delays) - restated in NumPy / SciPy, no pulser import: the fuzz
+# of the step-size controller (tests/test_gpu_fuzz.py, tools/fuzz_ctrl.py) runs on the GPU box.
+# ---------------------------------------------------------------------------------------------------------------------
+def _wf_constant(n, v):
+    return np.full(n, float(v))
+
+
+def _wf_ramp(n, a, b):
+    return P.ramp_samples(n, a, b) if n > 1 else np.full(n, float(a))
+
+
+def _wf_blackman(n, peak):
+    w = np.clip(np.blackman(n), 0, np.inf)
+    return peak * w / max(w.max(), 1e-300)
+
+
+def _wf_kaiser(n, peak, beta=14.0):
+    w = np.kaiser(n, beta)  # KaiserWaveform: np.kaiser window (waveforms.py), default beta 14
+    return peak * w / max(w.max(), 1e-300)
+
+
+def _wf_interpolated(rng, n, lo, hi, first=None, last=None):
+    """InterpolatedWaveform's default interpolator (PchipInterpolator through 3 - 6 equally spaced values)."""
+    from scipy.interpolate import PchipInterpolator
+
+    k = int(rng.integers(3, 7))
+    vals = rng.uniform(lo, hi, k)
+    if first is not None:
+        vals[0] = first
+    if last is not None:
+        vals[-1] = last
+    return PchipInterpolator(np.linspace(0, 1, k), vals)(np.linspace(0, 1, n))
+
+
+def random_pulse_samples(rng, duration, omega_max=None, det_max=None, complex_phase=True):
+    """{"amp", "det", "phase"} of ``duration + 1`` samples (the extra trailing sample of simulation.py:173: amp = det = 0)
+    of a random sequence of pulses on one global Rydberg channel."""
+    omega_max = float(rng.uniform(3.0, 30.0)) if omega_max is None else omega_max
+    det_max = float(rng.uniform(5.0, 80.0)) if det_max is None else det_max
+    amp, det, ph = [], [], []
+    t = 0
+    phase = 0.0
+    while t < duration:
+        n = int(min(duration - t, rng.integers(16, max(17, min(1500, duration)))))
+        if duration - t - n < 16:
+            n = duration - t
+        kind = rng.choice(["constant", "ramp", "blackman", "kaiser", "interp", "delay", "eom", "composite"])
+        peak = float(rng.uniform(0.2, 1.0)) * omega_max
+        if kind == "delay":
+            a = np.zeros(n)
+        elif kind == "constant" or kind == "eom":
+            a = _wf_constant(n, peak)
+        elif kind == "ramp":
+            lo, hi = sorted(rng.uniform(0.0, 1.0, 2) * omega_max)
+            a = _wf_ramp(n, lo, hi) if rng.random() < 0.5 else _wf_ramp(n, hi, lo)
+        elif kind == "blackman":
+            a = _wf_blackman(n, peak)
+        elif kind == "kaiser":
+            a = _wf_kaiser(n, peak, float(rng.uniform(4.0, 16.0)))
+        elif kind == "interp":
+            a = np.clip(_wf_interpolated(rng, n, 0.0, omega_max, first=0.0 if rng.random() < 0.5 else None,
+                                         last=0.0 if rng.random() < 0.5 else None), 0.0, None)
+        else:  # composite: rise - plateau - fall
+            k1 = max(1, n // 4)
+            a = np.concatenate([_wf_ramp(k1, 0.0, peak), _wf_constant(n - 2 * k1, peak), _wf_ramp(k1, peak, 0.0)])
+        dk = rng.choice(["constant", "ramp", "interp"])
+        if kind == "eom":  # square pulse: the detuning switches with the amplitude (EOM mode: detuning_on)
+            d = _wf_constant(n, rng.uniform(-1.0, 1.0) * det_max)
+        elif dk == "constant":
+            d = _wf_constant(n, rng.uniform(-1.0, 1.0) * det_max)
+        elif dk == "ramp":
+            d = _wf_ramp(n, *(rng.uniform(-1.0, 1.0, 2) * det_max))
+        else:
+            d = _wf_interpolated(rng, n, -det_max, det_max)
+        if complex_phase and rng.random() < 0.4:  # a phase jump between back-to-back pulses
+            phase = float(rng.uniform(0.0, 2 * np.pi))
+        amp.append(a)
+        det.append(d)
+        ph.append(np.full(n, phase))
+        t += n
+    amp = np.concatenate(amp + [[0.0]])
+    det = np.concatenate(det + [[0.0]])
+    ph = np.concatenate(ph + [[ph[-1][-1]]])
+    assert len(amp) == duration + 1
+    return {"amp": amp, "det": det, "phase": ph}
+
+
+def random_register(rng, n):
+    """coords of an n-atom chain / two-row triangular / rectangular register, spacing 4.5 - 10 um."""
+    spacing = float(rng.uniform(4.5, 10.0))
+    kinds = ["chain"]
+    if n % 2 == 0:
+        kinds += ["tri", "rect"]
+    kind = rng.choice(kinds)
+    if kind == "chain":
+        lay = P.square_rect(1, n)
+    elif kind == "tri":
+        lay = P.triangular_rect(2, n // 2)
+    else:
+        r = 4 if n == 16 else 2
+        lay = P.square_rect(r, n // r)
+    return P.register_coords(lay, spacing), spacing, str(kind)
+
+
+def fuzz_case(seed):
+    """One case of the controller fuzz: (problems of one batch, description)."""
+    rng = np.random.default_rng(10_000 + seed)
+    n = int(rng.choice([12, 12, 13, 13, 14, 14, 16]))
+    dur_cap = {12: 4000, 13: 2500, 14: 1500, 16: 300}[n]
+    duration = int(np.exp(rng.uniform(np.log(100), np.log(dur_cap))))
+    batch = 1 if n == 16 else int(rng.choice([1, 1, 2, 4]))
+    coords, spacing, kind = random_register(rng, n)
+    cplx = bool(rng.random() < 0.5)
+    probs = [P.make_ising_problem(coords, random_pulse_samples(rng, duration, complex_phase=cplx)) for _ in range(batch)]
+    return probs, f"seed {seed}: {n} atoms ({kind}, {spacing:.2f} um), {duration} ns, batch {batch}, phases {cplx}"

@@ -504,6 +504,30 @@ def test_register_resident_14_atom_kernel_equals_the_pass_by_pass_launches(t0, t
         assert np.max(np.abs(np.linalg.norm(outs[False], axis=1) - 1.0)) < 1e-11
 
 
+def test_register_resident_12_atom_kernel_against_the_passes():
+    """12 atoms: 16 amplitudes per lane on 256 lanes (k_split_reg<12, 4>, round 5: four waves per sequence instead of the two
+    of NR = 5 - the shape of the plain 12-atom kernel at every batch size).  The same stages in the same order as the tile
+    passes: agreement to rounding at every stored time, evaluation-time snapshots (stored inside the run) included."""
+    coords = P.register_coords(P.square_rect(1, 12), blockade_radius())
+    base = P.anneal_samples()
+    probs = []
+    for b in range(8):
+        f = 1.0 - 0.04 * b
+        probs.append(P.make_ising_problem(coords, {"amp": base["amp"] * f, "det": base["det"] * (2.0 - f), "phase": base["phase"]}))
+    times = np.array([0.0, 0.1, 0.35, 0.62])
+    outs, stats = {}, {}
+    for name, kw in (("loop", {}), ("passes", {"split_no_loop": True})):
+        with _engine(probs) as eng:
+            eng.set_path(False, **kw)
+            outs[name] = eng.solve(eng.new_state(), times, method="split").cpu().numpy()
+            stats[name] = eng.stats()
+    assert stats["loop"]["n_applications"] == stats["passes"]["n_applications"]
+    assert stats["loop"]["n_launches"] < stats["passes"]["n_launches"] / 20
+    assert np.max(np.abs(outs["loop"] - outs["passes"])) < 1e-12
+    assert np.max(np.abs(np.linalg.norm(outs["loop"][-1], axis=1) - 1.0)) < 1e-11
+    assert np.max(np.abs(outs["loop"][:, 0] - outs["loop"][:, 7])) > 1e-3  # the sequences really differ
+
+
 def test_register_resident_14_atom_kernel_complex_drives_and_per_sequence_interactions():
     """Per-atom complex, time-dependent drives and a different geometry (interaction diagonal) per sequence: the
     general rotation branch and the per-sequence E0 pieces, against the tile passes and against CF4 + Taylor."""
@@ -548,7 +572,7 @@ def test_14_atom_batches_choose_their_kernel_from_the_schedule_of_the_call():
     assert res["auto"][1]["n_applications"] < 0.5 * res["k_ket"][1]["n_applications"]
     assert np.max(np.abs(res["auto"][0] - res["k_ket"][0])) < 2e-8
     s_in = snaps["inside"][1]
-    assert s_in["reserved"][0] > 0 and 1 < s_in["n_launches"] <= 8  # the controller booked; runs, not one per evaluation time
+    assert s_in["reserved"][0] > 0 and 1 < s_in["n_launches"] <= 16  # the controller booked; runs (+ its early checks), not one per evaluation time
     assert s_in["n_applications"] < 0.6 * snaps["outside"][1]["n_applications"]
     assert np.max(np.abs(snaps["inside"][0] - snaps["outside"][0])) < 2e-8  # every stored time, every sequence
 
@@ -581,7 +605,7 @@ def test_snapshots_stored_inside_a_run_equal_a_closed_run_per_evaluation_time(n)
                 outs[name] = eng.solve(eng.new_state(), times, **opts).cpu().numpy()
                 stats[name] = eng.stats()
         assert stats["inside"]["reserved"][0] > 0, label  # the split-operator path ran
-        assert stats["inside"]["n_launches"] < max(8, 0.4 * len(times)), (label, stats["inside"])
+        assert stats["inside"]["n_launches"] < max(16, 0.5 * len(times)), (label, stats["inside"])
         assert np.max(np.abs(outs["inside"] - outs["outside"])) < 1e-12, label
         # (the controller's budget for a whole sequence is 5e-8; these are 0.9 us of three differently scaled anneals)
         assert np.max(np.abs(outs["inside"] - outs["taylor"])) < 5e-8, label

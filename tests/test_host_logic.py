@@ -1637,6 +1637,14 @@ def test_bench_flop_constants_match_the_compiled_kernels():
     cells = [c.strip() for c in row.strip("|").split("|")]
     assert abs(float(cells[-1]) - ns["KSPLITREG_FLOPS_PER_AMP_STAGE"]) < 0.01 * ns["KSPLITREG_FLOPS_PER_AMP_STAGE"], row
     assert int(cells[8]) <= 8 and int(cells[9]) == 4, row  # scratch reloads of loop invariants at most; 4 barriers per stage
+    # ... and the 12-atom shape of round 5 (16 amplitudes per lane on 256 lanes)
+    exec(re.search(r"^KSPLITREG_SHAPES = .*?\n\n", src, re.M | re.S).group(0), ns)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "count_isa.py"), "splitreg", "12", "4"], check=True,
+                         capture_output=True, text=True, timeout=900).stdout
+    row = [l for l in out.splitlines() if re.match(r"^\| \d+ \|", l)][0]
+    cells = [c.strip() for c in row.strip("|").split("|")]
+    assert ns["KSPLITREG_SHAPES"][12][0] == 4 and abs(float(cells[-1]) - ns["KSPLITREG_SHAPES"][12][1]) < 0.01 * float(cells[-1]), row
+    assert int(cells[8]) == 0 and int(cells[9]) == 4, row
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "count_isa.py"), "0"], check=True,
                          capture_output=True, text=True, timeout=900, env=dict(os.environ, RYD_ISA_TEXT=asm)).stdout
     per_half = [float(l.strip("|").split("|")[-1]) for l in out.splitlines() if re.match(r"^\| \d+\.\.\d+ \|", l)]

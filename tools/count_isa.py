@@ -6,8 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # round 5: the library is four translation units (k_split_reg_inst.hpp) - k_split_reg<14, ..> lives in the part unit
 # rydemu_splitreg.hip (-DRYD_SPLITR_N=14), everything else in rydemu.hip (-DRYD_SPLIT_TUS)
 splitreg = len(sys.argv) > 1 and sys.argv[1] == "splitreg"
+sr_n = int(sys.argv[2]) if splitreg and len(sys.argv) > 2 else 14   # count_isa.py splitreg [N [NR]]
+sr_nr = int(sys.argv[3]) if splitreg and len(sys.argv) > 3 else 5
 src = os.path.join(ROOT, "pulser_amd", "csrc", "rydemu_splitreg.hip" if splitreg else "rydemu.hip")
-defs = ["-DRYD_SPLITR_N=14"] if splitreg else ["-DRYD_SPLIT_TUS"]
+defs = [f"-DRYD_SPLITR_N={sr_n}"] if splitreg else ["-DRYD_SPLIT_TUS"]
 if os.environ.get("RYD_ISA_TEXT") and not splitreg:  # (a listing of rydemu.hip made earlier: the tests compile it once)
     text = open(os.environ["RYD_ISA_TEXT"]).read()
 else:
@@ -21,7 +23,7 @@ else:
         open(os.environ["RYD_ISA_KEEP"], "w").write(text)
 if len(sys.argv) > 1 and sys.argv[1] == "splitreg":
     # k_split_reg<14, 5, false>: fp64 work of the stage loop (ONE stage body per iteration, 32 amplitudes per lane)
-    m = re.search(r"^(_Z\d+k_split_regILi14ELi5ELb0ELb0ELb0ELb0E\w*):(.*?)s_endpgm", text, re.S | re.M)
+    m = re.search(r"^(_Z\d+k_split_regILi%dELi%dELb0ELb0ELb0ELb0E\w*):(.*?)s_endpgm" % (sr_n, sr_nr), text, re.S | re.M)
     body = m.group(2).split("\n")
     best = None
     for hdr in [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]:
@@ -33,12 +35,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "splitreg":
     c = lambda pat: sum(1 for l in reg if re.search(pat, l))
     fma, mul, add, rnd = c(r"\sv_fmac?_f64"), c(r"\sv_mul_f64"), c(r"\sv_add_f64"), c(r"v_rndne_f64")
     valu = c(r"^\s+v_")
-    print("# r04: instruction count of the stage loop of `k_split_reg<14, 5>` (hipcc 7.2, gfx950, -O3)\n")
-    print("The loop body holds ONE stage (positions, not parities: the same code runs even and odd stages), 32 amplitudes per lane.\n")
+    na = 1 << sr_nr
+    print(f"# instruction count of the stage loop of `k_split_reg<{sr_n}, {sr_nr}>` (hipcc 7.2, gfx950, -O3)\n")
+    print(f"The loop body holds ONE stage (positions, not parities: the same code runs even and odd stages), {na} amplitudes per lane.\n")
     print("| v_fma/v_fmac_f64 | v_mul_f64 | v_add_f64 | v_rndne_f64 | v_mov_b32_dpp | v_permlane*_swap | other VALU | ds ops | scratch ops | barriers | flops / amplitude / stage |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     dpp, swp, n_ds = c(r"v_mov_b32_dpp"), c(r"v_permlane\d+_swap"), c(r"^\s+ds_")
-    print(f"| {fma} | {mul} | {add} | {rnd} | {dpp} | {swp} | {valu - fma - mul - add - rnd - dpp - swp} | {n_ds} | {c('scratch_')} | {c('s_barrier')} | {(2 * fma + mul + add + rnd) / 32:.2f} |")
+    print(f"| {fma} | {mul} | {add} | {rnd} | {dpp} | {swp} | {valu - fma - mul - add - rnd - dpp - swp} | {n_ds} | {c('scratch_')} | {c('s_barrier')} | {(2 * fma + mul + add + rnd) / na:.2f} |")
     print("\nPer stage and amplitude: 14 tan-form rotations x 2 FMAs + the phase factor as a product (tree over the register bits, the")
     print("uniform factor, the amplitude: three complex multiplications) + 7 table-and-series sin / cos per lane.  On paper a stage")
     print("needs 14 x 2 FMAs + one complex multiplication = 62 flops per amplitude (bench.py: SPLIT_ALGORITHMIC_FLOPS_PER_AMP_STAGE).")
