@@ -86,6 +86,8 @@ struct ryd_handle {
   double* split_coefs = nullptr;  // [stages][B][N][4]
   size_t split_cap = 0;
   double* split_err = nullptr;    // [B] local-error accumulators
+  cplx* rows_chk = nullptr;       // [2][B][2^N]: the probed rows of the split-operator master equation (rows_split_probe)
+  int* rows_idx_dev = nullptr;    // [B]
   bool no_split = false;          // test hook: keep the Taylor polynomial for 15+ atoms
   bool split_fixed = false;       // test hook: no step-size control (sub-step = schedule step)
   bool no_merge = false;          // test hook: CF4 steps never span more than one knot interval
@@ -439,6 +441,8 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->wA);
   hipFree(h->split_coefs);
   hipFree(h->split_err);
+  hipFree(h->rows_chk);
+  hipFree(h->rows_idx_dev);
   hipFree(h->wB);
   hipFree(h->kbuf);
   hipFree(h->coefs_dev);

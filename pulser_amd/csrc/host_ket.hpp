@@ -330,6 +330,9 @@ static bool row_uniform_g(const ryd_handle* h) {
 // Half a block of the split-operator master equation, in knot intervals (what a multi-knot CF4
 // step must not exceed).
 static bool rows_split_ok(const ryd_handle* h, const ryd_opts& o);
+static double rows_split_estimate(const ryd_handle* h);
+static int rows_split_probe(ryd_handle* h, const cplx* rho, const std::vector<StepDesc>& sb, size_t i0, size_t i1,
+                            hipStream_t st, double* e_out, double* tau_out);
 static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
   static const int kh_env = dev_env_int("RYD_ROWS_KH", 0, 1, 8);  // dev A/B (RYD_DEV=1)
   if (kh_env > 0 && o.split_steps <= 0) return kh_env;
@@ -346,7 +349,15 @@ static int row_half_knots(const ryd_handle* h, const ryd_opts& o) {
     // dephasing - so the drive bound caps the rule too: measured at |c| = Omega / 2 = 12.6 rad / us, allowed up to 16)
     double cmax = 0.0;
     for (double v : h->bd_c1) cmax = std::max(cmax, v);
-    if (g <= 0.06 && cmax <= 16.0) Kh = 4;  // (0.06: entries of rho within ~7e-9 of the 12-atom tight oracle, its probe products within 8e-8)
+    // ... and only for drives without abrupt edges (round 5).  The rule was calibrated along the anneal, whose state follows
+    // the drive adiabatically; after a QUENCH - the all-ground matrix dropped into a strong drive, which is what every
+    // square / EOM pulse does - the four-knot halves left 1e-8 within 20 ns where the two-knot ones and the polynomial
+    // rows agree with the tight Lindbladian to 1e-9 (tools/rows_quench_probe.py).  No edge = the drive never changes by
+    // more than a tenth of its maximum within 10 ns.
+    double dcmax = 0.0;
+    for (double v : h->bd_dc) dcmax = std::max(dcmax, v);
+    const bool smooth_drive = dcmax * 0.01 <= 0.1 * std::max(cmax, 1e-300);
+    if (g <= 0.06 && cmax <= 16.0 && smooth_drive) Kh = 4;  // (0.06: entries of rho within ~7e-9 of the 12-atom tight oracle, its probe products within 8e-8)
   }
   return Kh;
 }
@@ -443,6 +454,19 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
   for (KetStep& k : ks) k.snap = -1;  // snapshots are whole-matrix copies between blocks
   if ((rc = upload_ket_steps(h, ks, st))) return rc;
   bool rsplit = rows_split_ok(h, o);  // (the k_ket schedule stays uploaded: a conjugation may fall back to it)
+  // Error control of the split-operator rows.  rows_split_ok has filtered by the caller's options and an
+  // a-priori estimate; here the local error of the unitary sub-steps is MEASURED on the heaviest row of the matrix
+  // (rows_split_probe: one sub-step whole against two halves) - at the first block, then after 16, 32, ... 256 knot
+  // intervals (a sequence starts from a product state, the least representative one) and whenever the drive bound has grown
+  // by half - against this solve's budget (5e-8 over a sequence, or 500 tol; the two-sided product U rho U^+ carries the
+  // error twice).  A probe that finds a sub-step more than 4 x over its allowance hands the REST of the call to the
+  // polynomial rows (k_ket: a-priori tolerance per exponential); the measured rate is booked in ryd_stats.reserved[0].
+  const double rows_budget = o.tol > 0 ? 500.0 * o.tol : 5e-8;
+  const double rows_T = std::max(h->tknots.size() >= 2 ? h->tknots.back() - h->tknots.front() : 0.0, 1e-12);
+  int probe_period = 16, probe_since = 0;
+  bool probed = false;
+  double probe_rate = 0.0, probe_amp = 0.0, amp_max_rows = 0.0;
+  for (double v : h->bd_c1) amp_max_rows = std::max(amp_max_rows, v);
   // |change of d under one bit flip|: (0,0)<->(0,1)/(1,0) and (1,1)<->(0,1)/(1,0)
   const double g01 = h->Sd[1].x - h->Sd[0].x, g10 = h->Sd[2].x - h->Sd[0].x;
   const double g31 = h->Sd[1].x - h->Sd[3].x, g32 = h->Sd[2].x - h->Sd[3].x;
@@ -534,6 +558,31 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
   for (const Block& b : blocks) {
     // rho <- D(tau/6) W2 ( D(2 tau/3) W1 ( D(tau/6) rho ) W1^+ ) W2^+ with halves of tau / 2 each
     const double tau = b.tau;
+    if (rsplit) {
+      int knots_b = 0;
+      double amp_b = 0.0;
+      for (size_t k = b.i0; k < b.i1; ++k) {
+        knots_b += std::max(1, sb[k].pad);
+        amp_b = std::max(amp_b, span_max(h->bd_c1, sb[k].idx, std::max(1, sb[k].pad)));
+      }
+      if (!probed || probe_since >= probe_period || amp_b > std::max(1.5 * probe_amp, 0.1 * amp_max_rows)) {
+        double e = 0.0, tau_s = 0.0;
+        if ((rc = rows_split_probe(h, cur, sb, b.i0, b.mid, st, &e, &tau_s))) return rc;
+        const double allowed = 0.5 * rows_budget * tau_s / rows_T;
+        if (tau_s > 0.0 && e > 4.0 * allowed) {
+          rsplit = false;                 // the polynomial rows from here on
+          h->stats.reserved[3] += 1.0;
+        } else if (tau_s > 0.0) {
+          probe_rate = std::max(0.5 * (probe_rate + e / tau_s), e / tau_s);
+        }
+        probed = true;
+        probe_since = 0;
+        probe_period = std::min(256, 2 * probe_period);
+        probe_amp = amp_b;
+      }
+      probe_since += knots_b;
+      if (rsplit) h->stats.reserved[0] += 2.0 * probe_rate * tau;
+    }
     const double eps = (uniform_g && !dbl) ? tau * tau * tau * gflip * gflip / 72.0 : 0.0;
     const StepDesc& m0 = sb[b.mid];
     const double kick_u = m0.u1 - kC1 * m0.h;  // start of the step `mid` inside its knot interval

@@ -515,20 +515,32 @@ static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, d
 // a caller who asks for a tolerance tighter than that, names another propagator (ryd_opts.method) or fixes the Taylor
 // order gets the polynomial rows (k_ket: pick_scheme(|h| bound, tol)), whose unitary part follows ryd_opts.
 static const double kRowsSplitCalibrated = 3e-9;
+// A-priori estimate of what the calibrated sub-steps leave over the whole sequence on THIS handle's generator.  The
+// leading error terms of a 4th-order composition over a sub-step tau are nested commutators of weight 5 in (drive c,
+// diagonal d = |detuning| + max_i sum_j U_ij): the worst of them goes like c d^4 tau^4 per unit time.  Calibration point:
+// the interacting 12- / 14-atom triangular registers at the blockade radius under the anneal (c = 12.6 rad/us, d = 130
+// rad/us, 3.1 us): 3e-9.  A 5-um chain (d ~ 800) scales to ~4e-6 - which is what the ket controller MEASURES there
+// (tools/fuzz_ctrl.py) - and is sent to the polynomial rows, whose exponentials follow an a-priori bound.
+static double rows_split_estimate(const ryd_handle* h) {
+  double c = 0.0, dl = 0.0;
+  for (double v : h->bd_c1) c = std::max(c, v);
+  for (double v : h->bd_dl) dl = std::max(dl, v);
+  const double d = dl + h->u_rowsum;
+  const double T = h->tknots.size() >= 2 ? h->tknots.back() - h->tknots.front() : 0.0;
+  const double r = d / 130.0;
+  return kRowsSplitCalibrated * std::max(c / 12.6, 1e-3) * std::max(r * r * r * r, 1.0) * std::max(T / 3.1, 1.0);
+}
 static bool rows_split_ok(const ryd_handle* h, const ryd_opts& o) {
   if (o.method != 0 && o.method != 2) return false;
   if (o.taylor_order > 0) return false;
+  if (!(h->cfg.mode == RYD_MESOLVE && h->N >= 12 && h->N <= 14 && h->drive_real && !h->rows_ket && !h->split_no_loop)) return false;
   // (ryd_opts.tol is a bound per exponential; over a sequence the split-operator paths take 500 tol as their budget - run_split)
-  if (o.tol > 0 && 500.0 * o.tol < kRowsSplitCalibrated) return false;
-  return h->cfg.mode == RYD_MESOLVE && h->N >= 12 && h->N <= 14 && h->drive_real && !h->rows_ket && !h->split_no_loop;
+  const double budget = o.tol > 0 ? 500.0 * o.tol : kSplitTolTotal;
+  return rows_split_estimate(h) <= budget;
 }
-static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>& sb, size_t i0, size_t i1, bool use_pre,
-                           bool use_post, const double* tdev, double kick_pre, double kick_post, int kick_idx,
-                           double kick_u, size_t n_rows, bool count_stages, hipStream_t st) {
-  int rc;
-  const int N = h->N, B = h->B;
-  std::vector<SubStep> subs;
-  bool multi = false;
+// the sub-steps of the unitary of a half block (steps [i0, i1) of the split schedule)
+static void rows_split_substeps(const ryd_handle* h, const std::vector<StepDesc>& sb, size_t i0, size_t i1,
+                                std::vector<SubStep>& subs, bool& multi) {
   for (size_t k = i0; k < i1; ++k) {
     // one sub-step per CF4 step of the schedule - or per PAIR of two-knot steps (four-knot halves, row_half_knots) where
     // the a-priori Magnus estimate accepted both and the waveforms are one polynomial across the knot between them: ONE
@@ -539,7 +551,7 @@ static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>
     const double t_end = h->tknots[d.idx] + (d.u1 - kC1 * d.h) + d.h;
     if (k + 1 < i1 && d.pad == 2 && sb[k + 1].pad == 2 && sb[k + 1].idx == d.idx + 2 && d.idx + 1 < (int)h->join_ok.size() &&
         h->join_ok[d.idx + 1] && std::fabs(h->tknots[sb[k + 1].idx] + (sb[k + 1].u1 - kC1 * sb[k + 1].h) - t_end) < 1e-12) {
-      subs.push_back({d.idx, d.u1 - kC1 * d.h, d.h + sb[k + 1].h});
+      subs.push_back({d.idx, d.u1 - kC1 * d.h, d.h + sb[k + 1].h, 0});
       multi = true;
       ++k;
       continue;
@@ -547,12 +559,84 @@ static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>
     split_substeps(h, d, 0.0, 1e300, subs);
     multi = multi || d.pad > 2;
   }
+}
+static const SplitScheme& rows_split_scheme(bool multi) {
+  static const int s_env = dev_env_int("RYD_ROWS_S", 0, 6, 10);  // dev A/B (RYD_DEV=1): 6 or 10
+  return s_env == 6 ? kSplitS6 : s_env == 10 ? kSplitS10 : multi ? kSplitS10 : kSplitS6;
+}
+
+// Measured local error of the unitary sub-steps of a half block (the row passes ran calibrated sub-steps with no
+// error control).  The heaviest row of every density matrix - the row of the largest diagonal entry; for a nearly pure
+// state every row is the ket times one amplitude, so it is as representative as the ket and its ABSOLUTE error is the
+// largest any row carries - is copied out and advanced over the longest sub-step of the half block once whole and once
+// as two halves on the plain kernel (the step-doubling check of run_split); returns the local-error estimate of that
+// sub-step (max over the batch) and its length.
+static int rows_split_probe(ryd_handle* h, const cplx* rho, const std::vector<StepDesc>& sb, size_t i0, size_t i1,
+                            hipStream_t st, double* e_out, double* tau_out) {
+  int rc;
+  const int N = h->N, B = h->B;
+  const size_t D = (size_t)1 << N;
+  std::vector<SubStep> subs;
+  bool multi = false;
+  rows_split_substeps(h, sb, i0, i1, subs, multi);
+  *e_out = 0.0;
+  *tau_out = 0.0;
+  if (subs.empty()) return RYD_OK;
+  SubStep s0 = subs[0];
+  for (const SubStep& s : subs) if (s.tau > s0.tau) s0 = s;
+  const SplitScheme& sc = rows_split_scheme(multi);
+  if (!h->rows_chk) HIPCHK(hipMalloc((void**)&h->rows_chk, 2 * (size_t)B * D * sizeof(cplx)));
+  if (!h->rows_idx_dev) HIPCHK(hipMalloc((void**)&h->rows_idx_dev, (size_t)B * sizeof(int)));
+  if ((rc = split_ensure_tables(h, 2 * sc.S + 1))) return rc;
+  hipLaunchKernelGGL(k_argmax_diag, dim3((unsigned)B), dim3(1024), 0, st, rho, N, h->rows_idx_dev);
+  HIPCHK(hipGetLastError());
+  std::vector<int> idx(B);
+  HIPCHK(hipMemcpyAsync(idx.data(), h->rows_idx_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  cplx* whole = h->rows_chk;
+  cplx* halves = h->rows_chk + (size_t)B * D;
+  for (int b = 0; b < B; ++b) {
+    const cplx* row = rho + ((size_t)b * D + (size_t)idx[b]) * D;
+    HIPCHK(hipMemcpyAsync(whole + (size_t)b * D, row, D * sizeof(cplx), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(halves + (size_t)b * D, row, D * sizeof(cplx), hipMemcpyDeviceToDevice, st));
+  }
+  // the ket machinery of this file on B kets of 2^N amplitudes (the handle's scheme switch borrowed for the call)
+  const bool keep_s10 = h->split_s10;
+  const ryd_stats keep_stats = h->stats;
+  h->split_s10 = sc.S == 10;
+  const SubStep two[2] = {{s0.idx, s0.u0, 0.5 * s0.tau, 0}, {s0.idx, s0.u0 + 0.5 * s0.tau, 0.5 * s0.tau, 0}};
+  rc = split_run(h, whole, &s0, 1, st, sc.S == 6);
+  if (!rc) rc = split_run(h, halves, two, 2, st, sc.S == 6);
+  h->split_s10 = keep_s10;
+  h->stats = keep_stats;
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)B * sizeof(double), st));
+  hipLaunchKernelGGL(k_split_diff, dim3(16, B), dim3(256), 0, st, halves, whole, N, h->split_err);
+  HIPCHK(hipGetLastError());
+  std::vector<double> errs(B);
+  HIPCHK(hipMemcpyAsync(errs.data(), h->split_err, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  double e = 0.0;
+  for (double v : errs) e = std::max(e, std::sqrt(std::max(v, 0.0)));
+  const double two_p = std::ldexp(1.0, sc.order);
+  *e_out = e * two_p / (two_p - 1.0);
+  *tau_out = s0.tau;
+  return RYD_OK;
+}
+
+static int rows_split_pass(ryd_handle* h, cplx* buf, const std::vector<StepDesc>& sb, size_t i0, size_t i1, bool use_pre,
+                           bool use_post, const double* tdev, double kick_pre, double kick_post, int kick_idx,
+                           double kick_u, size_t n_rows, bool count_stages, hipStream_t st) {
+  int rc;
+  const int N = h->N, B = h->B;
+  std::vector<SubStep> subs;
+  bool multi = false;
+  rows_split_substeps(h, sb, i0, i1, subs, multi);
   // half blocks are two knot intervals at most by default (row_half_knots): the 4th-order 6-stage composition holds
   // one- and two-knot sub-steps at ~3e-9 over the anneal (measured against the k_ket rows at 12 atoms, dephasing 0.05
   // and 0.5 / us: 2.7e-9 / 3.2e-9 with S6, 3.2e-9 / 2.8e-9 with S10) with 6 stages instead of 10; longer sub-steps
   // (split_steps set by the caller) take the 6th-order one
-  static const int s_env = dev_env_int("RYD_ROWS_S", 0, 6, 10);  // dev A/B (RYD_DEV=1): 6 or 10
-  const SplitScheme& sc = s_env == 6 ? kSplitS6 : s_env == 10 ? kSplitS10 : multi ? kSplitS10 : kSplitS6;
+  const SplitScheme& sc = rows_split_scheme(multi);
   double bmax = 0.0;
   for (int i = 0; i < sc.S; ++i) bmax = std::max(bmax, std::fabs(sc.b[i]));
   for (const SubStep& s : subs) {

@@ -741,3 +741,27 @@ __global__ __launch_bounds__(512) void k_local_exp(const LocalExpArgs A) {
   __syncthreads();
   for (int l = threadIdx.x; l < tileSize; l += 512) g[base_idx | deposit((unsigned long long)l, A.tile)] = xs[l];
 }
+
+
+// index of the largest diagonal entry of every density matrix of the batch (the row the split-operator master equation
+// probes its unitary sub-steps on: rows_split_probe, host_split.hpp); grid (B), 1024 lanes
+__global__ __launch_bounds__(1024) void k_argmax_diag(const cplx* __restrict__ rho, int N, int* __restrict__ idx_out) {
+  __shared__ double sv[1024];
+  __shared__ unsigned si[1024];
+  const size_t D = (size_t)1 << N;
+  const cplx* m = rho + (size_t)blockIdx.x * D * D;
+  double best = -1.0;
+  unsigned bi = 0;
+  for (size_t i = threadIdx.x; i < D; i += 1024) {
+    const double v = fabs(m[i * (D + 1)].x);
+    if (v > best) { best = v; bi = (unsigned)i; }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (unsigned o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o && sv[threadIdx.x + o] > sv[threadIdx.x]) { sv[threadIdx.x] = sv[threadIdx.x + o]; si[threadIdx.x] = si[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) idx_out[blockIdx.x] = (int)si[0];
+}

@@ -263,9 +263,10 @@ class Engine:
     def _split_budget_check(self, method: str, tol: float) -> None:
         """The split-operator controller books its local-error estimates in ``ryd_stats.reserved[0]``;
         when it could not hold the sequence budget (retries used up, nothing to roll back to) say so."""
-        if not (method == "split" or (method == "auto" and self.mode == RYD_SESOLVE and self.n >= 12)):
+        if not (method == "split" or (method == "auto" and self.n >= 12)):
             return  # (12 - 14 atoms may, 15+ atoms do take the split-operator path by default; quantum jumps included:
-            #          a jump solve cannot roll back, so an overrun is only ever booked - and must be reported)
+            #          a jump solve cannot roll back, so an overrun is only ever booked - and must be reported; the
+            #          split-operator master equation of 12 - 14 atoms books its a-priori estimate the same way)
         est = self.stats()["reserved"][0]
         budget = 500.0 * tol if tol > 0 else 5e-8
         if est > 2.0 * budget:

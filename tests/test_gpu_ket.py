@@ -476,3 +476,49 @@ def test_split_operator_rows_batch_of_two_different_12_atom_registers():
     assert np.max(np.abs(outs[False][0] - outs[False][1])) > 1e-3  # the matrices really differ
     for b in range(2):
         assert abs(np.trace(outs[False][b]).real - 1.0) < 1e-10
+
+
+def test_split_operator_rows_follow_the_options_and_measure_their_error():
+    """the split-operator sub-steps of the row passes (k_split_reg<.., ROWS>) used to be calibrated only.  Now
+    (a) a caller who asks for a tolerance tighter than the calibration, another propagator or a fixed Taylor order gets the
+    polynomial rows (k_ket, whose exponentials follow ryd_opts); (b) a generator far from the calibration point - a 5-um
+    chain: nearest-neighbour interaction 350 rad/us - does too (a-priori estimate c d^4 tau^4); (c) the local error of the
+    unitary sub-steps is MEASURED on the heaviest row of rho (one sub-step whole against two halves) and booked in
+    ryd_stats.reserved[0]; a probe far over its allowance hands the rest of the call to the polynomial rows; (d) drives with
+    abrupt edges (square / EOM pulses quench the state) keep blocks of 2 + 2 knots."""
+    ops = [(float(np.sqrt(2 * 0.05)), "sigma_rr")]
+    base = P.anneal_samples()
+    near = P.make_ising_problem(P.register_coords(P.triangular_rect(2, 6), blockade_radius()), base, collapse_ops=ops)
+    far = P.make_ising_problem(P.register_coords(P.square_rect(1, 12), 5.0), base, collapse_ops=ops)
+
+    def run(prob, t0, t1, path=None, **opts):
+        with _engine([prob], "mesolve") as eng:
+            if path:
+                eng.set_path(False, **path)
+            st = eng.new_state()
+            eng.evolve(st, t0, t1, **opts)
+            return st.cpu().numpy()[0], eng.stats()
+
+    # the physical start of the anneal: the split-operator rows run, their measured error is booked, nothing falls back
+    rho_split, s_split = run(near, 0.0, 0.04)
+    rho_ket, s_ket = run(near, 0.0, 0.04, {"rows_ket": True})
+    assert s_split["last_order"] in (6, 10) and s_split["reserved"][3] == 0 and 0 <= s_split["reserved"][0] < 5e-8
+    assert s_ket["reserved"][0] == 0.0 and np.max(np.abs(rho_split - rho_ket)) < 2e-9
+    # (a) options the calibrated sub-steps cannot honour -> the k_ket rows, bit for bit
+    for opts in ({"tol": 1e-12}, {"method": "taylor"}, {"taylor_order": 12}):
+        rho, s = run(near, 0.0, 0.02, **opts)
+        ref, _ = run(near, 0.0, 0.02, {"rows_ket": True}, **opts)
+        assert np.array_equal(rho, ref), opts
+    # (b) strong interactions -> the k_ket rows by the a-priori estimate
+    rho, s = run(far, 0.0, 0.02)
+    ref, _ = run(far, 0.0, 0.02, {"rows_ket": True})
+    assert np.array_equal(rho, ref) and abs(np.trace(rho).real - 1.0) < 1e-9
+    # (d) a square pulse (a quench of the all-ground matrix): blocks of 2 + 2 knots instead of the 4 + 4 calibrated along the
+    # adiabatic anneal (which left 1e-8 within 20 ns of a quench) - within 2e-9 of the polynomial rows at a tight tolerance
+    sq = {"amp": np.concatenate([np.full(60, base["amp"].max()), [0.0]]), "det": np.concatenate([np.full(60, -20.0), [0.0]]),
+          "phase": np.zeros(61)}
+    square = P.make_ising_problem(P.register_coords(P.triangular_rect(2, 6), blockade_radius()), sq, collapse_ops=ops)
+    rho, s = run(square, 0.0, 0.04)
+    ref, _ = run(square, 0.0, 0.04, {"rows_ket": True}, tol=1e-13, magnus_tol=1e-12)
+    assert s["last_order"] in (6, 10) and s["reserved"][0] < 5e-8
+    assert np.max(np.abs(rho - ref)) < 2e-9, np.max(np.abs(rho - ref))
