@@ -751,7 +751,7 @@ static const int kSplitCheckEvery = 256;  // (128: 24 + 6 checks on the headline
 // 16-atom chain under a square pulse (constant drive from t = 0, so no amplitude trigger) the first 9-ns step measured
 // 1.0e-9, the steps 100 ns later erred six times that, and the one check of the 283-ns sequence booked 2.8e-8 for a true
 // 1.85e-7 (tools/fuzz_ctrl.py seed 263).  Any check (amplitude, regime) counts as one doubling.
-static const int kSplitCheckFirst = 16;
+static const int kSplitCheckFirst = dev_env_int("RYD_SPLIT_FIRST", 16, 4, 256);  // (dev A/B: RYD_DEV=1)
 
 // RYD_DEV=1 RYD_SPLIT_TRACE=1 (dev): every check of the controller on stderr
 static bool split_trace_env() {

@@ -133,11 +133,21 @@ __device__ __forceinline__ double splitr_dpp(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+//   SPLITR_B2 1: the partner of lane bit 2 (xor 4: no single DPP pattern - two dependent v_mov_dpp per dword) over the LDS
+//                crossbar instead (ds_swizzle, xor mask 4: no vector-pipe cycles beyond the issue) - round-5 variant
+#ifndef SPLITR_B2
+#define SPLITR_B2 0
+#endif
 template <int F>
 __device__ __forceinline__ double splitr_partner(double v) {
   if constexpr (F == 0) return splitr_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
   else if constexpr (F == 1) return splitr_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
   else if constexpr (F == 3) return splitr_dpp<0x128>(v);  // row_ror:8
+  else if constexpr (SPLITR_B2 == 1) {
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x101F);  // bit-mask mode: and 0x1F, or 0, xor 4
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x101F);
+    return __hiloint2double(hi, lo);
+  }
   else return splitr_dpp<0x1B>(splitr_dpp<0x141>(v));      // xor 4 = (xor 3) o (xor 7): row_half_mirror, quad reverse
 }
 
