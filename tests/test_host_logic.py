@@ -1685,3 +1685,53 @@ def test_phase_gauge_of_the_split_operator_stages_is_an_identity():
         prev = theta[j]
     V = diag(delta[S] - prev) @ V
     assert np.max(np.abs(U - V)) < 1e-14
+
+
+def test_fuzz_cases_are_seeded_and_well_formed():
+    """tests/helpers.py: fuzz_case (the controller fuzz of tests/test_gpu_fuzz.py): a seed gives the same sequences every
+    time (named regressions stay the cases they were), samples carry the extra trailing sample of simulation.py:173 with
+    amp = det = 0, amplitudes are non-negative, all problems of a batch share register and duration."""
+    from helpers import fuzz_case
+
+    kinds = set()
+    for seed in (0, 40, 263, 279, 306):
+        probs, desc = fuzz_case(seed)
+        again, desc2 = fuzz_case(seed)
+        assert desc == desc2 and len(probs) == len(again)
+        for p, q in zip(probs, again):
+            a, b = p["samples"]["Global"]["ground-rydberg"], q["samples"]["Global"]["ground-rydberg"]
+            for k in ("amp", "det", "phase"):
+                assert np.array_equal(a[k], b[k])
+            assert len(a["amp"]) == p["duration"] and a["amp"][-1] == 0.0 and a["det"][-1] == 0.0
+            assert np.all(a["amp"] >= 0.0) and np.all(np.isfinite(a["det"])) and a["amp"].max() <= 30.0 + 1e-9
+            assert np.array_equal(p["coords"], probs[0]["coords"]) and p["duration"] == probs[0]["duration"]
+        kinds.add(desc.split("(")[1].split(",")[0])
+    assert fuzz_case(40)[1].startswith("seed 40: 12 atoms (chain, 5.03 um), 3415 ns")
+    assert fuzz_case(263)[1].startswith("seed 263: 16 atoms (chain, 6.51 um), 283 ns")
+    assert len(kinds) >= 1
+
+
+def test_every_launched_k_split_reg_instantiation_is_listed_for_the_part_units():
+    """The library is four translation units (k_split_reg_inst.hpp): rydemu.hip declares the k_split_reg instantiations
+    `extern template` and rydemu_splitreg.hip defines them from ONE list - an instantiation launched by host_split.hpp but
+    missing from the list would only fail at link time on the build box."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inst = open(os.path.join(root, "pulser_amd", "csrc", "k_split_reg_inst.hpp")).read()
+    host = open(os.path.join(root, "pulser_amd", "csrc", "host_split.hpp")).read()
+    generic = {tuple(x.strip() for x in m.split(",")) for m in re.findall(r"X\(N_, ([^)]*)\)", inst)}
+    extra = {(n,) + tuple(x.strip() for x in rest.split(",")) for n, rest in re.findall(r"X\((\d+), ([^)]*)\)", inst)}
+
+    def canon(args):
+        args = [a.strip() for a in args]
+        return tuple(args + ["false"] * (5 - len(args)))  # NR, DECAY, ROWS, CPLX, SNAP
+
+    launched = re.findall(r"k_split_reg<(N|\d+), ([^>]*)>", host)
+    assert launched
+    for n, rest in launched:
+        args = canon(rest.split(","))
+        if n == "N":
+            assert args in generic, (n, args)
+        else:
+            assert args in generic or (n,) + args in extra, (n, args)

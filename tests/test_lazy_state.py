@@ -1,0 +1,90 @@
+"""CPU: the lazily materialised states of ``results.states`` (pulser_amd/results.py: SnapshotStore, LazyState).
+
+The reference returns every state of ``result.states`` as a host ``qutip.Qobj`` (simulation.py:744-748); with its default
+``evaluation_times="Full"`` that is one state per sample.  Here the stored states stay on the device and read like the
+``QState`` they become; these tests use a stand-in for the device tensor (``.cpu().numpy()`` and indexing are all the store
+uses), the GPU tests exercise the real thing through the emulator (tests/test_gpu_fullsize.py)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from pulser_amd.results import LazyState, QState, SnapshotStore, StateResult
+
+
+class FakeTensor:
+    """Counts host copies and their sizes."""
+
+    def __init__(self, a, log):
+        self.a, self.log = a, log
+
+    def __getitem__(self, k):
+        return FakeTensor(self.a[k], self.log)
+
+    def cpu(self):
+        self.log.append(self.a.size)
+        return self
+
+    def numpy(self):
+        return self.a
+
+
+def _store(n=40, batch=2, dim=8, bulk_after=16):
+    rng = np.random.default_rng(1)
+    data = rng.normal(size=(n, batch, dim)) + 1j * rng.normal(size=(n, batch, dim))
+    log = []
+    return data, log, SnapshotStore(FakeTensor(data, log), bulk_after=bulk_after)
+
+
+def test_a_state_is_copied_when_it_is_read_and_a_loop_over_all_states_costs_one_bulk_copy():
+    data, log, store = _store()
+    states = [LazyState(store, i, 1, (8, 1)) for i in range(40)]
+    assert log == [] and states[3].shape == (8, 1) and states[3].isket and not states[3].isoper  # shape / kind: no copy
+    assert states[3].device_tensor is not None
+    assert np.array_equal(np.asarray(states[3])[:, 0], data[3, 1]) and log == [8]
+    np.asarray(states[3])
+    assert log == [8]  # materialised once
+    for s in states[4:19]:
+        np.asarray(s)
+    assert log == [8] * 16  # sixteen single reads ...
+    np.asarray(states[30])
+    assert log[-1] == data.size and len(log) == 17  # ... then everything in one transfer
+    for i, s in enumerate(states):
+        assert np.array_equal(np.asarray(s)[:, 0], data[i, 1])
+    assert len(log) == 17 and store.device_tensor is None and states[0].device_tensor is None
+
+
+def test_lazy_state_reads_like_the_qstate_it_becomes():
+    data, log, store = _store()
+    s = LazyState(store, 5, 0, (8, 1))
+    q = QState(data[5, 0])
+    ref = np.ones((8, 1))
+    assert np.allclose(s - ref, q - ref) and np.allclose(ref - s, ref - q) and np.allclose(2 * s, 2 * q) and np.allclose(s * 2, q * 2)
+    assert np.allclose(-s, -q) and np.allclose(abs(s), abs(q)) and np.allclose(s / 2, q / 2)
+    assert isinstance(s + ref, QState) and (s == q).all()
+    assert s.norm() == pytest.approx(q.norm()) and np.allclose(s.unit(), q.unit()) and s.full().shape == (8, 1)
+    assert s.dag().shape == (1, 8) and s.overlap(q) == pytest.approx(q.overlap(q)) and s.copy() is not s
+    assert s[2, 0] == q[2, 0] and len(s) == 8 and np.allclose(np.vdot(s, s), np.vdot(q, q)) and np.allclose(s.conj(), q.conj())
+    assert np.allclose(np.max(np.abs(s)), np.max(np.abs(q))) and s.dtype == np.dtype(complex) and s.ndim == 2
+    with pytest.raises(TypeError):
+        hash(s)
+    with pytest.raises(AttributeError):
+        s._no_such_private_attribute
+    # density matrices
+    rho, log2, store2 = _store(n=3, batch=1, dim=16)
+    d = LazyState(store2, 1, 0, (4, 4))
+    assert d.isoper and not d.isket and np.allclose(d.diag(), np.diag(rho[1, 0].reshape(4, 4))) and d.tr() == pytest.approx(np.trace(rho[1, 0].reshape(4, 4)))
+
+
+def test_state_result_samples_from_a_lazy_state_like_from_a_host_state():
+    """qutip_result.py:101-158 through StateResult._weights: the same Counter for the same seed."""
+    data, log, store = _store(n=2, batch=1, dim=8)
+    data /= np.linalg.norm(data, axis=2, keepdims=True)
+    lazy = StateResult(("q0", "q1", "q2"), "ground-rydberg", LazyState(store, 1, 0, (8, 1)), True)
+    host = StateResult(("q0", "q1", "q2"), "ground-rydberg", QState(data[1, 0]), True)
+    np.random.seed(4)
+    a = lazy.get_samples(500)
+    np.random.seed(4)
+    b = host.get_samples(500)
+    assert a == b and sum(a.values()) == 500
+    assert np.allclose(np.asarray(lazy.get_state()), np.asarray(host.get_state()))
