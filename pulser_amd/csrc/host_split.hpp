@@ -840,6 +840,8 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   auto tau_q = [&](int k) {
     return (slack_on && ctl[k].tau < 1e299) ? ctl[k].tau * std::pow(2.0, 1.0 / scheme_of(k).order) : ctl[k].tau;
   };
+  double no_growth_until[2] = {-1e300, -1e300};  // after a roll-back: the time (us) of the check that failed, by kind
+  bool probe[2] = {false, false};                // a growth probe is wanted on the next step the sub-step would cut
   double h_max[2] = {0.0, 0.0};  // longest step of this call, by kind
   for (const StepDesc& d : sched) { const int k = kind_of(d); h_max[k] = std::max(h_max[k], d.h); }
   double amp_max = 0.0;
@@ -902,7 +904,14 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     const bool informative = !ctl[kd].known || ctl[kd].tau >= 1e299 ||
                              (sched[i].h - off) / std::max(1.0, std::ceil((sched[i].h - off) / tau_q(kd) - 1e-9)) >=
                                  0.5 * std::min(ctl[kd].tau, h_max[kd]) * (1.0 - 1e-9);
-    if (control && informative && (check_due(i, kd, ctl[kd].since) || new_regime || amp_grown)) {
+    // (only a PERIODIC check may wait: a check that is due because the last measurement has gone stale - a kind never
+    // measured, a new regime, a drive that has grown by half - takes the step at hand whatever its length.  Seed 1197 of the
+    // fuzz: the sub-step of the 6th-order kind stood at 18 ns from two checks at zero amplitude, every later step of that
+    // kind was 2 - 3 knots long - "uninformative" against 18 ns - and ran whole and unchecked at 20 x its allowance: 8.1e-7
+    // with an estimate of 1.8e-9.)
+    const bool stale = !ctl[kd].known || new_regime || amp_grown;
+    const bool probe_here = control && probe[kd] && off == 0.0 && sched[i].h > tau_q(kd) * (1.0 + 1e-9);
+    if (control && (stale || probe_here || (informative && check_due(i, kd, ctl[kd].since)))) {
       // ---- check: one sub-step whole (wA) against two halves (state) ----
       const StepDesc& d = sched[i];
       subs.clear();
@@ -957,6 +966,13 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
           h->split_since_len = 0.0;
         }
         HIPCHK(hipMemcpyAsync(state, h->wB, bytes, hipMemcpyDeviceToDevice, st));
+        // The repeated stretch keeps the sub-step the FAILED check asked for until it has passed the place of the failure:
+        // the check period restarts (a periodic check was due at once at the checkpoint, where the generator may be tame -
+        // it measured 1e-13 there, grew the sub-step back to what had just failed and ran through the hard part at 40 x
+        // its allowance: 8.1e-7 with an estimate of 1.8e-9, tools/fuzz_ctrl.py seed 1197), and no check may GROW the
+        // sub-step of this kind before that time.
+        no_growth_until[kd] = std::max(no_growth_until[kd], h->tknots[s0.idx] + s0.u0 + s0.tau);
+        ctl[kd].since = 0;
         i = ck_i;
         off = ck_off;
         ctl[kd].tau = tau_new;
@@ -977,7 +993,22 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       // budget more closely: 7 360 -> 6 890 stages on the anneal, estimate 5.3e-9 -> 5.7e-9)
       // (the sub-step stays a LENGTH - the one this measurement stands for, times fac: until round 5 a check that found
       // its step within budget switched to "whole steps" of any length, see `informative` above)
-      if (ctl[kd].tau >= 1e299 || fac < 0.9 || fac > grow_env) ctl[kd].tau = tau_new;
+      // (the hysteresis is about the sub-step that was MEASURED: it may only leave the working sub-step alone when that is
+      // what was measured.  On a step much shorter than the working sub-step - 0.5-ns pieces while tau stood at 4 ns from
+      // a check at zero amplitude - a measurement at 0.97 of its own length used to leave the 4 ns in place, seed 1197)
+      {
+        const bool blocked = h->tknots[s0.idx] + s0.u0 < no_growth_until[kd] - 1e-12;
+        const double cur = ctl[kd].tau;
+        const bool measured_is_working = cur < 1e299 && cur <= 1.5 * s0.tau;
+        if (cur >= 1e299 || !measured_is_working || fac < 0.9 || fac > grow_env) ctl[kd].tau = tau_new;
+        if (blocked && cur < 1e299) ctl[kd].tau = std::min(ctl[kd].tau, cur);
+        // growth probes: a measurement comfortably inside its allowance (fac >= 1.5) whose result is still below the longest
+        // step of the kind - typically because it was taken on a short step - is followed by a check on the next step
+        // that the new sub-step would cut (each can double the sub-step; ends when the error binds or the steps are covered)
+        // (... or when a probe no longer moves the sub-step: with one-knot steps throughout, a sub-step of 0.75 knots is
+        // quantised to half a knot whatever the probe says)
+        probe[kd] = !blocked && fac >= 1.5 && ctl[kd].tau * 1.2 < h_max[kd] && (cur >= 1e299 || ctl[kd].tau > 1.05 * cur || !measured_is_working);
+      }
       // the stretch behind this check was booked at the rate of the PREVIOUS one: where the rate has grown in between the
       // mean of the two is the better figure (the booked estimate is what callers compare with their tolerance)
       if (e <= 4.0 * allowed && ctl[kd].known)
@@ -1017,7 +1048,8 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       int knots[2] = {ctl[0].since, ctl[1].since};
       for (size_t q = i; q < sched.size(); ++q) {
         const int kq = kind_of(sched[q]);
-        if (q > i && (regime_start(q) || check_due(q, kq, knots[kq]))) { stop = q; break; }
+        if (q > i && (regime_start(q) || check_due(q, kq, knots[kq]) ||
+                      (probe[kq] && sched[q].h > tau_q(kq) * (1.0 + 1e-9)))) { stop = q; break; }
         knots[kq] += std::max(1, sched[q].pad);
       }
     }

@@ -15,7 +15,10 @@ The named regressions are the cases the fuzz found while the controller was bein
 seed 40  - 1 240 one-knot steps of a strongly interacting chain ran unchecked (8.7e-8, estimate 2.1e-8);
 seed 263 - a square pulse from t = 0 on 16 atoms: the one check of the sequence measured the product state (1.85e-7 / 2.8e-8);
 seed 279 - the same on one-knot steps of the 6-stage scheme (4.8e-9 / 7.8e-10);
-seed 306, 72 - 4.5-um chains (7.3e-8 / 1.5e-8, 4.3e-8 / 2.8e-8).
+seed 306, 72 - 4.5-um chains (7.3e-8 / 1.5e-8, 4.3e-8 / 2.8e-8);
+seed 1197 - found by a second sweep (seeds 400 - 1199): the 6th-order kind's sub-step stood at 18 ns from two checks at zero
+           amplitude, every later step of that kind was 2 - 3 knots long and "uninformative" against it (8.1e-7 / 1.8e-9); and a
+           roll-back re-measured at the tame checkpoint and grew the sub-step back to what had just failed.
 """
 from __future__ import annotations
 
@@ -66,9 +69,9 @@ def test_controller_fuzz_default_path_against_a_priori_tolerance(block):
     print(f"block {block}: worst error / estimate above the floor = {worst:.2f}")
 
 
-@pytest.mark.parametrize("seed", [40, 72, 92, 129, 137, 177, 263, 265, 279, 306, 359])
+@pytest.mark.parametrize("seed", [40, 72, 92, 129, 137, 177, 263, 265, 279, 306, 359, 599, 1187, 1197])
 def test_controller_fuzz_named_regressions(seed):
     err, est, s, desc = _run_case(seed)
     print(f"{desc}: error {err:.2e}, estimate {est:.2e}, stages {s['n_applications']}, roll-backs {s['reserved'][3]:.0f}")
     assert err < AMP_TOL / 2, (desc, err, est)
-    assert est > 0.0 and err <= max(COVER * est, FLOOR), (desc, err, est)
+    assert est > 0.0 and err <= max(COVER * est, FLOOR) and est < 2.0 * 5e-8, (desc, err, est)
