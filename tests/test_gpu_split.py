@@ -605,7 +605,10 @@ def test_snapshots_stored_inside_a_run_equal_a_closed_run_per_evaluation_time(n)
                 outs[name] = eng.solve(eng.new_state(), times, **opts).cpu().numpy()
                 stats[name] = eng.stats()
         assert stats["inside"]["reserved"][0] > 0, label  # the split-operator path ran
-        assert stats["inside"]["n_launches"] < max(16, 0.5 * len(times)), (label, stats["inside"])
+        # runs (+ the controller's checks), not a run per evaluation time
+        assert stats["inside"]["n_launches"] < stats["outside"]["n_launches"], (label, stats["inside"], stats["outside"])
+        if label == "dense":
+            assert stats["inside"]["n_launches"] < 0.4 * len(times), (label, stats["inside"])
         assert np.max(np.abs(outs["inside"] - outs["outside"])) < 1e-12, label
         # (the controller's budget for a whole sequence is 5e-8; these are 0.9 us of three differently scaled anneals)
         assert np.max(np.abs(outs["inside"] - outs["taylor"])) < 5e-8, label
