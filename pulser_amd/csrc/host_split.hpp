@@ -752,6 +752,7 @@ static const int kSplitCheckEvery = 256;  // (128: 24 + 6 checks on the headline
 // 1.0e-9, the steps 100 ns later erred six times that, and the one check of the 283-ns sequence booked 2.8e-8 for a true
 // 1.85e-7 (tools/fuzz_ctrl.py seed 263).  Any check (amplitude, regime) counts as one doubling.
 static const int kSplitCheckFirst = dev_env_int("RYD_SPLIT_FIRST", 16, 4, 256);  // (dev A/B: RYD_DEV=1)
+static const double kSplitKind1Weight = dev_env_double("RYD_SPLIT_W1", 4.0, 1.0, 16.0);  // (dev A/B; run_split: w_kind)
 
 // RYD_DEV=1 RYD_SPLIT_TRACE=1 (dev): every check of the controller on stderr
 static bool split_trace_env() {
@@ -843,7 +844,16 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   double no_growth_until[2] = {-1e300, -1e300};  // after a roll-back: the time (us) of the check that failed, by kind
   bool probe[2] = {false, false};                // a growth probe is wanted on the next step the sub-step would cut
   double h_max[2] = {0.0, 0.0};  // longest step of this call, by kind
-  for (const StepDesc& d : sched) { const int k = kind_of(d); h_max[k] = std::max(h_max[k], d.h); }
+  double t_kind[2] = {0.0, 0.0};
+  for (const StepDesc& d : sched) { const int k = kind_of(d); h_max[k] = std::max(h_max[k], d.h); t_kind[k] += d.h; }
+  // How the budget is shared between the kinds.  Minimising the stages of a solve under a fixed sum of local errors gives every
+  // stretch an error allowance proportional to its COST rate (stages per unit time, over the order): the one-knot steps of
+  // kind 1 cost 6 stages per knot interval where the multi-knot steps cost 1 - 3, so a uniform allowance per unit time starves
+  // exactly the steps that are dearest - at the kink of the anneal at 0.5 us the 6-stage composition over one knot measured
+  // 2.3 x a uniform allowance and was cut in two (12 stages per knot) for want of 1e-11.  Kind 1 gets kSplitKind1Weight times
+  // the allowance rate of kind 0, both normalised so that the allowances of the call still add up to its budget.
+  const double w_kind[2] = {1.0, kSplitKind1Weight};
+  const double w_bar = (t_kind[0] + t_kind[1]) > 0.0 ? (w_kind[0] * t_kind[0] + w_kind[1] * t_kind[1]) / (t_kind[0] + t_kind[1]) : 1.0;
   double amp_max = 0.0;
   for (double v : h->bd_c1) amp_max = std::max(amp_max, v);
   auto amp_at = [&](const StepDesc& d) { return span_max(h->bd_c1, d.idx, std::max(1, d.pad)); };
@@ -945,7 +955,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       const int p_ord = sck.order;
       const double two_p = std::ldexp(1.0, p_ord);
       e *= two_p / (two_p - 1.0);
-      const double allowed = eps * s0.tau / t_total;
+      const double allowed = eps * s0.tau / t_total * (w_kind[kd] / w_bar);
       double fac = std::pow(0.5 * allowed / std::max(e, 1e-300), 1.0 / p_ord);
       fac = std::min(std::max(fac, 0.2), p_ord == 6 ? 2.0 : 4.0);  // (x 2 in tau is x 64 in the 6th-order error)
       const double tau_new = s0.tau * fac;
