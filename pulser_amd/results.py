@@ -216,6 +216,9 @@ class LazyState:
     def _materialise(self) -> QState:
         if self._q is None:
             self._q = QState(np.asarray(self._store.get(self._i, self._b)).reshape(self._shape))
+            # a materialised state holds its host data and lets go of the store: keeping ONE state of a run alive must not
+            # keep the 813 MB of the run's device snapshots alive with it
+            self._store = None
         return self._q
 
     @property
@@ -240,8 +243,8 @@ class LazyState:
 
     @property
     def device_tensor(self) -> Any:
-        """The snapshot on the GPU (a view), or None when the store has moved to the host."""
-        dev = self._store.device_tensor
+        """The snapshot on the GPU (a view), or None once this state (or the whole store) has moved to the host."""
+        dev = None if self._store is None else self._store.device_tensor
         return None if dev is None else dev[self._i, self._b]
 
     def __array__(self, dtype: Any = None, copy: Any = None) -> np.ndarray:

@@ -42,6 +42,8 @@ def test_a_state_is_copied_when_it_is_read_and_a_loop_over_all_states_costs_one_
     assert log == [] and states[3].shape == (8, 1) and states[3].isket and not states[3].isoper  # shape / kind: no copy
     assert states[3].device_tensor is not None
     assert np.array_equal(np.asarray(states[3])[:, 0], data[3, 1]) and log == [8]
+    # a materialised state has let go of the store (one kept state must not pin the run's device snapshots)
+    assert states[3]._store is None and states[3].device_tensor is None and states[4]._store is store
     np.asarray(states[3])
     assert log == [8]  # materialised once
     for s in states[4:19]:
