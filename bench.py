@@ -266,7 +266,9 @@ def roofline_valu(n_amp, rows, stages, flops_per_amp_stage, kernel_ms, launches,
            "stages": stages, "us_per_stage": kernel_ms * 1e3 / max(stages, 1),
            "flops_per_amplitude_per_stage": flops_per_amp_stage,
            "isa_flops_per_launch": flops / max(launches, 1),
-           "hbm_equivalent_GBps": 32.0 * n_amp * rows * stages / sec / 1e9 if sec > 0 else 0.0}
+           "hbm_equivalent_GBps": 32.0 * n_amp * rows * stages / sec / 1e9 if sec > 0 else 0.0,
+           # what HBM has to carry for a launch on paper: every ket once in and once out (16 B per amplitude each way)
+           "algorithmic_bytes_per_launch": 32.0 * n_amp * rows}
     if algorithmic_flops_per_amp_stage:
         alg = algorithmic_flops_per_amp_stage * n_amp * rows * stages
         out["algorithmic_flops_per_amplitude_per_stage"] = algorithmic_flops_per_amp_stage
@@ -275,6 +277,84 @@ def roofline_valu(n_amp, rows, stages, flops_per_amp_stage, kernel_ms, launches,
     if note:
         out["note"] = note
     return out
+
+
+# ----------------------------------------------------------------------------- the driver's line
+DETAIL_PREFIX = "BENCH_DETAIL "
+MAX_LINE_BYTES = 6144   # the driver keeps an 8-KB tail of stdout: the contract line must fit with room to spare
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "us_per_stage", "traffic",
+              "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "isa_flops_per_launch", "launches",
+              "avg_launch_ms", "hbm_equivalent_GBps")
+_CFG_KEYS = ("n_atoms", "sequences_per_gpu", "sim_us_per_sequence", "stages_per_sequence", "parity_max_abs",
+             "single_sequence_sim_us_per_s", "lindblad_seconds", "lindblad_sim_us_per_s", "lindblad_roofline_frac",
+             "n_trajectories", "sim_us_per_s", "n_measures", "histogram_total", "passes_per_application", "order",
+             "generator_applications_per_sequence")
+
+
+def _short(text, limit):
+    text = str(text)
+    return text if len(text) <= limit else text[: limit - 3] + "..."
+
+
+def _num(v):
+    """Numbers of the line at 6 significant digits (the detail file keeps every digit)."""
+    if isinstance(v, float) and v == v and abs(v) != float("inf") and not (abs(v) < 1e15 and v == int(v)):
+        return float(f"{v:.6g}")
+    return v
+
+
+def _find_leg(also, start):
+    for leg in also or []:
+        if str(leg.get("workload", "")).startswith(start):
+            return leg
+    return None
+
+
+def driver_line(out: dict) -> dict:
+    """The ONE short JSON line of the driver contract, cut from the full result `out` (which goes to
+    bench_detail.json): scalar fields only, names instead of descriptions, no notes.  Pure function of `out` (a CPU
+    test feeds it a canned dict); <= MAX_LINE_BYTES by construction of the key lists, asserted where it is printed."""
+    line = {k: _num(out[k]) for k in _TOP_KEYS if k in out}
+    cfg_in = out.get("config") or {}
+    cfg = {"workload": _short(cfg_in.get("workload", ""), 200)}
+    cfg.update({k: _num(cfg_in[k]) for k in _CFG_KEYS if k in cfg_in})
+    if "parallelism" in cfg_in:
+        cfg["parallelism"] = _short(cfg_in["parallelism"], 60).split(" (")[0]
+    api = cfg_in.get("api_end_to_end") or {}
+    for spec, key in (("Full", "api_full_ms"), ("Minimal", "api_minimal_ms")):
+        if spec in api:
+            cfg[key] = _num(api[spec]["ms"])
+    also = out.get("also")
+    for start, key, field in (("cfg2:", "cfg2_sim_us_per_s", "value"), ("cfg4:", "cfg4_traj_per_s", "value"),
+                              ("cfg5: 20-atom", "cfg5_sim_us_per_s", "value"),
+                              ("f-1:", "multilevel_sim_us_per_s", "value"), ("f-4:", "xy_sim_us_per_s", "value")):
+        leg = _find_leg(also, start)
+        if leg is not None:
+            cfg[key] = _num(leg[field])
+    line["config"] = cfg
+    roof = out.get("roofline")
+    if roof:
+        r = {k: _num(roof[k]) for k in _ROOF_KEYS if k in roof}
+        r["kernel"] = _short(str(roof.get("kernel", "")).split(" (")[0], 80)  # the name only
+        r.setdefault("traffic", None)
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    cpu = out.get("cpu_baseline")
+    if cpu:
+        c = {k: _num(cpu[k]) for k in ("value", "unit", "cores", "kind", "host_cpu_count") if k in cpu}
+        c["sample"] = _short(cpu.get("sample", ""), 120)
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    col = out.get("collective")
+    if col:
+        line["collective"] = {k: col[k] for k in ("backend", "world_size", "distinct_devices", "allreduce_of_ones")
+                              if k in col}
+    line["detail"] = "bench_detail.json"
+    return line
 
 
 # ----------------------------------------------------------------------------- CPU baselines
@@ -330,9 +410,9 @@ def cpu_baselines(full: bool):
     ncpu = os.cpu_count() or 1
     dt14, rhs14 = _oracle_sesolve_time(tri_problem(2, 7), T_SEQ_US)
     out = {"value": T_SEQ_US / dt14, "unit": "sim-us/s", "cores": 1, "kind": "port",
-           "sample": f"1 x one 14-atom triangular-register sequence (3.1 us), SciPy CSR terms + not-a-knot "
-                     f"spline + zvode Adams at QuTiP defaults (atol 1e-8, rtol 1e-6, max_step 1 ns): "
-                     f"{rhs14} RHS evaluations, {dt14:.2f} s",
+           "sample": f"one 14-atom sequence (3.1 us), zvode Adams at QuTiP defaults on SciPy CSR terms: {rhs14} RHS, {dt14:.1f} s",
+           "sample_detail": "the north-star sequence on the triangular register; SciPy CSR terms + not-a-knot spline + "
+                            "zvode Adams (atol 1e-8, rtol 1e-6, max_step 1 ns), one core",
            "host_cpu_count": ncpu}
     if not full:
         return out
@@ -560,7 +640,9 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # N > 1 always; a one-rank job under torch.distributed.run with RYD_BENCH_BACKEND set runs the same collective code
+    # at world size 1 (legal for RCCL): how the nccl branch is executed on a one-GPU box (tests/test_gpu_bench.py)
+    if world > 1 or ("RANK" in os.environ and os.environ.get("RYD_BENCH_BACKEND")):
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -639,9 +721,10 @@ def main() -> None:
             "metric": "sim-us/sec, 14-atom Rydberg anneal sequence, sesolve fp64 (aggregate over independent sequences)",
             "value": value, **common, "ms_per_step": sec * 1e3,
             "config": {
-                "workload": "north star (BASELINE.json): 14-atom triangular register (2 x 7, spacing R_b), "
-                            "analog Ising anneal 3100 ns, sesolve complex128; one step = the full 3.1 us for a "
-                            "batch of independent sequences per GPU (amplitude / detuning scale factors spread +-1 %)",
+                "workload": "north star: 14-atom triangular register (2 x 7 at R_b), analog Ising anneal 3100 ns, sesolve "
+                            "complex128; step = the full 3.1 us for a batch of different sequences per GPU",
+                "workload_detail": "BASELINE.json north_star; the sequences of a batch differ (amplitude / detuning scale "
+                                   "factors spread +-1 %), tables and initial states resident in HBM before the timed region",
                 "n_atoms": n, "sequences_per_gpu": B, "sim_us_per_sequence": T_SEQ_US,
                 "integrator": "CF4 Magnus; exponentials by the in-place symplectic scheme (k_ket), "
                               "2e-11 per exponential" if ket else
@@ -985,7 +1068,18 @@ def main() -> None:
             out["collective"] = collective
 
     if rank == 0:
-        print(json.dumps(out))
+        # everything measured goes to bench_detail.json and to an EARLIER stdout line (prefix DETAIL_PREFIX, so that
+        # no parser takes it for the contract line); the LAST line is the short contract line the driver parses
+        detail = json.dumps(out)
+        try:
+            with open(os.environ.get("RYD_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")), "w") as fh:
+                fh.write(detail + "\n")
+        except OSError as exc:  # a read-only checkout still prints both lines
+            print(f"bench.py: bench_detail.json not written ({exc})", file=sys.stderr)
+        print(DETAIL_PREFIX + detail, flush=True)
+        line = json.dumps(driver_line(out))
+        assert len(line) <= MAX_LINE_BYTES, len(line)
+        print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -18,7 +18,10 @@ is what makes sampled bitstring indices bit-exact:
 from __future__ import annotations
 
 import collections.abc
+import os
+import threading
 import warnings
+import weakref
 from collections import Counter
 from dataclasses import dataclass
 from functools import lru_cache
@@ -162,14 +165,78 @@ class SnapshotStore:
     ``evaluation_times="Full"`` - its default - that is 3 101 x 256 KiB = 813 MB for one 14-atom sequence, most of which
     nobody reads.  The snapshots stay in HBM; a state crosses PCIe when it is read (``LazyState``), and once more than
     ``bulk_after`` different states have been asked for the whole tensor is copied in one transfer (a loop over all
-    evaluation times - ``expect``, sampling at every time - then costs one copy, as before)."""
+    evaluation times - ``expect``, sampling at every time - then costs one copy, as before).
+
+    **Retention is bounded.**  Results objects a sweep keeps around would otherwise pin 813 MB of HBM each: every live
+    store is registered (weakly), and before a new one is added the OLDEST stores are spilled to the host until the
+    retained device bytes fit ``device_budget_bytes()`` (default 1/8 of the device's memory; ``PULSER_AMD_SNAPSHOT_GB``
+    overrides).  Spilling changes where a state is read from, never what is read.  ``spill_all()`` / a results object's
+    ``to_host()`` move everything explicitly."""
+
+    _live: "list[weakref.ref[SnapshotStore]]" = []   # registration order = age
+    _lock = threading.Lock()
 
     def __init__(self, tensor: Any, bulk_after: int = 16) -> None:
         self._dev = tensor
         self._host: np.ndarray | None = None
         self._reads = 0
         self._bulk_after = int(bulk_after)
+        self._register()
 
+    # -- the registry -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def device_budget_bytes() -> int:
+        env = os.environ.get("PULSER_AMD_SNAPSHOT_GB")
+        if env is not None:
+            return int(float(env) * 2**30)
+        try:
+            import torch
+
+            return int(torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory // 8)
+        except Exception:  # no device (CPU tests build stores over host tensors)
+            return 8 * 2**30
+
+    def device_bytes(self) -> int:
+        dev = self._dev
+        return 0 if dev is None else int(getattr(dev, "nbytes", 0))
+
+    @classmethod
+    def _alive(cls) -> "list[SnapshotStore]":
+        stores = [r() for r in cls._live]
+        cls._live = [r for r, s in zip(cls._live, stores) if s is not None and s._dev is not None]
+        return [s for s in stores if s is not None and s._dev is not None]
+
+    @classmethod
+    def retained_device_bytes(cls) -> int:
+        with cls._lock:
+            return sum(s.device_bytes() for s in cls._alive())
+
+    def _register(self) -> None:
+        cls = type(self)
+        with cls._lock:
+            budget = cls.device_budget_bytes()
+            alive = cls._alive()
+            held = sum(s.device_bytes() for s in alive) + self.device_bytes()
+            for s in alive:  # oldest first
+                if held <= budget:
+                    break
+                held -= s.device_bytes()
+                s.fetch_all()
+            cls._live = [r for r in cls._live if (r() is not None and r()._dev is not None)]
+            cls._live.append(weakref.ref(self))
+
+    @classmethod
+    def spill_all(cls) -> int:
+        """Move every live store to the host (frees their HBM); returns the bytes moved."""
+        with cls._lock:
+            moved = 0
+            for s in cls._alive():
+                moved += s.device_bytes()
+                s.fetch_all()
+            cls._live = []
+            return moved
+
+    # -- reads ----------------------------------------------------------------------------------------------------------
     @property
     def device_tensor(self) -> Any:
         """The torch tensor on the GPU (None once everything has been copied to the host)."""
@@ -187,7 +254,8 @@ class SnapshotStore:
             if self._reads <= self._bulk_after:
                 return self._dev[i, b].cpu().numpy()
             self.fetch_all()
-        return self._host[i, b]
+        # a copy: a state that outlives the run owns its own 2^N amplitudes, not a view that pins the whole host array
+        return self._host[i, b].copy()
 
 
 def _lazy_binary(name: str) -> Any:
@@ -588,6 +656,18 @@ class SimulationResults(collections.abc.Sequence):
                 vals.append(v.real if herm else v)
             out.append(np.array(vals))
         return out
+
+    def to_host(self) -> "SimulationResults":
+        """Move the stored states of this run from HBM to host memory now (what the reference always does,
+        simulation.py:744-748).  ``results.states`` reads the same afterwards; the device snapshots are released."""
+        seen: set[int] = set()
+        for r in self._results_seq:
+            st = getattr(r, "state", None)
+            store = getattr(st, "_store", None)
+            if store is not None and id(store) not in seen:
+                seen.add(id(store))
+                store.fetch_all()
+        return self
 
     def sample_state(self, t: float, n_samples: int = 1000, t_tol: float = 1.0e-3) -> Counter:
         t_index = self._get_index_from_time(t, t_tol)

@@ -1651,6 +1651,53 @@ def test_bench_flop_constants_match_the_compiled_kernels():
     assert per_half and abs(2 * sum(per_half) / len(per_half) - ns["KKET_FLOPS_PER_AMP_STAGE"]) < 0.02 * ns["KKET_FLOPS_PER_AMP_STAGE"]
 
 
+def test_bench_driver_line_is_short_scalar_and_round_trips():
+    """The driver keeps an 8-KB tail of stdout and parses its last line (round 5's 21-KB line came back `parsed: null`):
+    bench.driver_line cuts the contract line from the full record - here from the committed 21-KB record of round 5 and
+    from one stuffed with prose - and must stay below 6 KB, carry the contract's keys, and hold scalars only."""
+    import json
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    full = json.load(open(os.path.join(root, "profiles", "r05_bench.json")))
+    assert len(json.dumps(full)) > 20000
+    stuffed = json.loads(json.dumps(full))
+    stuffed["config"]["workload"] = "w" * 5000
+    stuffed["roofline"]["kernel"] = "k_split_reg<14, 5> (" + "x" * 5000 + ")"
+    stuffed["cpu_baseline"]["sample"] = "s" * 5000
+    stuffed["collective"] = {"backend": "nccl", "world_size": 8, "distinct_devices": 8, "allreduce_of_ones": 8.0,
+                             "ranks": [{"rank": r, "pci": "0000:%02x:00" % r, "name": "n" * 100} for r in range(8)]}
+    for rec in (full, stuffed):
+        line = bench.driver_line(rec)
+        text = json.dumps(line)
+        assert len(text) <= bench.MAX_LINE_BYTES < 8192, len(text)
+        assert json.loads(text) == line
+        assert {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"} <= set(line)
+        assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+        assert all(not isinstance(v, (dict, list)) for v in line["config"].values())
+        assert len(line["config"]["workload"]) <= 200 and len(line["cpu_baseline"]["sample"]) <= 120
+        assert {"n_atoms", "sequences_per_gpu", "stages_per_sequence", "parity_max_abs", "single_sequence_sim_us_per_s",
+                "lindblad_seconds", "api_full_ms", "api_minimal_ms", "cfg2_sim_us_per_s", "cfg4_traj_per_s",
+                "cfg5_sim_us_per_s"} <= set(line["config"])
+        roof = line["roofline"]
+        assert roof["kernel"] == "k_split_reg<14, 5>" and roof["bound"] == "valu_f64"
+        assert {"achieved", "peak", "unit", "frac", "frac_algorithmic", "us_per_stage", "traffic"} <= set(roof)
+        assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-4)
+        assert {"value", "unit", "cores", "kind", "sample", "host_cpu_count"} <= set(line["cpu_baseline"])
+    assert bench.driver_line(stuffed)["collective"] == {"backend": "nccl", "world_size": 8, "distinct_devices": 8,
+                                                        "allreduce_of_ones": 8.0}
+    # a line without legs / cpu leg (N > 1, --no-cpu) still carries the keys
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    bare["config"] = {"workload": "x"}
+    line = bench.driver_line(bare)
+    assert line["roofline"] is None and line["cpu_baseline"] is None
+
+
 def test_phase_gauge_of_the_split_operator_stages_is_an_identity():
     """SplitRun.gauge (k_split.hpp: k_split_coefs): a rotation by a complex drive c = |c| e^{i theta} is Z R(|c|) Z^+ with
     the diagonal Z = exp(-i theta n), and Z commutes with the D factors - so the composition D R(c_S) D ... R(c_1) D equals

@@ -21,6 +21,10 @@ class FakeTensor:
     def __getitem__(self, k):
         return FakeTensor(self.a[k], self.log)
 
+    @property
+    def nbytes(self):
+        return self.a.nbytes
+
     def cpu(self):
         self.log.append(self.a.size)
         return self
@@ -90,3 +94,48 @@ def test_state_result_samples_from_a_lazy_state_like_from_a_host_state():
     b = host.get_samples(500)
     assert a == b and sum(a.values()) == 500
     assert np.allclose(np.asarray(lazy.get_state()), np.asarray(host.get_state()))
+
+
+def test_retained_device_snapshots_are_bounded_and_the_oldest_spill_first(monkeypatch):
+    """results objects a sweep keeps alive must not accumulate HBM.  Every live store is
+    registered; a new one spills the oldest to the host until the budget holds; spilling never changes what is read."""
+    import gc
+
+    SnapshotStore.spill_all()
+    one = 40 * 2 * 8 * 16  # bytes of one stand-in store
+    monkeypatch.setenv("PULSER_AMD_SNAPSHOT_GB", str(2.5 * one / 2**30))
+    kept = [_store() for _ in range(2)]
+    assert SnapshotStore.retained_device_bytes() == 2 * one and all(log == [] for _, log, _ in kept)
+    data3, log3, store3 = _store()  # the third does not fit: the OLDEST goes to the host in one transfer
+    assert kept[0][2].device_tensor is None and kept[0][1] == [kept[0][0].size]
+    assert kept[1][2].device_tensor is not None and store3.device_tensor is not None
+    assert SnapshotStore.retained_device_bytes() == 2 * one
+    # the spilled store reads the same, and hands out copies (one kept state does not pin the run's host array)
+    st = LazyState(kept[0][2], 5, 1, (8, 1))
+    a = np.asarray(st)
+    assert np.array_equal(a[:, 0], kept[0][0][5, 1]) and not np.shares_memory(a, kept[0][2]._host)
+    # a store nobody holds any more does not count
+    del kept, st, a
+    gc.collect()
+    assert SnapshotStore.retained_device_bytes() == one
+    assert SnapshotStore.spill_all() == one and store3.device_tensor is None and log3 == [data3.size]
+    assert SnapshotStore.retained_device_bytes() == 0
+
+
+def test_results_to_host_moves_the_run_and_reads_the_same():
+    from pulser_amd.results import CoherentResults
+
+    SnapshotStore.spill_all()
+    data, log, store = _store(n=5, batch=1, dim=4)
+    times = np.linspace(0.0, 1.0, 6)
+    qids = ("q0", "q1")
+    res = [StateResult(qids, "ground-rydberg", QState(np.array([0, 0, 0, 1.0])), True, evaluation_time=0.0)]
+    res += [StateResult(qids, "ground-rydberg", LazyState(store, i, 0, (4, 1)), True, evaluation_time=float(times[i + 1]))
+            for i in range(5)]
+    cr = CoherentResults(res, 2, "ground-rydberg", times, "ground-rydberg")
+    assert SnapshotStore.retained_device_bytes() == data.nbytes
+    assert cr.to_host() is cr and store.device_tensor is None and log == [data.size]
+    assert SnapshotStore.retained_device_bytes() == 0
+    for i in range(5):
+        assert np.array_equal(np.asarray(cr.states[i + 1])[:, 0], data[i, 0])
+    assert log == [data.size]
