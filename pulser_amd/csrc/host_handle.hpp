@@ -58,6 +58,7 @@ struct ryd_handle {
   // polynomial", per-interval per-ATOM maxima of |c|, |dc/dt|, |delta|, |d delta/dt| over the batch
   std::vector<double> s_der;
   std::vector<char> join_ok;  // [n_int - 1]: pieces i and i + 1 of EVERY series coincide as polynomials
+  std::vector<char> lin_ok;   // [n_int]: piece i of EVERY series is linear in time (ramps, plateaus), to 1e-10 of the series' scale
   std::vector<double> bd_c1, bd_dc, bd_dl, bd_ddl;
   double u_rowsum = 0.0;      // max_i sum_j |U_ij|
   bool bounds_valid = false;
@@ -515,10 +516,13 @@ extern "C" int ryd_set_series(ryd_handle* h, int32_t n_series, int32_t n_knots,
   // knot i + 1 is removable when piece i, re-expanded about it, IS piece i + 1 (to rounding) for every
   // series: linear ramps, plateaus - not the ringing of the not-a-knot spline next to a kink
   h->join_ok.assign(std::max(n_int - 1, 0), 1);
+  h->lin_ok.assign(n_int, 1);
   for (int s = 0; s < n_series; ++s) {
     double smax = 0.0;
     for (int i = 0; i < n_int; ++i) smax = std::max(smax, h->s_abs[(size_t)s * n_int + i]);
     const double thr = 1e-13 * std::max(smax, 1e-300);
+    for (int i = 0; i < n_int; ++i)
+      if (!(h->s_curv[(size_t)s * n_int + i] <= 1e-10 * std::max(smax, 1e-300))) h->lin_ok[i] = 0;
     for (int i = 0; i + 1 < n_int; ++i) {
       const std::complex<double>* p = &h->pp_host[((size_t)s * n_int + i) * 4];
       const std::complex<double>* q = p + 4;

@@ -912,6 +912,91 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       return snapshot_copy(h, state, snaps + (size_t)sched[k].snap * h->dim * h->B, st);
     return RYD_OK;
   };
+  // Sub-steps across step boundaries (round 6).  The schedule cuts a smooth stretch - one polynomial over many knots - into
+  // steps of <= kSplitMergeMax knot intervals, and until round 5 a step was cut into k EQUAL sub-steps: 9 ns -> 9, 4.5, 3 ns.
+  // On the headline anneal the measured sub-step stood at 5 - 8 ns over 1.3 us of the sweep and the steps ran 4.5 ns (the
+  // trace of round 6: profiles/r06_ctrl_trace.md).  Consecutive kind-0 steps that continue one polynomial (the next one
+  // starts where this one ends, on the same piece or across a removable knot) and have no evaluation time between them
+  // form a GROUP; a group is cut into equal sub-steps of (almost) the working length, whatever the step boundaries - a
+  // sub-step {piece, offset, length} never cared which step it belongs to.  Steps stay the unit of the controller (checks,
+  // amplitude triggers, periods, evaluation times); a sub-step is re-based on the piece its start lies in, so a piece is
+  // never evaluated further than one sub-step beyond its own interval.  Sub-steps stay <= kSplitSubCap knot intervals.
+  static const bool groups_on = dev_env_flag("RYD_SPLIT_GROUPS", true);
+  static const int sub_cap_knots = dev_env_int("RYD_SPLIT_SUBCAP", 16, 1, 64);
+  auto step_t0 = [&](const StepDesc& d) { return h->tknots[d.idx] + (d.u1 - kC1 * d.h); };
+  auto last_piece = [&](const StepDesc& d) {  // the piece the END of the step lies in
+    int p = d.idx;
+    const double te = step_t0(d) + d.h;
+    while (p + 2 < h->n_knots && h->tknots[p + 1] < te - 1e-12) ++p;
+    return p;
+  };
+  auto whole = [&](const StepDesc& d) {
+    const int e = d.idx + std::max(1, d.pad);
+    return std::fabs(d.u1 - kC1 * d.h) < 1e-12 && e < h->n_knots && std::fabs(step_t0(d) + d.h - h->tknots[e]) < 1e-12;
+  };
+  auto linear = [&](const StepDesc& d) {
+    for (int q = d.idx; q < d.idx + std::max(1, d.pad) && q < (int)h->lin_ok.size(); ++q)
+      if (!h->lin_ok[q]) return false;
+    return true;
+  };
+  std::vector<char> link(sched.size(), 0);     // step q + 1 continues the polynomial of step q, nothing happens between
+  std::vector<double> glen(sched.size(), 0.0);  // length from the start of step q to the end of its group
+  if (groups_on && control && !jumps) {
+    for (size_t q = 0; q + 1 < sched.size(); ++q) {
+      const StepDesc &a = sched[q], &b = sched[q + 1];
+      if (kind_of(a) != 0 || kind_of(b) != 0) continue;
+      if (snaps && a.snap >= 0) continue;
+      if (std::fabs(step_t0(a) + a.h - step_t0(b)) > 1e-12) continue;
+      // only steps that cover WHOLE knot intervals join: a step inside a knot interval is there because the schedule cut the
+      // interval for the spline's own curvature (the ringing next to a kink, build_schedule: nsub) or for max_step - an
+      // a-priori bound the controller's measurement, taken elsewhere, knows nothing about (fuzz seed 202: the last 25
+      // knots of a pulse that ends on a step ran whole knots where the schedule asked for 0.25 ns: 2.9e-7, estimate 8e-10)
+      if (!whole(a) || !whole(b)) continue;
+      // ... and only where every waveform is LINEAR in time (ramps, plateaus: the analog sequences the long sub-steps are
+      // made for).  On a curved piece - the cubic interior of a PCHIP-interpolated pulse - the local error follows the
+      // waveforms' derivatives, which no trigger watches: fuzz seed 230 took 10-ns sub-steps down the flank of a bell
+      // measured on its top (1.9e-8 in one sub-step, 8 x the estimate).  Curved stretches keep their steps (<= 9 knots).
+      if (!linear(a) || !linear(b)) continue;
+      const int pa = last_piece(a);
+      if (b.idx == pa + 1 && pa < (int)h->join_ok.size() && h->join_ok[pa]) link[q] = 1;
+    }
+  }
+  for (size_t q = sched.size(); q-- > 0;) glen[q] = sched[q].h + (link[q] ? glen[q + 1] : 0.0);
+  auto knot_len = [&](int idx) { return h->tknots[std::min(idx + 1, h->n_knots - 1)] - h->tknots[std::min(idx, h->n_knots - 2)]; };
+  // equal sub-steps of target length tau_t over steps a .. b (a group) from offset `off` of step a
+  auto group_substeps = [&](size_t a, size_t b, double off_a, double tau_t, std::vector<SubStep>& out) {
+    const double T0 = step_t0(sched[a]) + off_a, T1 = step_t0(sched[b]) + sched[b].h;
+    const double H = T1 - T0;
+    tau_t = std::min(tau_t, sub_cap_knots * knot_len(sched[a].idx));
+    const int k = std::max(1, (int)std::ceil(H / tau_t - 1e-9));
+    const double tau = H / k;
+    const int p_max = last_piece(sched[b]);
+    int p = sched[a].idx;
+    for (int s2 = 0; s2 < k; ++s2) {
+      const double ts = T0 + s2 * tau;
+      while (p < p_max && h->tknots[p + 1] <= ts + 1e-12) ++p;
+      out.push_back({p, std::max(0.0, ts - h->tknots[p]), tau, 0});
+    }
+  };
+  auto group_end = [&](size_t a, size_t lim) {  // last step of the group that starts at step a (steps < lim)
+    size_t b = a;
+    while (b + 1 < lim && link[b]) ++b;
+    return b;
+  };
+  // the first sub-step the controller would take at (step q, offset o) with working sub-step tau_t
+  auto first_substep = [&](size_t q, double o, double tau_t, int k) {
+    std::vector<SubStep> tmp;
+    // (a kind never measured starts from the step at hand: its first measurement is not taken at the sub-step cap)
+    const size_t b = (k == 0 && kind_of(sched[q]) == 0 && tau_t < 1e299) ? group_end(q, sched.size()) : q;
+    if (b > q) group_substeps(q, b, o, tau_t, tmp);
+    else split_substeps(h, sched[q], o, tau_t, tmp, k);
+    return tmp[0];
+  };
+  if (groups_on && control && !jumps) {
+    // the longest sub-step a kind-0 step can be part of (growth probes stop there)
+    for (size_t q = 0; q < sched.size(); ++q)
+      if (kind_of(sched[q]) == 0) h_max[0] = std::max(h_max[0], std::min(glen[q], sub_cap_knots * knot_len(sched[q].idx)));
+  }
   while (i < sched.size()) {
     // A run of multi-knot steps that starts after knots which could not be removed (a waveform kink, the start of
     // the sequence) is a new regime: the local error measured before it says nothing about 8-knot sub-steps of the
@@ -932,22 +1017,21 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     // nothing, returned "whole steps", and the 9-knot steps ran unchecked while the drive grew - 3.8e-7 from a tight run
     // with an estimate of 4.5e-9, tools/snap_check.py.)  A check that is due waits for a step whose sub-step is at least
     // half the working sub-step of its kind (or half the longest step of that kind, where every step is short).
+    const double ahead = (kd == 0 ? glen[i] : sched[i].h) - off;  // what a sub-step starting here can be cut from
     const bool informative = !ctl[kd].known || ctl[kd].tau >= 1e299 ||
-                             (sched[i].h - off) / std::max(1.0, std::ceil((sched[i].h - off) / tau_q(kd) - 1e-9)) >=
-                                 0.5 * std::min(ctl[kd].tau, h_max[kd]) * (1.0 - 1e-9);
+                             first_substep(i, off, tau_q(kd), kd).tau >= 0.5 * std::min(ctl[kd].tau, h_max[kd]) * (1.0 - 1e-9);
     // (only a PERIODIC check may wait: a check that is due because the last measurement has gone stale - a kind never
     // measured, a new regime, a drive that has grown by half - takes the step at hand whatever its length.  Seed 1197 of the
     // fuzz: the sub-step of the 6th-order kind stood at 18 ns from two checks at zero amplitude, every later step of that
     // kind was 2 - 3 knots long - "uninformative" against 18 ns - and ran whole and unchecked at 20 x its allowance: 8.1e-7
     // with an estimate of 1.8e-9.)
     const bool stale = !ctl[kd].known || new_regime || amp_grown;
-    const bool probe_here = control && probe[kd] && off == 0.0 && sched[i].h > tau_q(kd) * (1.0 + 1e-9);
+    const bool probe_here = control && probe[kd] && off == 0.0 && ahead > tau_q(kd) * (1.0 + 1e-9);
     if (control && (stale || probe_here || (informative && check_due(i, kd, ctl[kd].since)))) {
       // ---- check: one sub-step whole (wA) against two halves (state) ----
       const StepDesc& d = sched[i];
       subs.clear();
-      split_substeps(h, d, off, tau_q(kd), subs, kd);
-      const SubStep s0 = subs[0];
+      const SubStep s0 = first_substep(i, off, tau_q(kd), kd);
       if (!have_ck && !jumps) {
         // the first check of a call: its own start is the checkpoint (a sub-step never measured here - 8 knots of the
         // 6th-order scheme, say - may be far over its allowance, and the two halves kept below would carry 2^-p
@@ -1046,11 +1130,12 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
         h->stats.reserved[0] += 0.5 * std::max(0.0, e / s0.tau - book_rate(kd, s0.tau)) * ctl[kd].len_since;
       h->stats.reserved[0] += e / two_p;  // the two halves are what was kept
       off += s0.tau;
-      if (off >= d.h * (1.0 - 1e-12)) {
+      while (i < sched.size() && off >= sched[i].h * (1.0 - 1e-12)) {  // (a sub-step of a group may end in a later step)
+        off -= sched[i].h;
         h->stats.n_steps++;
         if ((rc = finish_step(i))) return rc;
         ++i;
-        off = 0.0;
+        if (off < 1e-12) off = 0.0;
       }
       HIPCHK(hipMemcpyAsync(h->wB, state, bytes, hipMemcpyDeviceToDevice, st));
       ck_i = i;
@@ -1080,17 +1165,18 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       for (size_t q = i; q < sched.size(); ++q) {
         const int kq = kind_of(sched[q]);
         if (q > i && (regime_start(q) || check_due(q, kq, knots[kq]) ||
-                      (probe[kq] && sched[q].h > tau_q(kq) * (1.0 + 1e-9)))) { stop = q; break; }
+                      (probe[kq] && (kq == 0 ? glen[q] : sched[q].h) > tau_q(kq) * (1.0 + 1e-9)))) { stop = q; break; }
         knots[kq] += std::max(1, sched[q].pad);
       }
     }
     subs.clear();
     marks.clear();
     while (i < stop) {
-      const StepDesc& d = sched[i];
-      const int kb = kind_of(d), k = run_kind(d, d.h - off);
+      const int kb = kind_of(sched[i]), k = run_kind(sched[i], sched[i].h - off);
+      const size_t j = (kb == 0 && k == 0) ? group_end(i, stop) : i;  // the group i .. j is cut as one piece
       const size_t before = subs.size();
-      split_substeps(h, d, off, tau_q(k), subs, k);
+      if (j > i) group_substeps(i, j, off, tau_q(k), subs);
+      else split_substeps(h, sched[i], off, tau_q(k), subs, k);
       for (size_t q = before; q < subs.size(); ++q) {
         h->stats.reserved[0] += book_rate(k, subs[q].tau) * subs[q].tau;
         h->split_since_len += subs[q].tau;
@@ -1098,19 +1184,22 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       }
       marks.resize(subs.size(), -1);
       off = 0.0;
-      h->stats.n_steps++;
-      ctl[kb].since += std::max(1, d.pad);  // (the check period of a kind counts ITS steps, whatever they ran on)
+      for (size_t q = i; q <= j; ++q) {
+        h->stats.n_steps++;
+        ctl[kb].since += std::max(1, sched[q].pad);  // (the check period of a kind counts ITS steps, whatever they ran on)
+      }
+      const StepDesc& d = sched[j];  // (the inner steps of a group have no evaluation time: link)
       const bool snap = snaps && d.snap >= 0;
-      if (snap && snaps_inside && i + 1 != stop) {
+      if (snap && snaps_inside && j + 1 != stop) {
         // the evaluation time at the end of this step does not close the run (round 5): the snapshot is taken inside it
         marks.back() = d.snap;
-      } else if (snap || jumps || i + 1 == stop) {
+      } else if (snap || jumps || j + 1 == stop) {
         if ((rc = split_advance(h, state, subs, st, &marks, snaps))) return rc;
         subs.clear();
         marks.clear();
-        if ((rc = finish_step(i))) return rc;
+        if ((rc = finish_step(j))) return rc;
       }
-      ++i;
+      i = j + 1;
     }
   }
   if (control) {

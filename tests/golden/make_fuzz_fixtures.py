@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""Oracle-pinned cases of the step-size controller fuzz.
+
+The fuzz of tests/test_gpu_fuzz.py compares the default split-operator path with the repo's own CF4 + Taylor path - two
+algorithm families, but HIP against HIP.  This script integrates a subset of the same seeded cases (tests/helpers.py:
+fuzz_case - NumPy only, no reference import needed) with the TIGHT oracle (oracle/qutip_path.py: zvode Adams, rtol 1e-13,
+atol 1e-15 - the restatement of the reference's solver call, simulation.py:729-735, 768-780, with its tolerances tightened)
+and stores the final kets:
+
+    fuzz_oracle_12.npz   the first 24 seeds whose draw is a 12-atom register (k_split_reg<12, 4>), two sequences of a batch kept
+    fuzz_oracle_13.npz / fuzz_oracle_14.npz   the first 8 seeds each of 13 / 14 atoms (k_split_reg<13, 5> / <14, 5>), one kept
+    fuzz_oracle_small.npz  24 seeds re-drawn on 8 - 11 atoms (the split path is forced there: method = "split")
+
+A fixture is data: seeds, register sizes, final states, the number of right-hand sides, and a SHA-256 of every case's inputs
+(coords, amp, det, phase) so that a drift of fuzz_case itself is caught rather than compared against stale kets.
+
+    python tests/golden/make_fuzz_fixtures.py [12|13|14|small] [workers]
+
+Cost: seconds (8 atoms) to ~10 minutes (a 4-us 12-atom sequence on a 4.6-um chain) per case and core."""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import time
+
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import numpy as np  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from helpers import fuzz_case  # noqa: E402
+from oracle import qutip_path as qp  # noqa: E402
+
+# (seed, n_atoms override or None).  small: seeds 0 .. 23 re-drawn on 8, 9, 10, 11 atoms in turn
+KEEP_PER_CASE = 2  # sequences of a batch that are stored (64 KiB each at 12 atoms)
+
+
+def digest(prob) -> str:
+    s = prob["samples"]["Global"]["ground-rydberg"]
+    m = hashlib.sha256()
+    for a in (np.asarray(prob["coords"], float), np.asarray(s["amp"], float), np.asarray(s["det"], float),
+              np.asarray(s["phase"], float)):
+        m.update(np.ascontiguousarray(a).tobytes())
+    return m.hexdigest()
+
+
+def solve_case(args):
+    seed, n_over = args
+    probs, desc = fuzz_case(seed, n_over)
+    out = []
+    tic = time.time()
+    rhs_total = 0
+    for prob in probs[:KEEP_PER_CASE]:
+        s = prob["samples"]["Global"]["ground-rydberg"]
+        dur = prob["duration"]
+        t_end = (dur - 1) * 1e-3
+        opts = qp.default_options([(s["amp"], s["det"])], dur)
+        opts.update(qp.TIGHT)
+        counter = [0]
+        ham = qp.build_hamiltonian(prob)
+        psi0 = qp.all_ground_state(prob["n_qudits"], prob["eigenbasis"])
+        fin = qp.sesolve(ham, psi0, np.array([0.0, t_end]), counter=counter, **opts)[-1]
+        rhs_total += counter[0]
+        out.append((np.asarray(fin), digest(prob), t_end))
+    print(f"{desc}: {rhs_total} RHS in {time.time() - tic:.0f} s; norm drift {abs(np.linalg.norm(out[0][0]) - 1):.1e}", flush=True)
+    return seed, n_over, desc, rhs_total, out
+
+
+def cases_n(n_want, count):
+    """The first `count` seeds whose own draw is an n_want-atom register (no hand-picking by outcome)."""
+    picked = []
+    for seed in range(2000):
+        rng = np.random.default_rng(10_000 + seed)
+        if int(rng.choice([12, 12, 13, 13, 14, 14, 16])) == n_want:
+            picked.append((seed, None))
+        if len(picked) == count:
+            break
+    return picked
+
+
+def cases_small():
+    return [(seed, 8 + seed % 4) for seed in range(24)]
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "small"
+    workers = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    global KEEP_PER_CASE
+    if which in ("13", "14"):
+        KEEP_PER_CASE = 1
+    cases = {"12": lambda: cases_n(12, 24), "13": lambda: cases_n(13, 8), "14": lambda: cases_n(14, 8), "small": cases_small}[which]()
+    from multiprocessing import get_context
+
+    with get_context("fork").Pool(workers) as pool:
+        results = pool.map(solve_case, cases, chunksize=1)
+    seeds, n_atoms, n_over, descs, rhs, states, digests, owner, t_ends = [], [], [], [], [], [], [], [], []
+    for seed, over, desc, r, out in results:
+        seeds.append(seed)
+        n_over.append(-1 if over is None else over)
+        descs.append(desc)
+        rhs.append(r)
+        for b, (fin, dg, t_end) in enumerate(out):
+            states.append(fin)
+            digests.append(dg)
+            owner.append((len(seeds) - 1, b))
+            t_ends.append(t_end)
+            n_atoms.append(int(np.log2(fin.size)))
+    dim = max(s.size for s in states)
+    packed = np.zeros((len(states), dim), dtype=complex)
+    for k, s in enumerate(states):
+        packed[k, : s.size] = s
+    name = f"fuzz_oracle_{which}.npz"
+    np.savez_compressed(os.path.join(HERE, name), seeds=np.array(seeds), n_override=np.array(n_over), descriptions=np.array(descs),
+                        rhs_evals=np.array(rhs), states=packed, state_atoms=np.array(n_atoms), state_owner=np.array(owner),
+                        state_t_end=np.array(t_ends), input_sha256=np.array(digests),
+                        oracle="zvode Adams rtol 1e-13 atol 1e-15 (oracle.qutip_path.TIGHT), final time, all-ground start")
+    print("wrote", name, packed.shape, f"{os.path.getsize(os.path.join(HERE, name)) / 2**20:.2f} MiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -215,11 +215,14 @@ def random_register(rng, n):
     return P.register_coords(lay, spacing), spacing, str(kind)
 
 
-def fuzz_case(seed):
-    """One case of the controller fuzz: (problems of one batch, description)."""
+def fuzz_case(seed, n_atoms=None):
+    """One case of the controller fuzz: (problems of one batch, description).  `n_atoms`: the same draws on a smaller
+    register (8 - 11 atoms: the sizes a tight CPU oracle integrates in seconds, tests/golden/make_fuzz_fixtures.py)."""
     rng = np.random.default_rng(10_000 + seed)
     n = int(rng.choice([12, 12, 13, 13, 14, 14, 16]))
-    dur_cap = {12: 4000, 13: 2500, 14: 1500, 16: 300}[n]
+    if n_atoms is not None:
+        n = int(n_atoms)
+    dur_cap = {12: 4000, 13: 2500, 14: 1500, 16: 300}.get(n, 4000)
     duration = int(np.exp(rng.uniform(np.log(100), np.log(dur_cap))))
     batch = 1 if n == 16 else int(rng.choice([1, 1, 2, 4]))
     coords, spacing, kind = random_register(rng, n)

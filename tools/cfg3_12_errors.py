@@ -1,6 +1,7 @@
 """Errors of the split-operator master equation against the 12-atom tight fixture (tests/golden/cfg3_tri12_dephasing.npz) at
 every stored time: default row path (k_split_reg rows, four-knot halves) and the k_ket rows of round 3."""
 import os, sys
+os.environ.setdefault("RYD_DEV", "1")  # the RYD_* A/B switches this tool reads are ignored without it (dev_common.hpp)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

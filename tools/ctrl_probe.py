@@ -1,6 +1,7 @@
 """Dev probe (round 4): step-size controller of the split-operator path on the headline register: stages, estimate and TRUE
 error (tight-oracle fixture, six times) for a batch of 8 identical sequences.  RYD_SPLIT_GROW = hysteresis of growth."""
 import os, sys
+os.environ.setdefault("RYD_DEV", "1")  # the RYD_* A/B switches this tool reads are ignored without it (dev_common.hpp)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -1,5 +1,6 @@
 """Dev probe: controller behaviour on a batch of DIFFERENT sequences (amplitude x 1 .. 0.7, detuning x 1 .. 1.3)."""
 import os, sys
+os.environ.setdefault("RYD_DEV", "1")  # the RYD_* A/B switches this tool reads are ignored without it (dev_common.hpp)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -1,6 +1,7 @@
 """Dev probe (round 4): the one-launch 14-atom kernels against the pass-by-pass launches (same stages, same order:
 rounding-level agreement expected).  RYD_SPLIT_NR selects the variant (5 default, 6)."""
 import os, sys
+os.environ.setdefault("RYD_DEV", "1")  # the RYD_* A/B switches this tool reads are ignored without it (dev_common.hpp)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -2,6 +2,7 @@
 error against the k_ket rows (<= 1e-9 from the tight oracle at 10 atoms) on an interacting 12-atom register over
 0 -> 0.7 us, and ms per simulated ns at 14 atoms.  RYD_ROWS_KH (knots per half block), RYD_ROWS_S (6 / 10)."""
 import os, sys, time
+os.environ.setdefault("RYD_DEV", "1")  # the RYD_* A/B switches this tool reads are ignored without it (dev_common.hpp)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch

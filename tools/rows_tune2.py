@@ -1,6 +1,7 @@
 """Dev probe (round 4): block length of the split-operator master equation by dephasing rate: error over the FULL anneal at
 12 atoms against the two-knot halves (3e-9 from the tight oracle), and ms per simulated ns at 14 atoms.  RYD_ROWS_KH."""
 import os, sys, time
+os.environ.setdefault("RYD_DEV", "1")  # the RYD_* A/B switches this tool reads are ignored without it (dev_common.hpp)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
