@@ -71,6 +71,12 @@ struct ryd_handle {
   bool has_dbl = false;
   // work vectors
   cplx *wA = nullptr, *wB = nullptr, *kbuf = nullptr;
+  cplx* wC = nullptr;              // second checkpoint buffer of the split-operator controller (allocated on first use; round 6)
+  double* split_err_pin = nullptr; // [B] pinned host copy of split_err (the one read-back of a check)
+  // one-shot options of the next split_run on the register-resident kernel (run_split's check; consumed by the launch)
+  cplx *fuse_dst = nullptr, *fuse_dst2 = nullptr;
+  const cplx* fuse_cmp = nullptr;
+  bool fuse_done = false;
   std::vector<Pass> passes;
   bool passes_valid = false;
   StepDesc* sched_dev = nullptr;
@@ -445,6 +451,8 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->rows_chk);
   hipFree(h->rows_idx_dev);
   hipFree(h->wB);
+  if (h->wC) hipFree(h->wC);
+  if (h->split_err_pin) hipHostFree(h->split_err_pin);
   hipFree(h->kbuf);
   hipFree(h->coefs_dev);
   hipFree(h->e0_dev);

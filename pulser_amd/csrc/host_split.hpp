@@ -299,6 +299,15 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
   }
   if (reg_loop && N == 14 && !loop14) reg_loop = false;
   if (reg_loop || loop14) pass_tan = false;
+  if ((h->fuse_dst || h->fuse_dst2 || h->fuse_cmp) && !(reg_loop && !marks && !alt)) {
+    // the check's fused options are for the register-resident kernel only: an out-of-place run is NOT run at all (the
+    // caller copies and runs in place), an in-place run goes ahead unfused (the caller compares and copies); fuse_done
+    // stays false either way
+    const bool out_of_place = h->fuse_dst != nullptr;
+    h->fuse_dst = h->fuse_dst2 = nullptr;
+    h->fuse_cmp = nullptr;
+    if (out_of_place) return RYD_OK;
+  }
   if ((marks || alt) && (!reg_loop || h->mc || !split_real(h))) {
     // not the register-resident real-arithmetic kernel (a drive beyond the tan-form bound, a test hook, the dev switch
     // RYD_SPLIT_GAUGE=0): closed runs of one composition from mark to mark
@@ -366,6 +375,15 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
     A.T = N;
     A.dec_a = h->mc_a;  // H_eff: the decay diagonal a + b popc(index) over the D time of every stage
     A.dec_b = h->mc_b;
+    if (h->fuse_dst || h->fuse_dst2 || h->fuse_cmp) {  // run_split's check: see SplitArgs.dst / dst2 / cmp
+      A.dst = h->fuse_dst;
+      A.dst2 = h->fuse_dst2;
+      A.cmp = h->fuse_cmp;
+      A.cmp_err = h->split_err;
+      h->fuse_dst = h->fuse_dst2 = nullptr;
+      h->fuse_cmp = nullptr;
+      h->fuse_done = true;
+    }
     SplitSnapList Ls;
     Ls.n = 0;
     if (any_inner) {
@@ -823,7 +841,6 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   // snapshots inside the runs of the register-resident kernel (k_split_reg<.., SNAP>); quantum-jump solves close a run
   // per schedule step anyway
   const bool snaps_inside = snaps && split_reg_shape(h) && !jumps && !h->mc && !h->snaps_outside;
-  std::vector<double> errs(h->B);
   h->stats.reserved[0] = 0.0;  // accumulated local-error estimate of this solve
   // local error per us measured at sub-steps of rate_tau; sub-steps of another length are booked with the p-th power of
   // the ratio
@@ -922,6 +939,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   // amplitude triggers, periods, evaluation times); a sub-step is re-based on the piece its start lies in, so a piece is
   // never evaluated further than one sub-step beyond its own interval.  Sub-steps stay <= kSplitSubCap knot intervals.
   static const bool groups_on = dev_env_flag("RYD_SPLIT_GROUPS", true);
+  static const bool fuse_on = dev_env_flag("RYD_SPLIT_FUSE", true);  // (dev A/B: the check's copies / compare fused into its launches)
   static const int sub_cap_knots = dev_env_int("RYD_SPLIT_SUBCAP", 16, 1, 64);
   auto step_t0 = [&](const StepDesc& d) { return h->tknots[d.idx] + (d.u1 - kC1 * d.h); };
   auto last_piece = [&](const StepDesc& d) {  // the piece the END of the step lies in
@@ -1044,18 +1062,43 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
         have_ck = true;
       }
       const bool ck_here = ck_i == i && ck_off == off;
-      HIPCHK(hipMemcpyAsync(h->wA, state, bytes, hipMemcpyDeviceToDevice, st));
-      if ((rc = split_run(h, h->wA, &s0, 1, st, kd == 1))) return rc;
+      // On the register-resident kernel the check is two launches and one 8-byte-per-sequence read-back (round 6): the whole
+      // sub-step runs OUT OF PLACE from the state into wA, the two halves run in place, compare with wA on the way out
+      // and store the new checkpoint beside the state (wC; wB - the checkpoint a roll-back restores - stays intact until
+      // the verdict is in).  Before: a copy, two launches, memset + k_split_diff (two more reads of both buffers), another
+      // copy for the checkpoint = 5 x 16 B per amplitude of extra traffic and three more launches per check.  Where the run
+      // takes another kernel (the pass-by-pass launches, a drive beyond the tan-form bound) the options come back
+      // unconsumed and the old sequence runs.
+      const bool fuse_ok = fuse_on && split_reg_shape(h) && !jumps;
+      if (fuse_ok && !h->wC) HIPCHK(hipMalloc((void**)&h->wC, bytes));
+      if (!h->split_err_pin) HIPCHK(hipHostMalloc((void**)&h->split_err_pin, (size_t)h->B * sizeof(double)));
+      h->fuse_done = false;
+      if (fuse_ok) h->fuse_dst = h->wA;
+      else HIPCHK(hipMemcpyAsync(h->wA, state, bytes, hipMemcpyDeviceToDevice, st));
+      if ((rc = split_run(h, fuse_ok ? state : h->wA, &s0, 1, st, kd == 1))) return rc;
+      if (fuse_ok && !h->fuse_done) {  // not the register-resident kernel after all: the state is untouched, do it the old way
+        h->fuse_dst = nullptr;
+        HIPCHK(hipMemcpyAsync(h->wA, state, bytes, hipMemcpyDeviceToDevice, st));
+        if ((rc = split_run(h, h->wA, &s0, 1, st, kd == 1))) return rc;
+      }
+      const bool fused = fuse_ok && h->fuse_done;
       const SubStep halves[2] = {{s0.idx, s0.u0, 0.5 * s0.tau, kd}, {s0.idx, s0.u0 + 0.5 * s0.tau, 0.5 * s0.tau, kd}};
+      h->fuse_done = false;
+      if (fused) { h->fuse_cmp = h->wA; h->fuse_dst2 = h->wC; }
       if ((rc = split_run(h, state, halves, 2, st, kd == 1))) return rc;
-      HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)h->B * sizeof(double), st));
-      const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(h->dim >> 10, 1), 256);
-      hipLaunchKernelGGL(k_split_diff, dim3(nblk, h->B), dim3(256), 0, st, state, h->wA, h->nb, h->split_err);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(errs.data(), h->split_err, (size_t)h->B * sizeof(double), hipMemcpyDeviceToHost, st));
+      const bool fused2 = fused && h->fuse_done;
+      h->fuse_cmp = nullptr;
+      h->fuse_dst2 = nullptr;
+      if (!fused2) {
+        HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)h->B * sizeof(double), st));
+        const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(h->dim >> 10, 1), 256);
+        hipLaunchKernelGGL(k_split_diff, dim3(nblk, h->B), dim3(256), 0, st, state, h->wA, h->nb, h->split_err);
+        HIPCHK(hipGetLastError());
+      }
+      HIPCHK(hipMemcpyAsync(h->split_err_pin, h->split_err, (size_t)h->B * sizeof(double), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
       double e = 0.0;
-      for (double v : errs) e = std::max(e, std::sqrt(std::max(v, 0.0)));
+      for (int q = 0; q < h->B; ++q) e = std::max(e, std::sqrt(std::max(h->split_err_pin[q], 0.0)));
       // whole step against two halves: the difference is (1 - 2^-p) of the local error of the whole step
       const int p_ord = sck.order;
       const double two_p = std::ldexp(1.0, p_ord);
@@ -1137,7 +1180,8 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
         ++i;
         if (off < 1e-12) off = 0.0;
       }
-      HIPCHK(hipMemcpyAsync(h->wB, state, bytes, hipMemcpyDeviceToDevice, st));
+      if (fused2) std::swap(h->wB, h->wC);  // (the halves' launch stored the new checkpoint in wC)
+      else HIPCHK(hipMemcpyAsync(h->wB, state, bytes, hipMemcpyDeviceToDevice, st));
       ck_i = i;
       ck_off = off;
       ck_steps = h->stats.n_steps;

@@ -755,10 +755,52 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     __syncthreads();
     fl *= row_factor(1, odd ? L::index(true, t, 0u) : L::index(false, t, 0u), odd ? L::index(true, NT - 1, 0u) : L::index(false, NT - 1, 0u));
   }
+  bool stored = false;
+  if constexpr (!ROWS) {
+    if (A.dst || A.dst2 || A.cmp) {
+      // the controller's check (SplitArgs.dst / dst2 / cmp): out-of-place store, second store, comparison on the way out
+      stored = true;
+      const size_t boff = (size_t)b << N;
+      cplx* __restrict__ out = A.dst ? A.dst + boff : st;
+      cplx* __restrict__ out2 = A.dst2 ? A.dst2 + boff : nullptr;
+      const cplx* __restrict__ ref = A.cmp ? A.cmp + boff : nullptr;
+      const unsigned lw = odd ? L::index(true, t, 0u) : L::index(false, t, 0u);
+      double dmax = 0.0;
+      auto put = [&](unsigned ix, double vx, double vy) {
+        const cplx v = make_double2(vx, vy);
+        out[ix] = v;
+        if (out2) out2[ix] = v;
+        if (ref) {
+          const cplx c = ref[ix];
+          const double dx = vx - c.x, dy = vy - c.y;
+          dmax = fmax(dmax, fma(dx, dx, dy * dy));
+        }
+      };
+      if (odd) {
+        splitr_for<0, NA>([&](auto Rc) { constexpr int r = decltype(Rc)::value; put(lw + L::index(true, 0u, r), xr[r], xi[r]); });
+      } else {
+        splitr_for<0, NA>([&](auto Rc) { constexpr int r = decltype(Rc)::value; put(lw + L::index(false, 0u, r), xr[r], xi[r]); });
+      }
+      if (ref) {
+        for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+        double* red = reinterpret_cast<double*>(gtab);  // (the G tables are dead after the last stage)
+        __syncthreads();
+        if (l == 0) red[w] = dmax;
+        __syncthreads();
+        if (t == 0) {
+          double m = red[0];
+          for (int k = 1; k < NT / 64; ++k) m = fmax(m, red[k]);
+          A.cmp_err[b] = m;
+        }
+      }
+    }
+  }
+  if (!stored) {
   splitr_for<0, NA>([&](auto Rc) {
     constexpr int r = decltype(Rc)::value;
     const double f = (ROWS && A.use_post) ? fl * ftl[128 + r] : 1.0;
     st[odd ? L::index(true, t, r) : L::index(false, t, r)] = make_double2(xr[r] * f, xi[r] * (ROWS ? f * csgn : f));
   });
+  }
   }  // rows
 }

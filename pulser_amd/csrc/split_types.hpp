@@ -37,6 +37,16 @@ struct SplitArgs {
   // the cosine product to every stored snapshot of the run at once, across the chip
   cplx* snaps;
   long long snap_stride;
+  // k_split_reg (kets, not ROWS), round 6 - the step-size controller's check without copy / compare launches:
+  //   dst      the final state is stored HERE instead of in place (the whole sub-step of a check runs from the state into
+  //            the scratch buffer: no 2 x 16 B per amplitude copy before it);
+  //   dst2     ... and ALSO here (the checkpoint a roll-back restores, written by the launch that produced the state);
+  //   cmp      the final state is compared with this buffer on the way out: cmp_err[b] = max |x - cmp|^2 over the ket
+  //            (what k_split_diff computed from two more reads of both buffers).
+  cplx* dst;
+  cplx* dst2;
+  const cplx* cmp;
+  double* cmp_err;
 };
 
 // One closed run of the composition: consecutive sub-steps (knot interval, start offset, length),

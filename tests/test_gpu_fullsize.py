@@ -69,7 +69,9 @@ def test_headline_batch_default_kernel_full_anneal_against_tight_oracle(ns14):
     assert 1 < st["n_launches"] < 200 and st["n_applications"] < 12_000  # (k_ket: 26 253 stages in one launch)
     for b in (0, 7):
         errs = _worst(snaps[:, b], ref)
-        assert max(errs) < AMP_TOL / 10, errs
+        # (the controller spends its budget - half the bar - where that saves stages: round 6 measured 1.0e-8 at T with an
+        # estimate of 2.9e-8; until round 5 the 9-knot steps left most of the budget unused and this read 4e-9)
+        assert max(errs) < AMP_TOL / 2 and st["reserved"][0] < AMP_TOL / 2, (errs, st["reserved"])
         assert max(errs) < max(4 * st["reserved"][0], 2e-9), (errs, st["reserved"])  # the estimate covers the error
     assert np.array_equal(snaps[:, 0], snaps[:, 7])  # identical sequences, identical arithmetic
 
