@@ -763,7 +763,7 @@ static void split_substeps(const ryd_handle* h, const StepDesc& d, double off, d
 // of the ramp with whole 9-knot steps - 9.8e-8 from a tight run with an estimate of 1.7e-8, tools/gauge_probe.py), and a
 // check is also due when the drive bound has grown by half since the last one (above a tenth of its maximum): the
 // local error of a sub-step goes with a high power of the drive amplitude.
-static const int kSplitCheckEvery = 256;  // (128: 24 + 6 checks on the headline anneal, 0.35 ms each for 256 kets = 14 % of the step)
+static const int kSplitCheckEvery = dev_env_int("RYD_SPLIT_EVERY", 256, 16, 4096);  // (128: 24 + 6 checks on the headline anneal, 0.35 ms each for 256 kets = 14 % of the step)
 // Round 5: after a COLD start the period grows 16 -> 32 -> ... -> 256 knot intervals.  The local error of a sub-step is
 // measured on the state at hand, and the product state a sequence starts from is the least representative one: on a
 // 16-atom chain under a square pulse (constant drive from t = 0, so no amplitude trigger) the first 9-ns step measured
@@ -939,6 +939,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   // amplitude triggers, periods, evaluation times); a sub-step is re-based on the piece its start lies in, so a piece is
   // never evaluated further than one sub-step beyond its own interval.  Sub-steps stay <= kSplitSubCap knot intervals.
   static const bool groups_on = dev_env_flag("RYD_SPLIT_GROUPS", true);
+  static const bool dbl_on = dev_env_flag("RYD_SPLIT_DOUBLE", true);  // (dev A/B: double-step checks)
   static const bool fuse_on = dev_env_flag("RYD_SPLIT_FUSE", true);  // (dev A/B: the check's copies / compare fused into its launches)
   static const int sub_cap_knots = dev_env_int("RYD_SPLIT_SUBCAP", 16, 1, 64);
   auto step_t0 = [&](const StepDesc& d) { return h->tknots[d.idx] + (d.u1 - kC1 * d.h); };
@@ -1072,17 +1073,27 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       const bool fuse_ok = fuse_on && split_reg_shape(h) && !jumps;
       if (fuse_ok && !h->wC) HIPCHK(hipMalloc((void**)&h->wC, bytes));
       if (!h->split_err_pin) HIPCHK(hipHostMalloc((void**)&h->split_err_pin, (size_t)h->B * sizeof(double)));
+      // DOUBLE-STEP check (round 6).  Where two sub-steps of the working length fit into what lies ahead on the same polynomial,
+      // the scratch copy takes ONE step of 2 tau and the state its two regular sub-steps - which it would take anyway: the check
+      // costs the 10 stages of the double step instead of 20 (whole + two halves against the 10 of the plain sub-step).  The
+      // difference is (2^(p+1) - 2) x the local error of ONE sub-step of length tau: e(2 tau) - 2 e(tau).  A kind that has not been
+      // measured yet keeps the whole-against-halves check: what is kept then is the more accurate of the two, and a first
+      // sub-step far over its allowance is rolled back either way.
+      const double room = (kd == 0 ? glen[i] : sched[i].h) - off;
+      const bool dbl = dbl_on && ctl[kd].known && ctl[kd].tau < 1e299 && room >= 2.0 * s0.tau * (1.0 - 1e-9);
+      const SubStep wide = {s0.idx, s0.u0, (dbl ? 2.0 : 1.0) * s0.tau, kd};
       h->fuse_done = false;
       if (fuse_ok) h->fuse_dst = h->wA;
       else HIPCHK(hipMemcpyAsync(h->wA, state, bytes, hipMemcpyDeviceToDevice, st));
-      if ((rc = split_run(h, fuse_ok ? state : h->wA, &s0, 1, st, kd == 1))) return rc;
+      if ((rc = split_run(h, fuse_ok ? state : h->wA, &wide, 1, st, kd == 1))) return rc;
       if (fuse_ok && !h->fuse_done) {  // not the register-resident kernel after all: the state is untouched, do it the old way
         h->fuse_dst = nullptr;
         HIPCHK(hipMemcpyAsync(h->wA, state, bytes, hipMemcpyDeviceToDevice, st));
-        if ((rc = split_run(h, h->wA, &s0, 1, st, kd == 1))) return rc;
+        if ((rc = split_run(h, h->wA, &wide, 1, st, kd == 1))) return rc;
       }
       const bool fused = fuse_ok && h->fuse_done;
-      const SubStep halves[2] = {{s0.idx, s0.u0, 0.5 * s0.tau, kd}, {s0.idx, s0.u0 + 0.5 * s0.tau, 0.5 * s0.tau, kd}};
+      const SubStep halves[2] = {{s0.idx, s0.u0, (dbl ? 1.0 : 0.5) * s0.tau, kd},
+                                 {s0.idx, s0.u0 + (dbl ? 1.0 : 0.5) * s0.tau, (dbl ? 1.0 : 0.5) * s0.tau, kd}};
       h->fuse_done = false;
       if (fused) { h->fuse_cmp = h->wA; h->fuse_dst2 = h->wC; }
       if ((rc = split_run(h, state, halves, 2, st, kd == 1))) return rc;
@@ -1099,19 +1110,22 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       HIPCHK(hipStreamSynchronize(st));
       double e = 0.0;
       for (int q = 0; q < h->B; ++q) e = std::max(e, std::sqrt(std::max(h->split_err_pin[q], 0.0)));
-      // whole step against two halves: the difference is (1 - 2^-p) of the local error of the whole step
+      // whole step against two halves: the difference is (1 - 2^-p) of the local error of the whole step;
+      // double step against two sub-steps: (2^(p+1) - 2) x the local error of one sub-step
       const int p_ord = sck.order;
       const double two_p = std::ldexp(1.0, p_ord);
-      e *= two_p / (two_p - 1.0);
+      if (dbl) e /= 2.0 * two_p - 2.0;
+      else e *= two_p / (two_p - 1.0);
       const double allowed = eps * s0.tau / t_total * (w_kind[kd] / w_bar);
       double fac = std::pow(0.5 * allowed / std::max(e, 1e-300), 1.0 / p_ord);
       fac = std::min(std::max(fac, 0.2), p_ord == 6 ? 2.0 : 4.0);  // (x 2 in tau is x 64 in the 6th-order error)
       const double tau_new = s0.tau * fac;
       if (split_trace_env())
         std::fprintf(stderr, "[ryd split] check at t = %.4f us (step %zu of %zu, %d knots, h = %.4g ns, kind %d): sub-step %.4g ns, "
-                     "e = %.3g, allowed %.3g, fac %.3g, tau %.4g -> %.4g ns, scheme S%d, since %d%s%s\n",
+                     "e = %.3g, allowed %.3g, fac %.3g, tau %.4g -> %.4g ns, scheme S%d, since %d%s%s%s\n",
                      h->tknots[s0.idx] + s0.u0, i, sched.size(), d.pad, d.h * 1e3, kd, s0.tau * 1e3, e, allowed, fac,
-                     ctl[kd].tau * 1e3, tau_new * 1e3, sck.S, ctl[kd].since, new_regime ? " [regime]" : "", amp_grown ? " [amp]" : "");
+                     ctl[kd].tau * 1e3, tau_new * 1e3, sck.S, ctl[kd].since, new_regime ? " [regime]" : "", amp_grown ? " [amp]" : "",
+                     dbl ? " [double]" : "");
       h->stats.reserved[1] = e;
       h->stats.reserved[2] = s0.tau;
       if (e > 4.0 * allowed && have_ck && retries < 4 && !jumps) {  // (a roll-back would replay jumps)
@@ -1146,7 +1160,10 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
         h->stats.reserved[0] += std::max(0.0, e / s0.tau - book_rate(kd, s0.tau)) * h->split_since_len;
       }
       retries = 0;
-      static const double grow_env = dev_env_double("RYD_SPLIT_GROW", 1.3, 1.0, 4.0);  // dev A/B (RYD_DEV=1)
+      // (round 6: 1.3 -> 1.1.  The hysteresis kept a sub-step from hopping between the quantised cuts of a 9-knot step; with
+      // the sub-steps of a linear stretch cut to length it only withheld growth the measurement had paid for - the sweep of the
+      // headline anneal ran 3.6-ns sub-steps for 0.5 us where 4.6 had been measured: 5 818 -> 5 418 stages)
+      static const double grow_env = dev_env_double("RYD_SPLIT_GROW", 1.1, 1.0, 4.0);  // dev A/B (RYD_DEV=1)
       // (growth hysteresis: 1.6 until round 3; at 6th order x 1.3 in tau is x 4.8 in error - the sub-step follows its
       // budget more closely: 7 360 -> 6 890 stages on the anneal, estimate 5.3e-9 -> 5.7e-9)
       // (the sub-step stays a LENGTH - the one this measurement stands for, times fac: until round 5 a check that found
@@ -1171,8 +1188,8 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       // mean of the two is the better figure (the booked estimate is what callers compare with their tolerance)
       if (e <= 4.0 * allowed && ctl[kd].known)
         h->stats.reserved[0] += 0.5 * std::max(0.0, e / s0.tau - book_rate(kd, s0.tau)) * ctl[kd].len_since;
-      h->stats.reserved[0] += e / two_p;  // the two halves are what was kept
-      off += s0.tau;
+      h->stats.reserved[0] += dbl ? 2.0 * e : e / two_p;  // what was kept: two sub-steps of length tau / the two halves
+      off += dbl ? 2.0 * s0.tau : s0.tau;
       while (i < sched.size() && off >= sched[i].h * (1.0 - 1e-12)) {  // (a sub-step of a group may end in a later step)
         off -= sched[i].h;
         h->stats.n_steps++;
