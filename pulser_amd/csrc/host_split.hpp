@@ -63,7 +63,12 @@ static const SplitScheme& split_scheme(const ryd_handle* h) { return h->split_s1
 // Target of the accumulated local-error estimate (sum over the steps of the largest amplitude of the
 // local error) over a whole pulse sequence when ryd_opts.tol is 0 (else 500 tol).  The stated parity bar
 // is 1e-7 on amplitudes.
-static const double kSplitTolTotal = 5e-8;
+// Round 6: 5e-8 -> 4e-8.  Until round 5 the steps of <= 9 knots left most of the budget unused (headline anneal: estimate
+// 1.1e-8, true error 4e-9); with sub-steps cut to the working length on linear stretches the controller spends what it is
+// given (estimate 3e-8, true error 1.1e-8), and over 1 600 fuzz seeds the true error reached 2.1 x a LARGE estimate - so the
+// budget is 0.4 of the bar (4e-8 x 2.1 < 1e-7).  The row passes of the master equation keep their own figure (kRowsBudget).
+static const double kSplitTolTotal = 4e-8;
+static const double kRowsBudget = 5e-8;
 
 static int snapshot_copy(ryd_handle* h, const cplx* state, cplx* dst, hipStream_t st);
 static int mc_after_step(ryd_handle* h, cplx* state, hipStream_t st);
@@ -553,7 +558,7 @@ static bool rows_split_ok(const ryd_handle* h, const ryd_opts& o) {
   if (o.taylor_order > 0) return false;
   if (!(h->cfg.mode == RYD_MESOLVE && h->N >= 12 && h->N <= 14 && h->drive_real && !h->rows_ket && !h->split_no_loop)) return false;
   // (ryd_opts.tol is a bound per exponential; over a sequence the split-operator paths take 500 tol as their budget - run_split)
-  const double budget = o.tol > 0 ? 500.0 * o.tol : kSplitTolTotal;
+  const double budget = o.tol > 0 ? 500.0 * o.tol : kRowsBudget;
   return rows_split_estimate(h) <= budget;
 }
 // the sub-steps of the unitary of a half block (steps [i0, i1) of the split schedule)

@@ -479,6 +479,15 @@ class QutipEmulator:
                 "Incompatible shape of initial state."
                 + f"Expected {legal_shape}, got {shape}."
             )
+        if arr.ndim > 1 and int(np.prod(arr.shape[1:])) != 1:
+            # the reference builds qutip.Qobj(state, dims=[[d] * N, [1] * N]) (simulation.py:519-529): ket dimensions - a
+            # density matrix (or any matrix) does not fit them and qutip raises.  Same here, instead of flattening D x D
+            # numbers into a "ket" ("missing" item 3: the reference does not accept operators either)
+            raise ValueError(
+                "Incompatible shape of initial state: the initial state is a ket "
+                f"(dims [[{self.dim}] * {self._hamiltonian_data.n_qudits}, [1] * {self._hamiltonian_data.n_qudits}]), "
+                f"got an array of shape {arr.shape}."
+            )
         self._initial_state = QState(arr.reshape(-1)).unit()
         self._initial_is_ground = bool(
             np.array_equal(np.asarray(self._initial_state), np.asarray(self._all_ground()))
@@ -721,10 +730,6 @@ class QutipEmulator:
                 raise NotImplementedError(
                     "Quantum-jump trajectories need a ket as initial state; use "
                     "solver=Solver.MESOLVER with a density matrix.")
-            if on_device and not (init.ndim == 1 or 1 in init.shape):
-                raise NotImplementedError(
-                    f"A density matrix as initial state of a {n}-atom master equation is not supported; "
-                    "give the ket (the density matrix is built on the device).")
             state = eng.new_state(init.reshape(1, -1))
             first = None if on_device else state.cpu().numpy()
             first_dev = state.clone() if raw else None

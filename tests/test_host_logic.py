@@ -336,6 +336,14 @@ def test_emulator_validation_messages_and_defaults():
     with pytest.raises(ValueError, match="Incompatible shape of initial state.Expected 4096, got 3"):
         emu.set_initial_state(np.ones(3))
     assert np.asarray(emu.initial_state)[-1, 0] == 1.0
+    # a density matrix is no initial state: the reference wraps the input in ket dimensions (simulation.py:519-529:
+    # qutip.Qobj(state, dims=[[d] * N, [1] * N])), which qutip refuses for a D x D array; a column vector is a ket
+    with pytest.raises(ValueError, match="the initial state is a ket"):
+        emu.set_initial_state(np.eye(4096))
+    col = np.zeros((4096, 1)); col[5, 0] = 2.0
+    emu.set_initial_state(col)
+    assert np.asarray(emu.initial_state)[5, 0] == 1.0
+    emu.set_initial_state("all-ground")
     opts = {}
     emu._validate_options(opts)
     assert opts == {"max_step": 0.001, "nsteps": 3100 // 0.001}  # = 3099999.0, as simulation.py:778-780 computes it
