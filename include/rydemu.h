@@ -390,6 +390,22 @@ int ryd_set_kernel_timing(ryd_handle* h, int32_t enable);
 int ryd_get_kernel_timing(ryd_handle* h, double* total_ms, int64_t* launches);
 
 const char* ryd_last_error(void);
+/* Replaces (HOST arithmetic, no device work): the sampling of every trajectory state at every evaluation time inside
+ * QutipEmulator.run (pulser_simulation/simulation.py:853-861) - QutipResult._weights (pulser_simulation/qutip_result.py:
+ * 101-158: |psi|^2 or |diag rho|, reversed for the ground-rydberg measurement basis; `matching` = 0: weights = delta_0,
+ * :119-122), multinomial's searchsorted over the cumulative sums (pulser-core/pulser/math/multinomial.py:32-36) and the
+ * SPAM measurement flips (pulser_simulation/simresults.py:537-568) - for a block of rows at once, with the uniforms the
+ * caller drew in the reference's order.  Same IEEE operations in the same order as NumPy's: the histograms are
+ * identical to the Python replay's.
+ *   states_host  complex128[n_rows][dim] (kets, is_ket = 1) or the diagonals of density matrices (is_ket = 0), host memory
+ *   start/count  int64[n_rows]: where row r's uniforms sit in `rnd` (and its rows in flip_matrix[total][n_qubits], or NULL)
+ *   slot         int32[n_rows]: the histogram (evaluation time) row r adds to; hist int64[n_slots][dim], accumulated
+ *   n_threads    host threads (0 = min(16, half the cores)); rows are independent, integer histograms merge exactly */
+int ryd_replay_samples(const void* states_host, int64_t n_rows, int64_t dim, int32_t n_qubits, int32_t is_ket,
+                       int32_t reversed, int32_t matching, const int64_t* start, const int64_t* count,
+                       const int32_t* slot, int32_t n_slots, const double* rnd, const double* flip_matrix,
+                       double eps, double eps_p, int64_t* hist, int32_t n_threads);
+
 int ryd_abi_version(void);
 
 #ifdef __cplusplus

@@ -123,6 +123,9 @@ SYMBOLS = {
     "ryd_outer_accumulate_dim": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p]),
     "ryd_accumulate": (C.c_int, [C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "ryd_replay_samples": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_double, C.c_double, C.c_void_p, C.c_int32]),
     "ryd_get_stats": (C.c_int, [C.c_void_p, C.POINTER(RydStats)]),
     "ryd_reset_stats": (C.c_int, [C.c_void_p]),
     "ryd_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -78,3 +78,4 @@ SPLITR_INSTANCES_14(SPLITR_EXTERN)
 #include "host_split.hpp"
 #include "host_step.hpp"
 #include "host_observables.hpp"
+#include "host_replay.hpp"

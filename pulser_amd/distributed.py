@@ -111,6 +111,33 @@ def cumulative_weights(states: np.ndarray, is_ket: bool, meas_basis: str, matchi
     return np.cumsum(w, axis=-1)
 
 
+def replay_block_native(host: np.ndarray, is_ket: bool, meas_basis: str, matching: bool, n: int,
+                        starts: np.ndarray, counts: np.ndarray, rnd_all: np.ndarray, mat_all: np.ndarray | None,
+                        eps: float, eps_p: float, hist: np.ndarray, n_threads: int = 0) -> None:
+    """``hist[ti] += bincount(flips(searchsorted(cumulative_weights(host[ti, j]), rnd)))`` for every (ti, j) of a block in
+    one call of ``ryd_replay_samples`` (host threads, no GIL): ``host`` complex128[n_eval, B, 2^n] kets or diagonals,
+    ``starts`` / ``counts`` int64[n_eval, B] the slices of ``rnd_all`` (and rows of ``mat_all``).  Same histograms as
+    ``cumulative_weights`` + ``np.searchsorted`` + ``flips_with`` row by row (tests/test_host_logic.py)."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    n_eval, B, D = host.shape
+    host = np.ascontiguousarray(host, dtype=np.complex128)
+    st = np.ascontiguousarray(starts, dtype=np.int64).reshape(-1)
+    ct = np.ascontiguousarray(counts, dtype=np.int64).reshape(-1)
+    slot = np.repeat(np.arange(n_eval, dtype=np.int32), B)
+    rnd = np.ascontiguousarray(rnd_all, dtype=np.float64)
+    mat = None if mat_all is None else np.ascontiguousarray(mat_all, dtype=np.float64)
+    if not (hist.flags.c_contiguous and hist.dtype == np.int64 and hist.shape == (n_eval, D)):
+        raise ValueError("hist must be a C-contiguous int64[n_eval, 2^n] array")
+    _lib.check(lib.ryd_replay_samples(
+        host.ctypes.data, n_eval * B, D, n, int(is_ket), int(matching and meas_basis == "ground-rydberg"), int(matching),
+        st.ctypes.data, ct.ctypes.data, slot.ctypes.data, n_eval, rnd.ctypes.data,
+        None if mat is None else mat.ctypes.data, float(eps), float(eps_p), hist.ctypes.data, int(n_threads)))
+
+
 class _DiagonalState:
     """What the sampling chain needs of a density matrix (qutip_result.py:101-118): its diagonal."""
 
@@ -324,6 +351,11 @@ def run_ensemble(
         hist[ti] += np.bincount(ind, minlength=2**n)
         return w
 
+    # the C replay (ryd_replay_samples: the same arithmetic on host threads, outside the GIL); PULSER_AMD_NUMPY_REPLAY=1
+    # keeps the NumPy replay (A/B, and what the CPU tests compare it with)
+    native_replay = fast and not os.environ.get("PULSER_AMD_NUMPY_REPLAY")
+    pinned: Any = None       # the replay worker's pinned staging buffer and copy stream (one worker: used block after block)
+    copy_stream: Any = None
     pool = None
     lower_pool = None
     lowered: dict[int, Any] = {}
@@ -380,16 +412,36 @@ def run_ensemble(
                                 for j in range(len(block)):
                                     accumulate(x[j], rho_dev[ti], float(rb[j]) / n_traj)
                     if is_ket:
-                        host = _t.cat([first_dev[None], snaps_dev]).cpu().numpy()  # [n_eval, B, D]
+                        dev_all = _t.cat([first_dev[None], snaps_dev])  # [n_eval, B, D]
                     else:
-                        host = _t.cat([_t.diagonal(first_dev, dim1=-2, dim2=-1)[None],
-                                       _t.diagonal(snaps_dev, dim1=-2, dim2=-1)]).cpu().numpy()
+                        dev_all = _t.cat([_t.diagonal(first_dev, dim1=-2, dim2=-1)[None],
+                                          _t.diagonal(snaps_dev, dim1=-2, dim2=-1)]).contiguous()
+                    ready = _t.cuda.Event()
+                    ready.record(_t.cuda.current_stream(dev_all.device))
                     del first_dev, snaps_dev
                     # the reference's weights and cumulative sums (qutip_result.py:101-158, multinomial.py:32-36) for
                     # the whole block at once: the same elementwise operations and the same sequential row sums
                     # ... on a worker thread, so that the replay of this block overlaps the solve of the next one
                     # (the GPU work is asynchronous C calls; the histogram is only read after the last block)
-                    def replay(host: np.ndarray = host, block: list[int] = block, is_ket: bool = is_ket) -> None:
+                    def replay(dev_all: Any = dev_all, ready: Any = ready, block: list[int] = block, is_ket: bool = is_ket) -> None:
+                        # device -> pinned host memory on the worker's own stream (round 6: `.cpu()` on the main thread
+                        # was a pageable copy of 33 MB per block, 7 ms during which no solve could be queued)
+                        nonlocal pinned, copy_stream
+                        if copy_stream is None:
+                            copy_stream = _t.cuda.Stream(device=dev_all.device)
+                        if pinned is None or tuple(pinned.shape) != tuple(dev_all.shape):
+                            pinned = _t.empty(tuple(dev_all.shape), dtype=dev_all.dtype, pin_memory=True)
+                        with _t.cuda.stream(copy_stream):
+                            copy_stream.wait_event(ready)
+                            pinned.copy_(dev_all, non_blocking=True)
+                        copy_stream.synchronize()
+                        del dev_all
+                        host = pinned.numpy()
+                        if native_replay:
+                            ks = np.asarray(block, dtype=np.int64)[None, :] * n_eval + np.arange(n_eval, dtype=np.int64)[:, None]
+                            replay_block_native(host, is_ket, emulator._meas_basis, matching, n, offs[ks], offs[ks + 1] - offs[ks],
+                                                rnd_all, mat_all if meas_err else None, nm.p_false_pos, nm.p_false_neg, hist)
+                            return
                         cum = cumulative_weights(host, is_ket, emulator._meas_basis, matching)
                         for j, i in enumerate(block):
                             for ti in range(n_eval):

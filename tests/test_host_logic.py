@@ -1706,6 +1706,50 @@ def test_bench_driver_line_is_short_scalar_and_round_trips():
     assert line["roofline"] is None and line["cpu_baseline"] is None
 
 
+def test_c_replay_equals_the_numpy_replay():
+    """ryd_replay_samples (host_replay.hpp; host arithmetic only, so it runs without a GPU): weights, cumulative sums,
+    searchsorted and the SPAM flips of a block of states in the same IEEE operations as the NumPy replay
+    (distributed.cumulative_weights + np.searchsorted + flips_with = qutip_result.py:101-158, multinomial.py:32-36,
+    simresults.py:537-568) - identical histograms for kets and density-matrix diagonals, both measurement bases, a
+    non-matching basis, with and without measurement errors, empty rows, one and several host threads."""
+    from pulser_amd.distributed import cumulative_weights, flips_with, replay_block_native
+
+    rng = np.random.default_rng(0)
+    n, n_eval, B = 9, 3, 17
+    D = 2**n
+    for is_ket in (True, False):
+        for basis, matching in (("ground-rydberg", True), ("digital", True), ("ground-rydberg", False)):
+            for meas in (True, False):
+                host = rng.normal(size=(n_eval, B, D)) + 1j * rng.normal(size=(n_eval, B, D))
+                host[1, 2, 5:40] = 0.0  # runs of equal cumulative weights
+                if not is_ket:
+                    host = np.abs(host) ** 2 + 0j
+                counts = rng.integers(0, 700, size=(n_eval, B))
+                counts[0, 0] = 0
+                starts = np.concatenate([[0], np.cumsum(counts.reshape(-1))[:-1]]).reshape(n_eval, B)
+                total = int(counts.sum())
+                rnd, mat = rng.random(total), (rng.random((total, n)) if meas else None)
+                want = np.zeros((n_eval, D), dtype=np.int64)
+                cum = cumulative_weights(host, is_ket, basis, matching)
+                for ti in range(n_eval):
+                    for j in range(B):
+                        a, c = starts[ti, j], counts[ti, j]
+                        ind = flips_with(np.searchsorted(cum[ti, j], rnd[a:a + c]), n, mat[a:a + c] if meas else None, 0.03, 0.08)
+                        want[ti] += np.bincount(ind, minlength=D)
+                for threads in (1, 4):
+                    got = np.full((n_eval, D), 7, dtype=np.int64)  # (accumulates into what is there)
+                    replay_block_native(host, is_ket, basis, matching, n, starts, counts, rnd, mat, 0.03, 0.08, got, n_threads=threads)
+                    assert np.array_equal(got - 7, want), (is_ket, basis, matching, meas, threads)
+    # a uniform beyond the last cumulative weight is refused (NumPy would index past the histogram)
+    host = np.zeros((1, 1, 4), dtype=complex)
+    host[0, 0, 0] = 1.0
+    from pulser_amd import _lib
+
+    with pytest.raises(_lib.RydError, match="beyond the last cumulative weight"):
+        replay_block_native(host, True, "digital", True, 2, np.zeros((1, 1), dtype=np.int64), np.ones((1, 1), dtype=np.int64),
+                            np.array([1.5]), None, 0.0, 0.0, np.zeros((1, 4), dtype=np.int64))
+
+
 def test_phase_gauge_of_the_split_operator_stages_is_an_identity():
     """SplitRun.gauge (k_split.hpp: k_split_coefs): a rotation by a complex drive c = |c| e^{i theta} is Z R(|c|) Z^+ with
     the diagonal Z = exp(-i theta n), and Z commutes with the D factors - so the composition D R(c_S) D ... R(c_1) D equals

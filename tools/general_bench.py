@@ -60,7 +60,7 @@ def xy_problem(n=12):
     return p, np.asarray(emu.initial_state).reshape(-1), (int(p["duration"]) - 1) * 1e-3
 
 
-def run_leg(label, prob, init, t_end, mesolve=False):
+def run_leg(label, prob, init, t_end, mesolve=False, multi=None):
     import torch
 
     from pulser_amd.engine import GeneralEngine
@@ -71,6 +71,8 @@ def run_leg(label, prob, init, t_end, mesolve=False):
     tables = lower_general(prob, mesolve=mesolve, matrix_free=True)
     lower_s = time.perf_counter() - tic
     with GeneralEngine(tables) as eng:
+        if multi is not None:
+            eng.set_path(bool(multi))
         eng.solve(eng.new_state(init), [0.0, min(0.002, t_end)])  # warm-up: code objects, work buffers
         torch.cuda.synchronize()
         best, st, out = np.inf, None, None
@@ -109,8 +111,14 @@ def legs():
         prob, init, t_end = three_level_problem(n)
         out.append(run_leg(f"f-1: 3-level 'all' basis, {n} atoms (3^{n} amplitudes), global ground-rydberg + 3 local raman "
                            f"drives, sesolve, {t_end * 1e3:.0f} ns", prob, init, t_end))
-    prob, init, t_end = xy_problem(12)
-    out.append(run_leg(f"f-4: XY exchange, 12 atoms (2 x 6 at 4 um), global XY channel, sesolve, {t_end * 1e3:.0f} ns", prob, init, t_end))
+    # XY: a SLICE (the exchange couplings at 4 um are 567 rad/us: 670 000 generator applications over the full microsecond -
+    # round 6 measured 8 minutes for it on the one-workgroup kernel before the selection rule below existed)
+    slice_us = float(os.environ.get("GEN_XY_SLICE_US", "0.02"))
+    for n in (8, 12):
+        prob, init, _ = xy_problem(n)
+        for multi, tag in ((None, "default path"), (True, "multi-launch forced")):
+            out.append(run_leg(f"f-4: XY exchange, {n} atoms (2 x {n // 2} at 4 um), global XY channel, sesolve, "
+                               f"{slice_us * 1e3:.0f} ns slice [{tag}]", prob, init, slice_us, multi=multi))
     return out
 
 
