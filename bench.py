@@ -287,7 +287,7 @@ _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_ste
 _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "us_per_stage", "traffic",
               "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "isa_flops_per_launch", "launches",
               "avg_launch_ms", "hbm_equivalent_GBps")
-_CFG_KEYS = ("n_atoms", "sequences_per_gpu", "sim_us_per_sequence", "stages_per_sequence", "parity_max_abs",
+_CFG_KEYS = ("ms_min", "ms_median", "ms_max", "spread", "n_atoms", "sequences_per_gpu", "sim_us_per_sequence", "stages_per_sequence", "parity_max_abs",
              "single_sequence_sim_us_per_s", "lindblad_seconds", "lindblad_sim_us_per_s", "lindblad_roofline_frac",
              "n_trajectories", "sim_us_per_s", "n_measures", "histogram_total", "passes_per_application", "order",
              "generator_applications_per_sequence")
@@ -488,14 +488,20 @@ def cfg4_line(n_traj, steps, warmup, dist, torch, n_gpus, common):
     def one_pass(seed, density_matrix=False):
         np.random.seed(seed)
         emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=n_traj, evaluation_times="Minimal")
-        return run_ensemble(emu, dist=dist, batch=256, density_matrix=density_matrix)
+        # blocks of 512 trajectories: two 12-atom kets per CU (the register-resident kernel runs 41 300 sim-us/s at 512
+        # sequences against 29 700 at 256, profiles/r05_size_batch_map.md)
+        return run_ensemble(emu, dist=dist, batch=int(os.environ.get("RYD_CFG4_BATCH", "512")), density_matrix=density_matrix)
 
     for w in range(warmup):
         one_pass(100 + w)
     barrier(torch, dist)
     tic = time.perf_counter()
+    each = []
     for k in range(steps):
+        t_k = time.perf_counter()
         res = one_pass(k)
+        torch.cuda.synchronize()
+        each.append((time.perf_counter() - t_k) * 1e3)
     barrier(torch, dist)
     sec = (time.perf_counter() - tic) / steps
     if dist is not None:
@@ -520,6 +526,9 @@ def cfg4_line(n_traj, steps, warmup, dist, torch, n_gpus, common):
                                    "of the bitstring histograms", "n_atoms": 12, "n_trajectories": n_traj,
                        "sim_us_per_s": n_traj * T_SEQ_US / sec, "n_measures": int(res["n_measures"]),
                        "histogram_total": int(res["histograms"].sum()),
+                       # run-to-run spread of the end-to-end ensemble on this rank
+                       "ms_min": float(np.min(each)), "ms_median": float(np.median(each)), "ms_max": float(np.max(each)),
+                       "spread": float((np.max(each) - np.min(each)) / np.median(each)),
                        "mean_occupations_final": [float(v) for v in res["mean_occupations"][-1]],
                        "with_density_matrix": {"ms_per_step": sec_dm * 1e3, "ratio": sec_dm / sec,
                                                "trace_final": tr_dm,
@@ -1013,13 +1022,15 @@ def main() -> None:
         del psi, rho
         # cfg4 end to end: 1024 noise trajectories through run_ensemble (BASELINE configs[3]); the --workload cfg4 line
         # of an N-GPU run shards the same ensemble
-        c4 = cfg4_line(1024, 1, 1, None, torch, 1, {})
+        c4 = cfg4_line(1024, 5, 1, None, torch, 1, {})
         also.append({"workload": "cfg4: 1024 noise trajectories of the 12-atom anneal sequence, END TO END (noise draws, "
                                  "factored lowering, solve, reference-order sampling) through run_ensemble",
                      "value": c4["value"], "unit": "trajectories/s", "ms_per_ensemble": c4["ms_per_step"],
                      "sim_us_per_s": c4["config"]["sim_us_per_s"],
                      "with_density_matrix": c4["config"]["with_density_matrix"],
-                     "histogram_total": c4["config"]["histogram_total"], "n_measures": c4["config"]["n_measures"]})
+                     "histogram_total": c4["config"]["histogram_total"], "n_measures": c4["config"]["n_measures"],
+                     "repetitions": 5, "ms_min": c4["config"]["ms_min"], "ms_median": c4["config"]["ms_median"],
+                     "ms_max": c4["config"]["ms_max"], "spread": c4["config"]["spread"]})
         # cfg5: 20 atoms over the FULL 3.1 us: split-operator passes (default) with the Lanczos exponential (the solver
         # configs[4] names) and CF4 + Taylor beside it; 24 atoms = the HBM-bound regime (40 ns slice at t = 1 us)
         eng = Engine.from_problems([rect_problem(4, 5)], mode="sesolve")

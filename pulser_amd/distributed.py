@@ -308,6 +308,18 @@ def run_ensemble(
     shots = nm.samples_per_run * reps  # per (trajectory, evaluation time)
     offs = np.concatenate([[0], np.cumsum(np.repeat(shots, n_eval))])  # trajectory-major, time-minor
     total = int(offs[-1])
+    lo, hi = partition(reps, world)[rank]
+    # the factored lowering of this rank's FIRST block starts now, on its worker thread, and runs while rank 0 draws the
+    # sampling uniforms below (the legacy generator releases the GIL while it fills an array); round 6: it used to start
+    # after the draws and the first solve waited 10 - 15 ms for it
+    lower_pool = None
+    lowered: dict[int, Any] = {}
+    if solve_fn is None and lo < hi and emulator._fast_path_ok(emulator._current_problem):
+        from concurrent.futures import ThreadPoolExecutor as _TPE0
+
+        lower_pool = _TPE0(max_workers=1)
+        lowered[lo] = lower_pool.submit(hd.device_tables, [trajs[i] for i in range(lo, min(hi, lo + batch))],
+                                        emulator._sampling_rate)
     rnd_all = mat_all = None
     if rank == 0:  # the reference's call sequence: rand(n), then uniform(size=(n, N)) (simulation.py:853-861)
         rnd_all = np.empty(total)
@@ -321,7 +333,6 @@ def run_ensemble(
         rnd_all = _broadcast_array(dist, rnd_all, (total,))
         if meas_err:
             mat_all = _broadcast_array(dist, mat_all, (total, n))
-    lo, hi = partition(reps, world)[rank]
     n_traj = int(reps.sum())
     hist = np.zeros((n_eval, 2**n), dtype=np.int64)
     occ_sum = np.zeros((n_eval, n + 1), dtype=np.float64)
@@ -357,8 +368,6 @@ def run_ensemble(
     pinned: Any = None       # the replay worker's pinned staging buffer and copy stream (one worker: used block after block)
     copy_stream: Any = None
     pool = None
-    lower_pool = None
-    lowered: dict[int, Any] = {}
     pending: list[Any] = []
     try:
         for start in range(lo, hi, batch):

@@ -94,7 +94,7 @@ def run_leg(label, prob, init, t_end, mesolve=False, multi=None):
     dim = d**n
     apps = max(st["n_applications"], 1)
     bytes_per_app = 32.0 * dim
-    return {"workload": label, "levels": d, "n_atoms": n, "dim": dim, "sim_us": t_end, "value": t_end / best, "unit": "sim-us/s",
+    return {"workload": label, "levels": d, "n_atoms": n, "dim": dim, "n_terms": int(len(tables.series)), "sim_us": t_end, "value": t_end / best, "unit": "sim-us/s",
             "seconds": best, "lowering_s": lower_s, "applications": st["n_applications"], "launches": st["n_launches"],
             "steps": st["n_steps"], "taylor_order": st["last_order"], "us_per_application_wall": best * 1e6 / apps,
             "norm": norm,
@@ -129,5 +129,5 @@ if __name__ == "__main__":
     else:
         for r in res:
             print(f"{r['workload']}\n   {r['value']:.3f} sim-us/s ({r['seconds'] * 1e3:.1f} ms), {r['applications']} applications in "
-                  f"{r['launches']} launches, {r['us_per_application_wall']:.2f} us / application (wall), Taylor order {r['taylor_order']}, "
+                  f"{r['launches']} launches, {r['n_terms']} terms, {r['us_per_application_wall']:.2f} us / application (wall), Taylor order {r['taylor_order']}, "
                   f"HBM frac {r['roofline']['frac']:.4f} ({r['roofline']['achieved']:.1f} GB/s), norm {r['norm']:.12f}")
