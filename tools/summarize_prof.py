@@ -30,7 +30,7 @@ def pmc(name, counter):
     return acc
 
 md = [f"# {rnd}: rocprofv3 summaries (MI355X, gfx950)", "",
-      "Commands: `tools/profile.sh` / `tools/profile_r05.sh` (kernel-trace/stats runs and, separately, one `--pmc` pass per counter).",
+      "Commands: `tools/profile_r06.sh` (kernel-trace/stats runs and, separately, one `--pmc` pass per counter).",
       "`api` = `tools/api_bench.py`: the drop-in call with evaluation_times Minimal / Full / 0.1 (one 14-atom sequence each).",
       "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x",
       "(MI355X_MICROARCH.md, HBM section), so HBM read bytes = 2 x FETCH_SIZE x 1024.", ""]
