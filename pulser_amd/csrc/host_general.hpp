@@ -224,20 +224,151 @@ static void compute_bounds_general(ryd_handle* h) {
   h->bounds_valid = true;
 }
 
+struct GenSiteBuild {
+  GenSite g;
+  std::map<std::pair<int, int>, std::vector<std::pair<int, std::complex<double>>>> ent;  // (R, C) -> contributions
+};
+
+// LDS budget of k_gen_apply_fused (CDNA4: 160 KiB per CU; tables + optionally the whole vector)
+static const size_t kGenFusedLds = 150 * 1024;
+
+// Padded site tables of k_gen_apply_fused from the per-site entry maps: per site and local row the diagonal entry
+// and K = (fullest row's off-diagonal count) padded (value, row offset) entries; sites ordered by K.
+static int gen_build_fused(ryd_handle* h, const std::vector<GenSiteBuild>& sb, const std::vector<int>& diag_terms) {
+  h->gen_fused_ok = false;
+  if (h->gen_no_fused || sb.empty() || h->dim > ((size_t)1 << 30)) return RYD_OK;
+  const int d = h->gen_d;
+  struct Row { std::vector<std::pair<int, const std::vector<std::pair<int, std::complex<double>>>*>> off;
+               const std::vector<std::pair<int, std::complex<double>>>* diag = nullptr; };
+  std::vector<int> order(sb.size()), Ks(sb.size(), 0);
+  std::vector<std::vector<Row>> rows(sb.size());
+  for (size_t i = 0; i < sb.size(); ++i) {
+    order[i] = (int)i;
+    rows[i].resize(sb[i].g.ld);
+    for (auto& kv : sb[i].ent) {
+      Row& r = rows[i][kv.first.first];
+      if (kv.first.first == kv.first.second) r.diag = &kv.second;
+      else r.off.push_back({kv.first.second, &kv.second});
+    }
+    for (const Row& r : rows[i]) Ks[i] = std::max(Ks[i], (int)r.off.size());
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return Ks[a] < Ks[b]; });
+  std::vector<GenSiteF> sites;
+  std::vector<int> delta, cstart(1, 0), cterm;
+  std::vector<cplx> cval;
+  std::vector<std::vector<std::pair<int, std::complex<double>>>> diag_contribs;
+  GenFusedDev F{};
+  int E = 0, Dg = 0;
+  for (int oi = 0; oi < (int)order.size(); ++oi) {
+    const int i = order[oi];
+    const GenSite& g = sb[i].g;
+    const int K = Ks[i];
+    if (F.n_groups == 0 || F.gK[F.n_groups - 1] != K) {
+      if (F.n_groups == GEN_FUSED_MAX_GROUPS) return RYD_OK;  // (more distinct row lengths than a Hamiltonian of site sums has)
+      F.gK[F.n_groups] = K;
+      F.gBegin[F.n_groups] = oi;
+      F.gEnd[F.n_groups] = oi;
+      F.n_groups++;
+    }
+    F.gEnd[F.n_groups - 1] = oi + 1;
+    GenSiteF sf;
+    sf.shift0 = g.shift0;
+    sf.shift1 = g.n_per == 2 ? g.shift1 : 0;
+    sf.mask1 = g.n_per == 2 ? (d <= 4 ? 3 : 15) : 0;
+    sf.mul = g.n_per == 2 ? d : 1;
+    sf.ent_off = E;
+    sf.diag_off = Dg;
+    for (int R = 0; R < g.ld; ++R) {
+      const Row& r = rows[i][R];
+      const int a = g.n_per == 2 ? R / d : R, b = g.n_per == 2 ? R % d : 0;
+      for (int k = 0; k < K; ++k) {
+        if (k < (int)r.off.size()) {
+          const int Cc = r.off[k].first;
+          const int c0 = g.n_per == 2 ? Cc / d : Cc, c1 = g.n_per == 2 ? Cc % d : 0;
+          const long long dl = (long long)(c0 - a) * g.s0 + (long long)(c1 - b) * g.s1;
+          delta.push_back((int)dl);
+          for (auto& c : *r.off[k].second) {
+            cterm.push_back(c.first);
+            cval.push_back(make_double2(c.second.real(), c.second.imag()));
+          }
+        } else {
+          delta.push_back(0);  // padding: value 0 (no contributions) x the row's own amplitude
+        }
+        cstart.push_back((int)cterm.size());
+      }
+      diag_contribs.push_back(r.diag ? *r.diag : std::vector<std::pair<int, std::complex<double>>>());
+    }
+    E += g.ld * K;
+    Dg += g.ld;
+    sites.push_back(sf);
+  }
+  for (auto& dc : diag_contribs) {  // the diagonal entries follow the E off-diagonal ones
+    for (auto& c : dc) {
+      cterm.push_back(c.first);
+      cval.push_back(make_double2(c.second.real(), c.second.imag()));
+    }
+    cstart.push_back((int)cterm.size());
+  }
+  const size_t lds_tables = (size_t)(E + Dg) * sizeof(cplx) + (size_t)((E + 3) & ~3) * sizeof(int) +
+                            ((sites.size() * sizeof(GenSiteF) + 15) & ~(size_t)15) + 16;
+  if (lds_tables > kGenFusedLds) return RYD_OK;
+  const bool xlds = lds_tables + h->dim * sizeof(cplx) <= kGenFusedLds;
+  const size_t b_cval = std::max<size_t>(cval.size(), 1) * sizeof(cplx), b_mv = (size_t)(E + Dg) * sizeof(cplx),
+               b_sites = sites.size() * sizeof(GenSiteF), b_delta = std::max<size_t>(delta.size(), 1) * sizeof(int),
+               b_cs = cstart.size() * sizeof(int), b_ct = std::max<size_t>(cterm.size(), 1) * sizeof(int);
+  auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  if (h->gen_fused_pool) hipFree(h->gen_fused_pool);
+  h->gen_fused_pool = nullptr;
+  HIPCHK(hipMalloc(&h->gen_fused_pool, up16(b_cval) + up16(b_mv) + up16(b_sites) + up16(b_delta) + up16(b_cs) + up16(b_ct)));
+  char* p = (char*)h->gen_fused_pool;
+  auto put = [&](const void* src, size_t have, size_t bytes) -> void* {
+    void* dst = p;
+    if (src && have) hipMemcpy(dst, src, have, hipMemcpyHostToDevice);
+    p += up16(bytes);
+    return dst;
+  };
+  F.contrib_val = (const cplx*)put(cval.data(), cval.size() * sizeof(cplx), b_cval);
+  F.mvals = (cplx*)put(nullptr, 0, b_mv);
+  F.sites = (const GenSiteF*)put(sites.data(), b_sites, b_sites);
+  F.delta = (const int*)put(delta.data(), delta.size() * sizeof(int), b_delta);
+  F.contrib_start = (const int*)put(cstart.data(), b_cs, b_cs);
+  F.contrib_term = (const int*)put(cterm.data(), cterm.size() * sizeof(int), b_ct);
+  F.n_sites = (int)sites.size();
+  F.E = E;
+  F.Dg = Dg;
+  h->gen_fused = F;
+  h->gen_fused_xlds = xlds;
+  h->gen_fused_lds = lds_tables + (xlds ? h->dim * sizeof(cplx) : 0);
+  if (h->gen_diag_terms_dev) hipFree(h->gen_diag_terms_dev);
+  h->gen_diag_terms_dev = nullptr;
+  h->gen_n_diag = (int)diag_terms.size();
+  HIPCHK(hipMalloc((void**)&h->gen_diag_terms_dev, std::max<size_t>(diag_terms.size(), 1) * sizeof(int)));
+  if (!diag_terms.empty())
+    HIPCHK(hipMemcpy(h->gen_diag_terms_dev, diag_terms.data(), diag_terms.size() * sizeof(int), hipMemcpyHostToDevice));
+  {
+    static bool attr[64] = {};
+    const int dev = h->cfg.device;
+    if (dev < 0 || dev >= 64 || !attr[dev]) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_gen_apply_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gen_apply_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      if (dev >= 0 && dev < 64) attr[dev] = true;
+    }
+  }
+  h->gen_fused_ok = true;
+  return RYD_OK;
+}
+
 // Site table of a matrix-free handle (every term local or diagonal): which terms / groups act on which
 // site, the union of their sparsity patterns per site and, per pattern entry, the list of (term, weight x
 // entry) contributions that k_gen_sitevals adds up per exponential.
 static int gen_build_sites(ryd_handle* h) {
   h->gen_sites_valid = true;
   h->gen_sites_ok = false;
+  h->gen_fused_ok = false;
   if (h->gen_no_sites || h->gen_d == 0) return RYD_OK;
   for (const GenTermHost& t : h->gen_host)
     if (t.dev.kind == 0) return RYD_OK;  // explicit CSR terms: the term-by-term kernel
-  struct SiteBuild {
-    GenSite g;
-    std::map<std::pair<int, int>, std::vector<std::pair<int, std::complex<double>>>> ent;  // (R, C) -> contributions
-  };
-  std::vector<SiteBuild> sb;
+  std::vector<GenSiteBuild> sb;
   std::map<std::tuple<int, long long, long long>, int> index;
   std::vector<int> diag_terms;
   for (int ti = 0; ti < (int)h->gen_host.size(); ++ti) {
@@ -249,7 +380,7 @@ static int gen_build_sites(ryd_handle* h) {
       auto key = std::make_tuple(np, s0, s1);
       auto it = index.find(key);
       if (it == index.end()) {
-        SiteBuild b;
+        GenSiteBuild b;
         b.g.s0 = s0; b.g.s1 = s1;
         b.g.shift0 = t.h_shifts[(size_t)g * np];
         b.g.shift1 = np == 2 ? t.h_shifts[(size_t)g * np + 1] : 0;
@@ -257,15 +388,20 @@ static int gen_build_sites(ryd_handle* h) {
         it = index.emplace(key, (int)sb.size()).first;
         sb.push_back(std::move(b));
       }
-      SiteBuild& b = sb[it->second];
+      GenSiteBuild& b = sb[it->second];
       for (size_t e = 0; e < t.h_vals.size(); ++e)
         b.ent[{t.h_rows[e], t.h_cols[e]}].push_back({ti, t.h_weights[g] * t.h_vals[e]});
     }
   }
+  {
+    int rc = gen_build_fused(h, sb, diag_terms);
+    if (rc) return rc;
+    if (h->gen_fused_ok) return RYD_OK;  // (the round-3 tables are not needed)
+  }
   std::vector<GenSite> sites;
   std::vector<int> prs, pcol, cstart(1, 0), cterm;
   std::vector<cplx> cval;
-  for (SiteBuild& b : sb) {
+  for (GenSiteBuild& b : sb) {
     b.g.rs_off = (int)prs.size();
     int R = 0;
     prs.push_back((int)pcol.size());
@@ -324,6 +460,28 @@ static int apply_general(ryd_handle* h, const MixPoint& m, const cplx* in, const
                          cplx* out, double scale, hipStream_t st) {
   const int n = (int)h->gen_host.size();
   if (n == 0) return fail(RYD_ERR_STATE, "no terms: call ryd_general_add_term first");
+  if (h->gen_fused_ok) {
+    GenFusedArgs A;
+    A.in = in;
+    A.base = base;
+    A.out = out;
+    A.tcoef = h->gen_tcoef;
+    A.terms = h->gen_terms_dev;
+    A.diag_terms = h->gen_diag_terms_dev;
+    A.F = h->gen_fused;
+    A.dim = (long long)h->dim;
+    A.n_diag = h->gen_n_diag;
+    A.d = h->gen_d;
+    A.n_dig = h->gen_ndig;
+    A.scale = scale;
+    dim3 grid((unsigned)((h->dim + 255) / 256), h->B);
+    if (h->gen_fused_xlds) hipLaunchKernelGGL(k_gen_apply_fused<true>, grid, dim3(256), h->gen_fused_lds, st, A);
+    else hipLaunchKernelGGL(k_gen_apply_fused<false>, grid, dim3(256), h->gen_fused_lds, st, A);
+    HIPCHK(hipGetLastError());
+    h->stats.n_launches++;
+    h->stats.n_applications++;
+    return RYD_OK;
+  }
   if (h->gen_sites_ok) {
     GenSiteArgs A;
     A.in = in;
@@ -369,14 +527,20 @@ static int apply_general(ryd_handle* h, const MixPoint& m, const cplx* in, const
 
 static int launch_eval_general(ryd_handle* h, const MixPoint& m, hipStream_t st) {
   const int n = (int)h->gen_host.size();
-  hipLaunchKernelGGL(k_gen_coefs, dim3((n + 63) / 64), dim3(64), 0, st, h->pp_dev, h->n_knots - 1,
-                     h->gen_series_dev, h->gen_conj_dev, h->gen_scale_dev, n, m.idx1, m.u1, m.w1,
-                     m.u2, m.w2, h->gen_tcoef);
-  HIPCHK(hipGetLastError());
   if (!h->gen_sites_valid) {
     int rc = gen_build_sites(h);
     if (rc) return rc;
   }
+  if (h->gen_fused_ok) {  // coefficients and the padded site matrices of this exponential in one launch
+    hipLaunchKernelGGL(k_gen_coefs_fused, dim3(1), dim3(256), 0, st, h->pp_dev, h->n_knots - 1, h->gen_series_dev,
+                       h->gen_conj_dev, h->gen_scale_dev, n, m.idx1, m.u1, m.w1, m.u2, m.w2, h->gen_tcoef, h->gen_fused);
+    HIPCHK(hipGetLastError());
+    return RYD_OK;
+  }
+  hipLaunchKernelGGL(k_gen_coefs, dim3((n + 63) / 64), dim3(64), 0, st, h->pp_dev, h->n_knots - 1,
+                     h->gen_series_dev, h->gen_conj_dev, h->gen_scale_dev, n, m.idx1, m.u1, m.w1,
+                     m.u2, m.w2, h->gen_tcoef);
+  HIPCHK(hipGetLastError());
   if (h->gen_sites_ok) {  // the site matrices of this exponential
     hipLaunchKernelGGL(k_gen_sitevals, dim3((h->gen_sites.P + 127) / 128), dim3(128), 0, st, h->gen_sites, h->gen_tcoef);
     HIPCHK(hipGetLastError());

@@ -130,6 +130,12 @@ struct ryd_handle {
   int* gen_diag_terms_dev = nullptr;
   int gen_n_diag = 0;
   bool gen_no_sites = false;  // test hook: keep the term-by-term kernel
+  // padded site tables (k_gen_apply_fused, round 6)
+  bool gen_fused_ok = false, gen_fused_xlds = false;
+  bool gen_no_fused = false;  // test / A-B hook: keep k_gen_apply_sites (round 3)
+  GenFusedDev gen_fused{};
+  void* gen_fused_pool = nullptr;
+  size_t gen_fused_lds = 0;
   GenTermDev* gen_terms_dev = nullptr;
   int* gen_series_dev = nullptr;
   int* gen_conj_dev = nullptr;
@@ -467,6 +473,7 @@ extern "C" void ryd_destroy(ryd_handle* h) {
   hipFree(h->kry_pool);
   hipFree(h->gen_tcoef);
   hipFree(h->gen_sites_pool);
+  hipFree(h->gen_fused_pool);
   hipFree(h->gen_diag_terms_dev);
   hipFree(h->gen_terms_dev);
   hipFree(h->gen_series_dev);

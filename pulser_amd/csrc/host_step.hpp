@@ -726,6 +726,8 @@ extern "C" int ryd_set_path(ryd_handle* h, int32_t force_generic) {
     {
       const bool ns = (force_generic & 4096) != 0;  // general path: term-by-term kernel instead of the site-fused one
       if (ns != h->gen_no_sites) { h->gen_no_sites = ns; h->gen_sites_valid = false; }
+      const bool nf = (force_generic & 262144) != 0;  // general path: k_gen_apply_sites (round 3) instead of the padded site tables
+      if (nf != h->gen_no_fused) { h->gen_no_fused = nf; h->gen_sites_valid = false; }
     }
     {
       const bool small = (force_generic & 2048) != 0;

@@ -185,6 +185,163 @@ __global__ __launch_bounds__(256) void k_gen_apply_sites(const GenSiteArgs A) {
   A.out[boff + row] = r;
 }
 
+// ---------------------------------------------------------------------------
+// Padded site tables (round 6).  k_gen_apply_sites above chases four dependent LDS loads per site and a data-dependent
+// entry loop, one wave per SIMD: 9 us per application on 3^9 amplitudes, 35 us on the 66 exchange pairs of a 12-atom XY
+// register - pure latency.  Here every site carries, per local row R, its DIAGONAL entry and exactly K off-diagonal
+// entries (K = the site's fullest row; short rows are padded with (value 0, offset 0)), stored as (value, row offset):
+//     acc += M_s[R][k] * x[row + delta_s[R][k]],  k < K        dsum += Mdiag_s[R]
+// No branch, no pattern walk: the gathers of a site are independent of each other and of the next sites', the site loop
+// is unrolled and sites of equal K are contiguous (K is a template argument of the loop).  Vectors of up to ~6 000
+// amplitudes (XY on 12 atoms, 3-level on 7, 4-level on 6) are staged whole in LDS by every workgroup and gathered from
+// there (XLDS); larger ones gather from L2.  Coefficients and site matrices of an exponential come from ONE small launch
+// (k_gen_coefs_fused) instead of two.
+// ---------------------------------------------------------------------------
+struct GenSiteF {
+  int shift0, shift1;  // bit positions of the digit(s) in the packed digits of a row
+  int mask1, mul;      // pair sites: digit mask and d; single sites: 0 and 1  (R = a * mul + (b & mask1))
+  int ent_off;         // first padded entry of local row 0 (row R: ent_off + R * K)
+  int diag_off;        // diagonal entry of local row 0
+};
+
+#define GEN_FUSED_MAX_GROUPS 8
+struct GenFusedDev {
+  const GenSiteF* sites;
+  const int* delta;           // [E] row offset of every padded off-diagonal entry
+  const int* contrib_start;   // [E + Dg + 1]: contributions of every entry (off-diagonal entries first, then diagonal ones)
+  const int* contrib_term;
+  const cplx* contrib_val;
+  cplx* mvals;                // [E + Dg] entries of the current exponential
+  int n_sites, E, Dg, n_groups;
+  int gK[GEN_FUSED_MAX_GROUPS], gBegin[GEN_FUSED_MAX_GROUPS], gEnd[GEN_FUSED_MAX_GROUPS];
+};
+
+// tcoef[t] (as k_gen_coefs) and then the site-matrix entries, one workgroup
+__global__ __launch_bounds__(256) void k_gen_coefs_fused(const cplx* __restrict__ pp, int n_int, const int* __restrict__ series,
+                                                         const int* __restrict__ conjf, const cplx* __restrict__ scale,
+                                                         int n_terms, int idx, double u1, double w1, double u2, double w2,
+                                                         cplx* __restrict__ tcoef, const GenFusedDev F) {
+  __shared__ double tc_raw[2 * 96];  // MAX_GEN_TERMS coefficients
+  cplx* tc = reinterpret_cast<cplx*>(tc_raw);
+  for (int t = threadIdx.x; t < n_terms; t += blockDim.x) {
+    cplx v = make_double2(w1 + w2, 0.0);
+    if (series[t] >= 0) {
+      auto val = [&](double u) -> cplx {
+        const cplx* p = pp + ((size_t)series[t] * n_int + idx) * 4;
+        cplx r = p[0];
+        r = make_double2(fma(r.x, u, p[1].x), fma(r.y, u, p[1].y));
+        r = make_double2(fma(r.x, u, p[2].x), fma(r.y, u, p[2].y));
+        r = make_double2(fma(r.x, u, p[3].x), fma(r.y, u, p[3].y));
+        return r;
+      };
+      const cplx a = val(u1), b = val(u2);
+      v = make_double2(w1 * a.x + w2 * b.x, w1 * a.y + w2 * b.y);
+      if (conjf[t]) v.y = -v.y;
+    }
+    v = cmul(scale[t], v);
+    tc[t] = v;
+    tcoef[t] = v;
+  }
+  __syncthreads();
+  const int P = F.E + F.Dg;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    cplx m = make_double2(0.0, 0.0);
+    for (int k = F.contrib_start[p]; k < F.contrib_start[p + 1]; ++k) m = cfma(tc[F.contrib_term[k]], F.contrib_val[k], m);
+    F.mvals[p] = m;
+  }
+}
+
+struct GenFusedArgs {
+  const cplx* in;
+  const cplx* base;
+  cplx* out;
+  const cplx* tcoef;
+  const GenTermDev* terms;   // only the diagonal (kind 2) terms are read here
+  const int* diag_terms;     // [n_diag] indices into terms / tcoef
+  GenFusedDev F;
+  long long dim;
+  int n_diag, d, n_dig;
+  double scale;
+};
+
+template <int K, bool XLDS>
+__device__ __forceinline__ void gen_fused_sites(const GenSiteF* __restrict__ sites, int s0, int s1, const cplx* __restrict__ mv,
+                                                const cplx* __restrict__ mvd, const int* __restrict__ dl,
+                                                const cplx* __restrict__ x, int row, unsigned long long digits, unsigned mask,
+                                                int kdyn, cplx& acc, cplx& dsum) {
+#pragma unroll 4
+  for (int s = s0; s < s1; ++s) {
+    const GenSiteF si = sites[s];
+    const int R = (int)((digits >> si.shift0) & mask) * si.mul + (int)((digits >> si.shift1) & (unsigned)si.mask1);
+    const cplx dg = mvd[si.diag_off + R];
+    dsum.x += dg.x;
+    dsum.y += dg.y;
+    if (K > 0) {
+      const int e0 = si.ent_off + R * K;
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc = cfma(mv[e0 + k], x[row + dl[e0 + k]], acc);
+    } else {  // (K > 4: a dense two-digit superoperator)
+      const int e0 = si.ent_off + R * kdyn;
+      for (int k = 0; k < kdyn; ++k) acc = cfma(mv[e0 + k], x[row + dl[e0 + k]], acc);
+    }
+  }
+}
+
+template <bool XLDS>
+__global__ __launch_bounds__(256) void k_gen_apply_fused(const GenFusedArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int E = A.F.E, Dg = A.F.Dg;
+  cplx* mv = reinterpret_cast<cplx*>(smem);                          // [E] off-diagonal, [Dg] diagonal
+  cplx* mvd = mv + E;
+  int* dl = reinterpret_cast<int*>(mvd + Dg);                        // [E]
+  GenSiteF* sites = reinterpret_cast<GenSiteF*>(dl + ((E + 3) & ~3));  // [n_sites] (24-byte records of ints)
+  cplx* xs = reinterpret_cast<cplx*>(reinterpret_cast<char*>(sites) + ((A.F.n_sites * sizeof(GenSiteF) + 15) & ~(size_t)15));
+  const size_t boff = (size_t)blockIdx.y * A.dim;
+  const cplx* __restrict__ xg = A.in + boff;
+  for (int i = threadIdx.x; i < E + Dg; i += 256) mv[i] = A.F.mvals[i];
+  for (int i = threadIdx.x; i < E; i += 256) dl[i] = A.F.delta[i];
+  for (int i = threadIdx.x; i < A.F.n_sites; i += 256) sites[i] = A.F.sites[i];
+  if (XLDS)
+    for (int i = threadIdx.x; i < (int)A.dim; i += 256) xs[i] = xg[i];
+  __syncthreads();
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= A.dim) return;
+  const cplx* __restrict__ x = XLDS ? xs : xg;
+  const unsigned long long digits = gen_pack_digits(row, A.d, A.n_dig);
+  const unsigned mask = A.d <= 4 ? 3u : 15u;
+  const cplx xr = x[row];
+  cplx dsum = make_double2(0.0, 0.0);
+  for (int k = 0; k < A.n_diag; ++k) {
+    const int t = A.diag_terms[k];
+    dsum = cfma(A.tcoef[t], A.terms[t].val[row], dsum);
+  }
+  cplx acc = make_double2(0.0, 0.0);
+  for (int g = 0; g < A.F.n_groups; ++g) {
+    const int K = A.F.gK[g], s0 = A.F.gBegin[g], s1 = A.F.gEnd[g];
+    switch (K) {
+      case 0: for (int s = s0; s < s1; ++s) {  // diagonal-only sites
+                const GenSiteF si = sites[s];
+                const int R = (int)((digits >> si.shift0) & mask) * si.mul + (int)((digits >> si.shift1) & (unsigned)si.mask1);
+                const cplx dg = mvd[si.diag_off + R];
+                dsum.x += dg.x; dsum.y += dg.y;
+              } break;
+      case 1: gen_fused_sites<1, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+      case 2: gen_fused_sites<2, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+      case 3: gen_fused_sites<3, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+      case 4: gen_fused_sites<4, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+      default: gen_fused_sites<0, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+    }
+  }
+  acc = cfma(dsum, xr, acc);
+  cplx r = make_double2(A.scale * acc.x, A.scale * acc.y);
+  if (A.base) {
+    const cplx bb = A.base[boff + row];
+    r.x += bb.x;
+    r.y += bb.y;
+  }
+  A.out[boff + row] = r;
+}
+
 #define MAX_GEN_TERMS 96
 
 struct GenArgs {

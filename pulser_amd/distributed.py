@@ -246,6 +246,21 @@ def _broadcast_array(dist: Any, arr: np.ndarray | None, shape: tuple[int, ...], 
     return t.cpu().numpy()
 
 
+# pinned staging buffers of the sampling replay, kept between ensembles (allocating 67 MB of pinned host memory costs
+# more than copying it); one buffer per (shape, dtype), at most two kept
+_PINNED_CACHE: dict[tuple, Any] = {}
+
+
+def _pinned_like(torch: Any, dev_t: Any) -> Any:
+    key = (tuple(dev_t.shape), str(dev_t.dtype))
+    buf = _PINNED_CACHE.get(key)
+    if buf is None:
+        while len(_PINNED_CACHE) >= 2:
+            _PINNED_CACHE.pop(next(iter(_PINNED_CACHE)))
+        buf = _PINNED_CACHE[key] = torch.empty(key[0], dtype=dev_t.dtype, pin_memory=True)
+    return buf
+
+
 def run_ensemble(
     emulator: Any,
     solve_fn: Callable[[list[dict[str, Any]]], np.ndarray] | None = None,
@@ -272,8 +287,12 @@ def run_ensemble(
     occupations come from ``ryd_occupations``, the |psi><psi| sum from ``ryd_outer_accumulate_dim``
     and the result ``density_matrices`` is a CUDA tensor.
     """
+    import time as _time
+
     import torch
 
+    t_start = _time.perf_counter()
+    tm: dict[str, float] = {"lower_wait_ms": 0.0, "solve_ms": 0.0, "post_ms": 0.0}  # where the wall time went (bench detail)
     rank, _, world = env_world()
     if dist is None:
         world, rank = 1, 0
@@ -333,6 +352,7 @@ def run_ensemble(
         rnd_all = _broadcast_array(dist, rnd_all, (total,))
         if meas_err:
             mat_all = _broadcast_array(dist, mat_all, (total, n))
+    tm["draws_done_ms"] = (_time.perf_counter() - t_start) * 1e3
     n_traj = int(reps.sum())
     hist = np.zeros((n_eval, 2**n), dtype=np.int64)
     occ_sum = np.zeros((n_eval, n + 1), dtype=np.float64)
@@ -396,8 +416,13 @@ def run_ensemble(
                     if nxt < hi and nxt not in lowered:
                         lowered[nxt] = lower_pool.submit(
                             hd.device_tables, [trajs[i] for i in range(nxt, min(hi, nxt + batch))], emulator._sampling_rate)
+                    t_a = _time.perf_counter()
                     tables = lowered.pop(start).result()
+                    t_b = _time.perf_counter()
                     first_dev, snaps_dev, occ = emulator._solve_batch([], False, options, tables=tables, raw=True)
+                    t_c = _time.perf_counter()
+                    tm["lower_wait_ms"] += (t_b - t_a) * 1e3
+                    tm["solve_ms"] += (t_c - t_b) * 1e3
                     is_ket = first_dev.dim() == 2
                     rb = reps[block].astype(np.float64)
                     norm = occ[..., n]  # [n_eval, B]
@@ -438,8 +463,7 @@ def run_ensemble(
                         nonlocal pinned, copy_stream
                         if copy_stream is None:
                             copy_stream = _t.cuda.Stream(device=dev_all.device)
-                        if pinned is None or tuple(pinned.shape) != tuple(dev_all.shape):
-                            pinned = _t.empty(tuple(dev_all.shape), dtype=dev_all.dtype, pin_memory=True)
+                        pinned = _pinned_like(_t, dev_all)
                         with _t.cuda.stream(copy_stream):
                             copy_stream.wait_event(ready)
                             pinned.copy_(dev_all, non_blocking=True)
@@ -465,6 +489,7 @@ def run_ensemble(
 
                         pool = ThreadPoolExecutor(max_workers=1)  # one worker: the replays run in block order
                     pending.append(pool.submit(replay))
+                    tm["post_ms"] += (_time.perf_counter() - t_c) * 1e3
                     continue
                 states = solve_fn([hd.problem(trajs[i], emulator._sampling_rate) for i in block])
             finally:
@@ -484,8 +509,10 @@ def run_ensemble(
                         if rho_sum is None:
                             rho_sum = np.zeros((n_eval,) + r1.shape, dtype=np.complex128)
                         rho_sum[ti] += reps[i] * r1
+        t_a = _time.perf_counter()
         for fut in pending:
             fut.result()  # (re-raises what a replay raised)
+        tm["replay_tail_ms"] = (_time.perf_counter() - t_a) * 1e3
     finally:
         # on an error too: nothing may keep running behind the caller's back (a prefetched lowering holds device
         # tables, a queued replay would go on adding to `hist`)
@@ -534,6 +561,8 @@ def run_ensemble(
         "n_measures": n_traj * nm.samples_per_run,
         "block": (lo, hi),
     }
+    tm["total_ms"] = (_time.perf_counter() - t_start) * 1e3
+    out["timings"] = tm
     if density_matrix:
         # tuned path: a CUDA tensor complex128[n_eval, D, D] (it never existed on the host; ``.cpu()`` on
         # request); host solvers: a NumPy array

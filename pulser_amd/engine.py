@@ -633,11 +633,13 @@ class GeneralEngine:
                                                 self._stream()))
         return out
 
-    def set_path(self, force_multi_launch: bool, no_sites: bool = False) -> None:
+    def set_path(self, force_multi_launch: bool, no_sites: bool = False, no_fused: bool = False) -> None:
         """Test hook: one launch per Taylor stage instead of the persistent
         one-launch kernel used for vectors of at most 4096 entries; ``no_sites``: the term-by-term
-        kernel instead of the site-fused application of matrix-free terms."""
-        _lib.check(self.lib.ryd_set_path(self._h, int(bool(force_multi_launch)) | (4096 if no_sites else 0)))
+        kernel instead of the site-fused application of matrix-free terms; ``no_fused``: the round-3 site kernel
+        (k_gen_apply_sites) instead of the padded site tables of k_gen_apply_fused."""
+        _lib.check(self.lib.ryd_set_path(self._h, int(bool(force_multi_launch)) | (4096 if no_sites else 0)
+                                         | (262144 if no_fused else 0)))
 
     def stats(self) -> dict[str, Any]:
         s = RydStats()

@@ -731,7 +731,7 @@ class QutipEmulator:
                     "Quantum-jump trajectories need a ket as initial state; use "
                     "solver=Solver.MESOLVER with a density matrix.")
             state = eng.new_state(init.reshape(1, -1))
-            first = None if on_device else state.cpu().numpy()
+            first = None if (on_device or raw) else state.cpu().numpy()  # (raw: nothing is wrapped, no host copy)
             first_dev = state.clone() if raw else None
             if mode == "mcsolve":
                 snaps = eng.mc_solve(state, times, self._mc_seeds(n_batch, options), store=True,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """cProfile of one cfg4 ensemble (1024 noisy 12-atom trajectories through run_ensemble): where the host time goes.
-CFG4_BATCH = trajectories per engine batch (default 256)."""
+CFG4_BATCH = trajectories per engine batch (default 512)."""
 import cProfile
 import io
 import os
@@ -28,16 +28,16 @@ nm = NoiseModel(temperature=50.0, amp_sigma=0.05, state_prep_error=0.005, p_fals
 def one(seed):
     np.random.seed(seed)
     emu = QutipEmulator(inputs, noise_model=nm, n_trajectories=1024, evaluation_times="Minimal")
-    return run_ensemble(emu, dist=None, batch=int(os.environ.get("CFG4_BATCH", "256")))
+    return run_ensemble(emu, dist=None, batch=int(os.environ.get("CFG4_BATCH", "512")))
 
 
 one(100)
 torch.cuda.synchronize()
-for rep in range(2):
+for rep in range(6):
     tic = time.perf_counter()
-    one(rep)
+    r = one(rep)
     torch.cuda.synchronize()
-    print("ensemble", (time.perf_counter() - tic) * 1e3, "ms")
+    print("ensemble", (time.perf_counter() - tic) * 1e3, "ms", {k: round(v, 2) for k, v in r["timings"].items()})
 pr = cProfile.Profile()
 pr.enable()
 one(5)
