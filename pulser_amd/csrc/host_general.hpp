@@ -79,6 +79,7 @@ extern "C" int ryd_general_add_term(ryd_handle* h, int64_t nnz, const int32_t* r
   t.conj = conj;
   t.scale = std::complex<double>(scale_re, scale_im);
   t.row_norm = row_norm;
+  t.step_norm = row_norm;
   HIPCHK(hipMalloc((void**)&t.dev.row_ptr, (h->dim + 1) * sizeof(int)));
   HIPCHK(hipMalloc((void**)&t.dev.col, std::max<int64_t>(nnz, 1) * sizeof(int)));
   HIPCHK(hipMalloc((void**)&t.dev.val, std::max<int64_t>(nnz, 1) * sizeof(cplx)));
@@ -176,6 +177,15 @@ extern "C" int ryd_general_add_local_term(ryd_handle* h, int32_t local_dim, int3
   t.h_shifts = shifts;
   t.h_vals.resize(nnz);
   for (int e = 0; e < nnz; ++e) t.h_vals[e] = std::complex<double>(vals[2 * e], vals[2 * e + 1]);
+  {
+    // the term's own infinity norm (every group on its fullest local row at once): the caller's `row_norm` may be smaller
+    // when it has bounded several time-independent terms JOINTLY (pulser_amd/general.py: _tighten_static_norms)
+    std::vector<double> rs(ld, 0.0);
+    for (int e = 0; e < nnz; ++e) rs[rows[e]] += std::abs(t.h_vals[e]);
+    double wsum = 0.0;
+    for (int g = 0; g < n_groups; ++g) wsum += std::fabs(weights[g]);
+    t.step_norm = std::max(row_norm, wsum * *std::max_element(rs.begin(), rs.end()));
+  }
   h->gen_host.push_back(t);
   return gen_publish_terms(h);
 }
@@ -195,6 +205,7 @@ extern "C" int ryd_general_add_diag_term(ryd_handle* h, const double* values, in
   t.conj = conj;
   t.scale = std::complex<double>(scale_re, scale_im);
   t.row_norm = row_norm;
+  t.step_norm = row_norm;
   t.dev.kind = 2;
   HIPCHK(hipMalloc((void**)&t.dev.val, h->dim * sizeof(cplx)));
   HIPCHK(hipMemcpy((void*)t.dev.val, values, h->dim * sizeof(cplx), hipMemcpyHostToDevice));
@@ -208,14 +219,22 @@ static void compute_bounds_general(ryd_handle* h) {
   h->bd_pos.assign(n_int, 0.0);
   h->bd_neg.assign(n_int, 0.0);
   h->bd_curv.assign(n_int, 0.0);
+  // Two bounds per interval.  bd_drive (sum of the callers' row norms, jointly tightened for the time-independent terms):
+  // the argument of the Taylor series, i.e. its degree.  bd_step (sum of every term's OWN infinity norm, what bd_drive was
+  // up to round 5): the size of the CF4 steps - the general path has no estimate of the 4th-order Magnus error, the rule
+  // "argument near 1 against the crude bound" is what its oracle tests were passed with (host_sched.hpp), so a tighter
+  // norm lowers the polynomial degree and leaves the steps where they were.
+  h->bd_step.assign(n_int, 0.0);
   for (const GenTermHost& t : h->gen_host) {
-    const double w = std::abs(t.scale) * t.row_norm;
+    const double w = std::abs(t.scale) * t.row_norm, ws = std::abs(t.scale) * std::max(t.step_norm, t.row_norm);
     for (int i = 0; i < n_int; ++i) {
       if (t.series >= 0) {
         h->bd_drive[i] += w * h->s_abs[(size_t)t.series * n_int + i];
+        h->bd_step[i] += ws * h->s_abs[(size_t)t.series * n_int + i];
         h->bd_curv[i] += w * h->s_curv[(size_t)t.series * n_int + i];
       } else {
         h->bd_drive[i] += w;
+        h->bd_step[i] += ws;
       }
     }
   }
@@ -309,8 +328,8 @@ static int gen_build_fused(ryd_handle* h, const std::vector<GenSiteBuild>& sb, c
     }
     cstart.push_back((int)cterm.size());
   }
-  const size_t lds_tables = (size_t)(E + Dg) * sizeof(cplx) + (size_t)((E + 3) & ~3) * sizeof(int) +
-                            ((sites.size() * sizeof(GenSiteF) + 15) & ~(size_t)15) + 16;
+  // LDS: entries, the four waves' partial sums (4 x 64 x 2 complex), row offsets (site descriptors are scalar loads)
+  const size_t lds_tables = (size_t)(E + Dg) * sizeof(cplx) + 4 * 64 * 2 * sizeof(cplx) + (size_t)((E + 3) & ~3) * sizeof(int) + 16;
   if (lds_tables > kGenFusedLds) return RYD_OK;
   const bool xlds = lds_tables + h->dim * sizeof(cplx) <= kGenFusedLds;
   const size_t b_cval = std::max<size_t>(cval.size(), 1) * sizeof(cplx), b_mv = (size_t)(E + Dg) * sizeof(cplx),
@@ -342,6 +361,7 @@ static int gen_build_fused(ryd_handle* h, const std::vector<GenSiteBuild>& sb, c
   if (h->gen_diag_terms_dev) hipFree(h->gen_diag_terms_dev);
   h->gen_diag_terms_dev = nullptr;
   h->gen_n_diag = (int)diag_terms.size();
+  h->gen_diag_host = diag_terms;
   HIPCHK(hipMalloc((void**)&h->gen_diag_terms_dev, std::max<size_t>(diag_terms.size(), 1) * sizeof(int)));
   if (!diag_terms.empty())
     HIPCHK(hipMemcpy(h->gen_diag_terms_dev, diag_terms.data(), diag_terms.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -469,12 +489,17 @@ static int apply_general(ryd_handle* h, const MixPoint& m, const cplx* in, const
     A.terms = h->gen_terms_dev;
     A.diag_terms = h->gen_diag_terms_dev;
     A.F = h->gen_fused;
+    for (int k = 0; k < 4; ++k) {
+      const bool have = k < h->gen_n_diag;
+      A.diag_idx[k] = have ? h->gen_diag_host[k] : 0;
+      A.diag_val[k] = have ? h->gen_host[h->gen_diag_host[k]].dev.val : nullptr;
+    }
     A.dim = (long long)h->dim;
     A.n_diag = h->gen_n_diag;
     A.d = h->gen_d;
     A.n_dig = h->gen_ndig;
     A.scale = scale;
-    dim3 grid((unsigned)((h->dim + 255) / 256), h->B);
+    dim3 grid((unsigned)((h->dim + GEN_FUSED_ROWS - 1) / GEN_FUSED_ROWS), h->B);
     if (h->gen_fused_xlds) hipLaunchKernelGGL(k_gen_apply_fused<true>, grid, dim3(256), h->gen_fused_lds, st, A);
     else hipLaunchKernelGGL(k_gen_apply_fused<false>, grid, dim3(256), h->gen_fused_lds, st, A);
     HIPCHK(hipGetLastError());

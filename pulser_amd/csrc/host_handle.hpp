@@ -30,6 +30,7 @@ struct GenTermHost {
   int series = -1, conj = 0;
   std::complex<double> scale{1.0, 0.0};
   double row_norm = 0.0;
+  double step_norm = 0.0;  // what sizes the CF4 steps: sum_g |w_g| x the largest row sum of |M| (>= row_norm, see compute_bounds_general)
   // host copy of a matrix-free local term (the site-fused application is assembled from these)
   std::vector<long long> h_strides;
   std::vector<double> h_weights;
@@ -53,6 +54,7 @@ struct ryd_handle {
   std::vector<ryd_dterm> dterms_host;  // extra detuning terms (ryd_qdesc.extra)
   ryd_dterm* dterms_dev = nullptr;
   std::vector<double> bd_drive, bd_pos, bd_neg;  // per interval, max over batch
+  std::vector<double> bd_step;  // general path: the bound that sizes the steps (host_general.hpp)
   std::vector<double> bd_curv;                   // per interval: non-linearity of H(t)
   // multi-knot CF4 steps (host_sched.hpp): per-series slope bounds, per-knot "the next piece is the same
   // polynomial", per-interval per-ATOM maxima of |c|, |dc/dt|, |delta|, |d delta/dt| over the batch
@@ -136,6 +138,7 @@ struct ryd_handle {
   GenFusedDev gen_fused{};
   void* gen_fused_pool = nullptr;
   size_t gen_fused_lds = 0;
+  std::vector<int> gen_diag_host;  // indices of the diagonal (kind 2) terms
   GenTermDev* gen_terms_dev = nullptr;
   int* gen_series_dev = nullptr;
   int* gen_conj_dev = nullptr;

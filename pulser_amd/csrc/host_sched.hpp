@@ -186,16 +186,25 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
       plan_exp(h, idx, len / nsub, kA1, kA2, o, &ord, &sh, span);
       const double rho = (len / nsub) * h->stats.norm_bound * (kA1 + kA2);
       if (h->general) {
-        if (rho > 1.5) nsub *= (int)std::ceil(rho / 1.0);
+        // The argument of a general-path exponential stays near 1 AGAINST THE CRUDE BOUND bd_step (the sum of the terms'
+        // own norms).  This is more than a Taylor-series matter: the general path has no estimate of the CF4 (4th-order
+        // Magnus) error of a step with a time-dependent drive on top of a strong static interaction, and h ~ 1 / ||G|| is
+        // what bounds it.  The (tighter) joint bound bd_drive only lowers the degree of the polynomial (plan_exp).  Round 6 tried the tuned path's search (minimise
+        // sub-steps x degree, arguments up to 4: half the applications): the reference's XY sequence at 10-ns knots then
+        // ends 1e-7 from the converged solution (tools/cf4_probe.py: error ~ h^4, 9e-9 at an argument of 1.2, 1.6e-7 at 2.4).
+        const double rho_step = (len / nsub) * span_max(h->bd_step, idx, span) * (kA1 + kA2);
+        if (rho_step > 1.5) nsub *= (int)std::ceil(rho_step / 1.0);
       } else if (in_place_exp) {
         // k_ket splits an exponential into equal sub-exponentials itself (pick_scheme)
       } else if (o.taylor_order <= 0) {
         const int cap = std::min(o.max_order > 0 ? o.max_order : 32, 32);
+        const double r_max = 6.0;
+        const int k_max = 64;
         int best_n = 0;
         double best_cost = 0.0;
-        for (int k = 1; k <= 64; ++k) {
+        for (int k = 1; k <= k_max; ++k) {
           const double r = rho / k;
-          if (r > 6.0) continue;
+          if (r > r_max) continue;
           ryd_opts oo = o;
           const int m = taylor_order_for(r, oo, default_tol(h));
           double term = 1.0;

@@ -409,14 +409,17 @@ static int fill_gen_traj_args(ryd_handle* h, cplx* state, const std::vector<Step
   return RYD_OK;
 }
 
-// The one-workgroup kernel k_gen_traj walks its term list once per application: ~1.6 us per term and 1 024 rows
-// (measured, round 6: XY exchange on 8 atoms - 256 amplitudes, 28 pair terms - 72 us per application against 15.7 us on the
-// multi-launch site-fused kernel; 12 atoms - 4 096 amplitudes, 66 pairs - 736 against 34 us: profiles/r06_general_path.md).
-// It keeps the systems whose whole schedule is cheaper than the launches it saves: few terms on few rows.
+// The one-workgroup kernel k_gen_traj walks its term list once per application: ~0.5 us per (term, group) and 1 024 rows
+// (measured, round 6: XY exchange on 8 atoms - 256 amplitudes, 4 pair terms x 28 pairs + 4 site terms x 8 sites - 72 us per
+// application; the multi-launch padded-site kernel k_gen_apply_fused applies the same generator in 6 us, launch included:
+// profiles/r06_general_path.md).  It keeps the systems whose application is cheaper than a launch: a dozen groups on
+// up to 1 024 rows (the 2 - 3 atom sequences of the reference's own tests).
 static bool use_persistent_general(const ryd_handle* h) {
   if (!(h->general && h->B == 1 && h->dim <= 4096 && !h->force_generic && !h->gen_host.empty())) return false;
   const double rows = std::max(1.0, (double)h->dim / 1024.0);
-  return (double)h->gen_host.size() * rows <= 24.0;
+  double groups = 0.0;
+  for (const GenTermHost& t : h->gen_host) groups += t.dev.kind == 1 ? (double)t.dev.n_groups : 1.0;
+  return groups * rows <= 13.0;
 }
 
 static bool use_persistent_dm(const ryd_handle* h) {

@@ -258,79 +258,144 @@ struct GenFusedArgs {
   const cplx* tcoef;
   const GenTermDev* terms;   // only the diagonal (kind 2) terms are read here
   const int* diag_terms;     // [n_diag] indices into terms / tcoef
+  const cplx* diag_val[4];   // the first four diagonal terms' vectors and term indices inline (no descriptor load on the way)
+  int diag_idx[4];
   GenFusedDev F;
   long long dim;
   int n_diag, d, n_dig;
   double scale;
 };
 
-template <int K, bool XLDS>
-__device__ __forceinline__ void gen_fused_sites(const GenSiteF* __restrict__ sites, int s0, int s1, const cplx* __restrict__ mv,
-                                                const cplx* __restrict__ mvd, const int* __restrict__ dl,
-                                                const cplx* __restrict__ x, int row, unsigned long long digits, unsigned mask,
-                                                int kdyn, cplx& acc, cplx& dsum) {
-#pragma unroll 4
-  for (int s = s0; s < s1; ++s) {
-    const GenSiteF si = sites[s];
-    const int R = (int)((digits >> si.shift0) & mask) * si.mul + (int)((digits >> si.shift1) & (unsigned)si.mask1);
-    const cplx dg = mvd[si.diag_off + R];
-    dsum.x += dg.x;
-    dsum.y += dg.y;
-    if (K > 0) {
-      const int e0 = si.ent_off + R * K;
+// One workgroup = 64 rows x 4 waves: wave w takes the sites s0 + w, s0 + w + 4, ... of every group for the SAME 64 rows and
+// the four partial sums meet in LDS.  (First version, one row per thread and all sites per row: the 78 sites of a 12-atom
+// XY register read 5.9 KB of LDS per row - 16 workgroups, LDS-bandwidth-bound at 10 - 14 us; a 3-level register of 9
+// atoms ran 9 sites in series on 77 CUs.)  Site descriptors are wave-uniform: scalar loads from global memory, not LDS.
+template <int K>
+__device__ __forceinline__ void gen_fused_sites(const GenSiteF* __restrict__ sites, int s0, int s1, int wave,
+                                                const cplx* __restrict__ mv, const cplx* __restrict__ mvd,
+                                                const int* __restrict__ dl, const cplx* __restrict__ x, int row,
+                                                unsigned long long digits, unsigned mask, int kdyn, cplx& acc, cplx& dsum) {
+  if constexpr (K > 0) {
+    constexpr int UNR = K <= 2 ? 4 : 2;  // sites in flight per wave (x 4 waves)
+    for (int sb = s0 + wave; sb < s1; sb += 4 * UNR) {
+      cplx mvv[UNR * K], xv[UNR * K];
 #pragma unroll
-      for (int k = 0; k < K; ++k) acc = cfma(mv[e0 + k], x[row + dl[e0 + k]], acc);
-    } else {  // (K > 4: a dense two-digit superoperator)
+      for (int u = 0; u < UNR; ++u) {
+        const bool on = sb + 4 * u < s1;
+        const int s = on ? sb + 4 * u : sb;
+        const GenSiteF si = sites[s];  // (s is wave-uniform: scalar loads)
+        const int R = (int)((digits >> si.shift0) & mask) * si.mul + (int)((digits >> si.shift1) & (unsigned)si.mask1);
+        const cplx dg = mvd[si.diag_off + R];
+        dsum.x += on ? dg.x : 0.0;
+        dsum.y += on ? dg.y : 0.0;
+        const int e0 = si.ent_off + R * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const cplx m = mv[e0 + k];
+          mvv[u * K + k] = on ? m : make_double2(0.0, 0.0);
+          xv[u * K + k] = x[row + dl[e0 + k]];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < UNR * K; ++j) acc = cfma(mvv[j], xv[j], acc);
+    }
+  } else {  // (K > 4: a dense two-digit superoperator)
+    for (int s = s0 + wave; s < s1; s += 4) {
+      const GenSiteF si = sites[s];
+      const int R = (int)((digits >> si.shift0) & mask) * si.mul + (int)((digits >> si.shift1) & (unsigned)si.mask1);
+      const cplx dg = mvd[si.diag_off + R];
+      dsum.x += dg.x;
+      dsum.y += dg.y;
       const int e0 = si.ent_off + R * kdyn;
+#pragma unroll 4
       for (int k = 0; k < kdyn; ++k) acc = cfma(mv[e0 + k], x[row + dl[e0 + k]], acc);
     }
   }
 }
 
+#define GEN_FUSED_ROWS 64
 template <bool XLDS>
 __global__ __launch_bounds__(256) void k_gen_apply_fused(const GenFusedArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int E = A.F.E, Dg = A.F.Dg;
   cplx* mv = reinterpret_cast<cplx*>(smem);                          // [E] off-diagonal, [Dg] diagonal
   cplx* mvd = mv + E;
-  int* dl = reinterpret_cast<int*>(mvd + Dg);                        // [E]
-  GenSiteF* sites = reinterpret_cast<GenSiteF*>(dl + ((E + 3) & ~3));  // [n_sites] (24-byte records of ints)
-  cplx* xs = reinterpret_cast<cplx*>(reinterpret_cast<char*>(sites) + ((A.F.n_sites * sizeof(GenSiteF) + 15) & ~(size_t)15));
+  cplx* red = mvd + Dg;                                              // [4][64][2]: partial sums of the waves
+  int* dl = reinterpret_cast<int*>(red + 4 * GEN_FUSED_ROWS * 2);    // [E]
+  cplx* xs = reinterpret_cast<cplx*>(dl + ((E + 3) & ~3));           // [dim] (XLDS)
   const size_t boff = (size_t)blockIdx.y * A.dim;
   const cplx* __restrict__ xg = A.in + boff;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long row = (long long)blockIdx.x * GEN_FUSED_ROWS + lane;
+  const bool live = row < A.dim;
+  // wave 0 owns the row's own amplitude, the dense diagonal terms and the result: its loads go out first and are in
+  // flight while the tables are staged
+  cplx xr = make_double2(0.0, 0.0), dsum = make_double2(0.0, 0.0);
+  if (live && wave == 0) {
+    xr = xg[row];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < A.n_diag) dsum = cfma(A.tcoef[A.diag_idx[k]], A.diag_val[k][row], dsum);
+    for (int k = 4; k < A.n_diag; ++k) {
+      const int t = A.diag_terms[k];
+      dsum = cfma(A.tcoef[t], A.terms[t].val[row], dsum);
+    }
+  }
   for (int i = threadIdx.x; i < E + Dg; i += 256) mv[i] = A.F.mvals[i];
   for (int i = threadIdx.x; i < E; i += 256) dl[i] = A.F.delta[i];
-  for (int i = threadIdx.x; i < A.F.n_sites; i += 256) sites[i] = A.F.sites[i];
-  if (XLDS)
-    for (int i = threadIdx.x; i < (int)A.dim; i += 256) xs[i] = xg[i];
-  __syncthreads();
-  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (row >= A.dim) return;
-  const cplx* __restrict__ x = XLDS ? xs : xg;
-  const unsigned long long digits = gen_pack_digits(row, A.d, A.n_dig);
-  const unsigned mask = A.d <= 4 ? 3u : 15u;
-  const cplx xr = x[row];
-  cplx dsum = make_double2(0.0, 0.0);
-  for (int k = 0; k < A.n_diag; ++k) {
-    const int t = A.diag_terms[k];
-    dsum = cfma(A.tcoef[t], A.terms[t].val[row], dsum);
-  }
-  cplx acc = make_double2(0.0, 0.0);
-  for (int g = 0; g < A.F.n_groups; ++g) {
-    const int K = A.F.gK[g], s0 = A.F.gBegin[g], s1 = A.F.gEnd[g];
-    switch (K) {
-      case 0: for (int s = s0; s < s1; ++s) {  // diagonal-only sites
-                const GenSiteF si = sites[s];
-                const int R = (int)((digits >> si.shift0) & mask) * si.mul + (int)((digits >> si.shift1) & (unsigned)si.mask1);
-                const cplx dg = mvd[si.diag_off + R];
-                dsum.x += dg.x; dsum.y += dg.y;
-              } break;
-      case 1: gen_fused_sites<1, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
-      case 2: gen_fused_sites<2, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
-      case 3: gen_fused_sites<3, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
-      case 4: gen_fused_sites<4, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
-      default: gen_fused_sites<0, XLDS>(sites, s0, s1, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+  if (XLDS) {
+    // the whole vector into LDS, eight independent 16-byte loads per lane in flight
+    const int n = (int)A.dim;
+    for (int b0 = threadIdx.x; b0 < n; b0 += 256 * 8) {
+      cplx r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = b0 + u * 256;
+        r[u] = i < n ? xg[i] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = b0 + u * 256;
+        if (i < n) xs[i] = r[u];
+      }
     }
+  }
+  __syncthreads();
+  cplx acc = make_double2(0.0, 0.0);
+  if (live) {
+    const cplx* __restrict__ x = XLDS ? xs : xg;
+    const unsigned long long digits = gen_pack_digits(row, A.d, A.n_dig);
+    const unsigned mask = A.d <= 4 ? 3u : 15u;
+    const GenSiteF* __restrict__ sites = A.F.sites;
+    for (int g = 0; g < A.F.n_groups; ++g) {
+      const int K = A.F.gK[g], s0 = A.F.gBegin[g], s1 = A.F.gEnd[g];
+      switch (K) {
+        case 0: for (int s = s0 + wave; s < s1; s += 4) {  // diagonal-only sites
+                  const GenSiteF si = sites[s];
+                  const int R = (int)((digits >> si.shift0) & mask) * si.mul + (int)((digits >> si.shift1) & (unsigned)si.mask1);
+                  const cplx dg = mvd[si.diag_off + R];
+                  dsum.x += dg.x; dsum.y += dg.y;
+                } break;
+        case 1: gen_fused_sites<1>(sites, s0, s1, wave, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+        case 2: gen_fused_sites<2>(sites, s0, s1, wave, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+        case 3: gen_fused_sites<3>(sites, s0, s1, wave, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+        case 4: gen_fused_sites<4>(sites, s0, s1, wave, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+        default: gen_fused_sites<0>(sites, s0, s1, wave, mv, mvd, dl, x, (int)row, digits, mask, K, acc, dsum); break;
+      }
+    }
+  }
+  if (wave != 0) {
+    red[(wave * GEN_FUSED_ROWS + lane) * 2] = acc;
+    red[(wave * GEN_FUSED_ROWS + lane) * 2 + 1] = dsum;
+  }
+  __syncthreads();
+  if (wave != 0 || !live) return;
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const cplx a = red[(w * GEN_FUSED_ROWS + lane) * 2], dd = red[(w * GEN_FUSED_ROWS + lane) * 2 + 1];
+    acc.x += a.x; acc.y += a.y;
+    dsum.x += dd.x; dsum.y += dd.y;
   }
   acc = cfma(dsum, xr, acc);
   cplx r = make_double2(A.scale * acc.x, A.scale * acc.y);

@@ -229,3 +229,37 @@ def fuzz_case(seed, n_atoms=None):
     cplx = bool(rng.random() < 0.5)
     probs = [P.make_ising_problem(coords, random_pulse_samples(rng, duration, complex_phase=cplx)) for _ in range(batch)]
     return probs, f"seed {seed}: {n} atoms ({kind}, {spacing:.2f} um), {duration} ns, batch {batch}, phases {cplx}"
+
+
+# -- general-path problems shared by tests/test_gpu_general_free.py and tools/general_bench.py ---------------
+def three_level_problem(n, T=201, seed=5):
+    rng = np.random.default_rng(seed)
+    lay = P.square_rect(3, 3) if n == 9 else P.square_rect(2, n // 2)
+    coords = P.register_coords(lay, 6.5)
+    t = np.arange(T) / 1000.0
+    prob = P.make_ising_problem(coords, {"amp": 6.0 + 2.0 * np.sin(40 * t), "det": -3.0 + 50 * t, "phase": 0.4 * np.ones(T)})
+    prob["eigenbasis"] = ["r", "g", "h"]
+    prob["basis_name"] = "all"
+    prob["samples"]["Local"] = {"digital": {q: {"amp": rng.uniform(2, 8) * np.ones(T), "det": rng.uniform(-3, 3) * np.ones(T),
+                                                 "phase": rng.uniform(0, 1) * np.ones(T)} for q in (0, n // 2, n - 2)}}
+    init = np.zeros(3**n, dtype=complex)
+    init[sum(1 * 3**k for k in range(n))] = 1.0  # |g...g>
+    return prob, init, (T - 1) * 1e-3
+
+
+def xy_problem(n=12):
+    """The reference's mesolve-XY test sequence (tests/golden/noisy_xy_2.npz: inputs captured from pulser-core) on a 12-atom
+    2 x 6 register at the same 4-um pitch: global XY channel, magnetic field (0, 0, 30)."""
+    from pulser_amd import QutipEmulator
+    from pulser_amd.hamiltonian_data import SequenceInputs
+
+    prob, _ = load_fixture("noisy_xy_2.npz")
+    inp = dict(prob["inputs"])
+    inp["coords"] = P.register_coords(P.square_rect(2, n // 2), 4.0)
+    inp["qubit_ids"] = tuple(f"atom{k}" for k in range(n))
+    ch = dict(inp["channels"][0])
+    ch["slots"] = [np.array([int(s[0]), int(s[1])] + list(range(n)), dtype=np.int64) for s in ch["slots"]]
+    inp["channels"] = [ch]
+    emu = QutipEmulator(SequenceInputs.from_dict(inp), sampling_rate=1.0)
+    p = emu._current_problem
+    return p, np.asarray(emu.initial_state).reshape(-1), (int(p["duration"]) - 1) * 1e-3

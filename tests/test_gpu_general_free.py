@@ -125,3 +125,50 @@ def test_matrix_free_three_level_register_of_nine_atoms():
         assert res[False][2] < 0.6 * res[True][2]
     else:
         assert res[False][2] < 1.5 * res[True][2]
+
+
+@pytest.mark.parametrize("case", ["xy12", "all9", "xy8_mesolve", "digital_mesolve"])
+def test_padded_site_tables_against_the_round3_kernels(case):
+    """k_gen_apply_fused (round 6: padded (value, row offset) site tables, whole vector in LDS where it fits) against
+    k_gen_apply_sites (round 3) and the term-by-term kernel: the same generator applied to a random vector at two
+    times, and a short solve.  xy12: 66 exchange pairs on 4 096 amplitudes (vector staged in LDS); all9: 3-level
+    register, 19 683 amplitudes (gathers from L2); mesolve cases: two-digit superoperator sites on vec(rho)."""
+    import torch
+
+    from helpers import three_level_problem, xy_problem
+    from pulser_amd.engine import GeneralEngine
+    from pulser_amd.general import lower_general
+
+    mesolve = case.endswith("mesolve")
+    if case == "xy12":
+        prob, init, _ = xy_problem(12)
+        t_end = 0.004
+    elif case == "all9":
+        prob, init, _ = three_level_problem(9, T=41)
+        t_end = 0.02
+    elif case == "xy8_mesolve":
+        prob, init = _problem_and_state("noisy_xy_0.npz")
+        t_end = 0.02
+    else:
+        prob, init = _problem_and_state("noises_digital_6.npz")
+        t_end = 0.05
+    tables = lower_general(prob, mesolve=mesolve, matrix_free=True)
+    rng = np.random.default_rng(11)
+    xh = rng.normal(size=(1, tables.dim)) + 1j * rng.normal(size=(1, tables.dim))
+    res = {}
+    for name, kw in (("fused", {}), ("sites", {"no_fused": True}), ("terms", {"no_sites": True})):
+        with GeneralEngine(tables) as eng:
+            eng.set_path(True, **kw)
+            x = torch.from_numpy(xh).to(eng.device)
+            g = [eng.apply_generator(x, t).cpu().numpy() for t in (0.0, 0.37 * t_end)]
+            out = eng.solve(eng.new_state(init), [0.0, t_end]).cpu().numpy()[-1]
+            res[name] = (np.asarray(g), out, eng.stats())
+    scale = max(1.0, float(np.max(np.abs(res["terms"][0]))))
+    assert np.max(np.abs(res["fused"][0] - res["terms"][0])) < 1e-12 * scale
+    assert np.max(np.abs(res["sites"][0] - res["terms"][0])) < 1e-12 * scale
+    assert np.max(np.abs(res["fused"][1] - res["terms"][1])) < 1e-10
+    assert np.max(np.abs(res["fused"][1] - res["sites"][1])) < 1e-11
+    # (one launch per exponential for coefficients + site matrices instead of two)
+    assert res["fused"][2]["n_applications"] == res["sites"][2]["n_applications"]
+    if not mesolve:  # something happened on the slice
+        assert np.max(np.abs(res["fused"][1] - init)) > 1e-6

@@ -24,43 +24,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK = 8.0e12
 
 
-def three_level_problem(n, T=201, seed=5):
-    from pulser_amd import problem as P
-
-    rng = np.random.default_rng(seed)
-    lay = P.square_rect(3, 3) if n == 9 else P.square_rect(2, n // 2)
-    coords = P.register_coords(lay, 6.5)
-    t = np.arange(T) / 1000.0
-    prob = P.make_ising_problem(coords, {"amp": 6.0 + 2.0 * np.sin(40 * t), "det": -3.0 + 50 * t, "phase": 0.4 * np.ones(T)})
-    prob["eigenbasis"] = ["r", "g", "h"]
-    prob["basis_name"] = "all"
-    prob["samples"]["Local"] = {"digital": {q: {"amp": rng.uniform(2, 8) * np.ones(T), "det": rng.uniform(-3, 3) * np.ones(T),
-                                                 "phase": rng.uniform(0, 1) * np.ones(T)} for q in (0, n // 2, n - 2)}}
-    init = np.zeros(3**n, dtype=complex)
-    init[sum(1 * 3**k for k in range(n))] = 1.0  # |g...g>
-    return prob, init, (T - 1) * 1e-3
+from helpers import three_level_problem, xy_problem  # noqa: E402  (tests/helpers.py: the GPU tests use the same problems)
 
 
-def xy_problem(n=12):
-    """The reference's mesolve-XY test sequence (tests/golden/noisy_xy_2.npz: inputs captured from pulser-core) on a 12-atom
-    2 x 6 register at the same 4-um pitch: global XY channel, magnetic field (0, 0, 30)."""
-    from helpers import load_fixture
-    from pulser_amd import QutipEmulator, problem as P
-    from pulser_amd.hamiltonian_data import SequenceInputs
-
-    prob, _ = load_fixture("noisy_xy_2.npz")
-    inp = dict(prob["inputs"])
-    inp["coords"] = P.register_coords(P.square_rect(2, n // 2), 4.0)
-    inp["qubit_ids"] = tuple(f"atom{k}" for k in range(n))
-    ch = dict(inp["channels"][0])
-    ch["slots"] = [np.array([int(s[0]), int(s[1])] + list(range(n)), dtype=np.int64) for s in ch["slots"]]
-    inp["channels"] = [ch]
-    emu = QutipEmulator(SequenceInputs.from_dict(inp), sampling_rate=1.0)
-    p = emu._current_problem
-    return p, np.asarray(emu.initial_state).reshape(-1), (int(p["duration"]) - 1) * 1e-3
-
-
-def run_leg(label, prob, init, t_end, mesolve=False, multi=None):
+def run_leg(label, prob, init, t_end, mesolve=False, multi=None, variant="fused"):
     import torch
 
     from pulser_amd.engine import GeneralEngine
@@ -71,8 +38,9 @@ def run_leg(label, prob, init, t_end, mesolve=False, multi=None):
     tables = lower_general(prob, mesolve=mesolve, matrix_free=True)
     lower_s = time.perf_counter() - tic
     with GeneralEngine(tables) as eng:
-        if multi is not None:
-            eng.set_path(bool(multi))
+        # variant "sites": the round-3 kernel (k_gen_apply_sites) instead of the padded site tables (k_gen_apply_fused)
+        if multi is not None or variant != "fused":
+            eng.set_path(bool(multi), no_fused=variant == "sites")
         eng.solve(eng.new_state(init), [0.0, min(0.002, t_end)])  # warm-up: code objects, work buffers
         torch.cuda.synchronize()
         best, st, out = np.inf, None, None
@@ -98,32 +66,36 @@ def run_leg(label, prob, init, t_end, mesolve=False, multi=None):
             "seconds": best, "lowering_s": lower_s, "applications": st["n_applications"], "launches": st["n_launches"],
             "steps": st["n_steps"], "taylor_order": st["last_order"], "us_per_application_wall": best * 1e6 / apps,
             "norm": norm,
-            "roofline": {"bound": "hbm", "kernel": "k_gen_apply_sites", "achieved": bytes_per_app * apps / best / 1e9,
+            "variant": variant,
+            "roofline": {"bound": "hbm", "kernel": "k_gen_apply_fused" if variant == "fused" else "k_gen_apply_sites", "achieved": bytes_per_app * apps / best / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_per_app * apps / best / HBM_PEAK,
                          "algorithmic_bytes_per_launch": bytes_per_app, "traffic": None,
                          "basis": "wall clock of the solve (launch-bound at these sizes: d^N x 32 B = "
                                   f"{bytes_per_app / 1e6:.2f} MB per application)"}}
 
 
-def legs():
+def legs(variants=("fused", "sites")):
     out = []
     for n in (9, 10):
         prob, init, t_end = three_level_problem(n)
-        out.append(run_leg(f"f-1: 3-level 'all' basis, {n} atoms (3^{n} amplitudes), global ground-rydberg + 3 local raman "
-                           f"drives, sesolve, {t_end * 1e3:.0f} ns", prob, init, t_end))
-    # XY: a SLICE (the exchange couplings at 4 um are 567 rad/us: 670 000 generator applications over the full microsecond -
-    # round 6 measured 8 minutes for it on the one-workgroup kernel before the selection rule below existed)
+        for v in variants:
+            out.append(run_leg(f"f-1: 3-level 'all' basis, {n} atoms (3^{n} amplitudes), global ground-rydberg + 3 local raman "
+                               f"drives, sesolve, {t_end * 1e3:.0f} ns [{v}]", prob, init, t_end, variant=v))
+    # XY: a SLICE (the exchange couplings at 4 um are 567 rad/us: hundreds of thousands of generator applications over the
+    # full microsecond)
     slice_us = float(os.environ.get("GEN_XY_SLICE_US", "0.02"))
     for n in (8, 12):
         prob, init, _ = xy_problem(n)
-        for multi, tag in ((None, "default path"), (True, "multi-launch forced")):
+        for v in variants:
             out.append(run_leg(f"f-4: XY exchange, {n} atoms (2 x {n // 2} at 4 um), global XY channel, sesolve, "
-                               f"{slice_us * 1e3:.0f} ns slice [{tag}]", prob, init, slice_us, multi=multi))
+                               f"{slice_us * 1e3:.0f} ns slice [{v}, multi-launch]", prob, init, slice_us, multi=True, variant=v))
+        if n == 8:
+            out.append(run_leg(f"f-4: XY exchange, {n} atoms, the same slice [default path selection]", prob, init, slice_us))
     return out
 
 
 if __name__ == "__main__":
-    res = legs()
+    res = legs(("fused",) if "--fused-only" in sys.argv else ("fused", "sites"))
     if "--json" in sys.argv:
         print(json.dumps(res))
     else:
