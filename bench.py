@@ -1067,6 +1067,17 @@ def main() -> None:
                      "roofline": roofline_hbm(24, 1, stats, kms, kl, KSPLIT_NAME, "cfg5_24atoms:k_split")})
         del psi1
         eng.close()
+        # the multi-level ("all" basis, 3 levels) and XY path, k_gen_apply_fused behind ryd_solve of a
+        # GeneralEngine (tools/general_bench.py; kernel times: profiles/r06_general_path.md).  The 10-atom and the 12-atom
+        # legs first: they are the ones the contract line quotes
+        for extra_path in (os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
+            if extra_path not in sys.path:
+                sys.path.insert(0, extra_path)
+        import general_bench
+
+        gen_legs = general_bench.legs(("fused",))
+        gen_legs.sort(key=lambda leg: -int(leg["dim"]) if leg["workload"].startswith("f-1:") else -int(leg["n_atoms"]))
+        also.extend(gen_legs)
         out["also"] = also
         bw = device_copy_bandwidth(torch)
         out["device_copy_GBps"] = bw
