@@ -10,9 +10,9 @@ from pulser_amd import problem as P
 from pulser_amd.engine import Engine
 
 sizes = [int(a) for a in sys.argv[1:]] or [10, 11, 12, 13, 14, 15, 16]
-batches = [1, 2, 4, 8, 32, 256]
+batches = [1, 8, 32, 256, 512]
 base = P.anneal_samples()
-print("# r05: default path, full 3.1-us anneal, sim-us/s (whole batch) by register size and batch\n")
+print("# r06: default path, full 3.1-us anneal, sim-us/s (whole batch) by register size and batch\n")
 print("Register: the first N sites of a 2 x ceil(N/2) triangular lattice at the blockade radius; sequence b of a batch has its")
 print("amplitude scaled by 1 - 0.3 b / (B - 1) and its detuning by the inverse factor (as bench.py).  One MI355X, best of 2.\n")
 print("| N | " + " | ".join(f"B = {b}" for b in batches) + " |")
