@@ -33,14 +33,31 @@ static const char* dev_env(const char* name) {
     const char* d = std::getenv("RYD_DEV");
     return d && d[0] == '1' && d[1] == 0;
   }();
-  return dev ? std::getenv(name) : nullptr;
+  if (!dev) {
+    // a gated switch that is set without RYD_DEV=1 has no effect: say so once (a probe that labels its output with the
+    // variable would otherwise report an A/B that never happened - ADVICE r05)
+    const char* ignored = std::getenv(name);
+    if (ignored && ignored[0]) {
+      static std::atomic<bool> told{false};
+      if (!told.exchange(true))
+        std::fprintf(stderr, "librydemu: %s is set but ignored (development switches need RYD_DEV=1)\n", name);
+    }
+    return nullptr;
+  }
+  return std::getenv(name);
+}
+static void dev_env_rejected(const char* name, const char* value) {
+  std::fprintf(stderr, "librydemu: %s=%s is not a valid value, the default is used\n", name, value);
 }
 static int dev_env_int(const char* name, int dflt, int lo, int hi) {
   const char* e = dev_env(name);
   if (!e || !e[0]) return dflt;
   char* end = nullptr;
   const long v = std::strtol(e, &end, 10);
-  if (end == e || v < lo || v > hi) return dflt;  // garbage or out of range: the default, not a surprise
+  if (end == e || v < lo || v > hi) {  // garbage or out of range: the default, not a surprise - and not silently
+    dev_env_rejected(name, e);
+    return dflt;
+  }
   return (int)v;
 }
 static double dev_env_double(const char* name, double dflt, double lo, double hi) {
@@ -48,7 +65,10 @@ static double dev_env_double(const char* name, double dflt, double lo, double hi
   if (!e || !e[0]) return dflt;
   char* end = nullptr;
   const double v = std::strtod(e, &end);
-  if (end == e || !(v >= lo && v <= hi)) return dflt;
+  if (end == e || !(v >= lo && v <= hi)) {
+    dev_env_rejected(name, e);
+    return dflt;
+  }
   return v;
 }
 static bool dev_env_flag(const char* name, bool dflt) {  // "0" / "1"

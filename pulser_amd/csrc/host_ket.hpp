@@ -464,6 +464,7 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
   const double rows_budget = o.tol > 0 ? 500.0 * o.tol : 5e-8;
   const double rows_T = std::max(h->tknots.size() >= 2 ? h->tknots.back() - h->tknots.front() : 0.0, 1e-12);
   int probe_period = 16, probe_since = 0;
+  double probe_time_since = 0.0;  // simulated time (us) the blocks since the last probe have covered
   bool probed = false;
   double probe_rate = 0.0, probe_amp = 0.0, amp_max_rows = 0.0;
   for (double v : h->bd_c1) amp_max_rows = std::max(amp_max_rows, v);
@@ -572,15 +573,20 @@ static int run_rows(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sch
         if (tau_s > 0.0 && e > 4.0 * allowed) {
           rsplit = false;                 // the polynomial rows from here on
           h->stats.reserved[3] += 1.0;
+          // ... and the stretch since the last probe ran at a rate nobody had measured: booked at this probe's rate, like
+          // run_split books an overrun (the estimate a caller reads must not under-report)
+          h->stats.reserved[0] += 2.0 * std::max(0.0, e / tau_s - probe_rate) * probe_time_since;
         } else if (tau_s > 0.0) {
           probe_rate = std::max(0.5 * (probe_rate + e / tau_s), e / tau_s);
         }
         probed = true;
         probe_since = 0;
+        probe_time_since = 0.0;
         probe_period = std::min(256, 2 * probe_period);
         probe_amp = amp_b;
       }
       probe_since += knots_b;
+      probe_time_since += tau;
       if (rsplit) h->stats.reserved[0] += 2.0 * probe_rate * tau;
     }
     const double eps = (uniform_g && !dbl) ? tau * tau * tau * gflip * gflip / 72.0 : 0.0;

@@ -180,11 +180,13 @@ static bool split_loop14(const ryd_handle* h) {
 // round 4), the ket register-resident, one workgroup per sequence (14 atoms: one per CU; 13: two; 12: three).
 // Quantum-jump solves included (the decay factor of H_eff rides on the phase factors: template parameter DECAY).
 static int device_cu_count(int dev) {
-  static int n_cu_of[64] = {};  // per device (a process may hold handles on different device models)
-  int n_cu = (dev >= 0 && dev < 64) ? n_cu_of[dev] : 0;
+  // per device (a process may hold handles on different device models); atomics: handles of different
+  // threads may ask at once (the value is idempotent, the race was only formal - ADVICE r05)
+  static std::atomic<int> n_cu_of[64];
+  int n_cu = (dev >= 0 && dev < 64) ? n_cu_of[dev].load(std::memory_order_relaxed) : 0;
   if (!n_cu) {
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev < 0 ? 0 : dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    if (dev >= 0 && dev < 64) n_cu_of[dev] = n_cu;
+    if (dev >= 0 && dev < 64) n_cu_of[dev].store(n_cu, std::memory_order_relaxed);
   }
   return n_cu;
 }
@@ -277,6 +279,10 @@ static int split_run(ryd_handle* h, cplx* buf, const SubStep* subs, int nsub, hi
     if (all) s6_run = true;
     if (!any || all || &split_scheme(h) == &kSplitS6) alt = nullptr;
   }
+  // snapshot slots are strided by h->dim * B KETS: on a master-equation handle (the row probe borrows this routine)
+  // h->dim is 4^N and the slots would be wrong - that caller passes no marks, and must not start to
+  if (marks && snaps && h->dim != ((size_t)1 << N))
+    return fail(RYD_ERR_STATE, "split_run: snapshots inside a run need a ket handle (dim %zu, 2^N = %zu)", h->dim, (size_t)1 << N);
   bool any_inner = false;
   if (marks && snaps)
     for (int s = 0; s + 1 < nsub; ++s) any_inner = any_inner || marks[s] >= 0;
@@ -624,14 +630,20 @@ static int rows_split_probe(ryd_handle* h, const cplx* rho, const std::vector<St
     HIPCHK(hipMemcpyAsync(halves + (size_t)b * D, row, D * sizeof(cplx), hipMemcpyDeviceToDevice, st));
   }
   // the ket machinery of this file on B kets of 2^N amplitudes (the handle's scheme switch borrowed for the call)
-  const bool keep_s10 = h->split_s10;
-  const ryd_stats keep_stats = h->stats;
-  h->split_s10 = sc.S == 10;
-  const SubStep two[2] = {{s0.idx, s0.u0, 0.5 * s0.tau, 0}, {s0.idx, s0.u0 + 0.5 * s0.tau, 0.5 * s0.tau, 0}};
-  rc = split_run(h, whole, &s0, 1, st, sc.S == 6);
-  if (!rc) rc = split_run(h, halves, two, 2, st, sc.S == 6);
-  h->split_s10 = keep_s10;
-  h->stats = keep_stats;
+  {
+    // (a scope guard: whatever return path a later edit adds between here and the end of the two runs, the handle gets
+    // its scheme switch and its counters back - ADVICE r05)
+    struct Borrowed {
+      ryd_handle* h;
+      bool s10;
+      ryd_stats stats;
+      ~Borrowed() { h->split_s10 = s10; h->stats = stats; }
+    } borrowed{h, h->split_s10, h->stats};
+    h->split_s10 = sc.S == 10;
+    const SubStep two[2] = {{s0.idx, s0.u0, 0.5 * s0.tau, 0}, {s0.idx, s0.u0 + 0.5 * s0.tau, 0.5 * s0.tau, 0}};
+    rc = split_run(h, whole, &s0, 1, st, sc.S == 6);
+    if (!rc) rc = split_run(h, halves, two, 2, st, sc.S == 6);
+  }
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)B * sizeof(double), st));
   hipLaunchKernelGGL(k_split_diff, dim3(16, B), dim3(256), 0, st, halves, whole, N, h->split_err);

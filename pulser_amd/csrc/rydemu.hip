@@ -35,6 +35,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdarg>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
