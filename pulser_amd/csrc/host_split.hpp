@@ -878,21 +878,32 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
   // running estimate stays below the pro-rata budget by construction, and the moment it is not, the slack is back at 2^(1/p).
   // The case it was made for: evaluation times at every knot, where the 6-stage composition over one knot sits at 1.6 x
   // its allowance for 500 knots of the anneal and was cut in two there (12 stages per knot).
-  // OFF by default (RYD_DEV=1 RYD_SPLIT_BANK=1 switches it on): measured at the end of round 5 - headline anneal 7 038 -> 6 688
-  // stages, "Full" 22 176 -> 20 640 (226 -> 211 ms), errors on the anneal unchanged (4e-9) - but one of the first 400 fuzz
-  // seeds went to 1.13e-7 (the sub-step then sits at twice its allowance and a rate that doubles between two checks is four
-  // times over), and no GPU time was left to find the rule that keeps the gain and the fuzz clean.
+  // Round 5 measured it (headline anneal 7 038 -> 6 688 stages, "Full" 22 176 -> 20 640) and left it OFF: one of the first 400
+  // fuzz seeds went to 1.13e-7 (the sub-step then sits at twice its allowance and a rate that doubles between two checks is
+  // four times over).  Round 6: ON, behind the guard below; with the sub-steps of smooth stretches cut to length (groups) the
+  // gain is where the steps are capped by the evaluation times - "Full" 22 974 -> 20 634 stages (235 -> 212 ms), every 10th
+  // knot 6 748 -> 6 528, "Minimal" unchanged (5 648) - and the 2 000 fuzz seeds stay clean (profiles/r06_fuzz_summary.md).
+  // RYD_DEV=1 RYD_SPLIT_BANK=0 switches it off.
   static const bool slack_on = dev_env_flag("RYD_SPLIT_SLACK", true);
-  static const bool bank_on = dev_env_flag("RYD_SPLIT_BANK", false);
+  static const bool bank_on = dev_env_flag("RYD_SPLIT_BANK", true);  // (default ON since round 6, with the guard below)
   double slack_mult = 2.0;  // predicted error of a lengthened sub-step over HALF its allowance (tau aims at the half)
   auto tau_q = [&](int k) {
     return (slack_on && ctl[k].tau < 1e299) ? ctl[k].tau * std::pow(slack_mult, 1.0 / scheme_of(k).order) : ctl[k].tau;
   };
+  // Guard (round 6): nothing is banked before TWO checks of this call have passed (the first one after a
+  // cold start sits on the product state and measures next to nothing), nor within RYD_SPLIT_BANK_KNOTS knot intervals
+  // (default 64) of a cold start or of a roll-back - the case that broke the unguarded rule (seed 263: a square pulse on 16
+  // atoms from t = 0) had its rate double between two checks right after the start.
+  static const int bank_knots = dev_env_int("RYD_SPLIT_BANK_KNOTS", 64, 0, 4096);
+  const double knot0 = h->n_knots >= 2 ? h->tknots[1] - h->tknots[0] : 1e-3;
+  double bank_block_until = h->split_known ? -1e300 : t_start + bank_knots * knot0;
+  int bank_checks_ok = h->split_known ? 2 : 0;
   auto update_bank = [&](size_t at) {
     slack_mult = 2.0;
     if (!bank_on || !control || at >= sched.size()) return;
     const double t_at = h->tknots[sched[at].idx] + (sched[at].u1 - kC1 * sched[at].h);
     const double elapsed = t_at - t_start;
+    if (bank_checks_ok < 2 || t_at < bank_block_until) return;
     if (elapsed > 0.02 * t_total && h->stats.reserved[0] <= 0.5 * eps * elapsed / t_total) slack_mult = 4.0;
   };
   double no_growth_until[2] = {-1e300, -1e300};  // after a roll-back: the time (us) of the check that failed, by kind
@@ -1161,6 +1172,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
         // its allowance: 8.1e-7 with an estimate of 1.8e-9, tools/fuzz_ctrl.py seed 1197), and no check may GROW the
         // sub-step of this kind before that time.
         no_growth_until[kd] = std::max(no_growth_until[kd], h->tknots[s0.idx] + s0.u0 + s0.tau);
+        bank_block_until = std::max(bank_block_until, h->tknots[s0.idx] + s0.u0 + s0.tau + bank_knots * knot0);
         ctl[kd].since = 0;
         i = ck_i;
         off = ck_off;
@@ -1171,6 +1183,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
         h->stats.reserved[0] = ck_est;
         continue;
       }
+      if (e <= 4.0 * allowed) ++bank_checks_ok;
       if (e > 4.0 * allowed) {
         // the retries are used up (or a quantum-jump solve, which cannot roll back): the stretch behind us ran
         // at about this error rate - booked in full
