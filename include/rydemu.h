@@ -311,7 +311,9 @@ int ryd_general_solve_many(ryd_handle** hs, int32_t n, void* const* states_dev, 
  * stage) instead of k_split_reg,
  * 65536 = split-operator master equation: the row passes on the polynomial kernel (k_ket) instead of k_split_reg,
  * 131072 = every evaluation time closes a run of k_split_reg (round 4) instead of a snapshot stored from the registers
- * inside the run (k_split_reg<.., SNAP> + k_split_snap_close).
+ * inside the run (k_split_reg<.., SNAP> + k_split_snap_close),
+ * 262144 = general path: the round-3 site kernel (k_gen_apply_sites) instead of the padded site tables of
+ * k_gen_apply_fused (round 6).
  * Never needed for results. */
 int ryd_set_path(ryd_handle* h, int32_t force_generic);
 
