@@ -266,3 +266,46 @@ def test_16_atom_square_register_full_anneal_against_tight_oracle(ns16, method):
     if method == "auto":  # the split-operator passes: many launches, an error estimate that covers the truth
         assert st["reserved"][0] > 0 and st["n_launches"] >= st["n_applications"]
         assert st["reserved"][0] < AMP_TOL and max(errs) < max(4 * st["reserved"][0], 2e-9), (errs, st["reserved"])
+
+
+def test_full_evaluation_times_in_windows_equal_the_sequential_solve(monkeypatch):
+    """evaluation_times="Full" (the reference's default) since round 6: anchor states every 16 knots from the main solve, the
+    knots in between from ONE batched solve of all windows in parallel (simulation.py: _solve_in_windows; the windows carry
+    the spline pieces of the full sequence, cut, not re-splined).  Against the sequential path of round 5 (every knot ends
+    a step; PULSER_AMD_NO_WINDOWS=1) at every evaluation time, and against the tight oracle where it stores a state."""
+    from test_host_logic import _inputs_from_problem
+
+    from pulser_amd import QutipEmulator
+
+    prob, extra = load_fixture("cfg2_chain12_anneal.npz")
+    prob = with_anneal_samples(prob)
+    t_ref = np.asarray(extra["eval_times"])
+    ref = np.asarray(extra["oracle_states_tight"])
+    runs = {}
+    for name in ("windows", "sequential"):
+        if name == "sequential":
+            monkeypatch.setenv("PULSER_AMD_NO_WINDOWS", "1")
+        emu = QutipEmulator(_inputs_from_problem(prob, "ground-rydberg"), evaluation_times="Full")
+        with pytest.warns(DeprecationWarning):
+            res = emu.run()
+        st = emu.last_engine_stats
+        states = np.stack([np.asarray(s)[:, 0] for s in res.states])
+        runs[name] = (states, st, emu.evaluation_times)
+    (sw, stw, ev), (ss, sts, _) = runs["windows"], runs["sequential"]
+    assert "windows" in stw and "windows" not in sts
+    assert stw["windows"]["knots"] == 16 and stw["windows"]["n_windows"] == (len(ev) - 2) // 16
+    # far fewer stages on the critical path, the same states
+    assert stw["n_applications"] - stw["windows"]["n_applications"] < 0.5 * sts["n_applications"], (stw, sts)
+    gap = np.max(np.abs(sw - ss), axis=1)
+    assert gap.max() < stw["reserved"][0] + sts["reserved"][0] + 2e-9, (gap.max(), int(gap.argmax()), stw["reserved"], sts["reserved"])
+    assert gap.max() < 5e-8
+    checked = 0
+    for k, t in enumerate(t_ref):
+        hit = np.nonzero(np.abs(ev - t) < 1e-9)[0]
+        if len(hit) == 0:
+            continue
+        err = float(np.max(np.abs(sw[int(hit[0])] - ref[k])))
+        assert err < AMP_TOL and err < max(4 * stw["reserved"][0], 2e-9), (t, err, stw["reserved"])
+        checked += 1
+    assert checked >= 3
+    assert np.max(np.abs(np.sum(np.abs(sw) ** 2, axis=1) - 1.0)) < 1e-9  # every state of every window is normalised

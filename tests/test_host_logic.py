@@ -1834,3 +1834,42 @@ def test_every_launched_k_split_reg_instantiation_is_listed_for_the_part_units()
             assert args in generic, (n, args)
         else:
             assert args in generic or (n,) + args in extra, (n, args)
+
+
+def test_window_tables_are_cuts_of_the_full_sequence_tables():
+    """simulation.QutipEmulator._window_tables (round 6: evaluation_times="Full" in time-parallel windows): entry b * J + j of
+    the window batch carries the spline PIECES [a_j, a_j + m) of every series sequence b uses, bit for bit, over relative
+    knots; descriptors re-pointed, scales untouched."""
+    from pulser_amd.simulation import QutipEmulator
+    from pulser_amd.terms import DESC_DTYPE, DeviceTables
+
+    rng = np.random.default_rng(0)
+    B, n, K, m, n_ser = 2, 3, 41, 4, 5
+    tk = np.arange(K + 1) * 1e-3 + 0.25
+    pp = rng.normal(size=(n_ser, K, 4)) + 1j * rng.normal(size=(n_ser, K, 4))
+    desc = np.zeros((B, n), dtype=DESC_DTYPE)
+    desc["drive_series"] = rng.integers(-1, n_ser, size=(B, n))
+    desc["det_series"] = rng.integers(-1, n_ser, size=(B, n))
+    desc["off_series"] = -1
+    desc["drive_scale"] = rng.normal(size=(B, n))
+    tables = DeviceTables(n_qubits=n, batch=B, tknots=tk, pp=pp, desc=desc, interaction=rng.normal(size=(B, n, n)),
+                          dissipator=None, series_knots=[])
+    J = K // m
+    anchors = np.arange(J + 1) * m
+    wt = QutipEmulator._window_tables(tables, anchors, m)
+    assert wt.batch == B * J and wt.pp.shape == (n_ser * J, m, 4) and wt.desc.shape == (B * J, n)
+    assert np.allclose(wt.tknots, np.arange(m + 1) * 1e-3, rtol=0, atol=1e-15)
+    assert wt.interaction.shape == (B * J, n, n)
+    for b in range(B):
+        for j in range(J):
+            e = b * J + j
+            assert np.array_equal(wt.interaction[e], tables.interaction[b])
+            for k in range(n):
+                for f in ("drive_series", "det_series", "off_series"):
+                    sid, wid = int(desc[b, k][f]), int(wt.desc[e, k][f])
+                    if sid < 0:
+                        assert wid == -1
+                    else:
+                        assert np.array_equal(wt.pp[wid], pp[sid, anchors[j]: anchors[j] + m])
+                assert wt.desc[e, k]["drive_scale"] == desc[b, k]["drive_scale"]
+    assert tables.batch == B and tables.pp is pp  # the full tables are untouched
