@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 import warnings
 from collections import Counter
 from dataclasses import dataclass, field
@@ -691,18 +692,20 @@ class QutipEmulator:
     # every knot then ends a step - the 6-stage composition per knot, 20 634 stages for the 14-atom anneal where the same
     # sequence without intermediate states takes 5 618 - and a single sequence keeps ONE of the 256 CUs busy while it does
     # so.  The states between two times are independent of everything after them, so they are computed in parallel:
-    # the main solve stores ANCHOR states every `_WINDOW_KNOTS` knots (long sub-steps, as for "Minimal"), and ONE batched
+    # the main solve stores ANCHOR states every `_WINDOW_KNOTS` (32) knots (long sub-steps, as for "Minimal"), and ONE batched
     # solve then carries every anchor through the knots of its own window - n_windows kets on n_windows CUs, each with the
     # spline PIECES of the full sequence over its window (the tables are cut, never re-splined: a window's coefficients
-    # are the full sequence's polynomials, bit for bit).  Errors of a window do not travel beyond it.
-    _WINDOW_KNOTS = 16
+    # are the full sequence's polynomials, bit for bit).  Errors of a window do not travel beyond it.  12 - 16 atoms (measured,
+    # one sequence, warm: 12 atoms 80 -> 35 ms, 14: 213 -> 80, 16: 253 -> 146); PULSER_AMD_NO_WINDOWS=1 keeps the sequential path.
+    # (measured at 14 atoms, main solve + window solve: 16 knots 67.3 + 3.7 ms, 32: 61.3 + 4.7, 64: 58.6 + 6.8; the variable: tuning probe only)
+    _WINDOW_KNOTS = int(os.environ.get("PULSER_AMD_WINDOW_KNOTS", "32"))
     _WINDOW_TOL = 2e-11  # budget of a window solve = 500 x tol = 1e-8 (its error ends with the window)
 
     def _window_plan(self, tables: Any, mode: str, times: np.ndarray, kw: dict[str, Any]) -> Any:
         """(anchor indices, main evaluation indices) when the solve can take the windowed form, else None."""
         m = self._WINDOW_KNOTS
         n = self._hamiltonian_data.n_qudits
-        if os.environ.get("PULSER_AMD_NO_WINDOWS") or mode != "sesolve" or not (12 <= n <= 14):
+        if os.environ.get("PULSER_AMD_NO_WINDOWS") or mode != "sesolve" or not (12 <= n <= int(os.environ.get("PULSER_AMD_WINDOWS_MAX_ATOMS", "16"))):
             return None
         if tables.batch > 32 or tables.dterms is not None or len(times) < 4 * m:
             return None
@@ -761,31 +764,53 @@ class QutipEmulator:
         torch = eng.torch
         anchors, main = plan
         m, J, B = self._WINDOW_KNOTS, len(anchors) - 1, tables.batch
+        timing = bool(os.environ.get("PULSER_AMD_WINDOW_TIMING"))
+        marks: list[tuple[str, float]] = []
+
+        def mark(label: str) -> None:
+            if timing:
+                import time as _time
+
+                torch.cuda.synchronize()
+                marks.append((label, _time.perf_counter()))
+
+        mark("start")
         start = state.clone()
         snaps_main = eng.solve(state, times[main], store=True, **kw)            # [len(main) - 1, B, dim]
+        mark("main solve")
         stats = eng.stats()
+        # out[k - 1] = state at times[k].  The first J m slots seen as [J, m, B, dim]: row j holds the m - 1 knots inside
+        # window j and, last, anchor j + 1; the tail (times behind the last anchor) follows
         out = torch.empty((len(times) - 1,) + tuple(snaps_main.shape[1:]), dtype=snaps_main.dtype, device=snaps_main.device)
-        out[torch.as_tensor(main[1:] - 1, device=out.device)] = snaps_main
+        grid = out[: J * m].view((J, m) + tuple(out.shape[1:]))
+        grid[:, m - 1] = snaps_main[:J]
+        out[J * m:] = snaps_main[J:]
         # initial states of the windows: entry b * J + j = sequence b at anchor j
         init = torch.empty((B, J) + tuple(start.shape[1:]), dtype=start.dtype, device=start.device)
         init[:, 0] = start
         if J > 1:
             init[:, 1:] = snaps_main[: J - 1].transpose(0, 1)
         del start
+        mark("anchors placed")
         wkw = dict(kw)
         if not wkw.get("tol"):
             wkw["tol"] = self._WINDOW_TOL
         wt = self._window_tables(tables, anchors, m)
+        mark("window tables")
         with Engine(wt, mode="sesolve") as weng:
+            mark("window engine")
             wstate = init.reshape((B * J,) + tuple(init.shape[2:])).contiguous()
             del init
             wsnaps = weng.solve(wstate, np.asarray(wt.tknots[:m], dtype=np.float64), store=True, **wkw)  # [m - 1, B * J, dim]
             wstats = weng.stats()
-        # knot a_j + i (i = 1 .. m - 1) of sequence b sits at out[a_j + i - 1, b]
-        idx = (anchors[:J, None] + np.arange(1, m)[None, :] - 1).reshape(-1)                     # [J * (m - 1)]
-        w = wsnaps.reshape((m - 1, B, J) + tuple(wsnaps.shape[2:])).permute(2, 0, 1, *range(3, wsnaps.dim() + 1))
-        out[torch.as_tensor(idx, device=out.device)] = w.reshape((J * (m - 1), B) + tuple(wsnaps.shape[2:]))
+            mark("window solve")
+        # window j, knot i (i = 1 .. m - 1), sequence b: wsnaps[i - 1, b * J + j] -> grid[j, i - 1, b] (one strided copy)
+        w = wsnaps.view((m - 1, B, J) + tuple(wsnaps.shape[2:]))
+        grid[:, : m - 1] = w.permute(2, 0, 1, *range(3, w.dim()))
         del wsnaps, w
+        mark("assembled")
+        if timing:
+            print("[windows] " + ", ".join(f"{b[0]} {1e3 * (b[1] - a[1]):.2f} ms" for a, b in zip(marks, marks[1:])), file=sys.stderr)
         # what the caller reads as the engine's statistics: both solves, the error estimates added (a state inside a
         # window carries the error of its anchor and of its window)
         merged = dict(stats)

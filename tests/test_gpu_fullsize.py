@@ -268,8 +268,33 @@ def test_16_atom_square_register_full_anneal_against_tight_oracle(ns16, method):
         assert st["reserved"][0] < AMP_TOL and max(errs) < max(4 * st["reserved"][0], 2e-9), (errs, st["reserved"])
 
 
+def test_full_evaluation_times_in_windows_on_the_pass_kernels_at_15_atoms(monkeypatch):
+    """The same at 15 atoms, where a stage is a launch of the tile-pass kernel and the 96 windows are its batch:
+    windows against the sequential path on a sample of the 3 101 times (no oracle at this size: cross-path)."""
+    from test_host_logic import _inputs_from_problem
+
+    from pulser_amd import QutipEmulator
+
+    coords = P.register_coords(P.triangular_rect(2, 8), blockade_radius())[:15]
+    prob = P.make_ising_problem(coords, P.anneal_samples())
+    runs = {}
+    for name in ("windows", "sequential"):
+        if name == "sequential":
+            monkeypatch.setenv("PULSER_AMD_NO_WINDOWS", "1")
+        emu = QutipEmulator(_inputs_from_problem(prob, "ground-rydberg"), evaluation_times="Full")
+        with pytest.warns(DeprecationWarning):
+            res = emu.run()
+        idx = list(range(0, 3101, 211)) + [31, 32, 33, 500, 3071, 3072, 3073, 3100]
+        runs[name] = (np.stack([np.asarray(res.states[i])[:, 0] for i in idx]), emu.last_engine_stats)
+    (sw, stw), (ss, sts) = runs["windows"], runs["sequential"]
+    assert "windows" in stw and stw["windows"]["n_windows"] == 96 and "windows" not in sts
+    gap = float(np.max(np.abs(sw - ss)))
+    assert gap < stw["reserved"][0] + sts["reserved"][0] + 2e-9 and gap < 5e-8, (gap, stw["reserved"], sts["reserved"])
+    assert np.max(np.abs(np.sum(np.abs(sw) ** 2, axis=1) - 1.0)) < 1e-9
+
+
 def test_full_evaluation_times_in_windows_equal_the_sequential_solve(monkeypatch):
-    """evaluation_times="Full" (the reference's default) since round 6: anchor states every 16 knots from the main solve, the
+    """evaluation_times="Full" (the reference's default) since round 6: anchor states every 32 knots from the main solve, the
     knots in between from ONE batched solve of all windows in parallel (simulation.py: _solve_in_windows; the windows carry
     the spline pieces of the full sequence, cut, not re-splined).  Against the sequential path of round 5 (every knot ends
     a step; PULSER_AMD_NO_WINDOWS=1) at every evaluation time, and against the tight oracle where it stores a state."""
@@ -293,7 +318,7 @@ def test_full_evaluation_times_in_windows_equal_the_sequential_solve(monkeypatch
         runs[name] = (states, st, emu.evaluation_times)
     (sw, stw, ev), (ss, sts, _) = runs["windows"], runs["sequential"]
     assert "windows" in stw and "windows" not in sts
-    assert stw["windows"]["knots"] == 16 and stw["windows"]["n_windows"] == (len(ev) - 2) // 16
+    assert stw["windows"]["knots"] == 32 and stw["windows"]["n_windows"] == (len(ev) - 2) // 32
     # far fewer stages on the critical path, the same states
     assert stw["n_applications"] - stw["windows"]["n_applications"] < 0.5 * sts["n_applications"], (stw, sts)
     gap = np.max(np.abs(sw - ss), axis=1)
