@@ -793,8 +793,9 @@ class QutipEmulator:
         del start
         mark("anchors placed")
         wkw = dict(kw)
-        if not wkw.get("tol"):
-            wkw["tol"] = self._WINDOW_TOL
+        # the budget of a solve is 500 x tol for its whole time span; a window's span is 32 knots, and its error ends with it:
+        # a quarter of what the caller allowed the main solve, and never more than the default
+        wkw["tol"] = min(self._WINDOW_TOL, 0.25 * float(kw["tol"])) if kw.get("tol") else self._WINDOW_TOL
         wt = self._window_tables(tables, anchors, m)
         mark("window tables")
         with Engine(wt, mode="sesolve") as weng:
