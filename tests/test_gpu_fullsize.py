@@ -334,3 +334,35 @@ def test_full_evaluation_times_in_windows_equal_the_sequential_solve(monkeypatch
         checked += 1
     assert checked >= 3
     assert np.max(np.abs(np.sum(np.abs(sw) ** 2, axis=1) - 1.0)) < 1e-9  # every state of every window is normalised
+
+
+def test_full_evaluation_times_in_windows_for_a_batch_of_noisy_trajectories(monkeypatch):
+    """The windows of a BATCH (three noise trajectories of a 12-atom sequence solved in one engine, as _noisy_runs does):
+    entry b * J + j of the window batch is trajectory b in window j - every trajectory's states against the sequential path
+    on a sample of the times (amplitude noise: the trajectories differ, a mix-up of b and j would show at once)."""
+    from test_host_logic import _inputs_from_problem
+
+    from pulser_amd import NoiseModel, QutipEmulator
+
+    prob, _ = load_fixture("cfg2_chain12_anneal.npz")
+    prob = with_anneal_samples(prob)
+    np.random.seed(4)
+    emu = QutipEmulator(_inputs_from_problem(prob, "ground-rydberg"), evaluation_times="Full",
+                        noise_model=NoiseModel(amp_sigma=0.1, runs=3, samples_per_run=1))
+    hd = emu._hamiltonian_data
+    problems = [hd.problem(t, emu._sampling_rate) for t in hd.noise_trajectories[:3]]
+    assert len(problems) == 3
+    idx = list(range(0, 3101, 173)) + [31, 32, 33, 1000, 3071, 3072, 3073, 3100]
+    out = {}
+    for name in ("windows", "sequential"):
+        if name == "sequential":
+            monkeypatch.setenv("PULSER_AMD_NO_WINDOWS", "1")
+        res = emu._solve_batch(problems, False, {})
+        st = emu.last_engine_stats
+        out[name] = (np.stack([[np.asarray(r.states[i])[:, 0] for i in idx] for r in res]), st)
+    (sw, stw), (ss, sts) = out["windows"], out["sequential"]
+    assert "windows" in stw and stw["windows"]["n_windows"] == 3 * 96 and "windows" not in sts
+    gap = float(np.max(np.abs(sw - ss)))
+    assert gap < stw["reserved"][0] + sts["reserved"][0] + 2e-9 and gap < 5e-8, (gap, stw["reserved"], sts["reserved"])
+    # the trajectories really differ (amplitude noise of 10 %)
+    assert np.max(np.abs(sw[0] - sw[1])) > 1e-3 and np.max(np.abs(sw[1] - sw[2])) > 1e-3
