@@ -627,38 +627,110 @@ class SimulationResults(collections.abc.Sequence):
     def states(self) -> list:
         raise NotImplementedError
 
-    def expect(self, obs_list: Sequence[np.ndarray]) -> list:
-        """simresults.py:89-132 (``qutip.expect`` of dense observables)."""
+    @staticmethod
+    def _as_operator(obs: Any) -> Any:
+        """An observable as a dense array or a SciPy CSR matrix.  The reference takes ``qutip.Qobj`` or array-likes
+        (simresults.py:110-118); a ``Qobj`` is recognised by its interface (``shape`` + ``full``) without importing qutip,
+        and keeps its sparse storage when it offers one - a 14-atom occupation operator is 16 384 numbers, not 4.3 GB."""
+        import scipy.sparse as sp
+
+        if isinstance(obs, np.ndarray):
+            return np.asarray(obs)
+        if sp.issparse(obs):
+            return obs.tocsr()
+        if hasattr(obs, "full") and hasattr(obs, "shape"):
+            for getter in (lambda: obs.data_as("csr_matrix"), lambda: obs.to("CSR").data.as_scipy(),
+                           lambda: obs.data.as_scipy()):
+                try:
+                    m = getter()
+                    if sp.issparse(m):
+                        return m.tocsr()
+                except Exception:  # another storage / another qutip version: the dense form below always exists
+                    pass
+            return np.asarray(obs.full())
+        raise TypeError(
+            f"Incompatible type {type(obs)} of observable. "
+            "Type must be ArrayLike or qutip.Qobj."
+        )
+
+    def _expect_diagonal_on_device(self, states: Sequence[Any], diag: np.ndarray) -> np.ndarray | None:
+        """<psi_t| diag(d) |psi_t> for every evaluation time straight from the device snapshots (kets of one run, none of
+        them read yet): |psi|^2 . d as matrix-vector products over blocks of times - nothing crosses PCIe but the values.
+        None when the states are not (all) device snapshots of one store."""
+        live = [st for st in states if isinstance(st, LazyState) and st._store is not None and st._store.device_tensor is not None]
+        if not live:
+            return None
+        store, b = live[0]._store, live[0]._b
+        dev = store.device_tensor
+        if not hasattr(dev, "real") or getattr(dev, "dim", lambda: 0)() != 3:  # [times, sequences, amplitudes]: kets only
+            return None
+        import torch
+
+        on_dev = [isinstance(st, LazyState) and st._store is store and st._b == b for st in states]
+        w = torch.from_numpy(np.ascontiguousarray(diag)).to(dev.device)
+        rows = torch.as_tensor([st._i for st, f in zip(states, on_dev) if f], device=dev.device)
+        vals = torch.empty(len(rows), dtype=w.dtype, device=dev.device)
+        for c0 in range(0, len(rows), 128):
+            x = dev[rows[c0:c0 + 128], b]
+            p2 = x.real * x.real + x.imag * x.imag
+            vals[c0:c0 + 128] = (p2.to(w.dtype) @ w)
+        host = vals.cpu().numpy()
+        out = np.empty(len(states), dtype=host.dtype)
+        k = 0
+        for i, (st, f) in enumerate(zip(states, on_dev)):
+            if f:
+                out[i] = host[k]
+                k += 1
+            else:  # the initial state, states that were read before (they live on the host), another run's states
+                a = np.asarray(st).reshape(-1)
+                out[i] = np.sum((a.real**2 + a.imag**2) * diag)
+        return out
+
+    def expect(self, obs_list: Sequence[Any]) -> list:
+        """simresults.py:89-132 (``qutip.expect`` of the observables over the stored states).  Observables: arrays,
+        ``qutip.Qobj`` (by interface) or SciPy sparse matrices; sparse ones stay sparse, and DIAGONAL ones (occupations,
+        projectors, correlation products - what a Rydberg user plots) are evaluated on the device from the run's
+        snapshots without reading a single state back."""
+        import scipy.sparse as sp
+
         if not isinstance(obs_list, (list, np.ndarray)):
             raise TypeError("`obs_list` must be a list of operators.")
         dim = self._dim if not self._use_pseudo_dens else 2
         legal_shape = (dim**self._size, dim**self._size)
         mats = []
         for obs in obs_list:
-            if not isinstance(obs, np.ndarray):
-                raise TypeError(
-                    f"Incompatible type {type(obs)} of observable. "
-                    "Type must be ArrayLike or qutip.Qobj."
-                )
-            if obs.shape != legal_shape:
+            m = self._as_operator(obs)
+            if tuple(m.shape) != legal_shape:
                 raise ValueError(
                     "Incompatible shape of observable."
-                    + f"Expected {legal_shape}, got {obs.shape}."
+                    + f"Expected {legal_shape}, got {tuple(m.shape)}."
                 )
-            if self._use_pseudo_dens and np.count_nonzero(obs - np.diag(np.diagonal(obs))):
+            off = (m - sp.diags(m.diagonal())).count_nonzero() if sp.issparse(m) else np.count_nonzero(m - np.diag(np.diagonal(m)))
+            if self._use_pseudo_dens and off:
                 raise ValueError(f"Observable {obs!r} is non-diagonal.")
-            mats.append(np.asarray(obs))
+            mats.append((m, off == 0))
         if self._use_pseudo_dens:
             states = [self._calc_pseudo_density(i) for i in range(len(self))]
         else:
             states = self.states
         out = []
-        for m in mats:
-            herm = np.allclose(m, m.conj().T)
+        for m, is_diag in mats:
+            if sp.issparse(m):  # np.allclose(m, m^dag) for the stored entries: |m - m^dag| <= 1e-8 + 1e-5 |m^dag|
+                dm = abs(m - m.conj().T).tocoo()
+                ref = abs(m.conj().T).tocsr()
+                herm = bool(np.all(dm.data <= 1e-8 + 1e-5 * np.asarray(ref[dm.row, dm.col]).reshape(-1))) if dm.nnz else True
+            else:
+                herm = bool(np.allclose(m, m.conj().T))
+            if is_diag and not self._use_pseudo_dens:
+                d = np.asarray(m.diagonal())
+                fast = self._expect_diagonal_on_device(states, d.real.copy() if herm else d.astype(complex))
+                if fast is not None:
+                    out.append(np.array(fast.real if herm else fast))
+                    continue
             vals = []
-            for s in states:
-                a = np.asarray(s)
-                v = np.vdot(a, m @ a) if a.shape[1] == 1 and a.shape[0] > 1 else np.trace(m @ a)
+            for st in states:
+                a = np.asarray(st)
+                v = np.vdot(a, m @ a) if a.shape[1] == 1 and a.shape[0] > 1 else (m @ a).trace()
                 vals.append(v.real if herm else v)
             out.append(np.array(vals))
         return out

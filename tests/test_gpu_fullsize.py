@@ -131,6 +131,21 @@ def test_drop_in_call_with_the_reference_default_arguments_against_tight_oracle(
         counts = res.sample_final_state(200)
         assert sum(counts.values()) == 200
         assert abs(float(np.vdot(res.states[-1], res.states[-1]).real) - 1.0) < 1e-9
+        # ... an occupation over ALL 3 101 times: a sparse diagonal observable (a dense one would be 4.3 GB) is evaluated
+        # from the device snapshots - no state is read back for it
+        import scipy.sparse as sp
+        import time
+
+        n_r = sp.diags((((np.arange(2**14) >> 13) & 1) == 0).astype(float)).tocsr()  # atom 0 in |r> (local index 0)
+        tic = time.perf_counter()
+        occ = res.expect([n_r])[0]
+        dt_expect = time.perf_counter() - tic
+        assert occ.shape == (3101,) and occ.dtype == np.float64 and res.states[1000].device_tensor is not None
+        for i in (0, 1, 500, 2100, 3100):
+            a = np.asarray(res.states[i])[:, 0]
+            assert abs(occ[i] - float(np.sum(np.abs(a[: 2**13]) ** 2))) < 1e-12
+        assert 0.0 <= occ.min() and occ.max() <= 1.0 and occ[0] == 0.0 and occ.max() > 0.05
+        assert dt_expect < 1.0, dt_expect
 
 
 @pytest.mark.parametrize("no_merge", [False, True])

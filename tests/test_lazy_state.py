@@ -144,3 +144,61 @@ def test_results_to_host_moves_the_run_and_reads_the_same():
     for i in range(5):
         assert np.array_equal(np.asarray(cr.states[i + 1])[:, 0], data[i, 0])
     assert sum(log) == data.size and len(log) == 5
+
+
+def test_expect_takes_sparse_and_qobj_like_observables_and_evaluates_diagonal_ones_from_the_snapshots():
+    """simresults.py:89-132: `expect` takes qutip.Qobj or arrays.  Here: arrays, SciPy sparse matrices and anything with
+    the Qobj interface (shape + full, sparse storage kept when offered); diagonal observables are evaluated from the
+    (device) snapshots without materialising a state, everything else state by state - all equal to the dense
+    computation."""
+    import scipy.sparse as sp
+    import torch
+
+    from pulser_amd.results import CoherentResults
+
+    rng = np.random.default_rng(0)
+    n, T = 4, 40
+    D = 2**n
+    data = rng.normal(size=(T, 1, D)) + 1j * rng.normal(size=(T, 1, D))
+    data /= np.linalg.norm(data, axis=-1, keepdims=True)
+    store = SnapshotStore(torch.from_numpy(data))
+    times = np.linspace(0, 1, T + 1)
+    qids = tuple(f"q{i}" for i in range(n))
+    psi0 = np.zeros(D, complex)
+    psi0[-1] = 1
+    res = [StateResult(qids, "ground-rydberg", QState(psi0), True, evaluation_time=0.0)]
+    res += [StateResult(qids, "ground-rydberg", LazyState(store, i, 0, (D, 1)), True, evaluation_time=float(times[i + 1]))
+            for i in range(T)]
+    cr = CoherentResults(res, n, "ground-rydberg", times, "ground-rydberg")
+    dvec = rng.normal(size=D)
+    A = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    H = A + A.conj().T
+
+    class FakeQobj:  # what the code needs of a qutip.Qobj
+        def __init__(self, m):
+            self._m = sp.csr_matrix(m)
+            self.shape = m.shape
+
+        def full(self):
+            return self._m.toarray()
+
+        def data_as(self, kind):
+            assert kind == "csr_matrix"
+            return self._m
+
+    allst = [psi0] + [data[i, 0] for i in range(T)]
+    ref_d = np.array([np.vdot(a, dvec * a).real for a in allst])
+    out = cr.expect([np.diag(dvec).astype(complex), sp.diags(dvec).tocsr(), FakeQobj(np.diag(dvec))])
+    assert all(np.max(np.abs(o - ref_d)) < 1e-14 and o.dtype == np.float64 for o in out)
+    assert store.device_tensor is not None and all(s._store is store for s in cr.states[1:])  # nothing was read back
+    cd = rng.normal(size=D) + 1j * rng.normal(size=D)  # a non-Hermitian diagonal: complex values
+    out = cr.expect([sp.diags(cd).tocsr()])
+    assert np.max(np.abs(out[0] - np.array([np.vdot(a, cd * a) for a in allst]))) < 1e-14 and out[0].dtype == np.complex128
+    out = cr.expect([H, sp.csr_matrix(H), FakeQobj(H), A])
+    ref_h = np.array([np.vdot(a, H @ a).real for a in allst])
+    assert all(np.max(np.abs(o - ref_h)) < 1e-13 for o in out[:3])
+    assert np.max(np.abs(out[3] - np.array([np.vdot(a, A @ a) for a in allst]))) < 1e-13
+    with pytest.raises(TypeError, match="Incompatible type"):
+        cr.expect(["sigma_z"])
+    with pytest.raises(ValueError, match="Incompatible shape"):
+        cr.expect([sp.eye(D // 2).tocsr()])
