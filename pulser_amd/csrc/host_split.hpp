@@ -67,7 +67,23 @@ static const SplitScheme& split_scheme(const ryd_handle* h) { return h->split_s1
 // 1.1e-8, true error 4e-9); with sub-steps cut to the working length on linear stretches the controller spends what it is
 // given (estimate 3e-8, true error 1.1e-8), and over 1 600 fuzz seeds the true error reached 2.1 x a LARGE estimate - so the
 // budget is 0.4 of the bar (4e-8 x 2.1 < 1e-7).  The row passes of the master equation keep their own figure (kRowsBudget).
-static const double kSplitTolTotal = 4e-8;
+// Round 6 (second fuzz hold-out): which norm of the difference (whole step against halves) is the local error.  The bar is on
+// the largest amplitude error, and until now the controller measured exactly that - but errors travel with the UNITARY
+// evolution, which keeps their 2-norm and nothing else: while the state is spread over thousands of basis states the largest
+// entry of the error vector is a small fraction of its length (seed 2685 at 96 ns: 1.4e-9 of 4.9e-8), and a pulse that gathers
+// the population back into a few states gathers the error with it (the same seed from 120 ns on: no new local error at all,
+// 2-norm constant at 9.7e-8, largest entry 1.3e-8 -> 7.0e-8).  The sum of the local 2-norms bounds the final 2-norm, which
+// bounds every entry: 2 = measure the 2-norm (the bound holds), 0 = the largest entry (rounds 2 - 6 until this change).
+static const bool split_norm_two = dev_env_int("RYD_SPLIT_NORM", 2, 0, 2) == 2;
+// ... and the budget with it: the sum of the local 2-norms BOUNDS the final 2-norm (unitary propagation, triangle inequality)
+// and with it every amplitude error, where the sum of the largest entries was an estimate that the fuzz saw exceeded 3 x (and,
+// on the second hold-out, 8 x).  0.8 of the bar: the local errors are leading-order estimates measured every <= 256 knots.
+// Measured (tools/r06_norm_probe.sh, tools/r06_norm2_validate.sh; profiles/r06_fuzz_summary.md): fuzz seeds 2000 - 2999 on the
+// largest entry: 2 violations (1.19e-7; error / estimate 5.8 and 5.2); on the 2-norm: none, worst error 3.2e-8, and over
+// all cases above the 2e-9 floor the error never exceeds 0.88 x the booked estimate - it is a bound now, not a guess.  The
+// headline anneal pays 5 648 -> 6 818 stages (the 2-norm of its local errors is 3 - 23 x their largest entry) and ends
+// 3.3e-9 from the tight oracle instead of 1.1e-8.
+static const double kSplitTolTotal = split_norm_two ? 8e-8 : 4e-8;
 static const double kRowsBudget = 5e-8;
 
 static int snapshot_copy(ryd_handle* h, const cplx* state, cplx* dst, hipStream_t st);
@@ -145,7 +161,7 @@ static int split_ensure_tables(ryd_handle* h, int n_stages) {
     HIPCHK(hipMalloc((void**)&h->split_coefs, need * sizeof(double)));
     h->split_cap = need;
   }
-  if (!h->split_err) HIPCHK(hipMalloc((void**)&h->split_err, (size_t)h->B * sizeof(double)));
+  if (!h->split_err) HIPCHK(hipMalloc((void**)&h->split_err, (size_t)2 * h->B * sizeof(double)));  // [B] max, [B] sum
   return RYD_OK;
 }
 
@@ -645,7 +661,7 @@ static int rows_split_probe(ryd_handle* h, const cplx* rho, const std::vector<St
     if (!rc) rc = split_run(h, halves, two, 2, st, sc.S == 6);
   }
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)B * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)2 * B * sizeof(double), st));
   hipLaunchKernelGGL(k_split_diff, dim3(16, B), dim3(256), 0, st, halves, whole, N, h->split_err);
   HIPCHK(hipGetLastError());
   std::vector<double> errs(B);
@@ -937,8 +953,18 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
     const bool on_knot = std::fabs(sched[k].u1 - kC1 * sched[k].h) < 1e-12;
     return !(on_knot && at >= 1 && at - 1 < (int)h->join_ok.size() && h->join_ok[at - 1]);
   };
+  // Round 6, second hold-out of the fuzz (seeds 2000 - 2999, tools/fuzz_ctrl.py): the period is also capped at an EIGHTH of
+  // the pulse sequence.  The allowance of a sub-step is the budget pro rata, so on a SHORT sequence every sub-step sits close to
+  // a large allowance, and the error law of a sub-step depends on the state: seed 2685 (13-atom chain, 183 ns: ramp, plateau
+  // at 24 rad/us, ramp) had its last check 64 ns in (e = 0.3 x allowed), then the state spread over the excited sectors, the
+  // local error of the same sub-step doubled every 8 ns, and the remaining 119 ns - two thirds of the sequence, less than the
+  // period of 64 knots that had been reached - ran unchecked: 1.19e-7 with an estimate of 2.0e-8.  With at least eight checks
+  // per sequence a stretch that runs away is met by the next check while it still carries an eighth of the budget (and is
+  // rolled back when it is more than 4 x over).  Sequences of 2 048 knots and more (the anneal of the bench) are not affected.
+  static const int period_div = dev_env_int("RYD_SPLIT_PERIOD_DIV", 8, 1, 64);  // (dev A/B: RYD_DEV=1)
+  const int period_cap = std::max(kSplitCheckFirst, std::min(kSplitCheckEvery, (int)(t_total / knot0 / period_div)));
   // is a check due at step q (of kind k)?  `knots`: knot intervals of that kind since its last check
-  auto period_of = [&](int k) { return ctl[k].period > 0 ? ctl[k].period : kSplitCheckFirst; };
+  auto period_of = [&](int k) { return std::min(period_cap, ctl[k].period > 0 ? ctl[k].period : kSplitCheckFirst); };
   auto check_due = [&](size_t q, int k, int knots) {
     return !ctl[k].known || knots >= period_of(k) || amp_at(sched[q]) > std::max(1.5 * ctl[k].amp, 0.1 * amp_max);
   };
@@ -1100,7 +1126,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       // unconsumed and the old sequence runs.
       const bool fuse_ok = fuse_on && split_reg_shape(h) && !jumps;
       if (fuse_ok && !h->wC) HIPCHK(hipMalloc((void**)&h->wC, bytes));
-      if (!h->split_err_pin) HIPCHK(hipHostMalloc((void**)&h->split_err_pin, (size_t)h->B * sizeof(double)));
+      if (!h->split_err_pin) HIPCHK(hipHostMalloc((void**)&h->split_err_pin, (size_t)2 * h->B * sizeof(double)));
       // DOUBLE-STEP check (round 6).  Where two sub-steps of the working length fit into what lies ahead on the same polynomial,
       // the scratch copy takes ONE step of 2 tau and the state its two regular sub-steps - which it would take anyway: the check
       // costs the 10 stages of the double step instead of 20 (whole + two halves against the 10 of the plain sub-step).  The
@@ -1129,15 +1155,19 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       h->fuse_cmp = nullptr;
       h->fuse_dst2 = nullptr;
       if (!fused2) {
-        HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)h->B * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(h->split_err, 0, (size_t)2 * h->B * sizeof(double), st));
         const unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(h->dim >> 10, 1), 256);
         hipLaunchKernelGGL(k_split_diff, dim3(nblk, h->B), dim3(256), 0, st, state, h->wA, h->nb, h->split_err);
         HIPCHK(hipGetLastError());
       }
-      HIPCHK(hipMemcpyAsync(h->split_err_pin, h->split_err, (size_t)h->B * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(h->split_err_pin, h->split_err, (size_t)2 * h->B * sizeof(double), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      double e = 0.0;
-      for (int q = 0; q < h->B; ++q) e = std::max(e, std::sqrt(std::max(h->split_err_pin[q], 0.0)));
+      double e = 0.0, e_inf = 0.0, e_two = 0.0;
+      for (int q = 0; q < h->B; ++q) {
+        e_inf = std::max(e_inf, std::sqrt(std::max(h->split_err_pin[q], 0.0)));
+        e_two = std::max(e_two, std::sqrt(std::max(h->split_err_pin[h->B + q], 0.0)));
+      }
+      e = split_norm_two ? e_two : e_inf;
       // whole step against two halves: the difference is (1 - 2^-p) of the local error of the whole step;
       // double step against two sub-steps: (2^(p+1) - 2) x the local error of one sub-step
       const int p_ord = sck.order;
@@ -1150,10 +1180,10 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       const double tau_new = s0.tau * fac;
       if (split_trace_env())
         std::fprintf(stderr, "[ryd split] check at t = %.4f us (step %zu of %zu, %d knots, h = %.4g ns, kind %d): sub-step %.4g ns, "
-                     "e = %.3g, allowed %.3g, fac %.3g, tau %.4g -> %.4g ns, scheme S%d, since %d%s%s%s\n",
+                     "e = %.3g, allowed %.3g, fac %.3g, tau %.4g -> %.4g ns, scheme S%d, since %d%s%s%s  (2-norm / max of the difference %.2f)\n",
                      h->tknots[s0.idx] + s0.u0, i, sched.size(), d.pad, d.h * 1e3, kd, s0.tau * 1e3, e, allowed, fac,
                      ctl[kd].tau * 1e3, tau_new * 1e3, sck.S, ctl[kd].since, new_regime ? " [regime]" : "", amp_grown ? " [amp]" : "",
-                     dbl ? " [double]" : "");
+                     dbl ? " [double]" : "", e_two / std::max(e_inf, 1e-300));
       h->stats.reserved[1] = e;
       h->stats.reserved[2] = s0.tau;
       if (e > 4.0 * allowed && have_ck && retries < 4 && !jumps) {  // (a roll-back would replay jumps)
@@ -1239,7 +1269,7 @@ static int run_split(ryd_handle* h, cplx* state, const std::vector<StepDesc>& sc
       ctl[kd].rate_tau = s0.tau;
       ctl[kd].since = 0;
       ctl[kd].len_since = 0.0;
-      ctl[kd].period = std::min(kSplitCheckEvery, 2 * period_of(kd));
+      ctl[kd].period = std::min(period_cap, 2 * period_of(kd));
       ctl[kd].amp = amp_at(d);
       ctl[kd].known = true;
       h->split_known = true;

@@ -834,21 +834,28 @@ __global__ __launch_bounds__(SPLIT14_NT) void k_split14_loop(const SplitArgs A, 
   for (int r = 0; r < 32; ++r) st[t | (unsigned)(r << 9)] = make_double2(xr[r], xi[r]);
 }
 
-// err[b] = max |x - y|^2 over the amplitudes (local-error estimate of the step-size controller);
+// err[b] = max |x - y|^2 over the amplitudes, err[B + b] = their sum (local-error estimate of the step-size controller);
 // non-negative doubles order like their bit patterns
 __global__ __launch_bounds__(256) void k_split_diff(const cplx* __restrict__ x, const cplx* __restrict__ y, int nb,
                                                     double* err) {
   const size_t D = (size_t)1 << nb;
   const size_t boff = (size_t)blockIdx.y * D;
-  double s = 0.0;
+  double s = 0.0, q = 0.0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < D; i += (size_t)gridDim.x * 256) {
     const cplx a = x[boff + i], c = y[boff + i];
     const double dx = a.x - c.x, dy = a.y - c.y;
-    s = fmax(s, fma(dx, dx, dy * dy));
+    const double d2 = fma(dx, dx, dy * dy);
+    s = fmax(s, d2);
+    q += d2;
   }
-  for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_down(s, o, 64));
-  if ((threadIdx.x & 63) == 0)
+  for (int o = 32; o > 0; o >>= 1) {
+    s = fmax(s, __shfl_down(s, o, 64));
+    q += __shfl_down(q, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
     atomicMax(reinterpret_cast<unsigned long long*>(err + blockIdx.y), (unsigned long long)__double_as_longlong(s));
+    atomicAdd(err + gridDim.y + blockIdx.y, q);  // err[B + b] = sum |x - y|^2 (round 6: the controller's 2-norm)
+  }
 }
 
 // Evaluation-time snapshots taken inside a closed run of k_split_reg<.., SNAP> hold OPEN states (SplitArgs.snaps): this

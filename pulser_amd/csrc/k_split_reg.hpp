@@ -138,11 +138,26 @@ __device__ __forceinline__ double splitr_dpp(double v) {
 #ifndef SPLITR_B2
 #define SPLITR_B2 0
 #endif
+//   SPLITR_HM 1 (round 6, default): the third DPP lane bit is the DIRECTION xor 7 of the lane number instead of xor 4 - one
+//                row_half_mirror move per dword where xor 4 takes two dependent ones (640 -> 512 DPP moves per stage at
+//                32 amplitudes per lane).  {1, 2, 7, 8} is a basis of the 4-bit lane numbers of a row like {1, 2, 4, 8}: a lane
+//                holds the index bits (b0, b1, b2) = (l0 ^ l2, l1 ^ l2, l2) on its three low positions - splitr_lane() below;
+//                everything that asks "which index bits does this lane hold" goes through it, the LDS passes and the swaps
+//                only ever pair a lane with itself or with lanes of the same low bits and do not care.
+#ifndef SPLITR_HM
+#define SPLITR_HM 1
+#endif
+// the lane / thread number whose BITS are the index bits a lane holds (positions as in SplitRegLayout)
+// (only where lane bit 2 is a DPP bit, ND >= 3: with ND = 2 it is a T bit, the LDS transposition moves it, and the two low
+// bits must not depend on it)
+template <int ND>
+__device__ __forceinline__ unsigned splitr_lane(unsigned t) { return (SPLITR_HM && ND >= 3) ? t ^ ((t & 4u) ? 3u : 0u) : t; }
 template <int F>
 __device__ __forceinline__ double splitr_partner(double v) {
   if constexpr (F == 0) return splitr_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
   else if constexpr (F == 1) return splitr_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
   else if constexpr (F == 3) return splitr_dpp<0x128>(v);  // row_ror:8
+  else if constexpr (SPLITR_HM == 1) return splitr_dpp<0x141>(v);  // row_half_mirror: xor 7 (F == 2 is only asked for with ND >= 3)
   else if constexpr (SPLITR_B2 == 1) {
     const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x101F);  // bit-mask mode: and 0x1F, or 0, xor 4
     const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x101F);
@@ -187,6 +202,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
 
   const unsigned t = threadIdx.x;
   const unsigned l = t & 63u, w = t >> 6;
+  const unsigned tq = splitr_lane<ND>(t);  // the thread number by the index bits it holds (SPLITR_HM)
   const int b = ROWS ? (int)blockIdx.z : (int)blockIdx.y;
   const int n_pre = R.kick_pre != 0.0 ? 1 : 0;  // the opening kick is an extra stage 0 (no D)
   const int n_stages = splitrun_first(R, R.nsub) + 1 + n_pre;
@@ -213,9 +229,9 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
   double et[2], ev[2][NR], eg[2];
 #pragma unroll
   for (int o = 0; o < 2; ++o) {
-    et[o] = e0[L::index(o, t, NA - 1)];
+    et[o] = e0[L::index(o, tq, NA - 1)];
 #pragma unroll
-    for (int j = 0; j < NR; ++j) ev[o][j] = e0[L::index(o, t, (NA - 1) ^ (1u << j))] - et[o];
+    for (int j = 0; j < NR; ++j) ev[o][j] = e0[L::index(o, tq, (NA - 1) ^ (1u << j))] - et[o];
     eg[o] = e0[L::index(o, NT - 1, l & (NA - 1))];
     if (SPLITR_EMODE) {
       etab[(2 * o) * NT + t] = et[o];
@@ -267,10 +283,10 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
   if (ROWS && A.use_pre) __syncthreads();
   double xr[NA], xi[NA];
   {
-    const double fl = (ROWS && A.use_pre) ? row_factor(0, L::index(false, t, 0u), L::index(false, NT - 1, 0u)) : 1.0;
+    const double fl = (ROWS && A.use_pre) ? row_factor(0, L::index(false, tq, 0u), L::index(false, NT - 1, 0u)) : 1.0;
     splitr_for<0, NA>([&](auto Rc) {
       constexpr int r = decltype(Rc)::value;
-      const cplx v = st[L::index(false, t, r)];
+      const cplx v = st[L::index(false, tq, r)];
       const double f = (ROWS && A.use_pre) ? fl * ftl[128 + r] : 1.0;
       xr[r] = v.x * f;
       xi[r] = v.y * (ROWS ? f * csgn : f);
@@ -392,13 +408,13 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     if (!(SPLITR_KO & 8)) {
       double dthr = 0.0;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) dthr += ((t >> j) & 1u) ? 0.0 : Dl[j];
+      for (int j = 0; j < 6; ++j) dthr += ((tq >> j) & 1u) ? 0.0 : Dl[j];
 #pragma unroll
-      for (int j = 0; j < NW; ++j) dthr += ((t >> (6 + j)) & 1u) ? 0.0 : Dw[j];
+      for (int j = 0; j < NW; ++j) dthr += ((tq >> (6 + j)) & 1u) ? 0.0 : Dw[j];
       Bf = expmi(fma(wE, et_s, -dthr));
       double sc = cprod;
       if (DECAY)  // H_eff: the real factor exp(wE (dec_a + dec_b popc(index))): lane part here, register part in F
-        sc *= exp(wE * (A.dec_a + A.dec_b * (double)(__popc(t) + NR)));
+        sc *= exp(wE * (A.dec_a + A.dec_b * (double)(__popc(tq) + NR)));
       Bf = make_double2(Bf.x * sc, Bf.y * sc);
       const double dF = DECAY ? exp(-wE * A.dec_b) : 1.0;  // an excited register atom: one set bit fewer
 #pragma unroll
@@ -511,7 +527,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     double Us[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if constexpr (CPLX) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) Us[j] = ((l >> j) & 1u) ? Ul[j] : -Ul[j];
+      for (int j = 0; j < 6; ++j) Us[j] = ((tq >> j) & 1u) ? Ul[j] : -Ul[j];
     }
     // SPLITR_TMODE 3: partner of lane bit 4 (ds_swizzle, xor 16 inside 32 lanes) / 5 (ds_bpermute) of a double - the LDS
     // crossbar, no LDS memory, no vector-pipe cycles beyond the issue
@@ -712,7 +728,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
           // address = uniform base + the lane's word + a constant per register.  The lane's word is laundered through an
           // empty asm: loop-invariant otherwise, and the 32 hoisted 64-bit addresses cost 20 spilled vector registers
           // in every stage of the loop (measured: 10.6 instead of 9.4 us per stage)
-          unsigned lw = odd ? L::index(true, t, 0u) : L::index(false, t, 0u);
+          unsigned lw = odd ? L::index(true, tq, 0u) : L::index(false, tq, 0u);
           asm volatile("" : "+v"(lw));
           cplx* __restrict__ sd = A.snaps + (size_t)slot * A.snap_stride + ((size_t)b << N);
           if (odd) {
@@ -753,7 +769,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
     __syncthreads();
     if (t < NA) ftl[128 + t] = row_factor(1, odd ? L::index(true, 0u, t) : L::index(false, 0u, t), odd ? L::index(true, 0u, NA - 1) : L::index(false, 0u, NA - 1));
     __syncthreads();
-    fl *= row_factor(1, odd ? L::index(true, t, 0u) : L::index(false, t, 0u), odd ? L::index(true, NT - 1, 0u) : L::index(false, NT - 1, 0u));
+    fl *= row_factor(1, odd ? L::index(true, tq, 0u) : L::index(false, tq, 0u), odd ? L::index(true, NT - 1, 0u) : L::index(false, NT - 1, 0u));
   }
   bool stored = false;
   if constexpr (!ROWS) {
@@ -764,8 +780,8 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       cplx* __restrict__ out = A.dst ? A.dst + boff : st;
       cplx* __restrict__ out2 = A.dst2 ? A.dst2 + boff : nullptr;
       const cplx* __restrict__ ref = A.cmp ? A.cmp + boff : nullptr;
-      const unsigned lw = odd ? L::index(true, t, 0u) : L::index(false, t, 0u);
-      double dmax = 0.0;
+      const unsigned lw = odd ? L::index(true, tq, 0u) : L::index(false, tq, 0u);
+      double dmax = 0.0, dsum = 0.0;
       auto put = [&](unsigned ix, double vx, double vy) {
         const cplx v = make_double2(vx, vy);
         out[ix] = v;
@@ -773,7 +789,9 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
         if (ref) {
           const cplx c = ref[ix];
           const double dx = vx - c.x, dy = vy - c.y;
-          dmax = fmax(dmax, fma(dx, dx, dy * dy));
+          const double d2 = fma(dx, dx, dy * dy);
+          dmax = fmax(dmax, d2);
+          dsum += d2;
         }
       };
       if (odd) {
@@ -782,15 +800,19 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
         splitr_for<0, NA>([&](auto Rc) { constexpr int r = decltype(Rc)::value; put(lw + L::index(false, 0u, r), xr[r], xi[r]); });
       }
       if (ref) {
-        for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+        for (int o = 32; o > 0; o >>= 1) {
+          dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+          dsum += __shfl_xor(dsum, o, 64);
+        }
         double* red = reinterpret_cast<double*>(gtab);  // (the G tables are dead after the last stage)
         __syncthreads();
-        if (l == 0) red[w] = dmax;
+        if (l == 0) { red[2 * w] = dmax; red[2 * w + 1] = dsum; }
         __syncthreads();
         if (t == 0) {
-          double m = red[0];
-          for (int k = 1; k < NT / 64; ++k) m = fmax(m, red[k]);
-          A.cmp_err[b] = m;
+          double m = red[0], sm = red[1];
+          for (int k = 1; k < NT / 64; ++k) { m = fmax(m, red[2 * k]); sm += red[2 * k + 1]; }
+          A.cmp_err[b] = m;                 // max |x - cmp|^2
+          A.cmp_err[gridDim.y + b] = sm;    // sum |x - cmp|^2 (the 2-norm of the difference, squared)
         }
       }
     }
@@ -799,7 +821,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
   splitr_for<0, NA>([&](auto Rc) {
     constexpr int r = decltype(Rc)::value;
     const double f = (ROWS && A.use_post) ? fl * ftl[128 + r] : 1.0;
-    st[odd ? L::index(true, t, r) : L::index(false, t, r)] = make_double2(xr[r] * f, xi[r] * (ROWS ? f * csgn : f));
+    st[odd ? L::index(true, tq, r) : L::index(false, tq, r)] = make_double2(xr[r] * f, xi[r] * (ROWS ? f * csgn : f));
   });
   }
   }  // rows

@@ -10,6 +10,10 @@ from pulser_amd import problem as P
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+# Sequence budget of the split-operator step-size controller (host_split.hpp: kSplitTolTotal): since round 6 a bound on the
+# 2-NORM of the accumulated error (sum of the local 2-norms), 0.8 of the parity bar of 1e-7 on every amplitude.
+SPLIT_BUDGET = 8e-8
+
 def load_fixture(name):
     prob, extra = P.load_problem(os.path.join(GOLDEN, name))
     return prob, extra

@@ -15,7 +15,7 @@ from __future__ import annotations
 import numpy as np
 import pytest
 
-from helpers import blockade_radius, load_fixture, sketch_errors, tight_density_matrices, with_anneal_samples
+from helpers import SPLIT_BUDGET, blockade_radius, load_fixture, sketch_errors, tight_density_matrices, with_anneal_samples
 from pulser_amd import problem as P
 
 pytestmark = pytest.mark.gpu
@@ -72,7 +72,7 @@ def test_headline_batch_default_kernel_full_anneal_against_tight_oracle(ns14):
         errs = _worst(snaps[:, b], ref)
         # (the controller spends its budget - half the bar - where that saves stages: round 6 measured 1.0e-8 at T with an
         # estimate of 2.9e-8; until round 5 the 9-knot steps left most of the budget unused and this read 4e-9)
-        assert max(errs) < AMP_TOL / 2 and st["reserved"][0] < AMP_TOL / 2, (errs, st["reserved"])
+        assert max(errs) < AMP_TOL / 2 and st["reserved"][0] <= SPLIT_BUDGET, (errs, st["reserved"])
         assert max(errs) < max(4 * st["reserved"][0], 2e-9), (errs, st["reserved"])  # the estimate covers the error
     assert np.array_equal(snaps[:, 0], snaps[:, 7])  # identical sequences, identical arithmetic
 

@@ -27,7 +27,7 @@ import warnings
 import numpy as np
 import pytest
 
-from helpers import fuzz_case
+from helpers import SPLIT_BUDGET, fuzz_case
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +63,7 @@ def test_controller_fuzz_default_path_against_a_priori_tolerance(block):
         assert err < AMP_TOL, (desc, err, est)
         if est > 0.0:  # the split-operator path ran under its controller
             assert err <= max(COVER * est, FLOOR), (desc, err, est, s["reserved"][:4])
-            assert est < 2.0 * 5e-8, (desc, est)  # the budget of a sequence (the engine warns beyond 2 x)
+            assert est < 2.0 * SPLIT_BUDGET, (desc, est)  # the budget of a sequence (the engine warns beyond 2 x)
             if err > FLOOR:
                 worst = max(worst, err / est)
     print(f"block {block}: worst error / estimate above the floor = {worst:.2f}")
@@ -74,7 +74,7 @@ def test_controller_fuzz_named_regressions(seed):
     err, est, s, desc = _run_case(seed)
     print(f"{desc}: error {err:.2e}, estimate {est:.2e}, stages {s['n_applications']}, roll-backs {s['reserved'][3]:.0f}")
     assert err < AMP_TOL / 2, (desc, err, est)
-    assert est > 0.0 and err <= max(COVER * est, FLOOR) and est < 2.0 * 5e-8, (desc, err, est)
+    assert est > 0.0 and err <= max(COVER * est, FLOOR) and est < 2.0 * SPLIT_BUDGET, (desc, err, est)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
