@@ -11,7 +11,7 @@ fuzz_case).  Every case: the default path against CF4 + Taylor at tol 1e-12 (an 
 within the stated bar (1e-7) AND within 4 x the estimate the controller booked (ryd_stats.reserved[0], what the
 Python engine compares with the budget and warns about).
 
-The named regressions are the cases the fuzz found while the controller was being fixed in round 5:
+The named regressions are the cases the fuzz found while the controller was being fixed in round 5 (docs/KERNEL_NOTES.md 5.10 (vi)):
 seed 40  - 1 240 one-knot steps of a strongly interacting chain ran unchecked (8.7e-8, estimate 2.1e-8);
 seed 263 - a square pulse from t = 0 on 16 atoms: the one check of the sequence measured the product state (1.85e-7 / 2.8e-8);
 seed 279 - the same on one-knot steps of the 6-stage scheme (4.8e-9 / 7.8e-10);
@@ -20,7 +20,7 @@ seed 1197 - found by a second sweep (seeds 400 - 1199): the 6th-order kind's sub
            amplitude, every later step of that kind was 2 - 3 knots long and "uninformative" against it (8.1e-7 / 1.8e-9); and a
            roll-back re-measured at the tame checkpoint and grew the sub-step back to what had just failed.
 
-Round 6, second hold-out (seeds 2000 - 2999; DESIGN 5.10, last controller bullet; profiles/r06_fuzz_summary.md):
+Round 6, second hold-out (seeds 2000 - 2999; DESIGN 5.10, step-size control; profiles/r06_fuzz_summary.md):
 seed 2685 - ramp / plateau at 24 rad/us / ramp on a 13-atom chain, 183 ns: 1.19e-7 with an estimate of 2.0e-8.  The controller
            had measured the LARGEST ENTRY of the local error; the state was spread over thousands of basis states (largest entry
            of the error 1.4e-9 of a 2-norm of 4.9e-8), and the falling ramp gathered population and error back into a few of them.
