@@ -123,7 +123,8 @@ typedef struct ryd_opts {
                            symmetric composition: 6th order / 10 stages over sub-steps of up to 8 knot
                            intervals where the call's schedule has such steps, else 4th order / 6 stages
                            inside one knot interval; `tol` x 500 = target of the accumulated
-                           local-error estimate of a whole pulse sequence, default 5e-8),
+                           local-error estimate of a whole pulse sequence - the sum of the 2-NORMS of the
+                           local errors, which bounds every amplitude error - default 8e-8),
                            3 = Taylor polynomial (Horner) */
   double reserved[2];
 } ryd_opts;
@@ -136,8 +137,8 @@ typedef struct ryd_stats {
   int32_t last_order;     /* Taylor order used by the last step */
   double norm_bound;      /* last spectral-norm bound (rad/us) */
   double reserved[4];     /* split-operator path: [0] accumulated local-error estimate of the last
-                             solve (largest amplitude), [1] last measured local error, [2] its
-                             sub-step (us), [3] checkpoint restores */
+                             solve (sum of local 2-norms: a bound on every amplitude error), [1] last
+                             measured local error, [2] its sub-step (us), [3] checkpoint restores */
 } ryd_stats;
 
 /* Replaces: construction of Hamiltonian/QobjEvo objects
