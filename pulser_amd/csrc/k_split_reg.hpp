@@ -73,6 +73,12 @@
 #ifndef SPLITR_LATE
 #define SPLITR_LATE 1
 #endif
+//   SPLITR_P5 1 (round-6 variant, NTB == 2 shapes with TMODE 1): lane bit 5 changes places with T bit 1 INSIDE the LDS pass - the
+//                reader fetches from lane (l & 31) | (t1 << 5) - instead of by 64 v_permlane32_swap per stage; the pass then moves
+//                HALF the ket at a time (T bit 0 fixed: two super-chunks through the one 128-KiB buffer, 4 barriers as before)
+#ifndef SPLITR_P5
+#define SPLITR_P5 0
+#endif
 #ifndef SPLITR_LATE_REAL
 #define SPLITR_LATE_REAL 0  /* the same for real drives (A/B) */
 #endif
@@ -466,6 +472,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
         xi[r] = fma(ax, q.y, ay * q.x);
       });
     };
+    constexpr bool kP5 = SPLITR_P5 && SPLITR_TMODE == 1 && NTB == 2 && NW > 0 && !(SPLITR_KO & 4);
     auto swap_d = [](double& a, double& c, auto is32) {
       unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
       unsigned clo = (unsigned)__double2loint(c), chi = (unsigned)__double2hiint(c);
@@ -487,8 +494,10 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       constexpr int r0 = g, r1 = g | (1 << NW), r2 = g | (2 << NW), r3 = g | (3 << NW);
       swap_d(xr[r0], xr[r1], std::false_type{}); swap_d(xi[r0], xi[r1], std::false_type{});
       swap_d(xr[r2], xr[r3], std::false_type{}); swap_d(xi[r2], xi[r3], std::false_type{});
-      swap_d(xr[r0], xr[r2], std::true_type{}); swap_d(xi[r0], xi[r2], std::true_type{});
-      swap_d(xr[r1], xr[r3], std::true_type{}); swap_d(xi[r1], xi[r3], std::true_type{});
+      if constexpr (!kP5) {  // (SPLITR_P5: lane bit 5 <-> T bit 1 rides on the LDS pass)
+        swap_d(xr[r0], xr[r2], std::true_type{}); swap_d(xi[r0], xi[r2], std::true_type{});
+        swap_d(xr[r1], xr[r3], std::true_type{}); swap_d(xi[r1], xi[r3], std::true_type{});
+      }
     };
     auto t_write = [&](auto Gc) {
       constexpr int g = decltype(Gc)::value;
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       });
     };
     auto rot_t_new = [&](auto Gc) {  // the upper lane bits, now in the T registers
-      splitr_for<0, NTB>([&](auto Mc) {
+      splitr_for<0, (kP5 ? 1 : NTB)>([&](auto Mc) {  // (SPLITR_P5: lane bit 5 arrives with the pass; its rotation follows the read)
         constexpr int m = decltype(Mc)::value;
         rot_reg(splitr_c<NW + m>{}, Tl[ND + m], Ul[ND + m], splitr_c<PW>{}, Gc);
       });
@@ -678,7 +687,60 @@ __global__ __launch_bounds__(64 << (N - 6 - NR)) __attribute__((amdgpu_waves_per
       });
     };
     typedef splitr_c<0> C0; typedef splitr_c<1> C1; typedef splitr_c<2> C2; typedef splitr_c<3> C3;
-    if constexpr (NW == 0 || (SPLITR_KO & 4)) {
+    // SPLITR_P5: super-chunk S = the registers with T bit 0 (register bit NR - 2) = S, i.e. chunks S and S + 2;
+    // slot = lane + 64 (A + NG (B + NG t1)): writer A = wave, B = pass bits, t1 = its T bit 1, lane = its own;
+    //                                         reader A = its pass bits, B = its wave, t1 = ITS LANE BIT 5, lane = (l & 31) | (t1' << 5)
+    auto pass_write5 = [&](auto Sc) {
+      constexpr int S = decltype(Sc)::value;
+      cplx* __restrict__ pb = pbuf + t;
+      splitr_for<0, 2 * CH>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value, kp = k & PW, t1 = k >> NW;
+        constexpr int r = kp | (S << (NR - 2)) | (t1 << (NR - 1));
+        pb[64 * NG * (kp + NG * t1)] = make_double2(xr[r], xi[r]);
+      });
+    };
+    auto pass_read5 = [&](auto Sc) {
+      constexpr int S = decltype(Sc)::value;
+      const cplx* __restrict__ pb = pbuf + (l & 31u) + 64 * NG * (w + NG * (l >> 5));
+      splitr_for<0, 2 * CH>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value, kp = k & PW, t1 = k >> NW;
+        constexpr int r = kp | (S << (NR - 2)) | (t1 << (NR - 1));
+        const cplx v = pb[32 * t1 + 64 * kp];
+        xr[r] = v.x;
+        xi[r] = v.y;
+      });
+    };
+    auto pre5 = [&](auto Sc) {
+      constexpr int S = decltype(Sc)::value;
+      pre(splitr_c<S>{}); pre(splitr_c<S + 2>{});
+    };
+    auto post5 = [&](auto Sc) {  // the wave bits (register bits 0 .. NW-1) and lane bit 5's atom (T bit 1) of the half that arrived
+      constexpr int S = decltype(Sc)::value;
+      post(splitr_c<S>{}); post(splitr_c<S + 2>{});
+      rot_reg(splitr_c<NW + 1>{}, Tl[ND + 1], Ul[ND + 1], splitr_c<(1 << (NR - 2))>{}, splitr_c<(S << (NR - 2))>{});
+    };
+    if constexpr (kP5) {
+      static_assert(CH == (1 << NW), "SPLITR_P5: chunks of 2^NW registers");
+      pre5(C0{});
+      __syncthreads();  // the previous stage's pass_read5(1) of every wave is done: the buffer may be overwritten
+      pass_write5(C0{});
+      pre5(C1{});
+      __syncthreads();
+      pass_read5(C0{});
+      if (SPLITR_KWARM) {
+        typedef const __attribute__((address_space(4))) unsigned* uptr_t;
+        uptr_t nx = (uptr_t)(unsigned long long)(coefs + (size_t)(sg + 1 < n_stages ? sg + 1 : sg) * stage_stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) warm ^= nx[k < 7 ? 16 * k : 8 * N - 1];
+      }
+      __syncthreads();
+      pass_write5(C1{});
+      post5(C0{});
+      __syncthreads();
+      pass_read5(C1{});
+      if (SPLITR_PREF) load_next(sg + 1 < n_stages ? sg + 1 : sg, !odd);
+      post5(C1{});
+    } else if constexpr (NW == 0 || (SPLITR_KO & 4)) {
       pre(C0{}); pre(C1{}); pre(C2{}); pre(C3{});
       post(C0{}); post(C1{}); post(C2{}); post(C3{});
     } else {
