@@ -55,9 +55,11 @@ static int launch_apply14(ryd_handle* h, const Apply14Args& B, hipStream_t st) {
 
 // out = post * (base + scale * G~ in); all passes.  `in` must differ from `out`
 // unless single-element hazards are impossible (never used in place here).
+// `kry_acc` (Lanczos, host_krylov.hpp): [4 B] accumulators (stride 4) of <in | out> (re, im) and |out|^2, reduced by the final pass -
+// only for plans of ONE k_apply pass (kry_fusable)
 static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx* out,
                            double wmix, double scale, double shift, cplx post,
-                           hipStream_t st, bool with_decay = false) {
+                           hipStream_t st, bool with_decay = false, double* kry_acc = nullptr) {
   if (!h->passes_valid) plan_passes(h);
   // Monte-Carlo H_eff: real diagonal, centred (the centre is a scalar factor
   // of the exponential, applied by exp_step through `post`)
@@ -72,6 +74,7 @@ static int apply_generator(ryd_handle* h, const cplx* in, const cplx* base, cplx
     A.kin = pi > 0 ? h->kbuf : nullptr;
     A.kout = h->kbuf;
     A.final_pass = pi == np - 1;
+    A.kry_acc = (A.final_pass && !p.use14) ? kry_acc : nullptr;
     A.base = A.final_pass ? base : nullptr;
     A.out = out;
     A.coefs = h->coefs_dev;

@@ -89,6 +89,7 @@ struct ryd_handle {
   int kry_cap = 0;
   void* kry_pool = nullptr;
   KryScalars kry{};
+  double* kry_sq = nullptr;       // [B][KRY_MAX_M + 1] inside kry_pool (KryScalars.sq when the iteration is fused)
   size_t ksched_cap = 0;
   // split-operator ket path (host_split.hpp)
   std::vector<Pass> split_tilings;

@@ -26,7 +26,7 @@ static int ensure_krylov(ryd_handle* h, int m) {
   }
   if (!h->kry_pool) {
     const size_t B = (size_t)h->B;
-    const size_t n_dbl = 2 * B * KRY_MAX_M + 4 * B;
+    const size_t n_dbl = 2 * B * KRY_MAX_M + 4 * B + 64 * B + B * (KRY_MAX_M + 1);
     const size_t bytes = B * KRY_MAX_M * sizeof(cplx) + n_dbl * sizeof(double);
     HIPCHK(hipMalloc(&h->kry_pool, bytes));
     HIPCHK(hipMemset(h->kry_pool, 0, bytes));
@@ -37,7 +37,9 @@ static int ensure_krylov(ryd_handle* h, int m) {
     h->kry.dotre = (double*)p; p += B * sizeof(double);
     h->kry.dotim = (double*)p; p += B * sizeof(double);
     h->kry.nrm2 = (double*)p;  p += B * sizeof(double);
-    h->kry.norm0 = (double*)p;
+    h->kry.norm0 = (double*)p; p += B * sizeof(double);
+    h->kry.acc = (double*)p;   p += 64 * B * sizeof(double);
+    h->kry_sq = (double*)p;
   }
   return RYD_OK;
 }
@@ -64,9 +66,27 @@ static int exp_step_krylov(ryd_handle* h, cplx* state, double hstep, const MixPo
   hipLaunchKernelGGL(k_kry_scale, grid, blk, 0, st, (const cplx*)state, V, h->nb, h->kry.nrm2, h->kry.norm0, 1);
   h->stats.n_launches += 3;
   const cplx one = make_double2(1.0, 0.0);
+  // Round 6: where the generator is ONE k_apply pass (sesolve kets up to 20 atoms and beyond, not the 2^14 register tiles) the
+  // inner product and |w|^2 ride on that pass's store epilogue and the three-term recurrence + normalisation are one kernel:
+  // 2 launches and 6 vector transfers per iteration instead of 5 launches and 11 ("weak" 6).
+  static const bool fuse_env = dev_env_flag("RYD_KRY_FUSE", true);
+  if (!h->passes_valid) plan_passes(h);
+  const bool fused = fuse_env && h->passes.size() == 1 && !h->passes[0].use14;
+  if (fused) HIPCHK(hipMemsetAsync(h->kry.acc, 0, ((size_t)64 * h->B + (size_t)h->B * (KRY_MAX_M + 1)) * sizeof(double), st));  // acc + sq (adjacent)
+  h->kry.sq = fused ? h->kry_sq : nullptr;
   for (int j = 0; j < m; ++j) {
     cplx* vj = V + (size_t)j * per;
     cplx* w = V + (size_t)(j + 1) * per;
+    if (fused) {
+      double* acc = h->kry.acc + (size_t)(j & 1) * 32 * h->B;
+      double* acc_next = h->kry.acc + (size_t)((j + 1) & 1) * 32 * h->B;
+      if ((rc = apply_generator(h, vj, nullptr, w, wmix, 1.0, shift, one, st, false, acc))) return rc;
+      hipLaunchKernelGGL(k_kry_update_fused, grid, blk, 0, st, w, (const cplx*)vj,
+                         j > 0 ? (const cplx*)(V + (size_t)(j - 1) * per) : (const cplx*)nullptr, h->nb, j, h->kry,
+                         (const double*)acc, acc_next);
+      h->stats.n_launches += 1;
+      continue;
+    }
     hipLaunchKernelGGL(k_kry_reset, dim3(gb), dim3(128), 0, st, h->kry, h->B);
     if ((rc = apply_generator(h, vj, nullptr, w, wmix, 1.0, shift, one, st, false))) return rc;
     hipLaunchKernelGGL(k_kry_dot, grid, blk, 0, st, (const cplx*)vj, (const cplx*)w, h->nb, h->kry.dotre, h->kry.dotim);
@@ -75,7 +95,7 @@ static int exp_step_krylov(ryd_handle* h, cplx* state, double hstep, const MixPo
     hipLaunchKernelGGL(k_kry_normalize, grid, blk, 0, st, w, h->nb, j, h->kry);
     h->stats.n_launches += 4;
   }
-  hipLaunchKernelGGL(k_kry_small, dim3(gb), dim3(128), 0, st, h->kry, h->B, m, hstep, shift, rho);
+  hipLaunchKernelGGL(k_kry_small, dim3(h->B), dim3(64), 0, st, h->kry, h->B, m, hstep, shift, rho);  // one wave per batch entry
   hipLaunchKernelGGL(k_kry_combine, grid, blk, 0, st, (const cplx*)V, per, h->nb, m, (const cplx*)h->kry.coef, state);
   HIPCHK(hipGetLastError());
   h->stats.n_launches += 2;

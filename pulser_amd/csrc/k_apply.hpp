@@ -23,6 +23,10 @@ struct PassArgs {
   int N, nb, T;
   int n_flip, n_dbl;
   int include_diag, final_pass;
+  // Lanczos (round 6, host_krylov.hpp): with `kry_acc` set the final pass also reduces <x | out> (x = the vector G is applied to:
+  // the tile is in LDS) and |out|^2 into kry_acc[(4 b + 0 .. 2) 8 + (block & 7)] - what k_kry_dot and the norm pass of k_kry_update computed from
+  // two more reads of both vectors (stride 4 per batch entry)
+  double* kry_acc;
   signed char flip_q[MAXF];  // tile-local bit of each single flip
   signed char dbl_qb[MAXD], dbl_qa[MAXD];
   int n_oflip;                // single flips on bits outside the tile: the partner
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
   const unsigned Dm1 = (MODE == RYD_MESOLVE) ? ((1u << N) - 1u) : 0u;
   const int maskLo = (1 << TL) - 1;
 
+  double kd_re = 0.0, kd_im = 0.0, kd_nn = 0.0;  // Lanczos reductions (PassArgs.kry_acc)
   for (int l = tid; l < tileSize; l += NT) {
     const unsigned long long gi = base_idx | deposit((unsigned long long)l, A.tile);
     cplx acc = make_double2(0.0, 0.0);
@@ -221,9 +226,39 @@ __global__ __launch_bounds__(NT) void k_apply(const PassArgs A) {
         r.x += bv.x;
         r.y += bv.y;
       }
-      A.out[go] = cmul(A.post, r);
+      const cplx o = cmul(A.post, r);
+      A.out[go] = o;
+      if (A.kry_acc) {
+        const cplx x = xs[l];
+        kd_re = fma(x.x, o.x, fma(x.y, o.y, kd_re));   // <x | o>, conjugate-linear in x
+        kd_im = fma(x.x, o.y, fma(-x.y, o.x, kd_im));
+        kd_nn = fma(o.x, o.x, fma(o.y, o.y, kd_nn));
+      }
     } else {
       A.kout[go] = acc;
+    }
+  }
+  if (A.kry_acc && A.final_pass) {
+    // wave sums, one LDS slot per wave (the coefficient tables c0 / c1 / oc are dead: every thread is past its last read of
+    // them only after the barrier), one atomic per workgroup and accumulator
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      kd_re += __shfl_down(kd_re, o, 64);
+      kd_im += __shfl_down(kd_im, o, 64);
+      kd_nn += __shfl_down(kd_nn, o, 64);
+    }
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(xs);  // (the tile is dead too; NT / 64 <= 16 waves x 3 doubles)
+    if ((tid & 63) == 0) {
+      red[3 * (tid >> 6)] = kd_re;
+      red[3 * (tid >> 6) + 1] = kd_im;
+      red[3 * (tid >> 6) + 2] = kd_nn;
+    }
+    __syncthreads();
+    if (tid < 3) {
+      double sum = 0.0;
+      for (int wv = 0; wv < NT / 64; ++wv) sum += red[3 * wv + tid];
+      atomicAdd(A.kry_acc + (4 * b + tid) * 8 + (blockIdx.x & 7), sum);  // (8 sub-accumulators: atomics on one word serialise at ~12 ns)
     }
   }
 }

@@ -23,6 +23,8 @@ struct KryScalars {
   double* nrm2;    // [B]
   double* norm0;   // [B] |psi| of the exponential
   cplx* coef;      // [B][KRY_MAX_M] combination coefficients
+  double* acc;     // [2][32 B] (8 sub-accumulators x stride 4) fused iteration, by parity: Re <v~_j | w~>, Im <v~_j | w~>, |w~|^2 (k_apply's epilogue)
+  double* sq;      // [B][KRY_MAX_M + 1] fused iteration: |v~_j|^2 of the stored basis vectors (null: the basis is normalised)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -133,6 +135,59 @@ __global__ __launch_bounds__(256) void k_kry_normalize(cplx* __restrict__ u, int
   if (blockIdx.x == 0 && threadIdx.x == 0) S.beta[(size_t)b * KRY_MAX_M + j] = beta > 1e-14 ? beta : 0.0;
 }
 
+// Fused iteration (round 6): the generator kernel's final pass has left acc[4 b + 0 .. 2] = Re <x | w~>, Im <x | w~>, |w~|^2 for
+// the STORED vector x = v~_j (PassArgs.kry_acc, stride 4).  The stored basis vectors are not normalised exactly: v~_{j+1} = u / b_f
+// with a PROVISIONAL scale b_f (from |u|^2 = |w|^2 - alpha^2 - beta_{j-1}^2, which holds in exact arithmetic but cancels by a
+// factor |w|^2 / |u|^2 ~ (diagonal / drive)^2 in floating point - used as the true norm it made the recurrence unstable: 2e-5 on
+// the 12-atom anneal), while the kernel sums the TRUE |v~_{j+1}|^2 into sq[b][j + 1] on the way out.  The next iteration divides
+// by that known scale (v_j = v~_j / s_j, w = w~ / s_j, true beta_j = b_f s_{j+1}), k_kry_small does the same for the tridiagonal
+// matrix and the combination coefficients: exactly the Lanczos process, in ONE pass per iteration beside the generator's
+// (3 reads + 1 write per amplitude where dot + update + normalise took 6 + 3, and 2 launches instead of 5).
+// `acc_next`: the accumulators of the next iteration (the other parity), zeroed here.
+__global__ __launch_bounds__(256) void k_kry_update_fused(cplx* __restrict__ w, const cplx* __restrict__ vj,
+                                                          const cplx* __restrict__ vprev, int nb, int j, KryScalars S,
+                                                          const double* __restrict__ acc, double* __restrict__ acc_next) {
+  const size_t D = (size_t)1 << nb;
+  const int b = blockIdx.y;
+  const size_t boff = (size_t)b * D;
+  double* sq = S.sq + (size_t)b * (KRY_MAX_M + 1);
+  const double sj2 = j == 0 ? 1.0 : sq[j];
+  double a_im = 0.0, a_nn = 0.0;  // (8 sub-accumulators per sum: k_apply's epilogue)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { a_im += acc[(4 * b + 1) * 8 + q]; a_nn += acc[(4 * b + 2) * 8 + q]; }
+  const bool alive = sj2 > 1e-290 && a_nn > 0.0;
+  const double inv_s2 = alive ? 1.0 / sj2 : 0.0, inv_s = sqrt(inv_s2);
+  const double alpha = -a_im * inv_s2;
+  const double ww = a_nn * inv_s2;
+  const double bprev = j > 0 ? S.beta[(size_t)b * KRY_MAX_M + j - 1] * sqrt(sj2) : 0.0;  // the true beta_{j-1}
+  const double n2 = ww - alpha * alpha - bprev * bprev;
+  const double bf = !alive ? 0.0 : (n2 > 1e-8 * ww ? sqrt(n2) : sqrt(ww));
+  const double inv = bf > 0.0 ? 1.0 / bf : 0.0;
+  const double cw = inv_s * inv, ca = alpha * inv_s * inv;
+  const double sp2 = j > 1 ? sq[j - 1] : 1.0;
+  const double cp = (j > 0 && sp2 > 1e-290) ? bprev * inv / sqrt(sp2) : 0.0;
+  double sum = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < D; i += (size_t)gridDim.x * 256) {
+    const cplx x = w[boff + i], a = vj[boff + i];
+    cplx u = make_double2(-x.y * cw - ca * a.x, x.x * cw - ca * a.y);  // (i w - alpha v_j) / b_f
+    if (vprev) {
+      const cplx p = vprev[boff + i];
+      u.x -= cp * p.x;
+      u.y -= cp * p.y;
+    }
+    w[boff + i] = u;
+    sum = fma(u.x, u.x, fma(u.y, u.y, sum));
+  }
+  __shared__ double red[4];
+  sum = kry_block_sum(sum, red);
+  if (threadIdx.x == 0) atomicAdd(sq + j + 1, sum);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S.alpha[(size_t)b * KRY_MAX_M + j] = alpha;
+    S.beta[(size_t)b * KRY_MAX_M + j] = bf;  // provisional: the true beta_j is b_f sqrt(sq[j + 1])
+    for (int q = 0; q < 24; ++q) acc_next[32 * b + q] = 0.0;
+  }
+}
+
 __global__ void k_kry_reset(KryScalars S, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) { S.dotre[b] = 0.0; S.dotim[b] = 0.0; S.nrm2[b] = 0.0; }
@@ -140,46 +195,55 @@ __global__ void k_kry_reset(KryScalars S, int B) {
 
 // coef[b][:] = norm0 * e^{-i h sigma} * exp(-i h T_m) e_1 for the real symmetric tridiagonal T_m
 // (alpha, beta): sub-stepped Taylor series on the m-vector (m <= 40; ||h T|| <= rho).
-__global__ void k_kry_small(KryScalars S, int B, int m, double h, double sigma, double rho) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// (round 6: one WAVE per batch entry, lane k = component k, neighbours over __shfl - the one-thread version walked six
+// 40-entry scratch arrays and took 70 us per exponential at m = 11, a sixth of the Lanczos process it closes)
+__global__ __launch_bounds__(64) void k_kry_small(KryScalars S, int B, int m, double h, double sigma, double rho) {
+  const int b = blockIdx.x;
+  const int k = threadIdx.x;
   if (b >= B) return;
-  const double* al = S.alpha + (size_t)b * KRY_MAX_M;
-  const double* be = S.beta + (size_t)b * KRY_MAX_M;
-  double cr[KRY_MAX_M], ci[KRY_MAX_M], tr[KRY_MAX_M], ti[KRY_MAX_M], ur[KRY_MAX_M], ui[KRY_MAX_M];
-  for (int k = 0; k < m; ++k) { cr[k] = ci[k] = 0.0; }
-  cr[0] = 1.0;
+  const bool on = k < m;
+  // fused iteration: the stored beta_k are provisional scales and the stored basis vectors have the norms s_k = sqrt(sq[k])
+  const double s0 = (S.sq && on && k > 0) ? S.sq[(size_t)b * (KRY_MAX_M + 1) + k] : 1.0;
+  const double s1 = (S.sq && on) ? S.sq[(size_t)b * (KRY_MAX_M + 1) + k + 1] : 1.0;
+  const double isc = s0 > 1e-290 ? 1.0 / sqrt(s0) : 0.0;
+  const double al = on ? S.alpha[(size_t)b * KRY_MAX_M + k] : 0.0;
+  // be_up couples k and k + 1 (zero on the last component), be_dn couples k and k - 1
+  const double be_up = (on && k + 1 < m) ? S.beta[(size_t)b * KRY_MAX_M + k] * sqrt(s1 > 0.0 ? s1 : 0.0) : 0.0;
+  double be_dn = __shfl_up(be_up, 1, 64);
+  if (k == 0) be_dn = 0.0;
   // centre of the spectrum estimate: mean of alpha (keeps the series argument small)
-  double mu = 0.0;
-  for (int k = 0; k < m; ++k) mu += al[k];
+  double mu = al;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mu += __shfl_xor(mu, o, 64);
   mu /= m;
+  const double d = on ? al - mu : 0.0;
+  double cr = k == 0 ? 1.0 : 0.0, ci = 0.0;
   const int nsub = (int)ceil(fmax(rho, 1e-3));
   const double hs = h / nsub;
   for (int sub = 0; sub < nsub; ++sub) {
-    for (int k = 0; k < m; ++k) { tr[k] = cr[k]; ti[k] = ci[k]; }
+    double tr = cr, ti = ci;
     for (int term = 1; term <= 30; ++term) {
       // t <- (-i hs / term) (T - mu) t
-      for (int k = 0; k < m; ++k) {
-        double xr = (al[k] - mu) * tr[k], xi = (al[k] - mu) * ti[k];
-        if (k > 0) { xr += be[k - 1] * tr[k - 1]; xi += be[k - 1] * ti[k - 1]; }
-        if (k + 1 < m) { xr += be[k] * tr[k + 1]; xi += be[k] * ti[k + 1]; }
-        const double f = hs / term;
-        ur[k] = f * xi;
-        ui[k] = -f * xr;
-      }
-      double mag = 0.0;
-      for (int k = 0; k < m; ++k) {
-        tr[k] = ur[k]; ti[k] = ui[k];
-        cr[k] += ur[k]; ci[k] += ui[k];
-        mag = fmax(mag, fabs(ur[k]) + fabs(ui[k]));
-      }
+      const double tr_dn = __shfl_up(tr, 1, 64), ti_dn = __shfl_up(ti, 1, 64);
+      const double tr_up = __shfl_down(tr, 1, 64), ti_up = __shfl_down(ti, 1, 64);
+      const double xr = fma(be_up, tr_up, fma(be_dn, tr_dn, d * tr));
+      const double xi = fma(be_up, ti_up, fma(be_dn, ti_dn, d * ti));
+      const double f = hs / term;
+      tr = on ? f * xi : 0.0;
+      ti = on ? -f * xr : 0.0;
+      cr += tr;
+      ci += ti;
+      double mag = fabs(tr) + fabs(ti);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mag = fmax(mag, __shfl_xor(mag, o, 64));
       if (mag < 1e-18) break;
     }
   }
   double sn, cs;
   sincos(-h * (sigma + mu), &sn, &cs);
   const double n0 = S.norm0[b];
-  for (int k = 0; k < m; ++k)
-    S.coef[(size_t)b * KRY_MAX_M + k] = make_double2(n0 * (cr[k] * cs - ci[k] * sn), n0 * (cr[k] * sn + ci[k] * cs));
+  if (on)
+    S.coef[(size_t)b * KRY_MAX_M + k] = make_double2(n0 * isc * (cr * cs - ci * sn), n0 * isc * (cr * sn + ci * cs));
 }
 
 // out = sum_j coef[b][j] V[j]   (V[j] at V + j * stride)
