@@ -1047,7 +1047,7 @@ def main() -> None:
                          "applications": stats["n_applications"], "krylov_dimension": stats["last_order"],
                          "max_abs_vs_split": float((timed_run.last_state - psi_split).abs().max().item()),
                          "roofline": roofline_hbm(20, 1, stats, kms, kl, "k_apply<sesolve> inside the Lanczos process "
-                                                                        "(+ k_krylov dot / axpy kernels)", None)}
+                                                                        "(its epilogue reduces the inner products; + k_kry_update_fused: two launches per iteration)", None)}
         psi1 = eng.new_state()
         eng.evolve(psi1, 0.0, 1.0)
         sec, stats, kms, kl, occ = timed_run(eng, psi1.clone, 1.0, 1.02, 2, 1, None, torch, method="taylor")
