@@ -154,6 +154,42 @@ def test_default_path_and_taylor_reference_against_the_tight_oracle(name):
     print(f"{name}: {n_cases} cases, worst |default - oracle| {worst[0]:.2e}, worst |taylor - oracle| {worst[1]:.2e}")
 
 
+def test_second_holdout_cases_against_the_tight_oracle():
+    """The cases the second hold-out flagged under the largest-entry controller (seed 2685: 1.19e-7 then) and the worst cases of
+    the 2-norm controller - by error, by error / estimate, by 2-norm of the error / estimate - against the TIGHT ORACLE
+    (tests/golden/fuzz_oracle_holdout.npz, make_fuzz_fixtures.py holdout: 12 - 16 atoms, ten cases): default path and CF4 + Taylor
+    within the bar, and the booked estimate - a sum of local 2-norms - covers the 2-norm of the true error (measured <= 1.9 x)."""
+    from pulser_amd.engine import Engine
+
+    n_cases = 0
+    for probs, desc, refs in _oracle_cases("fuzz_oracle_holdout.npz"):
+        t_end = (probs[0]["duration"] - 1) * 1e-3
+        with Engine.from_problems(probs, mode="sesolve") as eng:
+            tay = eng.new_state()
+            eng.evolve(tay, 0.0, t_end, method="taylor", tol=1e-12, magnus_tol=1e-12)
+            st = eng.new_state()
+            eng.reset_stats()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                eng.evolve(st, 0.0, t_end)
+            est = eng.stats()["reserved"][0]
+            got, ref_t = st.cpu().numpy(), tay.cpu().numpy()
+        for b, ref in refs:
+            e_def = float(np.max(np.abs(got[b] - ref)))
+            e_two = float(np.linalg.norm(got[b] - ref))
+            e_tay = float(np.max(np.abs(ref_t[b] - ref)))
+            print(f"{desc}: |default - oracle| max {e_def:.2e} 2-norm {e_two:.2e}, estimate {est:.2e}; |taylor - oracle| {e_tay:.2e}")
+            # (the oracle shows that the largest "errors" the fuzz books on strongly interacting registers are the CF4 + Taylor
+            # REFERENCE's - seed 2799, a 4.56-um chain with a time-dependent phase: 3.2e-8; 2745, 2013: 1e-8 - its a-priori
+            # Magnus estimate is short there at tol 1e-12, while the default path sits 6e-11 .. 5e-10 from the oracle:
+            # profiles/r06_fuzz_summary.md, last table)
+            assert e_tay < AMP_TOL / 2, (desc, b, e_tay)
+            assert e_def < AMP_TOL / 2, (desc, b, e_def)
+            assert e_two <= max(2.5 * est, FLOOR), (desc, b, e_two, est)  # the estimate covers the 2-NORM of the error (measured: <= 1.9 x)
+        n_cases += 1
+    assert n_cases == 10
+
+
 def test_split_path_forced_on_small_registers_against_the_tight_oracle():
     """24 seeds re-drawn on 8 - 11 atoms with the split-operator path forced (method = "split": the pass kernels under the
     same controller), against the tight oracle: <= 1e-7 and covered by the estimate."""

@@ -30,10 +30,11 @@ for seed in range(first, first + count):
             eng.evolve(st, 0.0, t_end)
         s = eng.stats()
         err = float((st - ref).abs().max())
+        err2 = float(torch.linalg.vector_norm(st - ref, dim=1).max())  # largest 2-norm of a sequence's error vector
     est = s["reserved"][0]
     rows.append((err / max(est, 1e-300) if est > 0 else 0.0, err, est, s["n_applications"], s["n_launches"], s["reserved"][3],
                  time.perf_counter() - tic, len(w), desc))
-    print(f"err {err:.2e} est {est:.2e} ratio {rows[-1][0]:6.2f} stages {s['n_applications']:6d} launches {s['n_launches']:5d} "
+    print(f"err {err:.2e} est {est:.2e} ratio {rows[-1][0]:6.2f} err2 {err2:.2e} stages {s['n_applications']:6d} launches {s['n_launches']:5d} "
           f"rollbacks {s['reserved'][3]:.0f} warn {len(w)} {rows[-1][6]:.2f}s  {desc}", flush=True)
 print(f"\n{count} cases in {time.perf_counter() - t_all:.1f} s; worst error {max(r[1] for r in rows):.2e}; "
       f"worst error / estimate {max(r[0] for r in rows):.2f}")
