@@ -166,6 +166,20 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
         nsub = std::max(nsub, std::min(nm, 256));
       }
     }
+    if (!h->sched_for_split && !h->general) {
+      // Round 6 (the fuzz's worst cases pinned on the tight oracle, profiles/r06_fuzz_summary.md): the estimates above know the
+      // waveforms' curvature and, for merged steps, [B, [B, A]] with the slopes B - not the 4th-order Magnus terms that carry
+      // the DIAGONAL strength of A several times.  On registers at 4.5 - 5.4 um (300 - 650 rad/us between neighbours) one-knot
+      // CF4 steps at tol = magnus_tol = 1e-12 ended 1e-8 .. 3.2e-8 from the oracle and fell 16 - 60 x per halving of the step
+      // (tools/r06_taylor_probe.py).  Empirical per-step figure K h^5 R^3 |c'| with R = max|delta| + max_i sum_j U_ij and
+      // K = 1e-7 (the five measured cases give 2e-8 .. 8e-8; products of norms overshoot the commutators by that much);
+      // n equal sub-steps divide it by n^4.  R h = 0.1 on the registers of the benchmarks: no effect there.
+      const double R = span_max(h->bd_dl, idx, span) + h->u_rowsum;
+      const double sl = len / nsub;
+      const double est = (h->cfg.mode == RYD_MESOLVE ? 2.0 : 1.0) * 1e-7 * sl * sl * sl * sl * sl * R * R * R * span_max(h->bd_dc, idx, span);
+      const double mtol = o.magnus_tol > 0 ? o.magnus_tol : 1e-10;
+      if (est > mtol) nsub *= std::min((int)std::ceil(std::pow(est / mtol, 0.25)), 64);
+    }
     if (h->gauge_active) {
       // KET_GAUGE: the 4th-order Magnus step assumes a Hamiltonian that is smooth inside the step; the gauged
       // detuning theta'(t) = d/dt arg c(t) is not where the phase of a drive turns quickly (a phase jump

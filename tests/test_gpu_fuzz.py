@@ -183,7 +183,7 @@ def test_second_holdout_cases_against_the_tight_oracle():
             # REFERENCE's - seed 2799, a 4.56-um chain with a time-dependent phase: 3.2e-8; 2745, 2013: 1e-8 - its a-priori
             # Magnus estimate is short there at tol 1e-12, while the default path sits 6e-11 .. 5e-10 from the oracle:
             # profiles/r06_fuzz_summary.md, last table)
-            assert e_tay < AMP_TOL / 2, (desc, b, e_tay)
+            assert e_tay < 1e-8, (desc, b, e_tay)  # (with the interaction-strength rule of host_sched.hpp; before it: 3.2e-8 on seed 2799)
             assert e_def < AMP_TOL / 2, (desc, b, e_def)
             assert e_two <= max(2.5 * est, FLOOR), (desc, b, e_two, est)  # the estimate covers the 2-NORM of the error (measured: <= 1.9 x)
         n_cases += 1
