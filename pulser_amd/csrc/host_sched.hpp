@@ -166,7 +166,8 @@ static void build_schedule(ryd_handle* h, double t0, double t1, const ryd_opts& 
         nsub = std::max(nsub, std::min(nm, 256));
       }
     }
-    if (!h->sched_for_split && !h->general) {
+    static const bool int_rule = dev_env_flag("RYD_SCHED_INT", true);  // (dev A/B: RYD_DEV=1 RYD_SCHED_INT=0)
+    if (int_rule && !h->sched_for_split && !h->general) {
       // Round 6 (the fuzz's worst cases pinned on the tight oracle, profiles/r06_fuzz_summary.md): the estimates above know the
       // waveforms' curvature and, for merged steps, [B, [B, A]] with the slopes B - not the 4th-order Magnus terms that carry
       // the DIAGONAL strength of A several times.  On registers at 4.5 - 5.4 um (300 - 650 rad/us between neighbours) one-knot

@@ -190,6 +190,32 @@ def test_second_holdout_cases_against_the_tight_oracle():
     assert n_cases == 10
 
 
+def test_default_path_of_small_strongly_interacting_registers_against_the_tight_oracle():
+    """8 - 11 atoms at 4.5 - 5.4 um (300 - 650 rad/us between neighbours): the DEFAULT path there is the persistent polynomial
+    kernel (k_traj: CF4 steps from a-priori estimates).  Round 6 found those estimates short on such registers at 12 - 16 atoms
+    (CF4 + Taylor 3.2e-8 from the oracle at tol 1e-12) and added an interaction-strength rule to host_sched.hpp; here the default
+    call (default tolerances) and the tight Taylor call are held to the oracle on the small sizes."""
+    from pulser_amd.engine import Engine
+
+    n_cases = 0
+    for probs, desc, refs in _oracle_cases("fuzz_oracle_strong_small.npz"):
+        t_end = (probs[0]["duration"] - 1) * 1e-3
+        with Engine.from_problems(probs[:1], mode="sesolve") as eng:
+            st = eng.new_state()
+            eng.evolve(st, 0.0, t_end)
+            tay = eng.new_state()
+            eng.evolve(tay, 0.0, t_end, method="taylor", tol=1e-12, magnus_tol=1e-12)
+            got, ref_t = st.cpu().numpy(), tay.cpu().numpy()
+        for b, ref in refs:
+            e_def = float(np.max(np.abs(got[b] - ref)))
+            e_tay = float(np.max(np.abs(ref_t[b] - ref)))
+            print(f"{desc}: |default - oracle| {e_def:.2e}, |taylor(1e-12) - oracle| {e_tay:.2e}")
+            assert e_def < AMP_TOL, (desc, e_def)
+            assert e_tay < 1e-8, (desc, e_tay)
+        n_cases += 1
+    assert n_cases == 5
+
+
 def test_split_path_forced_on_small_registers_against_the_tight_oracle():
     """24 seeds re-drawn on 8 - 11 atoms with the split-operator path forced (method = "split": the pass kernels under the
     same controller), against the tight oracle: <= 1e-7 and covered by the estimate."""
