@@ -10,6 +10,7 @@ and stores the final kets:
     fuzz_oracle_12.npz   the first 24 seeds whose draw is a 12-atom register (k_split_reg<12, 4>), two sequences of a batch kept
     fuzz_oracle_13.npz / fuzz_oracle_14.npz   the first 8 seeds each of 13 / 14 atoms (k_split_reg<13, 5> / <14, 5>), one kept
     fuzz_oracle_small.npz  24 seeds re-drawn on 8 - 11 atoms (the split path is forced there: method = "split")
+    fuzz_oracle_strong.npz  16 seeds of 12 / 13 atoms at 4.5 - 5.5 um, picked by input (validation of the Magnus rule)
     fuzz_oracle_strong_small.npz  five draws on 8 - 11 atoms at 4.5 - 5.4 um (default path there: k_traj)
     fuzz_oracle_holdout.npz  the cases the second hold-out of round 6 flagged under the largest-entry controller (2685: 1.19e-7;
                              2570, 2327, 2244) and the worst cases of the 2-norm controller (2799: largest error, 985: largest
@@ -18,7 +19,7 @@ and stores the final kets:
 A fixture is data: seeds, register sizes, final states, the number of right-hand sides, and a SHA-256 of every case's inputs
 (coords, amp, det, phase) so that a drift of fuzz_case itself is caught rather than compared against stale kets.
 
-    python tests/golden/make_fuzz_fixtures.py [12|13|14|small|holdout|strong_small] [workers]
+    python tests/golden/make_fuzz_fixtures.py [12|13|14|small|holdout|strong_small|strong] [workers]
 
 Cost: seconds (8 atoms) to ~10 minutes (a 4-us 12-atom sequence on a 4.6-um chain) per case and core."""
 from __future__ import annotations
@@ -92,6 +93,12 @@ def cases_holdout():
     return [(seed, None) for seed in (2685, 2570, 2327, 2244, 2799, 985, 2745, 2343, 2340, 2013)]
 
 
+def cases_strong():
+    """The first 16 seeds from 2000 on whose draw is a 12- or 13-atom register at 4.5 - 5.5 um and lasts < 600 ns (picked by
+    INPUT, not by outcome - none of them was used to fit the interaction-strength rule of host_sched.hpp)."""
+    return [(seed, None) for seed in (2009, 2062, 2098, 2124, 2153, 2169, 2175, 2184, 2203, 2220, 2239, 2309, 2318, 2319, 2335, 2354)]
+
+
 def cases_strong_small():
     """Strongly interacting registers (4.5 - 5.4 um) on 8 - 11 atoms: the sizes whose DEFAULT path is the persistent polynomial
     kernel k_traj (CF4 with a-priori step estimates) - the seeds whose 12 - 16-atom draws exposed the Magnus estimate."""
@@ -106,10 +113,10 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     global KEEP_PER_CASE
-    if which in ("13", "14", "holdout", "strong_small"):
+    if which in ("13", "14", "holdout", "strong_small", "strong"):
         KEEP_PER_CASE = 1
     cases = {"12": lambda: cases_n(12, 24), "13": lambda: cases_n(13, 8), "14": lambda: cases_n(14, 8), "small": cases_small,
-             "holdout": cases_holdout, "strong_small": cases_strong_small}[which]()
+             "holdout": cases_holdout, "strong_small": cases_strong_small, "strong": cases_strong}[which]()
     from multiprocessing import get_context
 
     with get_context("fork").Pool(workers) as pool:

@@ -190,6 +190,40 @@ def test_second_holdout_cases_against_the_tight_oracle():
     assert n_cases == 10
 
 
+def test_strongly_interacting_registers_picked_by_input_against_the_tight_oracle():
+    """16 fuzz seeds of 12 / 13 atoms at 4.5 - 5.5 um picked by their INPUT (tests/golden/fuzz_oracle_strong.npz: none of them was
+    used to fit the interaction-strength rule of host_sched.hpp): the default path within the bar with its estimate covering the
+    2-norm of the error, and the CF4 + Taylor reference (tol = magnus_tol = 1e-12) within 1e-8 of the tight oracle."""
+    from pulser_amd.engine import Engine
+
+    worst = [0.0, 0.0, 0.0]
+    n_cases = 0
+    for probs, desc, refs in _oracle_cases("fuzz_oracle_strong.npz"):
+        t_end = (probs[0]["duration"] - 1) * 1e-3
+        with Engine.from_problems(probs, mode="sesolve") as eng:
+            tay = eng.new_state()
+            eng.evolve(tay, 0.0, t_end, method="taylor", tol=1e-12, magnus_tol=1e-12)
+            st = eng.new_state()
+            eng.reset_stats()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                eng.evolve(st, 0.0, t_end)
+            est = eng.stats()["reserved"][0]
+            got, ref_t = st.cpu().numpy(), tay.cpu().numpy()
+        for b, ref in refs:
+            e_def = float(np.max(np.abs(got[b] - ref)))
+            e_two = float(np.linalg.norm(got[b] - ref))
+            e_tay = float(np.max(np.abs(ref_t[b] - ref)))
+            worst = [max(worst[0], e_def), max(worst[1], e_tay), max(worst[2], e_two / est if e_two > FLOOR else 0.0)]
+            print(f"{desc}: |default - oracle| max {e_def:.2e} 2-norm {e_two:.2e}, estimate {est:.2e}; |taylor - oracle| {e_tay:.2e}")
+            assert e_def < AMP_TOL / 2, (desc, b, e_def)
+            assert e_two <= max(2.5 * est, FLOOR), (desc, b, e_two, est)
+            assert e_tay < 1e-8, (desc, b, e_tay)
+        n_cases += 1
+    assert n_cases == 16
+    print(f"worst |default - oracle| {worst[0]:.2e}, worst |taylor - oracle| {worst[1]:.2e}, worst 2-norm / estimate {worst[2]:.2f}")
+
+
 def test_default_path_of_small_strongly_interacting_registers_against_the_tight_oracle():
     """8 - 11 atoms at 4.5 - 5.4 um (300 - 650 rad/us between neighbours): the DEFAULT path there is the persistent polynomial
     kernel (k_traj: CF4 steps from a-priori estimates).  Round 6 found those estimates short on such registers at 12 - 16 atoms
